@@ -1,0 +1,225 @@
+/*
+ * bgs_hip.h — C ABI of libbgs_hip, the MI355X (gfx950) foreground-detection engine.
+ *
+ * This is the drop-in boundary for the reference's package_bgs hot path.  The
+ * reference's own surface is C++ with OpenCV types in the signature
+ *     IBGS::process(const cv::Mat&, cv::Mat&, cv::Mat&)     package_bgs/IBGS.h:24
+ *     USTC_BGS::Process(IplImage*) / GetMask()              ustc_src/ustc_bgs.cpp:79-113
+ * so what crosses here is exactly what those calls carry once the cv::Mat /
+ * IplImage header is peeled off: (data pointer, rows, cols, channels, row step)
+ * for the input frame, the foreground mask and the background image.
+ * No OpenCV, HIP or torch types appear in any signature; every function returns
+ * 0 on success or a negative bgs_status, never throws.
+ *
+ * One engine owns the model state of n_streams independent camera streams of one
+ * geometry, resident in HBM as SoA planes.  An engine is not
+ * thread-safe (neither is an IBGS instance); use one per thread.
+ */
+#ifndef BGS_HIP_H
+#define BGS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BGS_ABI_VERSION 1
+
+typedef struct bgs_engine bgs_engine;
+
+/* One id per reference IBGS class on the hot path.  The comment
+ * names the reference process() each one replaces. */
+typedef enum bgs_algo {
+  BGS_FRAME_DIFF = 0,        /* FrameDifferenceBGS::process        package_bgs/FrameDifferenceBGS.cpp:29-61 */
+  BGS_STATIC_FRAME_DIFF = 1, /* StaticFrameDifferenceBGS::process  package_bgs/StaticFrameDifferenceBGS.cpp:29-57 */
+  BGS_WMM = 2,               /* WeightedMovingMeanBGS::process     package_bgs/WeightedMovingMeanBGS.cpp:29-96 */
+  BGS_WMV = 3,               /* WeightedMovingVarianceBGS::process package_bgs/WeightedMovingVarianceBGS.cpp:30-117 */
+  BGS_ABL = 4,               /* AdaptiveBackgroundLearning::process package_bgs/AdaptiveBackgroundLearning.cpp:30-83 */
+  BGS_ASBL = 5,              /* AdaptiveSelectiveBackgroundLearning::process package_bgs/AdaptiveSelectiveBackgroundLearning.cpp:31-105 */
+  BGS_MOG2 = 6,              /* MixtureOfGaussianV2BGS::process    package_bgs/MixtureOfGaussianV2BGS.cpp:29-74 */
+  BGS_MOG1 = 7,              /* MixtureOfGaussianV1BGS::process    package_bgs/MixtureOfGaussianV1BGS.cpp:29-71 */
+  BGS_GMG = 8,               /* GMG::process                       package_bgs/GMG.cpp:35-77 */
+  BGS_SUBSENSE = 9,          /* SuBSENSEBGS::process               package_bgs/pl/SuBSENSE.cpp:21-45 */
+  BGS_LBSP_DESC = 10,        /* LBSP::computeRGBDescriptor         package_bgs/pl/LBSP.h:50-95 */
+  BGS_SIGMA_DELTA = 11,      /* SigmaDeltaBGS::process             package_bgs/bl/SigmaDeltaBGS.cpp */
+  BGS_ALGO_COUNT
+} bgs_algo;
+
+typedef enum bgs_status {
+  BGS_OK = 0,
+  BGS_ERR_INVALID = -1,      /* bad argument (NULL, negative size, unknown enum) */
+  BGS_ERR_UNSUPPORTED = -2,  /* input the reference would CV_Assert on (e.g. MOG2 background image of a 1-channel frame) */
+  BGS_ERR_GEOMETRY = -3,     /* rows/cols/channels differ from the first frame of this engine */
+  BGS_ERR_HIP = -4,          /* HIP runtime failure; text in bgs_last_error() */
+  BGS_ERR_NOMEM = -5,
+  BGS_ERR_STATE = -6         /* unknown state plane / buffer too small */
+} bgs_status;
+
+/* out_flags bits of bgs_process*: the reference leaves img_output / img_bgmodel
+ * untouched on warm-up frames and for algorithms that never write a background
+ * (SURVEY.md App. C 1-2); callers must not read a buffer whose bit is clear. */
+#define BGS_FG_VALID 1u
+#define BGS_BG_VALID 2u
+
+/*
+ * Parameters.  Field defaults are the values the reference's constructors and
+ * loadConfig() fall back to when ./config/<Class>.xml is absent (file:line in
+ * the comments).  Zero-initialise, set struct_size = sizeof(bgs_params), call
+ * bgs_default_params(algo, &p), then override.
+ */
+typedef struct bgs_params {
+  uint32_t struct_size;
+
+  /* wrapper-level, shared by every IBGS class: cv::threshold(fg, threshold, 255, THRESH_BINARY) */
+  int32_t enable_threshold;   /* 1   e.g. FrameDifferenceBGS.cpp:84 */
+  int32_t threshold;          /* 15  (ASBL: 25, AdaptiveSelectiveBackgroundLearning.cpp:127) */
+
+  /* WeightedMovingMeanBGS / WeightedMovingVarianceBGS */
+  int32_t enable_weight;      /* 1   WeightedMovingMeanBGS.cpp:117 */
+
+  /* AdaptiveBackgroundLearning, MixtureOfGaussianV1/V2 (learning rate) */
+  double alpha;               /* 0.05  AdaptiveBackgroundLearning.cpp:103, MixtureOfGaussianV2BGS.cpp:92 ; MOG1: 0.05 */
+  int32_t limit;              /* -1  AdaptiveBackgroundLearning.cpp:104 */
+
+  /* AdaptiveSelectiveBackgroundLearning */
+  int32_t learning_frames;    /* 90    AdaptiveSelectiveBackgroundLearning.cpp:124 */
+  double alpha_learn;         /* 0.05  :125 */
+  double alpha_detection;     /* 0.05  :126 */
+
+  /* cv::BackgroundSubtractorMOG2 defaults */
+  int32_t mog2_history;        /* 500 */
+  int32_t mog2_nmixtures;      /* 5 (compile-time K of the kernel; other values -> BGS_ERR_UNSUPPORTED) */
+  float mog2_var_threshold;    /* Tb = 16 */
+  float mog2_background_ratio; /* TB = 0.9 */
+  float mog2_var_threshold_gen;/* Tg = 9 */
+  float mog2_var_init;         /* 15 */
+  float mog2_var_min;          /* 4 */
+  float mog2_var_max;          /* 75 */
+  float mog2_ct;               /* 0.05 */
+  float mog2_tau;              /* 0.5 */
+  int32_t mog2_detect_shadows; /* 1 */
+  int32_t mog2_shadow_value;   /* 127 */
+
+  /* cv::BackgroundSubtractorMOG defaults */
+  int32_t mog1_history;        /* 200 */
+  int32_t mog1_nmixtures;      /* 5 */
+  double mog1_background_ratio;/* 0.7 */
+  double mog1_var_threshold;   /* 2.5*2.5 */
+  double mog1_noise_sigma;     /* 15 (30*0.5) */
+
+  /* LBSP descriptor / SuBSENSE (package_bgs/pl/SuBSENSE.cpp:8-14) */
+  float lbsp_rel_threshold;    /* 0.333 */
+  int32_t lbsp_threshold_offset;/* 0 (base-ctor default) */
+  int32_t subsense_min_color_dist_threshold; /* 30 */
+  int32_t subsense_n_samples;  /* 50 */
+  int32_t subsense_n_required; /* 2 */
+  int32_t subsense_samples_for_moving_avgs; /* 100 */
+
+  /* SigmaDelta (package_bgs/bl/SigmaDeltaBGS.cpp) */
+  int32_t sd_amp_factor;       /* 1 */
+  int32_t sd_min_var;          /* 15 */
+  int32_t sd_max_var;          /* 255 */
+
+  uint32_t reserved[16];
+} bgs_params;
+
+int bgs_abi_version(void);
+
+/* Fill *p (struct_size must be set) with the reference defaults for `algo`. */
+int bgs_default_params(bgs_algo algo, bgs_params* p);
+
+/* Create an engine for `n_streams` independent streams on HIP device `hip_device`.
+ * params == NULL selects the reference defaults.  Model memory is allocated
+ * lazily at the first frame (like every reference class) or by bgs_set_geometry. */
+int bgs_create(bgs_algo algo, const bgs_params* params, int hip_device, int n_streams, bgs_engine** out);
+
+/* Replace the wrapper-level parameters between frames.  The reference re-reads
+ * ./config/<Class>.xml at the top of every process() (e.g. MixtureOfGaussianV2BGS.cpp:34),
+ * so thresholds / alpha may change mid-stream; structural fields (nmixtures, n_samples)
+ * must stay what they were at bgs_create. */
+int bgs_set_params(bgs_engine* e, const bgs_params* params);
+
+/* Engine options.
+ *   BGS_OPT_BORROW_FRAMES  device path of the history-keeping classes (FrameDifference, WeightedMovingMean/Variance):
+ *                          1 = use the caller's previous d_frames buffers as history instead of copying each frame
+ *                          into the engine's ring; the buffers handed to the previous one (FD) or two (WMM/WMV)
+ *                          whole-batch calls must then stay valid and unchanged.  Default 0 (private copy).
+ *   BGS_OPT_MOG2_PIXELS_PER_LANE  1, 2 or 4 (tuning knob; 0 = widest the alignment allows). */
+#define BGS_OPT_BORROW_FRAMES 1
+#define BGS_OPT_MOG2_PIXELS_PER_LANE 2
+int bgs_set_option(bgs_engine* e, int option, int64_t value);
+
+/* Fix rows x cols x channels up front and allocate the model (device path). */
+int bgs_set_geometry(bgs_engine* e, int rows, int cols, int channels);
+
+/*
+ * One frame of one stream, host buffers (the IBGS::process call).
+ *   in       rows x cols x channels uint8, interleaved (BGR), row stride in_step bytes (>= cols*channels)
+ *   fg       rows x cols uint8 mask or NULL; written only if BGS_FG_VALID is reported
+ *   bg       rows x cols x channels (ASBL: x1) uint8 or NULL; written only if BGS_BG_VALID
+ * in == NULL or rows*cols == 0 is the reference's `if(img_input.empty()) return;`:
+ * returns BGS_OK with *out_flags = 0 and no state change.
+ * Synchronous: the outputs are complete on return.
+ */
+int bgs_process(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols, int channels, size_t in_step,
+                uint8_t* fg, size_t fg_step, uint8_t* bg, size_t bg_step, uint32_t* out_flags);
+
+/*
+ * One frame of EVERY stream, device buffers, asynchronous on `hip_stream`
+ * (a hipStream_t passed as void*; NULL = the default stream).  This is the
+ * roofline path: no PCIe traffic, one launch over streams x pixels.
+ *   d_frames  [n_streams][rows][cols][channels] uint8, contiguous
+ *   d_fg      [n_streams][rows][cols] uint8 or NULL
+ *   d_bg      [n_streams][rows][cols][channels] uint8 or NULL
+ *   d_fg_bits [n_streams][ceil(rows*cols/64)] uint64, bit i of word j = pixel 64j+i foreground, or NULL
+ * All streams must be in lock-step (same number of frames seen).
+ */
+int bgs_process_batch_device(bgs_engine* e, const void* d_frames, void* d_fg, void* d_bg, void* d_fg_bits,
+                             void* hip_stream, uint32_t* out_flags);
+
+/* Same, restricted to streams [first, first+count): d_* point at the first of `count` images. */
+int bgs_process_range_device(bgs_engine* e, int first, int count, const void* d_frames, void* d_fg, void* d_bg,
+                             void* d_fg_bits, void* hip_stream, uint32_t* out_flags);
+
+/*
+ * Copy one model plane of one stream to host memory, as a dense array in the
+ * canonical order documented in DESIGN.md §3 (e.g. MOG2: "w" float[K][N],
+ * "var" float[K][N], "mu" float[K][C][N], "nmodes" uint8[N]).  Returns the
+ * number of bytes written (>= 0) or a negative status.  Parity tests only.
+ */
+int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, size_t cap);
+
+/* Number of frames stream `stream` has consumed so far. */
+int64_t bgs_frames_seen(const bgs_engine* e, int stream);
+
+/* Average duration in ms of the dominant kernel of this engine since the last reset, measured
+ * with HIP events on the launch stream when timing is enabled (bench.py's roofline leg). */
+int bgs_enable_kernel_timing(bgs_engine* e, int on);
+int bgs_kernel_timing(bgs_engine* e, double* avg_ms, int64_t* launches, const char** kernel_name);
+
+void bgs_destroy(bgs_engine* e);
+
+/* Thread-local text of the last failure on this thread ("" if none). */
+const char* bgs_last_error(void);
+
+/* ---- stand-alone device primitives (rows §8a10, §8f N1) ------------------------------ */
+
+/* LBSP 16-bit double-cross descriptors of a whole 8UC3 / 8UC1 image (LBSP.h:50-95,
+ * LBSP_16bits_dbcross_{3ch3t,1ch}.i).  d_desc: [rows][cols][channels] uint16; the
+ * 2-pixel border (LBSP::validateROI, LBSP.cpp:311-318) is written as 0.
+ * t_lut: 256 absolute thresholds indexed by the centre value
+ * (BackgroundSubtractorSuBSENSE.cpp:209-210, 227-228), host pointer. */
+int bgs_lbsp_describe_device(int hip_device, const void* d_img, int rows, int cols, int channels,
+                             const uint8_t* t_lut, void* d_desc, void* hip_stream);
+
+/* 3x3 morphology / median / hole-fill post-processing of a byte mask on device
+ * (BackgroundSubtractorSuBSENSE.cpp:624-640). op: 0 erode3x3, 1 dilate3x3, 2 median(ksize). */
+int bgs_mask_morph_device(int hip_device, const void* d_src, void* d_dst, int rows, int cols, int op, int ksize,
+                          int iterations, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BGS_HIP_H */

@@ -1,0 +1,96 @@
+"""CPU-side checks of the drop-in boundary: the library loads, exports every symbol include/bgs_hip.h declares,
+the ctypes struct mirrors the C struct, and — on a box without a GPU — compute entry points fail loudly."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from tracking_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "bgs_hip.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bgs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported():
+    names = declared_functions()
+    assert len(names) >= 15
+    lib = C.CDLL(capi.LIB_PATH)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(n for n, _, _ in capi.SYMBOLS) == names, "capi.SYMBOLS must bind exactly what the header declares"
+
+
+def test_params_struct_matches_c(tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "bgs_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(bgs_params), '
+                   'offsetof(bgs_params, alpha), offsetof(bgs_params, mog2_var_threshold), offsetof(bgs_params, sd_max_var));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    size, a, b, c = map(int, subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split())
+    assert size == C.sizeof(capi.BgsParams)
+    assert a == capi.BgsParams.alpha.offset and b == capi.BgsParams.mog2_var_threshold.offset and c == capi.BgsParams.sd_max_var.offset
+
+
+def test_abi_version_and_defaults():
+    assert capi.lib().bgs_abi_version() == 1
+    p = capi.default_params(capi.MOG2)
+    assert (p.threshold, p.enable_threshold, p.alpha) == (15, 1, 0.05)  # MixtureOfGaussianV2BGS.cpp:90-97
+    assert (p.mog2_nmixtures, p.mog2_var_threshold, p.mog2_var_threshold_gen) == (5, 16.0, 9.0)
+    assert capi.default_params(capi.ASBL).threshold == 25  # AdaptiveSelectiveBackgroundLearning.cpp:127
+    assert capi.default_params(capi.ASBL).learning_frames == 90
+
+
+def test_defaults_agree_with_oracle():
+    from oracle import pyoracle
+    for algo in range(12):
+        a = capi.default_params(algo)
+        b = capi.BgsParams()
+        b.struct_size = C.sizeof(capi.BgsParams)
+        assert pyoracle.lib().orc_default_params(algo, C.byref(b)) == 0
+        assert bytes(a) == bytes(b), algo
+
+
+def test_bad_arguments_are_reported():
+    h = C.c_void_p()
+    assert capi.lib().bgs_create(99, None, 0, 1, C.byref(h)) == capi.ERR_INVALID
+    assert b"unknown algorithm" in capi.lib().bgs_last_error()
+    assert capi.lib().bgs_create(capi.MOG2, None, 0, 0, C.byref(h)) == capi.ERR_INVALID
+    p = capi.default_params(capi.MOG2)
+    p.struct_size = 8
+    assert capi.lib().bgs_create(capi.MOG2, C.byref(p), 0, 1, C.byref(h)) == capi.ERR_INVALID
+    p = capi.default_params(capi.MOG2)
+    p.mog2_nmixtures = 3
+    assert capi.lib().bgs_create(capi.MOG2, C.byref(p), 0, 1, C.byref(h)) == capi.ERR_UNSUPPORTED
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    rc = capi.lib().bgs_create(capi.MOG2, None, 0, 1, C.byref(h))
+    assert rc == capi.ERR_HIP and not h.value
+    assert b"no CPU path" in capi.lib().bgs_last_error()
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under tracking_amd/ or include/ may reference it."""
+    bad = []
+    for base in ("tracking_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            if os.sep + "lib" in dp:
+                continue
+            for fn in fns:
+                if fn.endswith((".py", ".h", ".hip", ".cpp", ".c", "Makefile")):
+                    t = open(os.path.join(dp, fn), errors="replace").read()
+                    if "oracle" in t.replace("no oracle", ""):
+                        bad.append(os.path.join(dp, fn))
+    assert not bad, bad

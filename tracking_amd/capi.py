@@ -1,0 +1,123 @@
+"""ctypes binding of libbgs_hip's C ABI (include/bgs_hip.h) — plumbing only.
+
+This module never computes anything itself and has no CPU path: if the HIP library is
+missing it raises at import of the symbols, and every call into a box without a GPU
+fails with BgsError(BGS_ERR_HIP).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbgs_hip.so")
+
+# bgs_algo (include/bgs_hip.h)
+FRAME_DIFF, STATIC_FRAME_DIFF, WMM, WMV, ABL, ASBL, MOG2, MOG1, GMG, SUBSENSE, LBSP_DESC, SIGMA_DELTA = range(12)
+FG_VALID, BG_VALID = 1, 2
+OPT_BORROW_FRAMES, OPT_MOG2_PIXELS_PER_LANE = 1, 2
+
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_GEOMETRY, ERR_HIP, ERR_NOMEM, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
+
+
+class BgsParams(C.Structure):
+    """struct bgs_params, field for field."""
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("enable_threshold", C.c_int32),
+        ("threshold", C.c_int32),
+        ("enable_weight", C.c_int32),
+        ("alpha", C.c_double),
+        ("limit", C.c_int32),
+        ("learning_frames", C.c_int32),
+        ("alpha_learn", C.c_double),
+        ("alpha_detection", C.c_double),
+        ("mog2_history", C.c_int32),
+        ("mog2_nmixtures", C.c_int32),
+        ("mog2_var_threshold", C.c_float),
+        ("mog2_background_ratio", C.c_float),
+        ("mog2_var_threshold_gen", C.c_float),
+        ("mog2_var_init", C.c_float),
+        ("mog2_var_min", C.c_float),
+        ("mog2_var_max", C.c_float),
+        ("mog2_ct", C.c_float),
+        ("mog2_tau", C.c_float),
+        ("mog2_detect_shadows", C.c_int32),
+        ("mog2_shadow_value", C.c_int32),
+        ("mog1_history", C.c_int32),
+        ("mog1_nmixtures", C.c_int32),
+        ("mog1_background_ratio", C.c_double),
+        ("mog1_var_threshold", C.c_double),
+        ("mog1_noise_sigma", C.c_double),
+        ("lbsp_rel_threshold", C.c_float),
+        ("lbsp_threshold_offset", C.c_int32),
+        ("subsense_min_color_dist_threshold", C.c_int32),
+        ("subsense_n_samples", C.c_int32),
+        ("subsense_n_required", C.c_int32),
+        ("subsense_samples_for_moving_avgs", C.c_int32),
+        ("sd_amp_factor", C.c_int32),
+        ("sd_min_var", C.c_int32),
+        ("sd_max_var", C.c_int32),
+        ("reserved", C.c_uint32 * 16),
+    ]
+
+
+class BgsError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("libbgs_hip error %d: %s" % (code, text))
+        self.code = code
+
+
+# every symbol include/bgs_hip.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ("bgs_abi_version", C.c_int, []),
+    ("bgs_default_params", C.c_int, [C.c_int, C.POINTER(BgsParams)]),
+    ("bgs_create", C.c_int, [C.c_int, C.POINTER(BgsParams), C.c_int, C.c_int, C.POINTER(_P)]),
+    ("bgs_set_params", C.c_int, [_P, C.POINTER(BgsParams)]),
+    ("bgs_set_option", C.c_int, [_P, C.c_int, C.c_int64]),
+    ("bgs_set_geometry", C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    ("bgs_process", C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_size_t, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_uint32)]),
+    ("bgs_process_batch_device", C.c_int, [_P, _P, _P, _P, _P, _P, C.POINTER(C.c_uint32)]),
+    ("bgs_process_range_device", C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.POINTER(C.c_uint32)]),
+    ("bgs_get_state", C.c_int64, [_P, C.c_int, C.c_char_p, _P, C.c_size_t]),
+    ("bgs_frames_seen", C.c_int64, [_P, C.c_int]),
+    ("bgs_enable_kernel_timing", C.c_int, [_P, C.c_int]),
+    ("bgs_kernel_timing", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_char_p)]),
+    ("bgs_destroy", None, [_P]),
+    ("bgs_last_error", C.c_char_p, []),
+    ("bgs_lbsp_describe_device", C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    ("bgs_mask_morph_device", C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+]
+
+_lib = None
+
+
+def lib():
+    """Load libbgs_hip.so (built in-tree by __graft_entry__.build()).  No fallback of any kind."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libbgs_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` (%s)" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(l, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def last_error():
+    return (lib().bgs_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc):
+    if rc < 0:
+        raise BgsError(rc, last_error())
+    return rc
+
+
+def default_params(algo):
+    p = BgsParams()
+    p.struct_size = C.sizeof(BgsParams)
+    check(lib().bgs_default_params(algo, C.byref(p)))
+    return p

@@ -1,0 +1,118 @@
+// bgs_device.h — device-side helpers shared by every kernel of libbgs_hip (gfx950 only).
+//
+// Numeric contract: the uint8 masks must equal the reference's bit for bit, so every
+// float expression rounds exactly where the reference's does.  The library is compiled with
+// -ffp-contract=off (no FMA fusion), divisions and square roots use the correctly rounded
+// __fdiv_rn/__fsqrt_rn, u8 conversion is round-half-to-even then clamp (cv::saturate_cast<uchar>(float)).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bgs {
+
+constexpr int kWave = 64;       // CDNA4 wavefront
+constexpr int kBlock = 256;     // 4 waves, one per SIMD
+
+// cv::cvtColor(CV_BGR2GRAY) on 8U: fixed point, shift 14
+__device__ __forceinline__ int gray_bgr(int b, int g, int r) { return (b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14; }
+
+// cv::saturate_cast<uchar>(float): cvRound (half-to-even) then clamp
+__device__ __forceinline__ int sat_u8(float v) {
+  int i = __float2int_rn(v);
+  return min(max(i, 0), 255);
+}
+
+// cv::threshold(..., THRESH_BINARY) when enabled, identity otherwise
+__device__ __forceinline__ int thr_bin(int v, int thr, int enable) { return enable ? (v > thr ? 255 : 0) : v; }
+
+// cv::addWeighted on 32F: (float)((double)a*alpha + (double)b*beta)   [the +gamma(0.0) is an identity for the non-negative values here]
+__device__ __forceinline__ float add_weighted(float a, double alpha, float b, double beta) {
+  return (float)__dadd_rn(__dmul_rn((double)a, alpha), __dmul_rn((double)b, beta));
+}
+
+// byte j (0..3) of a dword
+__device__ __forceinline__ int byte_of(uint32_t w, int j) { return (int)((w >> (8 * j)) & 0xffu); }
+
+// G consecutive pixels of C interleaved bytes, held as dwords in registers.
+template <int NBYTES>
+struct Bytes {
+  static_assert(NBYTES % 4 == 0, "whole dwords");
+  uint32_t w[NBYTES / 4];
+  __device__ __forceinline__ int get(int i) const { return byte_of(w[i >> 2], i & 3); }
+  __device__ __forceinline__ void set(int i, int v) { w[i >> 2] = (w[i >> 2] & ~(0xffu << (8 * (i & 3)))) | ((uint32_t)v << (8 * (i & 3))); }
+};
+
+// Coalesced vector load/store of NBYTES per lane.  p must be 4-byte aligned (16-byte when NBYTES % 16 == 0).
+template <int NBYTES>
+__device__ __forceinline__ Bytes<NBYTES> load_bytes(const uint8_t* p) {
+  Bytes<NBYTES> r;
+  if constexpr (NBYTES % 16 == 0) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < NBYTES / 16; ++i) {
+      uint4 v = q[i];
+      r.w[4 * i] = v.x, r.w[4 * i + 1] = v.y, r.w[4 * i + 2] = v.z, r.w[4 * i + 3] = v.w;
+    }
+  } else {
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+#pragma unroll
+    for (int i = 0; i < NBYTES / 4; ++i) r.w[i] = q[i];
+  }
+  return r;
+}
+template <int NBYTES>
+__device__ __forceinline__ void store_bytes(uint8_t* p, const Bytes<NBYTES>& r) {
+  if constexpr (NBYTES % 16 == 0) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < NBYTES / 16; ++i) q[i] = make_uint4(r.w[4 * i], r.w[4 * i + 1], r.w[4 * i + 2], r.w[4 * i + 3]);
+  } else {
+    uint32_t* q = reinterpret_cast<uint32_t*>(p);
+#pragma unroll
+    for (int i = 0; i < NBYTES / 4; ++i) q[i] = r.w[i];
+  }
+}
+
+// PX consecutive floats of one SoA plane
+template <int PX>
+__device__ __forceinline__ void load_f(const float* p, float (&d)[PX]) {
+  if constexpr (PX == 4) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+  } else if constexpr (PX == 2) {
+    float2 v = *reinterpret_cast<const float2*>(p);
+    d[0] = v.x, d[1] = v.y;
+  } else {
+#pragma unroll
+    for (int i = 0; i < PX; ++i) d[i] = p[i];
+  }
+}
+template <int PX>
+__device__ __forceinline__ void store_f(float* p, const float (&d)[PX]) {
+  if constexpr (PX == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(d[0], d[1], d[2], d[3]);
+  } else if constexpr (PX == 2) {
+    *reinterpret_cast<float2*>(p) = make_float2(d[0], d[1]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < PX; ++i) p[i] = d[i];
+  }
+}
+
+// OR-combine the low `bits` of every lane's value into 64-bit words in pixel order and let the first lane
+// of each group store it: packed foreground mask, bit i of word j = pixel 64 j + i.  Each lane holds PX mask
+// bits (pixel order) in `nib`; 64/PX lanes share one word.
+template <int PX>
+__device__ __forceinline__ void store_packed_mask(uint64_t* words, size_t first_pixel_of_lane, uint32_t nib, bool lane_in_range) {
+  constexpr int LANES = 64 / PX;  // lanes per 64-bit word
+  const int lane = threadIdx.x & (kWave - 1);
+  uint64_t v = (uint64_t)nib << (PX * (lane % LANES));
+#pragma unroll
+  for (int off = 1; off < LANES; off <<= 1) {
+    uint32_t lo = __shfl_xor((uint32_t)v, off, kWave), hi = __shfl_xor((uint32_t)(v >> 32), off, kWave);
+    v |= ((uint64_t)hi << 32) | lo;
+  }
+  if (lane % LANES == 0 && lane_in_range) words[first_pixel_of_lane >> 6] = v;
+}
+
+}  // namespace bgs

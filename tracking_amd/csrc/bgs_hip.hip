@@ -1,0 +1,583 @@
+// bgs_hip.hip — the C ABI of libbgs_hip (include/bgs_hip.h) and the engine behind it.
+//
+// The engine is the device-side twin of one reference IBGS object per stream: it owns the model state of
+// n_streams independent streams as SoA planes in HBM and turns every IBGS::process call
+// (package_bgs/IBGS.h:24) into ONE fused kernel launch.  Host entry points stage through pinned memory;
+// device entry points take HBM pointers and launch over streams x pixels.  There is no CPU fallback: if HIP
+// is unavailable every compute entry point fails with BGS_ERR_HIP.
+#include "../../include/bgs_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernel_mog2.h"
+#include "kernel_pointwise.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                           \
+  do {                                                                                          \
+    hipError_t e__ = (expr);                                                                    \
+    if (e__ != hipSuccess) return fail(BGS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__)); \
+  } while (0)
+
+inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+inline unsigned blocks_for(size_t groups) { return (unsigned)((groups + bgs::kBlock - 1) / bgs::kBlock); }
+
+}  // namespace
+
+struct bgs_engine {
+  bgs_algo algo;
+  bgs_params p;
+  int device = 0;
+  int S = 1;
+  int rows = 0, cols = 0, ch = 0;
+  size_t n = 0;  // pixels per stream; 0 until the geometry is known
+  std::vector<int64_t> seen, counter;
+
+  // frame history ring (FD: 2 slots, WMM/WMV: 3): frame t of stream s lives in ring[t % nring] + s*n*ch
+  uint8_t* ring[3] = {nullptr, nullptr, nullptr};
+  int nring = 0;
+  bool borrow = false;               // device path: history = the caller's previous d_frames, no copies
+  const uint8_t* borrowed[2] = {nullptr, nullptr};
+  // byte state (SFD background, ABL/ASBL background): [S][n*state_ch]
+  uint8_t* bgstate = nullptr;
+  int state_ch = 0;
+  // MOG2 planes
+  float *w = nullptr, *var = nullptr, *mu = nullptr;
+  uint8_t* nmodes = nullptr;
+  int mog2_px = 0;  // 0 = auto
+
+  // host staging (bgs_process)
+  uint8_t *h_in = nullptr, *h_fg = nullptr, *h_bg = nullptr;
+  uint8_t *d_in = nullptr, *d_fg = nullptr, *d_bg = nullptr;
+  hipStream_t stream = nullptr;
+
+  // dominant-kernel timing
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  const char* kernel_name = "";
+};
+
+namespace {
+
+void free_all(bgs_engine* e) {
+  for (auto& r : e->ring)
+    if (r) (void)hipFree(r), r = nullptr;
+  void* dev[] = {e->bgstate, e->w, e->var, e->mu, e->nmodes, e->d_in, e->d_fg, e->d_bg};
+  for (void* d : dev)
+    if (d) (void)hipFree(d);
+  e->bgstate = nullptr, e->w = e->var = e->mu = nullptr, e->nmodes = nullptr, e->d_in = e->d_fg = e->d_bg = nullptr;
+  void* host[] = {e->h_in, e->h_fg, e->h_bg};
+  for (void* h : host)
+    if (h) (void)hipHostFree(h);
+  e->h_in = e->h_fg = e->h_bg = nullptr;
+  for (auto& ev : e->events) (void)hipEventDestroy(ev.first), (void)hipEventDestroy(ev.second);
+  e->events.clear();
+}
+
+int check_params(bgs_algo algo, const bgs_params& p) {
+  if (algo == BGS_MOG2 && p.mog2_nmixtures != bgs::kMog2K) return fail(BGS_ERR_UNSUPPORTED, "MOG2 kernel is built for K=%d mixtures, got %d", bgs::kMog2K, p.mog2_nmixtures);
+  return BGS_OK;
+}
+
+int allocate(bgs_engine* e, int rows, int cols, int ch) {
+  if (rows <= 0 || cols <= 0) return fail(BGS_ERR_INVALID, "bad geometry %dx%d", rows, cols);
+  if (ch != 1 && ch != 3) return fail(BGS_ERR_UNSUPPORTED, "channels must be 1 or 3, got %d", ch);
+  if (e->algo == BGS_MOG2 && ch != 3)
+    return fail(BGS_ERR_UNSUPPORTED, "MixtureOfGaussianV2BGS needs 3 channels: getBackgroundImage asserts nchannels == 3 (MixtureOfGaussianV2BGS.cpp:59)");
+  HIP_TRY(hipSetDevice(e->device));
+  e->rows = rows, e->cols = cols, e->ch = ch, e->n = (size_t)rows * cols;
+  const size_t P = e->n * e->S, fb = P * ch;
+  switch (e->algo) {
+    case BGS_FRAME_DIFF: e->nring = 2; break;
+    case BGS_WMM:
+    case BGS_WMV: e->nring = 3; break;
+    case BGS_STATIC_FRAME_DIFF:
+    case BGS_ABL: e->state_ch = ch; break;
+    case BGS_MOG2: break;
+    default: return fail(BGS_ERR_UNSUPPORTED, "algorithm %d is not implemented in this build", (int)e->algo);
+  }
+  for (int i = 0; i < e->nring; ++i) HIP_TRY(hipMalloc((void**)&e->ring[i], fb));
+  if (e->state_ch) HIP_TRY(hipMalloc((void**)&e->bgstate, P * e->state_ch));
+  if (e->algo == BGS_MOG2) {
+    const int K = bgs::kMog2K;
+    HIP_TRY(hipMalloc((void**)&e->w, P * K * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&e->var, P * K * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&e->mu, P * K * 3 * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&e->nmodes, P));
+  }
+  if (!e->stream) HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  return BGS_OK;
+}
+
+int ensure_staging(bgs_engine* e) {
+  if (e->h_in) return BGS_OK;
+  const size_t fb = e->n * e->ch;
+  HIP_TRY(hipHostMalloc((void**)&e->h_in, fb, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&e->h_fg, e->n, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&e->h_bg, fb, hipHostMallocDefault));
+  HIP_TRY(hipMalloc((void**)&e->d_in, fb));
+  HIP_TRY(hipMalloc((void**)&e->d_fg, e->n));
+  HIP_TRY(hipMalloc((void**)&e->d_bg, fb));
+  return BGS_OK;
+}
+
+struct Timed {
+  bgs_engine* e;
+  hipStream_t s;
+  hipEvent_t a = nullptr, b = nullptr;
+  Timed(bgs_engine* e_, hipStream_t s_, const char* name) : e(e_), s(s_) {
+    e->kernel_name = name;
+    if (e->timing && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, s);
+  }
+  ~Timed() {
+    if (a && b) {
+      (void)hipEventRecord(b, s);
+      e->events.emplace_back(a, b);
+    }
+  }
+};
+
+#define LAUNCH_FRAME_KERNEL(KERNEL, name)                                                             \
+  do {                                                                                                \
+    Timed t__(e, s, name);                                                                            \
+    if (C == 3) {                                                                                     \
+      if (G == 16)                                                                                    \
+        hipLaunchKernelGGL((bgs::KERNEL<16, 3>), dim3(blocks_for(a.npix / 16)), dim3(bgs::kBlock), 0, s, a); \
+      else if (G == 4)                                                                                \
+        hipLaunchKernelGGL((bgs::KERNEL<4, 3>), dim3(blocks_for(a.npix / 4)), dim3(bgs::kBlock), 0, s, a);   \
+      else                                                                                            \
+        hipLaunchKernelGGL((bgs::KERNEL<1, 3>), dim3(blocks_for(a.npix)), dim3(bgs::kBlock), 0, s, a);       \
+    } else {                                                                                          \
+      if (G == 16)                                                                                    \
+        hipLaunchKernelGGL((bgs::KERNEL<16, 1>), dim3(blocks_for(a.npix / 16)), dim3(bgs::kBlock), 0, s, a); \
+      else if (G == 4)                                                                                \
+        hipLaunchKernelGGL((bgs::KERNEL<4, 1>), dim3(blocks_for(a.npix / 4)), dim3(bgs::kBlock), 0, s, a);   \
+      else                                                                                            \
+        hipLaunchKernelGGL((bgs::KERNEL<1, 1>), dim3(blocks_for(a.npix)), dim3(bgs::kBlock), 0, s, a);       \
+    }                                                                                                 \
+  } while (0)
+
+// widest pixel group every pointer and the pixel count allow
+int pick_group(const bgs::FrameArgs& a, int C) {
+  const void* ptrs[] = {a.cur, a.p1, a.p2, a.state_out, a.fg, a.bg};
+  int G = 16;
+  if (a.npix % 16) G = (a.npix % 4) ? 1 : 4;
+  for (const void* p : ptrs) {
+    if (!p) continue;
+    if (G == 16 && !aligned(p, 16)) G = 4;
+    if (G == 4 && !aligned(p, 4)) G = 1;
+  }
+  if (const char* env = getenv("BGS_FRAME_GROUP")) {
+    const int want = atoi(env);
+    if ((want == 1 || want == 4 || want == 16) && want <= G) G = want;
+  }
+  (void)C;
+  return G;
+}
+
+int launch_mog2(bgs_engine* e, bgs::Mog2Args& a, hipStream_t s) {
+  const bgs_params& p = e->p;
+  // shadow test only when it can change the delivered mask: not thresholded, or the threshold separates shadow from foreground
+  const bool shadow = p.mog2_detect_shadows && (!p.enable_threshold || ((p.mog2_shadow_value > p.threshold) != (255 > p.threshold)));
+  const bool bgimg = a.bgimg != nullptr, packed = a.fg_bits != nullptr;
+  int PX = 4;
+  if (a.npix % 4 || a.state_off % 4 || !aligned(a.frame, 4) || (a.fg && !aligned(a.fg, 4)) || (a.bgimg && !aligned(a.bgimg, 4))) PX = 1;
+  if (e->mog2_px == 1 || e->mog2_px == 2) {
+    if (!(e->mog2_px == 2 && (a.npix % 2 || a.state_off % 2 || !aligned(a.frame, 2)))) PX = std::min(PX, e->mog2_px);
+  }
+  if (PX == 2 && a.fg && !aligned(a.fg, 2)) PX = 1;
+  if (packed && a.npix % 64) return fail(BGS_ERR_UNSUPPORTED, "packed mask needs pixels %% 64 == 0");
+  Timed t(e, s, "mog2_update_kernel");
+  const dim3 grid(blocks_for(a.npix / PX)), block(bgs::kBlock);
+#define MOG2_CASE(PXV, SH, BG, PK) \
+  if (PX == PXV && shadow == SH && bgimg == BG && packed == PK) hipLaunchKernelGGL((bgs::mog2_update_kernel<PXV, SH, BG, PK>), grid, block, 0, s, a);
+#define MOG2_PX(PXV)                                                                                        \
+  MOG2_CASE(PXV, false, false, false) MOG2_CASE(PXV, false, false, true) MOG2_CASE(PXV, false, true, false) \
+  MOG2_CASE(PXV, false, true, true) MOG2_CASE(PXV, true, false, false) MOG2_CASE(PXV, true, false, true)   \
+  MOG2_CASE(PXV, true, true, false) MOG2_CASE(PXV, true, true, true)
+  MOG2_PX(4) MOG2_PX(2) MOG2_PX(1)
+#undef MOG2_PX
+#undef MOG2_CASE
+  return BGS_OK;
+}
+
+// One frame for streams [first, first+count), device pointers, asynchronous on s.
+int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, uint8_t* d_fg, uint8_t* d_bg, uint64_t* d_bits, hipStream_t s,
+                  uint32_t* out_flags) {
+  if (out_flags) *out_flags = 0;
+  if (!e->n) return fail(BGS_ERR_INVALID, "geometry not set: call bgs_set_geometry or bgs_process first");
+  if (first < 0 || count <= 0 || first + count > e->S) return fail(BGS_ERR_INVALID, "stream range [%d,%d) outside 0..%d", first, first + count, e->S);
+  if (!d_frames) return fail(BGS_ERR_INVALID, "d_frames is NULL");
+  const int64_t t = e->seen[first];
+  for (int i = first; i < first + count; ++i)
+    if (e->seen[i] != t) return fail(BGS_ERR_INVALID, "streams %d and %d are not in lock-step (%lld vs %lld frames)", first, i, (long long)t, (long long)e->seen[i]);
+  HIP_TRY(hipSetDevice(e->device));
+  const bgs_params& p = e->p;
+  const int C = e->ch;
+  const size_t npix = e->n * count, off = e->n * first, fb = npix * C;
+  if (d_bits && npix % 64) return fail(BGS_ERR_UNSUPPORTED, "packed mask needs rows*cols %% 64 == 0");
+  uint32_t flags = 0;
+
+  bgs::FrameArgs a{};
+  a.cur = d_frames, a.fg = d_fg, a.bg = d_bg, a.fg_bits = d_bits, a.npix = npix;
+  a.thr = p.threshold, a.enable_thr = p.enable_threshold, a.enable_weight = p.enable_weight;
+
+  const bool whole = (first == 0 && count == e->S);
+  if (e->borrow && !whole && e->nring) return fail(BGS_ERR_INVALID, "borrowed frame history needs whole-batch calls");
+
+  switch (e->algo) {
+    case BGS_FRAME_DIFF:
+    case BGS_WMM:
+    case BGS_WMV: {
+      const int R = e->nring, warm = R - 1;
+      const uint8_t *cur = d_frames, *h1 = nullptr, *h2 = nullptr;
+      if (e->borrow) {
+        h1 = e->borrowed[0], h2 = e->borrowed[1];
+      } else {
+        uint8_t* slot = e->ring[t % R] + off * C;
+        if (cur != slot) HIP_TRY(hipMemcpyAsync(slot, cur, fb, hipMemcpyDeviceToDevice, s));  // keep a private copy as history
+        cur = slot;
+        if (t >= 1) h1 = e->ring[(t - 1) % R] + off * C;
+        if (t >= 2 && R == 3) h2 = e->ring[(t - 2) % R] + off * C;
+      }
+      if (t >= warm) {
+        a.cur = cur, a.p1 = h1, a.p2 = h2;
+        const int G = pick_group(a, C);
+        if (e->algo == BGS_FRAME_DIFF)
+          LAUNCH_FRAME_KERNEL(framediff_kernel, "framediff_kernel");
+        else if (e->algo == BGS_WMM)
+          LAUNCH_FRAME_KERNEL(wmm_kernel, "wmm_kernel");
+        else
+          LAUNCH_FRAME_KERNEL(wmv_kernel, "wmv_kernel");
+        flags = BGS_FG_VALID | (e->algo == BGS_WMM ? BGS_BG_VALID : 0u);
+      }
+      if (e->borrow) e->borrowed[1] = e->borrowed[0], e->borrowed[0] = d_frames;
+      break;
+    }
+    case BGS_STATIC_FRAME_DIFF:
+    case BGS_ABL: {
+      uint8_t* st = e->bgstate + off * C;
+      if (t == 0) HIP_TRY(hipMemcpyAsync(st, d_frames, fb, hipMemcpyDeviceToDevice, s));  // img_input.copyTo(img_background)
+      a.p1 = st;
+      if (e->algo == BGS_STATIC_FRAME_DIFF) {
+        a.bg = nullptr;
+        const int G = pick_group(a, C);
+        LAUNCH_FRAME_KERNEL(framediff_kernel, "framediff_kernel");
+        if (d_bg) HIP_TRY(hipMemcpyAsync(d_bg, st, fb, hipMemcpyDeviceToDevice, s));
+      } else {
+        a.state_out = st;
+        a.alpha = p.alpha, a.beta = 1 - p.alpha;
+        const int64_t cnt = e->counter[first];
+        a.update = ((p.limit > 0 && p.limit < cnt) || p.limit == -1) ? 1 : 0;
+        const int G = pick_group(a, C);
+        LAUNCH_FRAME_KERNEL(abl_kernel, "abl_kernel");
+        if (a.update && p.limit > 0 && p.limit < cnt)
+          for (int i = first; i < first + count; ++i) e->counter[i]++;
+      }
+      flags = BGS_FG_VALID | BGS_BG_VALID;
+      break;
+    }
+    case BGS_MOG2: {
+      const int K = bgs::kMog2K;
+      const size_t P = e->n * e->S;
+      double lr = p.alpha;
+      int64_t nframes = t;
+      if (nframes == 0 || lr >= 1) {  // needToInitialize: bgmodel = zeros, modesUsed = 0
+        for (int k = 0; k < K; ++k) {
+          HIP_TRY(hipMemsetAsync(e->w + k * P + off, 0, npix * sizeof(float), s));
+          HIP_TRY(hipMemsetAsync(e->var + k * P + off, 0, npix * sizeof(float), s));
+          for (int c = 0; c < 3; ++c) HIP_TRY(hipMemsetAsync(e->mu + (k * 3 + c) * P + off, 0, npix * sizeof(float), s));
+        }
+        HIP_TRY(hipMemsetAsync(e->nmodes + off, 0, npix, s));
+        nframes = 0;
+      }
+      ++nframes;
+      const int64_t n2 = 2 * nframes;
+      lr = (lr >= 0 && nframes > 1) ? lr : 1. / (double)std::min<int64_t>(n2, p.mog2_history);
+      bgs::Mog2Args m{};
+      m.frame = d_frames, m.fg = d_fg, m.bgimg = d_bg, m.fg_bits = d_bits;
+      m.w = e->w, m.var = e->var, m.mu = e->mu, m.nmodes = e->nmodes;
+      m.plane = P, m.state_off = off, m.npix = npix;
+      m.alphaT = (float)lr, m.alpha1 = 1.f - m.alphaT, m.prune = (float)(-lr * (double)p.mog2_ct);
+      m.Tb = p.mog2_var_threshold, m.TB = p.mog2_background_ratio, m.Tg = p.mog2_var_threshold_gen;
+      m.varInit = p.mog2_var_init, m.varMin = p.mog2_var_min, m.varMax = p.mog2_var_max, m.tau = p.mog2_tau;
+      m.thr = p.threshold, m.enable_thr = p.enable_threshold, m.shadow_val = p.mog2_shadow_value;
+      int rc = launch_mog2(e, m, s);
+      if (rc) return rc;
+      for (int i = first; i < first + count; ++i) e->seen[i] = nframes - 1;  // re-initialisation restarts the count
+      flags = BGS_FG_VALID | BGS_BG_VALID;
+      break;
+    }
+    default: return fail(BGS_ERR_UNSUPPORTED, "algorithm %d is not implemented in this build", (int)e->algo);
+  }
+  HIP_TRY(hipGetLastError());
+  for (int i = first; i < first + count; ++i) e->seen[i]++;
+  if (out_flags) *out_flags = flags;
+  return BGS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bgs_abi_version(void) { return BGS_ABI_VERSION; }
+
+const char* bgs_last_error(void) { return g_err.c_str(); }
+
+int bgs_default_params(bgs_algo algo, bgs_params* p) {
+  if (!p) return fail(BGS_ERR_INVALID, "params is NULL");
+  if ((int)algo < 0 || algo >= BGS_ALGO_COUNT) return fail(BGS_ERR_INVALID, "unknown algorithm %d", (int)algo);
+  std::memset(p, 0, sizeof(*p));
+  p->struct_size = (uint32_t)sizeof(*p);
+  p->enable_threshold = 1;
+  p->threshold = (algo == BGS_ASBL) ? 25 : 15;
+  p->enable_weight = 1;
+  p->alpha = 0.05;
+  p->limit = -1;
+  p->learning_frames = 90;
+  p->alpha_learn = 0.05;
+  p->alpha_detection = 0.05;
+  p->mog2_history = 500;
+  p->mog2_nmixtures = 5;
+  p->mog2_var_threshold = 16.f;
+  p->mog2_background_ratio = 0.9f;
+  p->mog2_var_threshold_gen = 9.f;
+  p->mog2_var_init = 15.f;
+  p->mog2_var_min = 4.f;
+  p->mog2_var_max = 75.f;
+  p->mog2_ct = 0.05f;
+  p->mog2_tau = 0.5f;
+  p->mog2_detect_shadows = 1;
+  p->mog2_shadow_value = 127;
+  p->mog1_history = 200;
+  p->mog1_nmixtures = 5;
+  p->mog1_background_ratio = 0.7;
+  p->mog1_var_threshold = 2.5 * 2.5;
+  p->mog1_noise_sigma = 30 * 0.5;
+  p->lbsp_rel_threshold = 0.333f;
+  p->lbsp_threshold_offset = 0;
+  p->subsense_min_color_dist_threshold = 30;
+  p->subsense_n_samples = 50;
+  p->subsense_n_required = 2;
+  p->subsense_samples_for_moving_avgs = 100;
+  p->sd_amp_factor = 1;
+  p->sd_min_var = 15;
+  p->sd_max_var = 255;
+  return BGS_OK;
+}
+
+int bgs_create(bgs_algo algo, const bgs_params* params, int hip_device, int n_streams, bgs_engine** out) {
+  if (!out) return fail(BGS_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if ((int)algo < 0 || algo >= BGS_ALGO_COUNT) return fail(BGS_ERR_INVALID, "unknown algorithm %d", (int)algo);
+  if (n_streams < 1) return fail(BGS_ERR_INVALID, "n_streams must be >= 1");
+  if (params && params->struct_size != sizeof(bgs_params)) return fail(BGS_ERR_INVALID, "bgs_params.struct_size %u != %zu (ABI mismatch)", params->struct_size, sizeof(bgs_params));
+  bgs_engine* e = new (std::nothrow) bgs_engine();
+  if (!e) return fail(BGS_ERR_NOMEM, "out of host memory");
+  e->algo = algo;
+  if (params)
+    e->p = *params;
+  else
+    bgs_default_params(algo, &e->p);
+  int rc = check_params(algo, e->p);
+  if (rc) {
+    delete e;
+    return rc;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+    delete e;
+    return fail(BGS_ERR_HIP, "no HIP device visible: libbgs_hip has no CPU path");
+  }
+  if (hip_device < 0 || hip_device >= ndev) {
+    delete e;
+    return fail(BGS_ERR_INVALID, "hip_device %d outside 0..%d", hip_device, ndev - 1);
+  }
+  e->device = hip_device;
+  e->S = n_streams;
+  e->seen.assign(n_streams, 0);
+  e->counter.assign(n_streams, 0);
+  if (const char* env = getenv("BGS_MOG2_PX")) e->mog2_px = atoi(env);
+  *out = e;
+  return BGS_OK;
+}
+
+int bgs_set_params(bgs_engine* e, const bgs_params* params) {
+  if (!e || !params) return fail(BGS_ERR_INVALID, "NULL argument");
+  if (params->struct_size != sizeof(bgs_params)) return fail(BGS_ERR_INVALID, "bgs_params.struct_size mismatch");
+  int rc = check_params(e->algo, *params);
+  if (rc) return rc;
+  e->p = *params;
+  return BGS_OK;
+}
+
+int bgs_set_geometry(bgs_engine* e, int rows, int cols, int channels) {
+  if (!e) return fail(BGS_ERR_INVALID, "engine is NULL");
+  if (e->n) {
+    if (rows == e->rows && cols == e->cols && channels == e->ch) return BGS_OK;
+    return fail(BGS_ERR_GEOMETRY, "engine is %dx%dx%d, asked for %dx%dx%d", e->rows, e->cols, e->ch, rows, cols, channels);
+  }
+  int rc = allocate(e, rows, cols, channels);
+  if (rc) {
+    free_all(e);
+    e->n = 0;
+  }
+  return rc;
+}
+
+// option 1: borrow the caller's frame buffers as history (device path of FD/WMM/WMV): the buffers passed to the
+// previous one (FD) or two (WMM/WMV) bgs_process_batch_device calls must stay valid and unchanged.
+int bgs_set_option(bgs_engine* e, int option, int64_t value) {
+  if (!e) return fail(BGS_ERR_INVALID, "engine is NULL");
+  switch (option) {
+    case 1: e->borrow = value != 0; return BGS_OK;
+    case 2: e->mog2_px = (int)value; return BGS_OK;
+    default: return fail(BGS_ERR_INVALID, "unknown option %d", option);
+  }
+}
+
+int bgs_process_range_device(bgs_engine* e, int first, int count, const void* d_frames, void* d_fg, void* d_bg, void* d_fg_bits, void* hip_stream,
+                             uint32_t* out_flags) {
+  if (!e) return fail(BGS_ERR_INVALID, "engine is NULL");
+  return process_range(e, first, count, (const uint8_t*)d_frames, (uint8_t*)d_fg, (uint8_t*)d_bg, (uint64_t*)d_fg_bits, (hipStream_t)hip_stream, out_flags);
+}
+
+int bgs_process_batch_device(bgs_engine* e, const void* d_frames, void* d_fg, void* d_bg, void* d_fg_bits, void* hip_stream, uint32_t* out_flags) {
+  if (!e) return fail(BGS_ERR_INVALID, "engine is NULL");
+  return process_range(e, 0, e->S, (const uint8_t*)d_frames, (uint8_t*)d_fg, (uint8_t*)d_bg, (uint64_t*)d_fg_bits, (hipStream_t)hip_stream, out_flags);
+}
+
+int bgs_process(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols, int channels, size_t in_step, uint8_t* fg, size_t fg_step, uint8_t* bg,
+                size_t bg_step, uint32_t* out_flags) {
+  if (out_flags) *out_flags = 0;
+  if (!e) return fail(BGS_ERR_INVALID, "engine is NULL");
+  if (stream < 0 || stream >= e->S) return fail(BGS_ERR_INVALID, "stream %d outside 0..%d", stream, e->S - 1);
+  if (!in || rows <= 0 || cols <= 0) return BGS_OK;  // if(img_input.empty()) return;
+  if (channels != 1 && channels != 3) return fail(BGS_ERR_UNSUPPORTED, "channels must be 1 or 3");
+  if (in_step < (size_t)cols * channels) return fail(BGS_ERR_INVALID, "in_step %zu < cols*channels", in_step);
+  int rc = bgs_set_geometry(e, rows, cols, channels);
+  if (rc) return rc;
+  rc = ensure_staging(e);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t rb = (size_t)cols * channels, fb = e->n * channels;
+  for (int y = 0; y < rows; ++y) std::memcpy(e->h_in + (size_t)y * rb, in + (size_t)y * in_step, rb);
+  // history-keeping algorithms receive the upload straight in their ring slot (zero-copy history)
+  uint8_t* dst = e->d_in;
+  if (e->nring) dst = e->ring[e->seen[stream] % e->nring] + (size_t)stream * fb;
+  HIP_TRY(hipMemcpyAsync(dst, e->h_in, fb, hipMemcpyHostToDevice, e->stream));
+  uint32_t flags = 0;
+  const bool saved_borrow = e->borrow;
+  e->borrow = false;
+  rc = process_range(e, stream, 1, dst, fg ? e->d_fg : nullptr, bg ? e->d_bg : nullptr, nullptr, e->stream, &flags);
+  e->borrow = saved_borrow;
+  if (rc) return rc;
+  const int bg_ch = channels;
+  if (fg && (flags & BGS_FG_VALID)) HIP_TRY(hipMemcpyAsync(e->h_fg, e->d_fg, e->n, hipMemcpyDeviceToHost, e->stream));
+  if (bg && (flags & BGS_BG_VALID)) HIP_TRY(hipMemcpyAsync(e->h_bg, e->d_bg, e->n * bg_ch, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (fg && (flags & BGS_FG_VALID))
+    for (int y = 0; y < rows; ++y) std::memcpy(fg + (size_t)y * fg_step, e->h_fg + (size_t)y * cols, (size_t)cols);
+  if (bg && (flags & BGS_BG_VALID))
+    for (int y = 0; y < rows; ++y) std::memcpy(bg + (size_t)y * bg_step, e->h_bg + (size_t)y * cols * bg_ch, (size_t)cols * bg_ch);
+  if (out_flags) *out_flags = flags;
+  return BGS_OK;
+}
+
+int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, size_t cap) {
+  if (!e || !plane || !dst) return fail(BGS_ERR_INVALID, "NULL argument");
+  if (!e->n) return fail(BGS_ERR_STATE, "no model yet");
+  if (stream < 0 || stream >= e->S) return fail(BGS_ERR_INVALID, "stream %d outside 0..%d", stream, e->S - 1);
+  if (hipSetDevice(e->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(BGS_ERR_HIP, "device sync failed");
+  const size_t n = e->n, P = n * e->S, off = n * stream;
+  const int C = e->ch;
+  auto copy_planes = [&](const float* base, int planes) -> int64_t {
+    if (cap < (size_t)planes * n * 4) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
+    for (int k = 0; k < planes; ++k)
+      if (hipMemcpy((float*)dst + (size_t)k * n, base + (size_t)k * P + off, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+    return (int64_t)planes * n * 4;
+  };
+  auto copy_bytes = [&](const uint8_t* src, size_t nb) -> int64_t {
+    if (cap < nb) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
+    if (hipMemcpy(dst, src, nb, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+    return (int64_t)nb;
+  };
+  if (e->algo == BGS_MOG2) {
+    if (!strcmp(plane, "w")) return copy_planes(e->w, bgs::kMog2K);
+    if (!strcmp(plane, "var")) return copy_planes(e->var, bgs::kMog2K);
+    if (!strcmp(plane, "mu")) return copy_planes(e->mu, bgs::kMog2K * 3);
+    if (!strcmp(plane, "nmodes")) return copy_bytes(e->nmodes + off, n);
+  }
+  if (!strcmp(plane, "bg") && e->bgstate) return copy_bytes(e->bgstate + off * e->state_ch, n * e->state_ch);
+  const int64_t t = e->seen[stream];
+  if (!strcmp(plane, "prev1") && e->nring && t >= 1) return copy_bytes(e->ring[(t - 1) % e->nring] + off * C, n * C);
+  if (!strcmp(plane, "prev2") && e->nring == 3 && t >= 2) return copy_bytes(e->ring[(t - 2) % e->nring] + off * C, n * C);
+  return fail(BGS_ERR_STATE, "unknown state plane '%s' for algorithm %d", plane, (int)e->algo);
+}
+
+int64_t bgs_frames_seen(const bgs_engine* e, int stream) {
+  if (!e || stream < 0 || stream >= e->S) return BGS_ERR_INVALID;
+  return e->seen[stream];
+}
+
+int bgs_enable_kernel_timing(bgs_engine* e, int on) {
+  if (!e) return fail(BGS_ERR_INVALID, "engine is NULL");
+  e->timing = on != 0;
+  for (auto& ev : e->events) (void)hipEventDestroy(ev.first), (void)hipEventDestroy(ev.second);
+  e->events.clear();
+  return BGS_OK;
+}
+
+int bgs_kernel_timing(bgs_engine* e, double* avg_ms, int64_t* launches, const char** kernel_name) {
+  if (!e) return fail(BGS_ERR_INVALID, "engine is NULL");
+  HIP_TRY(hipSetDevice(e->device));
+  double total = 0;
+  for (auto& ev : e->events) {
+    HIP_TRY(hipEventSynchronize(ev.second));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+    total += ms;
+  }
+  if (avg_ms) *avg_ms = e->events.empty() ? 0.0 : total / (double)e->events.size();
+  if (launches) *launches = (int64_t)e->events.size();
+  if (kernel_name) *kernel_name = e->kernel_name;
+  return BGS_OK;
+}
+
+void bgs_destroy(bgs_engine* e) {
+  if (!e) return;
+  if (e->n || e->stream) {
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+  }
+  free_all(e);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int bgs_lbsp_describe_device(int, const void*, int, int, int, const uint8_t*, void*, void*) { return fail(BGS_ERR_UNSUPPORTED, "not implemented in this build"); }
+int bgs_mask_morph_device(int, const void*, void*, int, int, int, int, int, void*) { return fail(BGS_ERR_UNSUPPORTED, "not implemented in this build"); }
+
+}  // extern "C"

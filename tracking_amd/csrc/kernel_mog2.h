@@ -1,0 +1,284 @@
+// kernel_mog2.h — K4: MixtureOfGaussianV2BGS (cv::BackgroundSubtractorMOG2 update + classify + wrapper threshold,
+// optionally the getBackgroundImage pass) as ONE pointwise CDNA4 kernel.
+//
+// Replaces  MixtureOfGaussianV2BGS::process  package_bgs/MixtureOfGaussianV2BGS.cpp:56-62
+//           (mog(img, fg, alpha); mog.getBackgroundImage(bg); cv::threshold(fg, 15))
+// Algorithm: Zivkovic adaptive GMM as implemented by OpenCV 2.4 bgfg_gaussmix2.cpp MOG2Invoker.
+//
+// Layout: SoA planes in HBM, P = streams*pixels floats per plane:
+//   w[k][P], var[k][P], mu[k][c][P] (k < K = 5, c < 3), nmodes u8[P].  Modes of a pixel are kept sorted by weight
+//   (descending) exactly like the reference's per-pixel GMM array, so plane k holds every pixel's k-th heaviest mode.
+// Mapping: one lane owns PX consecutive pixels -> every plane access is one PX*4-byte vector load/store per lane
+//   (PX = 4: global_load_dwordx4, 1 KiB per wave instruction), the frame is PX*3 bytes per lane, the mask PX bytes.
+//   The whole per-pixel model (25 floats) lives in VGPRs; K is a compile-time constant so the insertion sort is a
+//   fully unrolled network of predicated swaps.  No LDS: the op is pointwise and HBM-bound
+//   (206 B/pixel/frame algorithmic traffic vs ~400 VALU ops).
+#pragma once
+#include "bgs_device.h"
+
+namespace bgs {
+
+constexpr int kMog2K = 5;
+
+struct Mog2Args {
+  const uint8_t* frame;  // [P][3] interleaved BGR
+  uint8_t* fg;           // [P] or null
+  uint8_t* bgimg;        // [P][3] or null
+  uint64_t* fg_bits;     // [P/64] or null
+  float* w;              // [K][plane]
+  float* var;            // [K][plane]
+  float* mu;             // [K][3][plane]
+  uint8_t* nmodes;       // [plane]
+  size_t plane;          // floats per plane (= streams * pixels of the engine)
+  size_t state_off;      // first pixel of this launch inside the planes
+  size_t npix;           // pixels in this launch
+  float alphaT, alpha1, prune;
+  float Tb, TB, Tg, varInit, varMin, varMax, tau;
+  int thr, enable_thr, shadow_val;
+};
+
+struct Mog2Px {
+  float w[kMog2K], var[kMog2K], m0[kMog2K], m1[kMog2K], m2[kMog2K];
+};
+
+__device__ __forceinline__ void mog2_swap(Mog2Px& s, int i, int j) {
+  float t;
+  t = s.w[i], s.w[i] = s.w[j], s.w[j] = t;
+  t = s.var[i], s.var[i] = s.var[j], s.var[j] = t;
+  t = s.m0[i], s.m0[i] = s.m0[j], s.m0[j] = t;
+  t = s.m1[i], s.m1[i] = s.m1[j], s.m1[j] = t;
+  t = s.m2[i], s.m2[i] = s.m2[j], s.m2[j] = t;
+}
+
+// detectShadowGMM of bgfg_gaussmix2.cpp, predicated form of its early returns
+__device__ __forceinline__ bool mog2_shadow(const Mog2Px& s, int nmodes, float x0, float x1, float x2, const Mog2Args& a) {
+  bool done = false, result = false;
+  float tWeight = 0.f;
+#pragma unroll
+  for (int mode = 0; mode < kMog2K; ++mode) {
+    if (mode < nmodes && !done) {
+      float num = 0.0f, den = 0.0f;
+      num += x0 * s.m0[mode];
+      den += s.m0[mode] * s.m0[mode];
+      num += x1 * s.m1[mode];
+      den += s.m1[mode] * s.m1[mode];
+      num += x2 * s.m2[mode];
+      den += s.m2[mode] * s.m2[mode];
+      if (den == 0) {
+        done = true;
+      } else {
+        if (num <= den && num >= a.tau * den) {
+          const float q = __fdiv_rn(num, den);
+          float d2a = 0.0f, dD;
+          dD = q * s.m0[mode] - x0, d2a += dD * dD;
+          dD = q * s.m1[mode] - x1, d2a += dD * dD;
+          dD = q * s.m2[mode] - x2, d2a += dD * dD;
+          if (d2a < a.Tb * s.var[mode] * q * q) result = true, done = true;
+        }
+        if (!done) {
+          tWeight += s.w[mode];
+          if (tWeight > a.TB) done = true;
+        }
+      }
+    }
+  }
+  return result;
+}
+
+// One pixel of MOG2Invoker::operator() — same statement order as the reference so every float rounds identically.
+// Returns the raw mask value (0 background, shadow_val, 255 foreground) before the wrapper's threshold.
+template <bool SHADOW>
+__device__ __forceinline__ int mog2_pixel(Mog2Px& s, int& nmodes_io, float x0, float x1, float x2, const Mog2Args& a) {
+  bool background = false, fitsPDF = false;
+  int nmodes = nmodes_io;
+  const int nNewModes = nmodes;
+  float totalWeight = 0.f;
+#pragma unroll
+  for (int mode = 0; mode < kMog2K; ++mode) {
+    if (mode < nmodes) {  // nmodes shrinks inside the loop when a mode is pruned (reference quirk)
+      float weight = a.alpha1 * s.w[mode] + a.prune;
+      bool matched = false;
+      if (!fitsPDF) {
+        const float var = s.var[mode];
+        const float d0 = s.m0[mode] - x0, d1 = s.m1[mode] - x1, d2 = s.m2[mode] - x2;
+        const float dist2 = d0 * d0 + d1 * d1 + d2 * d2;
+        if (totalWeight < a.TB && dist2 < a.Tb * var) background = true;
+        if (dist2 < a.Tg * var) {
+          fitsPDF = true;
+          matched = true;
+          weight += a.alphaT;
+          const float k = __fdiv_rn(a.alphaT, weight);
+          s.m0[mode] -= k * d0;
+          s.m1[mode] -= k * d1;
+          s.m2[mode] -= k * d2;
+          float varnew = var + k * (dist2 - var);
+          varnew = varnew > a.varMin ? varnew : a.varMin;
+          varnew = varnew < a.varMax ? varnew : a.varMax;
+          s.var[mode] = varnew;
+        }
+      }
+      const bool pruned = weight < -a.prune;
+      if (pruned) nmodes--;
+      // The reference stores the weight at gmm[mode - swap_count] after the bubble; storing it first and letting it
+      // travel with the swaps is the same thing.  The bubble compares the UNPRUNED weight, as the reference does.
+      s.w[mode] = pruned ? 0.f : weight;
+      if (matched) {
+        bool moving = true;
+#pragma unroll
+        for (int i = mode; i > 0; --i) {
+          moving = moving && !(weight < s.w[i - 1]);
+          if (moving) mog2_swap(s, i, i - 1);
+        }
+      }
+      totalWeight += pruned ? 0.f : weight;
+    }
+  }
+  totalWeight = __fdiv_rn(1.f, totalWeight);
+#pragma unroll
+  for (int mode = 0; mode < kMog2K; ++mode)
+    if (mode < nmodes) s.w[mode] *= totalWeight;
+  nmodes = nNewModes;  // sic: the pruned count is discarded
+  if (!fitsPDF) {
+    const int mode = (nmodes == kMog2K) ? kMog2K - 1 : nmodes++;
+#pragma unroll
+    for (int k = 0; k < kMog2K; ++k) {
+      if (k == mode) {
+        s.w[k] = (nmodes == 1) ? 1.f : a.alphaT;
+        s.m0[k] = x0, s.m1[k] = x1, s.m2[k] = x2;
+        s.var[k] = a.varInit;
+      } else if (nmodes != 1 && k < nmodes - 1) {
+        s.w[k] *= a.alpha1;
+      }
+    }
+    bool moving = true;
+#pragma unroll
+    for (int i = kMog2K - 1; i > 0; --i) {
+      if (i <= nmodes - 1) {
+        moving = moving && !(a.alphaT < s.w[i - 1]);
+        if (moving) mog2_swap(s, i, i - 1);
+      }
+    }
+  }
+  nmodes_io = nmodes;
+  if (background) return 0;
+  if constexpr (SHADOW) {
+    if (mog2_shadow(s, nmodes, x0, x1, x2, a)) return a.shadow_val;
+  }
+  return 255;
+}
+
+// cv::BackgroundSubtractorMOG2::getBackgroundImage, one pixel, from the registers that already hold the model
+__device__ __forceinline__ void mog2_background(const Mog2Px& s, int nmodes, float TB, int& b0, int& b1, int& b2) {
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f, totalWeight = 0.f;
+  bool stop = false;
+#pragma unroll
+  for (int g = 0; g < kMog2K; ++g) {
+    if (g < nmodes && !stop) {
+      const float w = s.w[g];
+      v0 += w * s.m0[g];
+      v1 += w * s.m1[g];
+      v2 += w * s.m2[g];
+      totalWeight += w;
+      if (totalWeight > TB) stop = true;
+    }
+  }
+  const float inv = __fdiv_rn(1.f, totalWeight);
+  b0 = sat_u8(v0 * inv), b1 = sat_u8(v1 * inv), b2 = sat_u8(v2 * inv);
+}
+
+// grid: ceil(npix / PX / kBlock) blocks of kBlock lanes; npix % PX == 0 (the host picks PX = 1 otherwise).
+template <int PX, bool SHADOW, bool BGIMG, bool PACKED>
+__global__ __launch_bounds__(kBlock) void mog2_update_kernel(const Mog2Args a) {
+  const size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const size_t p0 = g * PX;  // first pixel of this lane, launch-relative
+  const bool active = p0 < a.npix;
+  uint32_t bits = 0;
+  if (active) {
+    const size_t sp = a.state_off + p0;  // index inside the planes
+    constexpr int FB = (PX * 3 + 3) / 4 * 4;  // frame bytes per lane, rounded up to dwords
+    Bytes<FB> pix;
+    if constexpr (PX == 1) {
+      const uint8_t* f = a.frame + p0 * 3;
+      pix.w[0] = (uint32_t)f[0] | ((uint32_t)f[1] << 8) | ((uint32_t)f[2] << 16);
+    } else if constexpr (PX == 2) {
+      const uint16_t* f = reinterpret_cast<const uint16_t*>(a.frame + p0 * 3);
+      pix.w[0] = (uint32_t)f[0] | ((uint32_t)f[1] << 16);
+      pix.w[1] = f[2];
+    } else {
+      pix = load_bytes<PX * 3>(a.frame + p0 * 3);
+    }
+    float w[kMog2K][PX], var[kMog2K][PX], m0[kMog2K][PX], m1[kMog2K][PX], m2[kMog2K][PX];
+#pragma unroll
+    for (int k = 0; k < kMog2K; ++k) {
+      load_f<PX>(a.w + k * a.plane + sp, w[k]);
+      load_f<PX>(a.var + k * a.plane + sp, var[k]);
+      load_f<PX>(a.mu + (k * 3 + 0) * a.plane + sp, m0[k]);
+      load_f<PX>(a.mu + (k * 3 + 1) * a.plane + sp, m1[k]);
+      load_f<PX>(a.mu + (k * 3 + 2) * a.plane + sp, m2[k]);
+    }
+    uint32_t nmw;
+    if constexpr (PX == 4)
+      nmw = *reinterpret_cast<const uint32_t*>(a.nmodes + sp);
+    else if constexpr (PX == 2)
+      nmw = *reinterpret_cast<const uint16_t*>(a.nmodes + sp);
+    else
+      nmw = a.nmodes[sp];
+
+    uint32_t mask_word = 0, nm_out = 0;
+    Bytes<FB> bgout;
+#pragma unroll
+    for (int i = 0; i < FB / 4; ++i) bgout.w[i] = 0;
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+      Mog2Px s;
+#pragma unroll
+      for (int k = 0; k < kMog2K; ++k) s.w[k] = w[k][j], s.var[k] = var[k][j], s.m0[k] = m0[k][j], s.m1[k] = m1[k][j], s.m2[k] = m2[k][j];
+      int nm = (int)((nmw >> (8 * j)) & 0xffu);
+      const float x0 = (float)pix.get(3 * j), x1 = (float)pix.get(3 * j + 1), x2 = (float)pix.get(3 * j + 2);
+      const int raw = mog2_pixel<SHADOW>(s, nm, x0, x1, x2, a);
+      const int m = thr_bin(raw, a.thr, a.enable_thr);
+      mask_word |= (uint32_t)m << (8 * j);
+      bits |= (uint32_t)(m != 0) << j;
+      nm_out |= (uint32_t)nm << (8 * j);
+      if constexpr (BGIMG) {
+        int b0, b1, b2;
+        mog2_background(s, nm, a.TB, b0, b1, b2);
+        bgout.set(3 * j, b0), bgout.set(3 * j + 1, b1), bgout.set(3 * j + 2, b2);
+      }
+#pragma unroll
+      for (int k = 0; k < kMog2K; ++k) w[k][j] = s.w[k], var[k][j] = s.var[k], m0[k][j] = s.m0[k], m1[k][j] = s.m1[k], m2[k][j] = s.m2[k];
+    }
+#pragma unroll
+    for (int k = 0; k < kMog2K; ++k) {
+      store_f<PX>(a.w + k * a.plane + sp, w[k]);
+      store_f<PX>(a.var + k * a.plane + sp, var[k]);
+      store_f<PX>(a.mu + (k * 3 + 0) * a.plane + sp, m0[k]);
+      store_f<PX>(a.mu + (k * 3 + 1) * a.plane + sp, m1[k]);
+      store_f<PX>(a.mu + (k * 3 + 2) * a.plane + sp, m2[k]);
+    }
+    if constexpr (PX == 4) {
+      *reinterpret_cast<uint32_t*>(a.nmodes + sp) = nm_out;
+      if (a.fg) *reinterpret_cast<uint32_t*>(a.fg + p0) = mask_word;
+    } else if constexpr (PX == 2) {
+      *reinterpret_cast<uint16_t*>(a.nmodes + sp) = (uint16_t)nm_out;
+      if (a.fg) *reinterpret_cast<uint16_t*>(a.fg + p0) = (uint16_t)mask_word;
+    } else {
+      a.nmodes[sp] = (uint8_t)nm_out;
+      if (a.fg) a.fg[p0] = (uint8_t)mask_word;
+    }
+    if constexpr (BGIMG) {
+      if constexpr (PX == 4) {
+        store_bytes<12>(a.bgimg + p0 * 3, bgout);
+      } else {
+#pragma unroll
+        for (int i = 0; i < PX * 3; ++i) a.bgimg[p0 * 3 + i] = (uint8_t)bgout.get(i);
+      }
+    }
+  }
+  if constexpr (PACKED) {
+    // every lane of the wave takes part (inactive tail lanes contribute 0); npix % 64 == 0 is checked by the host
+    store_packed_mask<PX>(a.fg_bits, p0, bits, active);
+  }
+}
+
+}  // namespace bgs

@@ -1,0 +1,184 @@
+// kernel_pointwise.h — K1/K2/K3: the byte-in / byte-out IBGS classes, each ONE fused kernel
+// (the reference runs 3-15 full-frame OpenCV passes with float temporaries for the same result).
+//
+//   K1 framediff_kernel  FrameDifferenceBGS::process        package_bgs/FrameDifferenceBGS.cpp:45-51
+//                        StaticFrameDifferenceBGS::process  package_bgs/StaticFrameDifferenceBGS.cpp:42-48
+//   K2 wmm_kernel        WeightedMovingMeanBGS::process     package_bgs/WeightedMovingMeanBGS.cpp:52-84
+//      wmv_kernel        WeightedMovingVarianceBGS::process package_bgs/WeightedMovingVarianceBGS.cpp:53-106, 126-137
+//   K3 abl_kernel        AdaptiveBackgroundLearning::process package_bgs/AdaptiveBackgroundLearning.cpp:43-71
+//
+// Mapping: one lane owns G consecutive pixels (G*C bytes, whole dwords: G = 16 -> C x 16-byte loads, G = 4 -> 12/4 bytes,
+// G = 1 -> byte loads for ragged sizes), mask store G bytes.  HBM-bound byte streams, no reuse, no LDS.
+// The OpenCV primitive semantics (P1..P8) are listed in DESIGN.md §5.
+#pragma once
+#include "bgs_device.h"
+
+namespace bgs {
+
+struct FrameArgs {
+  const uint8_t* cur;   // [npix][C]
+  const uint8_t* p1;    // previous frame / static background / ABL state (read)
+  const uint8_t* p2;    // frame before that
+  uint8_t* state_out;   // ABL: updated background state (may alias p1)
+  uint8_t* fg;          // [npix] or null
+  uint8_t* bg;          // [npix][C] or null
+  uint64_t* fg_bits;    // [npix/64] or null
+  size_t npix;
+  int thr, enable_thr, enable_weight, update;
+  double alpha, beta;   // ABL: alpha, 1-alpha
+};
+
+template <int G, int C>
+struct PxGroup {
+  static constexpr int NB = (G * C + 3) / 4 * 4;
+  Bytes<NB> b;
+  __device__ __forceinline__ void load(const uint8_t* p) {
+    if constexpr ((G * C) % 4 == 0) {
+      b = load_bytes<NB>(p);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NB / 4; ++i) b.w[i] = 0;
+#pragma unroll
+      for (int i = 0; i < G * C; ++i) b.set(i, p[i]);
+    }
+  }
+  __device__ __forceinline__ void store(uint8_t* p) const {
+    if constexpr ((G * C) % 4 == 0) {
+      store_bytes<NB>(p, b);
+    } else {
+#pragma unroll
+      for (int i = 0; i < G * C; ++i) p[i] = (uint8_t)b.get(i);
+    }
+  }
+};
+
+// gray (3ch) + threshold of a per-channel u8 difference image, G pixels; returns the mask bytes and the bit nibble
+template <int G, int C>
+__device__ __forceinline__ void gray_thr_store(const PxGroup<G, C>& d, const FrameArgs& a, size_t p0, bool active, bool packed) {
+  PxGroup<G, 1> m;
+#pragma unroll
+  for (int i = 0; i < PxGroup<G, 1>::NB / 4; ++i) m.b.w[i] = 0;
+  uint32_t bits = 0;
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    const int g = (C == 3) ? gray_bgr(d.b.get(3 * j), d.b.get(3 * j + 1), d.b.get(3 * j + 2)) : d.b.get(j);
+    const int v = thr_bin(g, a.thr, a.enable_thr);
+    m.b.set(j, v);
+    bits |= (uint32_t)(v != 0) << j;
+  }
+  if (active && a.fg) m.store(a.fg + p0);
+  if (packed) {
+    if constexpr (64 % G == 0) store_packed_mask<G>(a.fg_bits, p0, active ? bits : 0u, active);
+  }
+}
+
+template <int G, int C>
+__global__ __launch_bounds__(kBlock) void framediff_kernel(const FrameArgs a) {
+  const size_t p0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * G;
+  const bool active = p0 < a.npix;
+  PxGroup<G, C> d;
+  if (active) {
+    PxGroup<G, C> x, y;
+    x.load(a.cur + p0 * C);
+    y.load(a.p1 + p0 * C);
+#pragma unroll
+    for (int i = 0; i < G * C; ++i) d.b.set(i, abs(x.b.get(i) - y.b.get(i)));  // cv::absdiff 8U
+  }
+  gray_thr_store<G, C>(d, a, p0, active, a.fg_bits != nullptr);
+}
+
+// the f32 image the reference builds with convertTo(CV_32F, 1./255.)
+__device__ __forceinline__ float to_unit(int v) { return (float)v * (float)(1. / 255.); }
+
+// weighted mean of three frames as the reference's MatExpr evaluates it:
+//   weighted  : t = addWeighted(I,w0,P1,w1) ; mean = P2*(float)w2 + t   (scaleAdd, float)
+template <bool WMM_UNWEIGHTED>
+__device__ __forceinline__ float mean3(float i0, float i1, float i2, double w0, double w1, double w2) {
+  if constexpr (WMM_UNWEIGHTED) {
+    const float t = i0 + i1;  // WeightedMovingMeanBGS.cpp:66: (A + B + C) / 3.0
+    return add_weighted(t, 1. / 3.0, i2, 1. / 3.0);
+  } else {
+    const float t = add_weighted(i0, w0, i1, w1);
+    return i2 * (float)w2 + t;
+  }
+}
+
+template <int G, int C>
+__global__ __launch_bounds__(kBlock) void wmm_kernel(const FrameArgs a) {
+  const size_t p0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * G;
+  const bool active = p0 < a.npix;
+  PxGroup<G, C> d;
+  if (active) {
+    PxGroup<G, C> x, y, z, bgq;
+    x.load(a.cur + p0 * C);
+    y.load(a.p1 + p0 * C);
+    z.load(a.p2 + p0 * C);
+#pragma unroll
+    for (int i = 0; i < PxGroup<G, C>::NB / 4; ++i) bgq.b.w[i] = 0;
+#pragma unroll
+    for (int i = 0; i < G * C; ++i) {
+      const int xi = x.b.get(i);
+      const float i0 = to_unit(xi), i1 = to_unit(y.b.get(i)), i2 = to_unit(z.b.get(i));
+      const float bgf = a.enable_weight ? mean3<false>(i0, i1, i2, 0.5, 0.3, 0.2) : mean3<true>(i0, i1, i2, 0, 0, 0);
+      const int b8 = sat_u8(bgf * 255.f);
+      bgq.b.set(i, b8);
+      d.b.set(i, abs(xi - b8));
+    }
+    if (a.bg) bgq.store(a.bg + p0 * C);
+  }
+  gray_thr_store<G, C>(d, a, p0, active, a.fg_bits != nullptr);
+}
+
+// WeightedMovingVarianceBGS.cpp:126-137: weight * (|x - mean|)^2, every step rounded to float
+__device__ __forceinline__ float wvar(float x, float mean, double w) {
+  const float dd = fabsf(x - mean);
+  const float p = dd * dd;
+  return p * (float)w;
+}
+
+template <int G, int C>
+__global__ __launch_bounds__(kBlock) void wmv_kernel(const FrameArgs a) {
+  const size_t p0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * G;
+  const bool active = p0 < a.npix;
+  PxGroup<G, C> d;
+  if (active) {
+    PxGroup<G, C> x, y, z;
+    x.load(a.cur + p0 * C);
+    y.load(a.p1 + p0 * C);
+    z.load(a.p2 + p0 * C);
+    const double w0 = a.enable_weight ? 0.5 : 0.3, w1 = 0.3, w2 = a.enable_weight ? 0.2 : 0.3;  // :68-70 (unweighted = 0.3 x3, sic)
+#pragma unroll
+    for (int i = 0; i < G * C; ++i) {
+      const float i0 = to_unit(x.b.get(i)), i1 = to_unit(y.b.get(i)), i2 = to_unit(z.b.get(i));
+      const float m = mean3<false>(i0, i1, i2, w0, w1, w2);
+      const float v = (wvar(i0, m, w0) + wvar(i1, m, w1)) + wvar(i2, m, w2);  // :83
+      const float sd = __fsqrt_rn(v);                                        // :95
+      d.b.set(i, sat_u8(sd * 255.f));                                         // :99
+    }
+  }
+  gray_thr_store<G, C>(d, a, p0, active, a.fg_bits != nullptr);
+}
+
+template <int G, int C>
+__global__ __launch_bounds__(kBlock) void abl_kernel(const FrameArgs a) {
+  const size_t p0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * G;
+  const bool active = p0 < a.npix;
+  PxGroup<G, C> d;
+  if (active) {
+    PxGroup<G, C> x, bgq;
+    x.load(a.cur + p0 * C);
+    bgq.load(a.p1 + p0 * C);
+#pragma unroll
+    for (int i = 0; i < G * C; ++i) {
+      const float i_f = to_unit(x.b.get(i)), b_f = to_unit(bgq.b.get(i));
+      const float df = fabsf(i_f - b_f);                                                  // :50
+      if (a.update) bgq.b.set(i, sat_u8(add_weighted(i_f, a.alpha, b_f, a.beta) * 255.f));  // :54-58
+      d.b.set(i, sat_u8(df * 255.f));                                                      // :64-65
+    }
+    if (a.update) bgq.store(a.state_out + p0 * C);
+    if (a.bg) bgq.store(a.bg + p0 * C);
+  }
+  gray_thr_store<G, C>(d, a, p0, active, a.fg_bits != nullptr);
+}
+
+}  // namespace bgs

@@ -1,0 +1,115 @@
+"""Engine — thin Python handle on a bgs_engine (include/bgs_hip.h), used by tests and bench.py.
+
+Two call shapes, mirroring the two C entry points:
+  process(frame)            host numpy frame in, (mask, background) out   == IBGS::process (package_bgs/IBGS.h:24)
+  process_batch_device(...) torch CUDA tensors, asynchronous, all streams == the roofline path
+numpy/torch only carry memory here; all arithmetic happens inside libbgs_hip.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class Engine:
+    def __init__(self, algo, params=None, device=0, n_streams=1):
+        self._h = C.c_void_p()
+        self.algo = algo
+        self.n_streams = n_streams
+        self.params = params if params is not None else capi.default_params(algo)
+        capi.check(capi.lib().bgs_create(algo, C.byref(self.params), device, n_streams, C.byref(self._h)))
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            capi.lib().bgs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- configuration ------------------------------------------------------
+    def set_params(self, params):
+        capi.check(capi.lib().bgs_set_params(self._h, C.byref(params)))
+        self.params = params
+
+    def set_option(self, option, value):
+        capi.check(capi.lib().bgs_set_option(self._h, option, int(value)))
+
+    def set_geometry(self, rows, cols, channels):
+        capi.check(capi.lib().bgs_set_geometry(self._h, rows, cols, channels))
+
+    # -- host path (IBGS::process) -------------------------------------------
+    def process(self, frame, stream=0, want_bg=True):
+        """frame: HxW or HxWxC uint8 (any row stride).  Returns (mask or None, background or None):
+        None where the reference leaves the output untouched (warm-up frames, classes that write no background)."""
+        if frame is None or frame.size == 0:
+            flags = C.c_uint32(0)
+            capi.check(capi.lib().bgs_process(self._h, stream, None, 0, 0, 3, 0, None, 0, None, 0, C.byref(flags)))
+            return None, None
+        assert frame.dtype == np.uint8
+        rows, cols = frame.shape[:2]
+        ch = 1 if frame.ndim == 2 else frame.shape[2]
+        if frame.strides[-1] != 1 or (frame.ndim == 3 and frame.strides[1] != ch):
+            frame = np.ascontiguousarray(frame)
+        step = frame.strides[0]
+        fg = np.empty((rows, cols), np.uint8)
+        bg_ch = 1 if self.algo == capi.ASBL else ch
+        bg = np.empty((rows, cols, bg_ch), np.uint8) if want_bg else None
+        flags = C.c_uint32(0)
+        capi.check(capi.lib().bgs_process(
+            self._h, stream, frame.ctypes.data_as(C.c_void_p), rows, cols, ch, step,
+            fg.ctypes.data_as(C.c_void_p), cols,
+            bg.ctypes.data_as(C.c_void_p) if bg is not None else None, cols * bg_ch, C.byref(flags)))
+        f = flags.value
+        if bg is not None and bg_ch == 1:
+            bg = bg[:, :, 0]
+        return (fg if f & capi.FG_VALID else None), (bg if (bg is not None and f & capi.BG_VALID) else None)
+
+    # -- device path -----------------------------------------------------------
+    @staticmethod
+    def _ptr(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else None
+
+    def process_batch_device(self, frames, fg=None, bg=None, fg_bits=None, hip_stream=None, first=None, count=None):
+        """frames/fg/bg/fg_bits: torch CUDA tensors laid out as bgs_process_batch_device documents.
+        Asynchronous on hip_stream (default: torch's current stream).  Returns the out_flags."""
+        import torch
+        if hip_stream is None:
+            hip_stream = torch.cuda.current_stream().cuda_stream
+        flags = C.c_uint32(0)
+        l = capi.lib()
+        if first is None:
+            capi.check(l.bgs_process_batch_device(self._h, self._ptr(frames), self._ptr(fg), self._ptr(bg), self._ptr(fg_bits), C.c_void_p(hip_stream), C.byref(flags)))
+        else:
+            capi.check(l.bgs_process_range_device(self._h, first, count, self._ptr(frames), self._ptr(fg), self._ptr(bg), self._ptr(fg_bits), C.c_void_p(hip_stream), C.byref(flags)))
+        return flags.value
+
+    # -- introspection -----------------------------------------------------------
+    def get_state(self, plane, shape, dtype, stream=0):
+        out = np.empty(shape, dtype)
+        n = capi.lib().bgs_get_state(self._h, stream, plane.encode(), out.ctypes.data_as(C.c_void_p), out.nbytes)
+        capi.check(n)
+        assert n == out.nbytes, (n, out.nbytes)
+        return out
+
+    def frames_seen(self, stream=0):
+        return capi.lib().bgs_frames_seen(self._h, stream)
+
+    def enable_kernel_timing(self, on=True):
+        capi.check(capi.lib().bgs_enable_kernel_timing(self._h, 1 if on else 0))
+
+    def kernel_timing(self):
+        ms, n, name = C.c_double(0), C.c_int64(0), C.c_char_p()
+        capi.check(capi.lib().bgs_kernel_timing(self._h, C.byref(ms), C.byref(n), C.byref(name)))
+        return ms.value, n.value, (name.value or b"").decode()
