@@ -37,12 +37,26 @@ def make_pool(kind, streams, period, device, seed0):
     return pool
 
 
+def host_cores():
+    """Threads this job may really use: the cgroup CPU quota when there is one, else the affinity mask capped at the
+    GPU box's per-GPU share of 16 (an OpenMP team larger than the quota only thrashes)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    env = os.environ.get("BGS_BENCH_THREADS")
+    return int(env) if env else min(n, 16)
+
+
 def cpu_baseline(pool, kind, budget_s=16.0):
     """The oracle (CPU restatement, kind='port') timed on this box's host cores on a bounded sample of the same
     workload: stream 0's frames, model warmed for 2 periods, then as many 1080p frames as fit in ~budget_s."""
     from oracle import pyoracle
     from tracking_amd import capi
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     frames = pool[:, 0].cpu().numpy()
     period = frames.shape[0]
     res = {}
@@ -81,6 +95,7 @@ def main():
     ap.add_argument("--input", choices=["sat", "surv"], default="sat")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-bg", action="store_true", help="also produce the background image every frame (+3 B/px)")
+    ap.add_argument("--px", type=int, default=0, help="MOG2 pixels per lane (tuning; 0 = auto = 4)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,6 +122,8 @@ def main():
 
     eng = Engine(capi.MOG2, device=local, n_streams=S)
     eng.set_geometry(ROWS, COLS, CH)
+    if args.px:
+        eng.set_option(capi.OPT_MOG2_PIXELS_PER_LANE, args.px)
     fg = torch.empty((S, ROWS, COLS), dtype=torch.uint8, device=dev)
     bg = torch.empty((S, ROWS, COLS, CH), dtype=torch.uint8, device=dev) if args.with_bg else None
     words = ROWS * COLS // 64

@@ -146,9 +146,15 @@ int bgs_set_params(bgs_engine* e, const bgs_params* params);
  *                          1 = use the caller's previous d_frames buffers as history instead of copying each frame
  *                          into the engine's ring; the buffers handed to the previous one (FD) or two (WMM/WMV)
  *                          whole-batch calls must then stay valid and unchanged.  Default 0 (private copy).
- *   BGS_OPT_MOG2_PIXELS_PER_LANE  1, 2 or 4 (tuning knob; 0 = widest the alignment allows). */
+ *   BGS_OPT_MOG2_PIXELS_PER_LANE  1, 2 or 4 (tuning knob; 0 = widest the alignment allows).
+ *   BGS_OPT_MOG2_TILED     1 (default) = tiled AoSoA model, 0 = planar SoA (A/B measurements); before the geometry is set.
+ *   BGS_OPT_XCD_SWIZZLE    1 (default) = XCD-aware workgroup order.
+ *   BGS_OPT_PLACEMENT_PROBE  number of model placements tried at allocation (default 6, <= 1 = off); before the geometry. */
 #define BGS_OPT_BORROW_FRAMES 1
 #define BGS_OPT_MOG2_PIXELS_PER_LANE 2
+#define BGS_OPT_MOG2_TILED 3
+#define BGS_OPT_XCD_SWIZZLE 4
+#define BGS_OPT_PLACEMENT_PROBE 5
 int bgs_set_option(bgs_engine* e, int option, int64_t value);
 
 /* Fix rows x cols x channels up front and allocate the model (device path). */

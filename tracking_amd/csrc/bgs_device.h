@@ -2,8 +2,9 @@
 //
 // Numeric contract: the uint8 masks must equal the reference's bit for bit, so every
 // float expression rounds exactly where the reference's does.  The library is compiled with
-// -ffp-contract=off (no FMA fusion), divisions and square roots use the correctly rounded
-// __fdiv_rn/__fsqrt_rn, u8 conversion is round-half-to-even then clamp (cv::saturate_cast<uchar>(float)).
+// -ffp-contract=off (no FMA fusion) and -fhip-fp32-correctly-rounded-divide-sqrt, so `/` and sqrt_rn() are IEEE
+// correctly rounded (NOT HIP's __fsqrt_rn: without OCML_BASIC_ROUNDED_OPERATIONS that is the 1-ulp native v_sqrt_f32);
+// u8 conversion is round-half-to-even then clamp (cv::saturate_cast<uchar>(float)).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -12,6 +13,10 @@ namespace bgs {
 
 constexpr int kWave = 64;       // CDNA4 wavefront
 constexpr int kBlock = 256;     // 4 waves, one per SIMD
+
+// IEEE correctly rounded f32 square root / division (see the header comment)
+__device__ __forceinline__ float sqrt_rn(float x) { return __builtin_sqrtf(x); }
+__device__ __forceinline__ float div_rn(float a, float b) { return a / b; }
 
 // cv::cvtColor(CV_BGR2GRAY) on 8U: fixed point, shift 14
 __device__ __forceinline__ int gray_bgr(int b, int g, int r) { return (b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14; }
@@ -73,7 +78,7 @@ __device__ __forceinline__ void store_bytes(uint8_t* p, const Bytes<NBYTES>& r) 
   }
 }
 
-// PX consecutive floats of one SoA plane
+// PX consecutive floats of one model plane
 template <int PX>
 __device__ __forceinline__ void load_f(const float* p, float (&d)[PX]) {
   if constexpr (PX == 4) {
@@ -83,8 +88,7 @@ __device__ __forceinline__ void load_f(const float* p, float (&d)[PX]) {
     float2 v = *reinterpret_cast<const float2*>(p);
     d[0] = v.x, d[1] = v.y;
   } else {
-#pragma unroll
-    for (int i = 0; i < PX; ++i) d[i] = p[i];
+    d[0] = p[0];
   }
 }
 template <int PX>
@@ -94,8 +98,7 @@ __device__ __forceinline__ void store_f(float* p, const float (&d)[PX]) {
   } else if constexpr (PX == 2) {
     *reinterpret_cast<float2*>(p) = make_float2(d[0], d[1]);
   } else {
-#pragma unroll
-    for (int i = 0; i < PX; ++i) p[i] = d[i];
+    p[0] = d[0];
   }
 }
 

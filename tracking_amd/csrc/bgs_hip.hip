@@ -63,10 +63,15 @@ struct bgs_engine {
   // byte state (SFD background, ABL/ASBL background): [S][n*state_ch]
   uint8_t* bgstate = nullptr;
   int state_ch = 0;
-  // MOG2 planes
-  float *w = nullptr, *var = nullptr, *mu = nullptr;
-  uint8_t* nmodes = nullptr;
-  int mog2_px = 0;  // 0 = auto
+  // MOG2 model (kernel_mog2.h: tiled AoSoA by default, planar kept for A/B runs)
+  float* mog2_state = nullptr;
+  uint8_t* mog2_nmodes = nullptr;  // planar layout only
+  bool mog2_tiled = true;
+  int mog2_px = 0;                 // pixels per lane, 0 = widest the alignment allows
+  int xcd_swizzle = 1;             // XCD-aware block order (kernel_mog2.h)
+  int probe_max = 6;               // placement probe: candidates tried at allocation (<= 1: off)
+  float probe_ms[8] = {0};         // what the probe measured (diagnostics)
+  int probe_n = 0, probe_pick = -1;
 
   // host staging (bgs_process)
   uint8_t *h_in = nullptr, *h_fg = nullptr, *h_bg = nullptr;
@@ -84,10 +89,10 @@ namespace {
 void free_all(bgs_engine* e) {
   for (auto& r : e->ring)
     if (r) (void)hipFree(r), r = nullptr;
-  void* dev[] = {e->bgstate, e->w, e->var, e->mu, e->nmodes, e->d_in, e->d_fg, e->d_bg};
+  void* dev[] = {e->bgstate, e->mog2_state, e->mog2_nmodes, e->d_in, e->d_fg, e->d_bg};
   for (void* d : dev)
     if (d) (void)hipFree(d);
-  e->bgstate = nullptr, e->w = e->var = e->mu = nullptr, e->nmodes = nullptr, e->d_in = e->d_fg = e->d_bg = nullptr;
+  e->bgstate = nullptr, e->mog2_state = nullptr, e->mog2_nmodes = nullptr, e->d_in = e->d_fg = e->d_bg = nullptr;
   void* host[] = {e->h_in, e->h_fg, e->h_bg};
   for (void* h : host)
     if (h) (void)hipHostFree(h);
@@ -99,6 +104,138 @@ void free_all(bgs_engine* e) {
 int check_params(bgs_algo algo, const bgs_params& p) {
   if (algo == BGS_MOG2 && p.mog2_nmixtures != bgs::kMog2K) return fail(BGS_ERR_UNSUPPORTED, "MOG2 kernel is built for K=%d mixtures, got %d", bgs::kMog2K, p.mog2_nmixtures);
   return BGS_OK;
+}
+
+struct Timed {
+  bgs_engine* e;
+  hipStream_t s;
+  hipEvent_t a = nullptr, b = nullptr;
+  Timed(bgs_engine* e_, hipStream_t s_, const char* name, bool enable = true) : e(e_), s(s_) {
+    if (enable) e->kernel_name = name;
+    if (enable && e->timing && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, s);
+  }
+  ~Timed() {
+    if (a && b) {
+      (void)hipEventRecord(b, s);
+      e->events.emplace_back(a, b);
+    }
+  }
+};
+
+int launch_mog2(bgs_engine* e, bgs::Mog2Args& a, hipStream_t s, bool timed = true) {
+  const bgs_params& p = e->p;
+  // shadow test only when it can change the delivered mask: not thresholded, or the threshold separates shadow from foreground
+  a.shadow = p.mog2_detect_shadows && (!p.enable_threshold || ((p.mog2_shadow_value > p.threshold) != (255 > p.threshold)));
+  a.want_bg = a.bgimg != nullptr, a.packed = a.fg_bits != nullptr;
+  a.xcd_swizzle = e->xcd_swizzle;
+  int PX = 4;
+  if (a.npix % 4 || a.state_off % 4 || !aligned(a.frame, 4) || (a.fg && !aligned(a.fg, 4)) || (a.bgimg && !aligned(a.bgimg, 4))) PX = 1;
+  if (e->mog2_px == 1 || e->mog2_px == 2) {
+    if (!(e->mog2_px == 2 && (a.npix % 2 || a.state_off % 2 || !aligned(a.frame, 2)))) PX = std::min(PX, e->mog2_px);
+  }
+  if (PX == 2 && a.fg && !aligned(a.fg, 2)) PX = 1;
+  if (a.packed && a.npix % 64) return fail(BGS_ERR_UNSUPPORTED, "packed mask needs pixels %% 64 == 0");
+  Timed t(e, s, "mog2_update_kernel", timed);
+  const dim3 grid(blocks_for(a.npix / PX)), block(bgs::kBlock);
+  const bool tiled = e->mog2_tiled;
+#define MOG2_CASE(PXV, TL) \
+  if (PX == PXV && tiled == TL) hipLaunchKernelGGL((bgs::mog2_update_kernel<PXV, TL>), grid, block, 0, s, a);
+  MOG2_CASE(4, true) MOG2_CASE(2, true) MOG2_CASE(1, true) MOG2_CASE(4, false) MOG2_CASE(2, false) MOG2_CASE(1, false)
+#undef MOG2_CASE
+  return BGS_OK;
+}
+
+void mog2_fill_args(const bgs_engine* e, bgs::Mog2Args& m, double lr) {
+  const bgs_params& p = e->p;
+  m.state = e->mog2_state, m.nmodes_planar = e->mog2_nmodes, m.plane = e->n * e->S;
+  m.alphaT = (float)lr, m.alpha1 = 1.f - m.alphaT, m.prune = (float)(-lr * (double)p.mog2_ct);
+  m.Tb = p.mog2_var_threshold, m.TB = p.mog2_background_ratio, m.Tg = p.mog2_var_threshold_gen;
+  m.varInit = p.mog2_var_init, m.varMin = p.mog2_var_min, m.varMax = p.mog2_var_max, m.tau = p.mog2_tau;
+  m.thr = p.threshold, m.enable_thr = p.enable_threshold, m.shadow_val = p.mog2_shadow_value;
+}
+
+void mog2_clear(bgs_engine* e, const bgs::Mog2Args& m, hipStream_t s) {
+  if (e->mog2_tiled)
+    hipLaunchKernelGGL((bgs::mog2_clear_kernel<true>), dim3(blocks_for(m.npix)), dim3(bgs::kBlock), 0, s, m);
+  else
+    hipLaunchKernelGGL((bgs::mog2_clear_kernel<false>), dim3(blocks_for(m.npix)), dim3(bgs::kBlock), 0, s, m);
+}
+
+size_t mog2_state_bytes(const bgs_engine* e) {
+  const size_t P = e->n * e->S;
+  if (e->mog2_tiled) return (P + bgs::kMog2Tile - 1) / bgs::kMog2Tile * bgs::kMog2TileFloats * sizeof(float);
+  return P * bgs::kMog2Planes * sizeof(float);
+}
+
+// Model allocation with a PLACEMENT PROBE.  Measured on MI355X: the same kernel on the same layout runs in
+// one of two modes, ~5.5 TB/s or ~6.1 TB/s, depending only on which physical VRAM pages hipMalloc handed out (a physically
+// contiguous block always lands in the slow mode).  The model lives for the life of the stream, so it pays to look: allocate
+// a few candidates, time the real update kernel on each (zero model, zero frame: traffic is data-independent), keep the
+// fastest, free the rest.  Costs well under a second; skipped for models too small to be HBM-bound.
+int mog2_allocate(bgs_engine* e) {
+  const size_t P = e->n * e->S, bytes = mog2_state_bytes(e);
+  if (!e->mog2_tiled) {
+    HIP_TRY(hipMalloc((void**)&e->mog2_state, bytes));
+    HIP_TRY(hipMalloc((void**)&e->mog2_nmodes, P));
+    return BGS_OK;
+  }
+  const int tries = std::min(e->probe_max, 8);
+  if (tries <= 1 || bytes < ((size_t)768 << 20)) {
+    HIP_TRY(hipMalloc((void**)&e->mog2_state, bytes));
+    return BGS_OK;
+  }
+  uint8_t* d_frame = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_frame, P * 3));
+  HIP_TRY(hipMemsetAsync(d_frame, 0, P * 3, e->stream));
+  hipEvent_t ev0, ev1;
+  HIP_TRY(hipEventCreate(&ev0));
+  HIP_TRY(hipEventCreate(&ev1));
+  float* cand[8] = {nullptr};
+  int n = 0, best = 0;
+  float tmin = 1e30f, tmax = 0.f;
+  int rc = BGS_OK;
+  for (; n < tries; ++n) {
+    if (hipMalloc((void**)&cand[n], bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      break;  // out of memory: settle for what we have
+    }
+    e->mog2_state = cand[n];
+    bgs::Mog2Args m{};
+    mog2_fill_args(e, m, 0.05);
+    m.frame = d_frame, m.state_off = 0, m.npix = P;
+    mog2_clear(e, m, e->stream);
+    for (int i = 0; i < 2 && !rc; ++i) rc = launch_mog2(e, m, e->stream, false);
+    (void)hipEventRecord(ev0, e->stream);
+    for (int i = 0; i < 4 && !rc; ++i) rc = launch_mog2(e, m, e->stream, false);
+    (void)hipEventRecord(ev1, e->stream);
+    if (rc || hipEventSynchronize(ev1) != hipSuccess) {
+      rc = rc ? rc : fail(BGS_ERR_HIP, "placement probe failed: %s", hipGetErrorString(hipGetLastError()));
+      ++n;
+      break;
+    }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    e->probe_ms[n] = ms / 4;
+    if (ms < tmin) tmin = ms, best = n;
+    tmax = std::max(tmax, ms);
+    if (n >= 1 && tmin < 0.95f * tmax) {  // both modes seen: the fast one is in hand
+      ++n;
+      break;
+    }
+  }
+  e->probe_n = n, e->probe_pick = best;
+  for (int i = 0; i < n; ++i)
+    if (i != best || rc) (void)hipFree(cand[i]);
+  e->mog2_state = rc ? nullptr : cand[best];
+  (void)hipFree(d_frame);
+  (void)hipEventDestroy(ev0), (void)hipEventDestroy(ev1);
+  if (!rc && !e->mog2_state) return fail(BGS_ERR_NOMEM, "out of device memory for the MOG2 model (%zu bytes)", bytes);
+  if (getenv("BGS_DEBUG_PROBE")) {
+    fprintf(stderr, "[bgs] placement probe: %d candidates, ms/launch:", n);
+    for (int i = 0; i < n; ++i) fprintf(stderr, " %.3f%s", e->probe_ms[i], i == best ? "*" : "");
+    fprintf(stderr, "\n");
+  }
+  return rc;
 }
 
 int allocate(bgs_engine* e, int rows, int cols, int ch) {
@@ -120,12 +257,10 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
   }
   for (int i = 0; i < e->nring; ++i) HIP_TRY(hipMalloc((void**)&e->ring[i], fb));
   if (e->state_ch) HIP_TRY(hipMalloc((void**)&e->bgstate, P * e->state_ch));
+  if (!e->stream) HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   if (e->algo == BGS_MOG2) {
-    const int K = bgs::kMog2K;
-    HIP_TRY(hipMalloc((void**)&e->w, P * K * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&e->var, P * K * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&e->mu, P * K * 3 * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&e->nmodes, P));
+    int rc = mog2_allocate(e);
+    if (rc) return rc;
   }
   if (!e->stream) HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   return BGS_OK;
@@ -142,22 +277,6 @@ int ensure_staging(bgs_engine* e) {
   HIP_TRY(hipMalloc((void**)&e->d_bg, fb));
   return BGS_OK;
 }
-
-struct Timed {
-  bgs_engine* e;
-  hipStream_t s;
-  hipEvent_t a = nullptr, b = nullptr;
-  Timed(bgs_engine* e_, hipStream_t s_, const char* name) : e(e_), s(s_) {
-    e->kernel_name = name;
-    if (e->timing && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, s);
-  }
-  ~Timed() {
-    if (a && b) {
-      (void)hipEventRecord(b, s);
-      e->events.emplace_back(a, b);
-    }
-  }
-};
 
 #define LAUNCH_FRAME_KERNEL(KERNEL, name)                                                             \
   do {                                                                                                \
@@ -195,32 +314,6 @@ int pick_group(const bgs::FrameArgs& a, int C) {
   }
   (void)C;
   return G;
-}
-
-int launch_mog2(bgs_engine* e, bgs::Mog2Args& a, hipStream_t s) {
-  const bgs_params& p = e->p;
-  // shadow test only when it can change the delivered mask: not thresholded, or the threshold separates shadow from foreground
-  const bool shadow = p.mog2_detect_shadows && (!p.enable_threshold || ((p.mog2_shadow_value > p.threshold) != (255 > p.threshold)));
-  const bool bgimg = a.bgimg != nullptr, packed = a.fg_bits != nullptr;
-  int PX = 4;
-  if (a.npix % 4 || a.state_off % 4 || !aligned(a.frame, 4) || (a.fg && !aligned(a.fg, 4)) || (a.bgimg && !aligned(a.bgimg, 4))) PX = 1;
-  if (e->mog2_px == 1 || e->mog2_px == 2) {
-    if (!(e->mog2_px == 2 && (a.npix % 2 || a.state_off % 2 || !aligned(a.frame, 2)))) PX = std::min(PX, e->mog2_px);
-  }
-  if (PX == 2 && a.fg && !aligned(a.fg, 2)) PX = 1;
-  if (packed && a.npix % 64) return fail(BGS_ERR_UNSUPPORTED, "packed mask needs pixels %% 64 == 0");
-  Timed t(e, s, "mog2_update_kernel");
-  const dim3 grid(blocks_for(a.npix / PX)), block(bgs::kBlock);
-#define MOG2_CASE(PXV, SH, BG, PK) \
-  if (PX == PXV && shadow == SH && bgimg == BG && packed == PK) hipLaunchKernelGGL((bgs::mog2_update_kernel<PXV, SH, BG, PK>), grid, block, 0, s, a);
-#define MOG2_PX(PXV)                                                                                        \
-  MOG2_CASE(PXV, false, false, false) MOG2_CASE(PXV, false, false, true) MOG2_CASE(PXV, false, true, false) \
-  MOG2_CASE(PXV, false, true, true) MOG2_CASE(PXV, true, false, false) MOG2_CASE(PXV, true, false, true)   \
-  MOG2_CASE(PXV, true, true, false) MOG2_CASE(PXV, true, true, true)
-  MOG2_PX(4) MOG2_PX(2) MOG2_PX(1)
-#undef MOG2_PX
-#undef MOG2_CASE
-  return BGS_OK;
 }
 
 // One frame for streams [first, first+count), device pointers, asynchronous on s.
@@ -300,30 +393,20 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
       break;
     }
     case BGS_MOG2: {
-      const int K = bgs::kMog2K;
-      const size_t P = e->n * e->S;
       double lr = p.alpha;
       int64_t nframes = t;
+      bgs::Mog2Args m{};
+      m.state_off = off, m.npix = npix;
+      mog2_fill_args(e, m, 0.0);
       if (nframes == 0 || lr >= 1) {  // needToInitialize: bgmodel = zeros, modesUsed = 0
-        for (int k = 0; k < K; ++k) {
-          HIP_TRY(hipMemsetAsync(e->w + k * P + off, 0, npix * sizeof(float), s));
-          HIP_TRY(hipMemsetAsync(e->var + k * P + off, 0, npix * sizeof(float), s));
-          for (int c = 0; c < 3; ++c) HIP_TRY(hipMemsetAsync(e->mu + (k * 3 + c) * P + off, 0, npix * sizeof(float), s));
-        }
-        HIP_TRY(hipMemsetAsync(e->nmodes + off, 0, npix, s));
+        mog2_clear(e, m, s);
         nframes = 0;
       }
       ++nframes;
       const int64_t n2 = 2 * nframes;
       lr = (lr >= 0 && nframes > 1) ? lr : 1. / (double)std::min<int64_t>(n2, p.mog2_history);
-      bgs::Mog2Args m{};
+      mog2_fill_args(e, m, lr);
       m.frame = d_frames, m.fg = d_fg, m.bgimg = d_bg, m.fg_bits = d_bits;
-      m.w = e->w, m.var = e->var, m.mu = e->mu, m.nmodes = e->nmodes;
-      m.plane = P, m.state_off = off, m.npix = npix;
-      m.alphaT = (float)lr, m.alpha1 = 1.f - m.alphaT, m.prune = (float)(-lr * (double)p.mog2_ct);
-      m.Tb = p.mog2_var_threshold, m.TB = p.mog2_background_ratio, m.Tg = p.mog2_var_threshold_gen;
-      m.varInit = p.mog2_var_init, m.varMin = p.mog2_var_min, m.varMax = p.mog2_var_max, m.tau = p.mog2_tau;
-      m.thr = p.threshold, m.enable_thr = p.enable_threshold, m.shadow_val = p.mog2_shadow_value;
       int rc = launch_mog2(e, m, s);
       if (rc) return rc;
       for (int i = first; i < first + count; ++i) e->seen[i] = nframes - 1;  // re-initialisation restarts the count
@@ -420,6 +503,9 @@ int bgs_create(bgs_algo algo, const bgs_params* params, int hip_device, int n_st
   e->seen.assign(n_streams, 0);
   e->counter.assign(n_streams, 0);
   if (const char* env = getenv("BGS_MOG2_PX")) e->mog2_px = atoi(env);
+  if (const char* env = getenv("BGS_MOG2_LAYOUT")) e->mog2_tiled = strcmp(env, "planar") != 0;
+  if (const char* env = getenv("BGS_XCD_SWIZZLE")) e->xcd_swizzle = atoi(env);
+  if (const char* env = getenv("BGS_PLACEMENT_PROBE")) e->probe_max = atoi(env);
   *out = e;
   return BGS_OK;
 }
@@ -454,6 +540,15 @@ int bgs_set_option(bgs_engine* e, int option, int64_t value) {
   switch (option) {
     case 1: e->borrow = value != 0; return BGS_OK;
     case 2: e->mog2_px = (int)value; return BGS_OK;
+    case 3:
+      if (e->n) return fail(BGS_ERR_INVALID, "the model layout must be chosen before the geometry is set");
+      e->mog2_tiled = value != 0;
+      return BGS_OK;
+    case 4: e->xcd_swizzle = value != 0; return BGS_OK;
+    case 5:
+      if (e->n) return fail(BGS_ERR_INVALID, "the placement probe runs when the geometry is set");
+      e->probe_max = (int)value;
+      return BGS_OK;
     default: return fail(BGS_ERR_INVALID, "unknown option %d", option);
   }
 }
@@ -525,10 +620,33 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
     return (int64_t)nb;
   };
   if (e->algo == BGS_MOG2) {
-    if (!strcmp(plane, "w")) return copy_planes(e->w, bgs::kMog2K);
-    if (!strcmp(plane, "var")) return copy_planes(e->var, bgs::kMog2K);
-    if (!strcmp(plane, "mu")) return copy_planes(e->mu, bgs::kMog2K * 3);
-    if (!strcmp(plane, "nmodes")) return copy_bytes(e->nmodes + off, n);
+    // canonical export: "w" [K][n], "var" [K][n], "mu" [K][3][n] floats, "nmodes" [n] bytes — whatever the device layout
+    int p0 = -1, np = 0;
+    if (!strcmp(plane, "w")) p0 = 0, np = 5;
+    if (!strcmp(plane, "var")) p0 = 5, np = 5;
+    if (!strcmp(plane, "mu")) p0 = 10, np = 15;
+    const bool nm = !strcmp(plane, "nmodes");
+    if (p0 >= 0 || nm) {
+      if (!e->mog2_tiled) {
+        if (nm) return copy_bytes(e->mog2_nmodes + off, n);
+        return copy_planes(e->mog2_state + (size_t)p0 * P, np);
+      }
+      const size_t need = nm ? n : (size_t)np * n * 4;
+      if (cap < need) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
+      const size_t T = bgs::kMog2Tile, TF = bgs::kMog2TileFloats;
+      const size_t t0 = off / T, t1 = (off + n + T - 1) / T;
+      std::vector<float> tiles((t1 - t0) * TF);
+      if (hipMemcpy(tiles.data(), e->mog2_state + t0 * TF, tiles.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+      for (size_t i = 0; i < n; ++i) {
+        const size_t sp = off + i, tl = sp / T - t0, in = sp % T;
+        const float* tb = tiles.data() + tl * TF;
+        if (nm)
+          ((uint8_t*)dst)[i] = reinterpret_cast<const uint8_t*>(tb + bgs::kMog2Planes * T)[in];
+        else
+          for (int q = 0; q < np; ++q) ((float*)dst)[(size_t)q * n + i] = tb[(p0 + q) * T + in];
+      }
+      return (int64_t)need;
+    }
   }
   if (!strcmp(plane, "bg") && e->bgstate) return copy_bytes(e->bgstate + off * e->state_ch, n * e->state_ch);
   const int64_t t = e->seen[stream];

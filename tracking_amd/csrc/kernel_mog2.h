@@ -25,17 +25,42 @@ struct Mog2Args {
   uint8_t* fg;           // [P] or null
   uint8_t* bgimg;        // [P][3] or null
   uint64_t* fg_bits;     // [P/64] or null
-  float* w;              // [K][plane]
-  float* var;            // [K][plane]
-  float* mu;             // [K][3][plane]
-  uint8_t* nmodes;       // [plane]
-  size_t plane;          // floats per plane (= streams * pixels of the engine)
-  size_t state_off;      // first pixel of this launch inside the planes
+  float* state;          // model, layout below (updated in place)
+  uint8_t* nmodes_planar;// planar layout only: [plane] bytes
+  size_t plane;          // planar layout only: floats per plane (= streams * pixels of the engine)
+  size_t state_off;      // first pixel of this launch inside the model
   size_t npix;           // pixels in this launch
   float alphaT, alpha1, prune;
   float Tb, TB, Tg, varInit, varMin, varMax, tau;
   int thr, enable_thr, shadow_val;
+  int shadow, want_bg, packed;  // wave-uniform feature switches
+  int xcd_swizzle;              // workgroups that share an XCD walk one contiguous eighth of the launch
 };
+
+// Model layouts.  25 float "planes" per pixel: w[k] = k, var[k] = 5+k, mu[k][c] = 10+3k+c, plus nmodes (u8).
+//   TILED  (default): AoSoA — pixels are grouped in tiles of 256; a tile is 25 x 256 floats followed by 256 nmodes bytes
+//            (25 856 B, contiguous).  One wave (PX = 4) owns one tile: it streams ONE contiguous 25 KB block in and out,
+//            every access still a coalesced 1 KiB wave instruction.  With the XCD-aware block order each of the 8 XCDs
+//            then reads and writes one sequential stream, which is what HBM likes best (measured: DESIGN.md §6).
+//   PLANAR : 25 planes of P floats + one plane of P bytes (52 concurrent DRAM streams; kept for A/B measurements).
+constexpr int kMog2Planes = 25;
+constexpr int kMog2Tile = 256;                                            // pixels per tile
+constexpr int kMog2TileFloats = kMog2Planes * kMog2Tile + kMog2Tile / 4;  // 6464 floats = 25 856 B
+
+template <bool TILED>
+__device__ __forceinline__ size_t mog2_plane_off(const Mog2Args& a, int p, size_t sp) {
+  if constexpr (TILED)
+    return (sp >> 8) * kMog2TileFloats + p * kMog2Tile + (sp & 255);
+  else
+    return (size_t)p * a.plane + sp;
+}
+template <bool TILED>
+__device__ __forceinline__ uint8_t* mog2_nmodes(const Mog2Args& a, size_t sp) {
+  if constexpr (TILED)
+    return reinterpret_cast<uint8_t*>(a.state + (sp >> 8) * kMog2TileFloats + kMog2Planes * kMog2Tile) + (sp & 255);
+  else
+    return a.nmodes_planar + sp;
+}
 
 struct Mog2Px {
   float w[kMog2K], var[kMog2K], m0[kMog2K], m1[kMog2K], m2[kMog2K];
@@ -68,7 +93,7 @@ __device__ __forceinline__ bool mog2_shadow(const Mog2Px& s, int nmodes, float x
         done = true;
       } else {
         if (num <= den && num >= a.tau * den) {
-          const float q = __fdiv_rn(num, den);
+          const float q = div_rn(num, den);
           float d2a = 0.0f, dD;
           dD = q * s.m0[mode] - x0, d2a += dD * dD;
           dD = q * s.m1[mode] - x1, d2a += dD * dD;
@@ -87,7 +112,6 @@ __device__ __forceinline__ bool mog2_shadow(const Mog2Px& s, int nmodes, float x
 
 // One pixel of MOG2Invoker::operator() — same statement order as the reference so every float rounds identically.
 // Returns the raw mask value (0 background, shadow_val, 255 foreground) before the wrapper's threshold.
-template <bool SHADOW>
 __device__ __forceinline__ int mog2_pixel(Mog2Px& s, int& nmodes_io, float x0, float x1, float x2, const Mog2Args& a) {
   bool background = false, fitsPDF = false;
   int nmodes = nmodes_io;
@@ -107,7 +131,7 @@ __device__ __forceinline__ int mog2_pixel(Mog2Px& s, int& nmodes_io, float x0, f
           fitsPDF = true;
           matched = true;
           weight += a.alphaT;
-          const float k = __fdiv_rn(a.alphaT, weight);
+          const float k = div_rn(a.alphaT, weight);
           s.m0[mode] -= k * d0;
           s.m1[mode] -= k * d1;
           s.m2[mode] -= k * d2;
@@ -133,7 +157,7 @@ __device__ __forceinline__ int mog2_pixel(Mog2Px& s, int& nmodes_io, float x0, f
       totalWeight += pruned ? 0.f : weight;
     }
   }
-  totalWeight = __fdiv_rn(1.f, totalWeight);
+  totalWeight = div_rn(1.f, totalWeight);
 #pragma unroll
   for (int mode = 0; mode < kMog2K; ++mode)
     if (mode < nmodes) s.w[mode] *= totalWeight;
@@ -161,7 +185,7 @@ __device__ __forceinline__ int mog2_pixel(Mog2Px& s, int& nmodes_io, float x0, f
   }
   nmodes_io = nmodes;
   if (background) return 0;
-  if constexpr (SHADOW) {
+  if (a.shadow) {
     if (mog2_shadow(s, nmodes, x0, x1, x2, a)) return a.shadow_val;
   }
   return 255;
@@ -182,19 +206,27 @@ __device__ __forceinline__ void mog2_background(const Mog2Px& s, int nmodes, flo
       if (totalWeight > TB) stop = true;
     }
   }
-  const float inv = __fdiv_rn(1.f, totalWeight);
+  const float inv = div_rn(1.f, totalWeight);
   b0 = sat_u8(v0 * inv), b1 = sat_u8(v1 * inv), b2 = sat_u8(v2 * inv);
 }
 
 // grid: ceil(npix / PX / kBlock) blocks of kBlock lanes; npix % PX == 0 (the host picks PX = 1 otherwise).
-template <int PX, bool SHADOW, bool BGIMG, bool PACKED>
+template <int PX, bool TILED>
 __global__ __launch_bounds__(kBlock) void mog2_update_kernel(const Mog2Args a) {
-  const size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  size_t blk = blockIdx.x;
+  if (a.xcd_swizzle) {
+    // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 says which blocks share an XCD and its L2).  Give
+    // each XCD one CONTIGUOUS eighth of the launch instead of every 8th block, so every XCD reads and writes a single
+    // sequential run of the model (measured +16 % on HBM; placement only ever changes speed, never results).
+    const size_t per = gridDim.x >> 3, main = per << 3;
+    if (blk < main) blk = (blk & 7) * per + (blk >> 3);
+  }
+  const size_t g = blk * kBlock + threadIdx.x;
   const size_t p0 = g * PX;  // first pixel of this lane, launch-relative
   const bool active = p0 < a.npix;
   uint32_t bits = 0;
   if (active) {
-    const size_t sp = a.state_off + p0;  // index inside the planes
+    const size_t sp = a.state_off + p0;  // index inside the model
     constexpr int FB = (PX * 3 + 3) / 4 * 4;  // frame bytes per lane, rounded up to dwords
     Bytes<FB> pix;
     if constexpr (PX == 1) {
@@ -207,22 +239,17 @@ __global__ __launch_bounds__(kBlock) void mog2_update_kernel(const Mog2Args a) {
     } else {
       pix = load_bytes<PX * 3>(a.frame + p0 * 3);
     }
-    float w[kMog2K][PX], var[kMog2K][PX], m0[kMog2K][PX], m1[kMog2K][PX], m2[kMog2K][PX];
+    float st[kMog2Planes][PX];
 #pragma unroll
-    for (int k = 0; k < kMog2K; ++k) {
-      load_f<PX>(a.w + k * a.plane + sp, w[k]);
-      load_f<PX>(a.var + k * a.plane + sp, var[k]);
-      load_f<PX>(a.mu + (k * 3 + 0) * a.plane + sp, m0[k]);
-      load_f<PX>(a.mu + (k * 3 + 1) * a.plane + sp, m1[k]);
-      load_f<PX>(a.mu + (k * 3 + 2) * a.plane + sp, m2[k]);
-    }
+    for (int q = 0; q < kMog2Planes; ++q) load_f<PX>(a.state + mog2_plane_off<TILED>(a, q, sp), st[q]);
+    uint8_t* const nmp = mog2_nmodes<TILED>(a, sp);
     uint32_t nmw;
     if constexpr (PX == 4)
-      nmw = *reinterpret_cast<const uint32_t*>(a.nmodes + sp);
+      nmw = *reinterpret_cast<const uint32_t*>(nmp);
     else if constexpr (PX == 2)
-      nmw = *reinterpret_cast<const uint16_t*>(a.nmodes + sp);
+      nmw = *reinterpret_cast<const uint16_t*>(nmp);
     else
-      nmw = a.nmodes[sp];
+      nmw = *nmp;
 
     uint32_t mask_word = 0, nm_out = 0;
     Bytes<FB> bgout;
@@ -232,41 +259,37 @@ __global__ __launch_bounds__(kBlock) void mog2_update_kernel(const Mog2Args a) {
     for (int j = 0; j < PX; ++j) {
       Mog2Px s;
 #pragma unroll
-      for (int k = 0; k < kMog2K; ++k) s.w[k] = w[k][j], s.var[k] = var[k][j], s.m0[k] = m0[k][j], s.m1[k] = m1[k][j], s.m2[k] = m2[k][j];
+      for (int k = 0; k < kMog2K; ++k)
+        s.w[k] = st[k][j], s.var[k] = st[5 + k][j], s.m0[k] = st[10 + 3 * k][j], s.m1[k] = st[11 + 3 * k][j], s.m2[k] = st[12 + 3 * k][j];
       int nm = (int)((nmw >> (8 * j)) & 0xffu);
       const float x0 = (float)pix.get(3 * j), x1 = (float)pix.get(3 * j + 1), x2 = (float)pix.get(3 * j + 2);
-      const int raw = mog2_pixel<SHADOW>(s, nm, x0, x1, x2, a);
+      const int raw = mog2_pixel(s, nm, x0, x1, x2, a);
       const int m = thr_bin(raw, a.thr, a.enable_thr);
       mask_word |= (uint32_t)m << (8 * j);
       bits |= (uint32_t)(m != 0) << j;
       nm_out |= (uint32_t)nm << (8 * j);
-      if constexpr (BGIMG) {
+      if (a.want_bg) {
         int b0, b1, b2;
         mog2_background(s, nm, a.TB, b0, b1, b2);
         bgout.set(3 * j, b0), bgout.set(3 * j + 1, b1), bgout.set(3 * j + 2, b2);
       }
 #pragma unroll
-      for (int k = 0; k < kMog2K; ++k) w[k][j] = s.w[k], var[k][j] = s.var[k], m0[k][j] = s.m0[k], m1[k][j] = s.m1[k], m2[k][j] = s.m2[k];
+      for (int k = 0; k < kMog2K; ++k)
+        st[k][j] = s.w[k], st[5 + k][j] = s.var[k], st[10 + 3 * k][j] = s.m0[k], st[11 + 3 * k][j] = s.m1[k], st[12 + 3 * k][j] = s.m2[k];
     }
 #pragma unroll
-    for (int k = 0; k < kMog2K; ++k) {
-      store_f<PX>(a.w + k * a.plane + sp, w[k]);
-      store_f<PX>(a.var + k * a.plane + sp, var[k]);
-      store_f<PX>(a.mu + (k * 3 + 0) * a.plane + sp, m0[k]);
-      store_f<PX>(a.mu + (k * 3 + 1) * a.plane + sp, m1[k]);
-      store_f<PX>(a.mu + (k * 3 + 2) * a.plane + sp, m2[k]);
-    }
+    for (int q = 0; q < kMog2Planes; ++q) store_f<PX>(a.state + mog2_plane_off<TILED>(a, q, sp), st[q]);
     if constexpr (PX == 4) {
-      *reinterpret_cast<uint32_t*>(a.nmodes + sp) = nm_out;
+      *reinterpret_cast<uint32_t*>(nmp) = nm_out;
       if (a.fg) *reinterpret_cast<uint32_t*>(a.fg + p0) = mask_word;
     } else if constexpr (PX == 2) {
-      *reinterpret_cast<uint16_t*>(a.nmodes + sp) = (uint16_t)nm_out;
+      *reinterpret_cast<uint16_t*>(nmp) = (uint16_t)nm_out;
       if (a.fg) *reinterpret_cast<uint16_t*>(a.fg + p0) = (uint16_t)mask_word;
     } else {
-      a.nmodes[sp] = (uint8_t)nm_out;
+      *nmp = (uint8_t)nm_out;
       if (a.fg) a.fg[p0] = (uint8_t)mask_word;
     }
-    if constexpr (BGIMG) {
+    if (a.want_bg) {
       if constexpr (PX == 4) {
         store_bytes<12>(a.bgimg + p0 * 3, bgout);
       } else {
@@ -275,10 +298,21 @@ __global__ __launch_bounds__(kBlock) void mog2_update_kernel(const Mog2Args a) {
       }
     }
   }
-  if constexpr (PACKED) {
+  if (a.packed) {
     // every lane of the wave takes part (inactive tail lanes contribute 0); npix % 64 == 0 is checked by the host
     store_packed_mask<PX>(a.fg_bits, p0, bits, active);
   }
+}
+
+// (re)initialisation of a pixel range: bgmodel = zeros, modesUsed = 0 (BackgroundSubtractorMOG2::initialize)
+template <bool TILED>
+__global__ __launch_bounds__(kBlock) void mog2_clear_kernel(const Mog2Args a) {
+  const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= a.npix) return;
+  const size_t sp = a.state_off + p;
+#pragma unroll
+  for (int q = 0; q < kMog2Planes; ++q) a.state[mog2_plane_off<TILED>(a, q, sp)] = 0.f;
+  *mog2_nmodes<TILED>(a, sp) = 0;
 }
 
 }  // namespace bgs

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void wmv_kernel(const FrameArgs a) {
       const float i0 = to_unit(x.b.get(i)), i1 = to_unit(y.b.get(i)), i2 = to_unit(z.b.get(i));
       const float m = mean3<false>(i0, i1, i2, w0, w1, w2);
       const float v = (wvar(i0, m, w0) + wvar(i1, m, w1)) + wvar(i2, m, w2);  // :83
-      const float sd = __fsqrt_rn(v);                                        // :95
+      const float sd = sqrt_rn(v);                                        // :95
       d.b.set(i, sat_u8(sd * 255.f));                                         // :99
     }
   }

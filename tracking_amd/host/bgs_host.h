@@ -1,0 +1,434 @@
+// bgs_host.h — host-side C++ mirror of the reference's plugin surface, above the C ABI (include/bgs_hip.h).
+//
+// Mirrors, name for name:
+//   class IBGS                      package_bgs/IBGS.h:21-33          process(in, fg, bg); private saveConfig/loadConfig
+//   FrameDifferenceBGS ...          package_bgs/<Class>.{h,cpp}        same class names, same ./config/<Class>.xml keys,
+//                                                                      loadConfig() on every process(), saveConfig() on the first
+// so a caller written against the reference (FrameProcessor.cpp:157-167, Demo.cpp:179, ustc_src/ustc_bgs.cpp:94) changes
+// one `new` expression.  The image type is bgs_hip::Image — the four things IBGS::process reads from a cv::Mat
+// (data, rows, cols, channels, step) plus copyTo()-style reallocation; the cv::Mat overloads a maintainer adds where
+// OpenCV exists are in INTEGRATION.md (OpenCV is not in this image, so they are not compiled here).
+//
+// Behaviour kept from the reference:
+//   * empty input  -> silent return, outputs untouched
+//   * warm-up frames / classes that never write a background -> that output is left untouched
+//   * hard failures -> exception derived from std::exception (the reference: CV_Assert -> cv::Exception), nothing else
+//   * imshow side effects are dropped; the showOutput keys are still read and written so the XML files stay compatible
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/bgs_hip.h"
+
+namespace bgs_hip {
+
+// ---------------------------------------------------------------------------------------------- Image
+// Owning or viewing 8-bit interleaved image; the subset of cv::Mat that IBGS::process touches.
+class Image {
+ public:
+  uint8_t* data = nullptr;
+  int rows = 0, cols = 0;
+  size_t step = 0;
+
+  Image() {}
+  Image(int r, int c, int ch) { create(r, c, ch); }
+  // non-owning view (what `cv::Mat img_input(frame)` is for an IplImage, VideoCapture.cpp:209)
+  Image(int r, int c, int ch, uint8_t* p, size_t step_bytes) : data(p), rows(r), cols(c), step(step_bytes), ch_(ch) {}
+  int channels() const { return ch_; }
+  bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+  bool isContinuous() const { return step == (size_t)cols * ch_; }
+  void create(int r, int c, int ch) {
+    if (owned_.size() == (size_t)r * c * ch && rows == r && cols == c && ch_ == ch && data == owned_.data()) return;
+    owned_.assign((size_t)r * c * ch, 0);
+    data = owned_.data(), rows = r, cols = c, ch_ = ch, step = (size_t)c * ch;
+  }
+  void copyTo(Image& dst) const {
+    if (empty()) {
+      dst = Image();
+      return;
+    }
+    dst.create(rows, cols, ch_);
+    for (int y = 0; y < rows; ++y) std::memcpy(dst.data + (size_t)y * dst.step, data + (size_t)y * step, (size_t)cols * ch_);
+  }
+  uint8_t* ptr(int y) { return data + (size_t)y * step; }
+  const uint8_t* ptr(int y) const { return data + (size_t)y * step; }
+
+ private:
+  int ch_ = 0;
+  std::vector<uint8_t> owned_;
+};
+
+// ---------------------------------------------------------------------------------------------- XML config
+// Flat CvFileStorage XML as the reference reads/writes it with cvReadIntByName / cvWriteInt etc.:
+//   <?xml version="1.0"?>\n<opencv_storage>\n<key>value</key>\n...</opencv_storage>
+// Missing file or key -> the in-code default, exactly like cvRead*ByName(fs, 0, key, default) on a NULL storage.
+class XmlConfig {
+ public:
+  bool load(const std::string& path) {
+    kv_.clear();
+    std::ifstream f(path.c_str());
+    if (!f) return false;
+    std::stringstream ss;
+    ss << f.rdbuf();
+    const std::string t = ss.str();
+    size_t pos = 0;
+    while ((pos = t.find('<', pos)) != std::string::npos) {
+      size_t end = t.find('>', pos);
+      if (end == std::string::npos) break;
+      std::string tag = t.substr(pos + 1, end - pos - 1);
+      pos = end + 1;
+      if (tag.empty() || tag[0] == '?' || tag[0] == '/' || tag[0] == '!' || tag == "opencv_storage") continue;
+      const std::string close = "</" + tag + ">";
+      size_t c = t.find(close, pos);
+      if (c == std::string::npos) continue;
+      std::string val = t.substr(pos, c - pos);
+      size_t a = val.find_first_not_of(" \t\r\n"), b = val.find_last_not_of(" \t\r\n");
+      val = (a == std::string::npos) ? "" : val.substr(a, b - a + 1);
+      if (val.size() >= 2 && val.front() == '"' && val.back() == '"') val = val.substr(1, val.size() - 2);
+      kv_[tag] = val;
+      pos = c + close.size();
+    }
+    return true;
+  }
+  int readInt(const std::string& k, int def) const {
+    auto it = kv_.find(k);
+    if (it == kv_.end() || it->second.empty()) return def;
+    return (int)std::strtod(it->second.c_str(), nullptr);  // cvReadInt rounds a real node; integers pass through
+  }
+  double readReal(const std::string& k, double def) const {
+    auto it = kv_.find(k);
+    if (it == kv_.end() || it->second.empty()) return def;
+    return std::strtod(it->second.c_str(), nullptr);
+  }
+  std::string readString(const std::string& k, const std::string& def) const {
+    auto it = kv_.find(k);
+    return it == kv_.end() ? def : it->second;
+  }
+
+  // writer: keys in insertion order, like consecutive cvWrite* calls
+  void beginWrite() { out_.clear(); }
+  void writeInt(const std::string& k, int v) { out_.push_back(k + ">" + std::to_string(v)); }
+  void writeReal(const std::string& k, double v) {
+    char buf[64];
+    std::snprintf(buf, sizeof(buf), "%.16g", v);
+    std::string s = buf;
+    if (s.find_first_of(".eE") == std::string::npos) s += ".";  // CvFileStorage writes reals with a decimal point
+    out_.push_back(k + ">" + s);
+  }
+  void writeString(const std::string& k, const std::string& v) { out_.push_back(k + ">\"" + v + "\""); }
+  bool save(const std::string& path) const {
+    std::ofstream f(path.c_str());
+    if (!f) return false;  // the reference's cvOpenFileStorage also fails silently when ./config is missing
+    f << "<?xml version=\"1.0\"?>\n<opencv_storage>\n";
+    for (const std::string& e : out_) {
+      const size_t gt = e.find('>');
+      f << "<" << e.substr(0, gt) << ">" << e.substr(gt + 1) << "</" << e.substr(0, gt) << ">\n";
+    }
+    f << "</opencv_storage>\n";
+    return true;
+  }
+
+ private:
+  std::map<std::string, std::string> kv_;
+  std::vector<std::string> out_;
+};
+
+// ---------------------------------------------------------------------------------------------- errors
+// What a failed CV_Assert is in the reference: an exception derived from std::exception, caught at Main.cpp:63-72.
+class Exception : public std::runtime_error {
+ public:
+  Exception(int code_, const std::string& what_) : std::runtime_error(what_), code(code_) {}
+  int code;
+};
+
+// ---------------------------------------------------------------------------------------------- IBGS
+class IBGS {  // package_bgs/IBGS.h:21-33
+ public:
+  virtual void process(const Image& img_input, Image& img_foreground, Image& img_background) = 0;
+  virtual ~IBGS() {}
+
+ private:
+  virtual void saveConfig() = 0;
+  virtual void loadConfig() = 0;
+};
+
+// Common machinery of every class below: one single-stream engine, per-frame config reload, output conventions.
+class HipBGSBase : public IBGS {
+ public:
+  ~HipBGSBase() override {
+    if (engine_) bgs_destroy(engine_);
+  }
+  void process(const Image& img_input, Image& img_output, Image& img_bgmodel) override {
+    if (img_input.empty()) return;  // first line of every reference process()
+    loadConfig();
+    if (firstTime) saveConfig();
+    if (!engine_) {
+      int rc = bgs_create(algo_, &params_, device_, 1, &engine_);
+      if (rc) throw Exception(rc, std::string(name_) + ": " + bgs_last_error());
+    } else {
+      int rc = bgs_set_params(engine_, &params_);
+      if (rc) throw Exception(rc, std::string(name_) + ": " + bgs_last_error());
+    }
+    const int bg_ch = (algo_ == BGS_ASBL) ? 1 : img_input.channels();
+    fg_.create(img_input.rows, img_input.cols, 1);
+    bg_.create(img_input.rows, img_input.cols, bg_ch);
+    uint32_t flags = 0;
+    int rc = bgs_process(engine_, 0, img_input.data, img_input.rows, img_input.cols, img_input.channels(), img_input.step, fg_.data, fg_.step, bg_.data,
+                         bg_.step, &flags);
+    if (rc) throw Exception(rc, std::string(name_) + ": " + bgs_last_error());
+    if (flags & BGS_FG_VALID) fg_.copyTo(img_output);  // img_foreground.copyTo(img_output)
+    if (flags & BGS_BG_VALID)
+      bg_.copyTo(img_bgmodel);  // img_background.copyTo(img_bgmodel)
+    else if (clears_bg_)
+      img_bgmodel = Image();    // MixtureOfGaussianV1BGS.cpp:68: copyTo of an empty Mat releases the destination
+    firstTime = false;
+  }
+  // which HIP device the lazily created engine uses (default 0); the reference has no such notion
+  void setDevice(int d) { device_ = d; }
+
+ protected:
+  HipBGSBase(bgs_algo algo, const char* name, bool clears_bg = false) : firstTime(true), algo_(algo), name_(name), clears_bg_(clears_bg) {
+    std::memset(&params_, 0, sizeof(params_));
+    params_.struct_size = sizeof(params_);
+    bgs_default_params(algo, &params_);
+    std::cout << name_ << "()" << std::endl;  // the reference's ctor banner
+  }
+  std::string configPath() const { return std::string("./config/") + name_ + ".xml"; }
+  bool firstTime;
+  bgs_params params_;
+
+ private:
+  bgs_algo algo_;
+  const char* name_;
+  bool clears_bg_;
+  int device_ = 0;
+  bgs_engine* engine_ = nullptr;
+  Image fg_, bg_;
+};
+
+#define BGS_HIP_BANNER_DTOR(Class) \
+  ~Class() override { std::cout << "~" #Class "()" << std::endl; }
+
+// package_bgs/FrameDifferenceBGS.{h,cpp}
+class FrameDifferenceBGS : public HipBGSBase {
+ public:
+  FrameDifferenceBGS() : HipBGSBase(BGS_FRAME_DIFF, "FrameDifferenceBGS"), showOutput(true) {}
+  BGS_HIP_BANNER_DTOR(FrameDifferenceBGS)
+ private:
+  bool showOutput;
+  void saveConfig() override {  // FrameDifferenceBGS.cpp:65-74
+    XmlConfig fs;
+    fs.beginWrite();
+    fs.writeInt("enableThreshold", params_.enable_threshold);
+    fs.writeInt("threshold", params_.threshold);
+    fs.writeInt("showOutput", showOutput);
+    fs.save(configPath());
+  }
+  void loadConfig() override {  // :76-85
+    XmlConfig fs;
+    fs.load(configPath());
+    params_.enable_threshold = fs.readInt("enableThreshold", true);
+    params_.threshold = fs.readInt("threshold", 15);
+    showOutput = fs.readInt("showOutput", true);
+  }
+};
+
+// package_bgs/StaticFrameDifferenceBGS.{h,cpp}
+class StaticFrameDifferenceBGS : public HipBGSBase {
+ public:
+  StaticFrameDifferenceBGS() : HipBGSBase(BGS_STATIC_FRAME_DIFF, "StaticFrameDifferenceBGS"), showOutput(true) {}
+  BGS_HIP_BANNER_DTOR(StaticFrameDifferenceBGS)
+ private:
+  bool showOutput;
+  void saveConfig() override {
+    XmlConfig fs;
+    fs.beginWrite();
+    fs.writeInt("enableThreshold", params_.enable_threshold);
+    fs.writeInt("threshold", params_.threshold);
+    fs.writeInt("showOutput", showOutput);
+    fs.save(configPath());
+  }
+  void loadConfig() override {
+    XmlConfig fs;
+    fs.load(configPath());
+    params_.enable_threshold = fs.readInt("enableThreshold", true);
+    params_.threshold = fs.readInt("threshold", 15);
+    showOutput = fs.readInt("showOutput", true);
+  }
+};
+
+// package_bgs/WeightedMovingMeanBGS.{h,cpp}
+class WeightedMovingMeanBGS : public HipBGSBase {
+ public:
+  WeightedMovingMeanBGS() : HipBGSBase(BGS_WMM, "WeightedMovingMeanBGS"), showOutput(true), showBackground(false) {}
+  BGS_HIP_BANNER_DTOR(WeightedMovingMeanBGS)
+ private:
+  bool showOutput, showBackground;
+  void saveConfig() override {  // WeightedMovingMeanBGS.cpp:98-109
+    XmlConfig fs;
+    fs.beginWrite();
+    fs.writeInt("enableWeight", params_.enable_weight);
+    fs.writeInt("enableThreshold", params_.enable_threshold);
+    fs.writeInt("threshold", params_.threshold);
+    fs.writeInt("showOutput", showOutput);
+    fs.writeInt("showBackground", showBackground);
+    fs.save(configPath());
+  }
+  void loadConfig() override {  // :111-122
+    XmlConfig fs;
+    fs.load(configPath());
+    params_.enable_weight = fs.readInt("enableWeight", true);
+    params_.enable_threshold = fs.readInt("enableThreshold", true);
+    params_.threshold = fs.readInt("threshold", 15);
+    showOutput = fs.readInt("showOutput", true);
+    showBackground = fs.readInt("showBackground", false);
+  }
+};
+
+// package_bgs/WeightedMovingVarianceBGS.{h,cpp}
+class WeightedMovingVarianceBGS : public HipBGSBase {
+ public:
+  WeightedMovingVarianceBGS() : HipBGSBase(BGS_WMV, "WeightedMovingVarianceBGS"), showOutput(true) {}
+  BGS_HIP_BANNER_DTOR(WeightedMovingVarianceBGS)
+ private:
+  bool showOutput;
+  void saveConfig() override {  // WeightedMovingVarianceBGS.cpp:139-149
+    XmlConfig fs;
+    fs.beginWrite();
+    fs.writeInt("enableWeight", params_.enable_weight);
+    fs.writeInt("enableThreshold", params_.enable_threshold);
+    fs.writeInt("threshold", params_.threshold);
+    fs.writeInt("showOutput", showOutput);
+    fs.save(configPath());
+  }
+  void loadConfig() override {  // :151-161
+    XmlConfig fs;
+    fs.load(configPath());
+    params_.enable_weight = fs.readInt("enableWeight", true);
+    params_.enable_threshold = fs.readInt("enableThreshold", true);
+    params_.threshold = fs.readInt("threshold", 15);
+    showOutput = fs.readInt("showOutput", true);
+  }
+};
+
+// package_bgs/AdaptiveBackgroundLearning.{h,cpp}
+class AdaptiveBackgroundLearning : public HipBGSBase {
+ public:
+  AdaptiveBackgroundLearning() : HipBGSBase(BGS_ABL, "AdaptiveBackgroundLearning"), showForeground(true), showBackground(true) {}
+  BGS_HIP_BANNER_DTOR(AdaptiveBackgroundLearning)
+ private:
+  bool showForeground, showBackground;
+  void saveConfig() override {  // AdaptiveBackgroundLearning.cpp:85-97
+    XmlConfig fs;
+    fs.beginWrite();
+    fs.writeReal("alpha", params_.alpha);
+    fs.writeInt("limit", params_.limit);
+    fs.writeInt("enableThreshold", params_.enable_threshold);
+    fs.writeInt("threshold", params_.threshold);
+    fs.writeInt("showForeground", showForeground);
+    fs.writeInt("showBackground", showBackground);
+    fs.save(configPath());
+  }
+  void loadConfig() override {  // :99-111
+    XmlConfig fs;
+    fs.load(configPath());
+    params_.alpha = fs.readReal("alpha", 0.05);
+    params_.limit = fs.readInt("limit", -1);
+    params_.enable_threshold = fs.readInt("enableThreshold", true);
+    params_.threshold = fs.readInt("threshold", 15);
+    showForeground = fs.readInt("showForeground", true);
+    showBackground = fs.readInt("showBackground", true);
+  }
+};
+
+// package_bgs/AdaptiveSelectiveBackgroundLearning.{h,cpp}
+class AdaptiveSelectiveBackgroundLearning : public HipBGSBase {
+ public:
+  AdaptiveSelectiveBackgroundLearning() : HipBGSBase(BGS_ASBL, "AdaptiveSelectiveBackgroundLearning"), showOutput(true) {}
+  BGS_HIP_BANNER_DTOR(AdaptiveSelectiveBackgroundLearning)
+ private:
+  bool showOutput;
+  void saveConfig() override {  // AdaptiveSelectiveBackgroundLearning.cpp:107-118
+    XmlConfig fs;
+    fs.beginWrite();
+    fs.writeInt("learningFrames", params_.learning_frames);
+    fs.writeReal("alphaLearn", params_.alpha_learn);
+    fs.writeReal("alphaDetection", params_.alpha_detection);
+    fs.writeInt("threshold", params_.threshold);
+    fs.writeInt("showOutput", showOutput);
+    fs.save(configPath());
+  }
+  void loadConfig() override {  // :120-131 (defaults 90 / 25 differ from the ctor's -1 / 15)
+    XmlConfig fs;
+    fs.load(configPath());
+    params_.learning_frames = fs.readInt("learningFrames", 90);
+    params_.alpha_learn = fs.readReal("alphaLearn", 0.05);
+    params_.alpha_detection = fs.readReal("alphaDetection", 0.05);
+    params_.threshold = fs.readInt("threshold", 25);
+    showOutput = fs.readInt("showOutput", true);
+  }
+};
+
+// package_bgs/MixtureOfGaussianV2BGS.{h,cpp}
+class MixtureOfGaussianV2BGS : public HipBGSBase {
+ public:
+  MixtureOfGaussianV2BGS() : HipBGSBase(BGS_MOG2, "MixtureOfGaussianV2BGS"), showOutput(true) {}
+  BGS_HIP_BANNER_DTOR(MixtureOfGaussianV2BGS)
+ private:
+  bool showOutput;
+  void saveConfig() override {  // MixtureOfGaussianV2BGS.cpp:76-86
+    XmlConfig fs;
+    fs.beginWrite();
+    fs.writeReal("alpha", params_.alpha);
+    fs.writeInt("enableThreshold", params_.enable_threshold);
+    fs.writeInt("threshold", params_.threshold);
+    fs.writeInt("showOutput", showOutput);
+    fs.save(configPath());
+  }
+  void loadConfig() override {  // :88-98
+    XmlConfig fs;
+    fs.load(configPath());
+    params_.alpha = fs.readReal("alpha", 0.05);
+    params_.enable_threshold = fs.readInt("enableThreshold", true);
+    params_.threshold = fs.readInt("threshold", 15);
+    showOutput = fs.readInt("showOutput", true);
+  }
+};
+
+// package_bgs/MixtureOfGaussianV1BGS.{h,cpp}
+class MixtureOfGaussianV1BGS : public HipBGSBase {
+ public:
+  MixtureOfGaussianV1BGS() : HipBGSBase(BGS_MOG1, "MixtureOfGaussianV1BGS", /*clears_bg=*/true), showOutput(true) {}
+  BGS_HIP_BANNER_DTOR(MixtureOfGaussianV1BGS)
+ private:
+  bool showOutput;
+  void saveConfig() override {  // MixtureOfGaussianV1BGS.cpp:73-83
+    XmlConfig fs;
+    fs.beginWrite();
+    fs.writeReal("alpha", params_.alpha);
+    fs.writeInt("enableThreshold", params_.enable_threshold);
+    fs.writeInt("threshold", params_.threshold);
+    fs.writeInt("showOutput", showOutput);
+    fs.save(configPath());
+  }
+  void loadConfig() override {  // :85-95
+    XmlConfig fs;
+    fs.load(configPath());
+    params_.alpha = fs.readReal("alpha", 0.05);
+    params_.enable_threshold = fs.readInt("enableThreshold", true);
+    params_.threshold = fs.readInt("threshold", 15);
+    showOutput = fs.readInt("showOutput", true);
+  }
+};
+
+#undef BGS_HIP_BANNER_DTOR
+
+}  // namespace bgs_hip
