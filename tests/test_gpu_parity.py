@@ -21,6 +21,8 @@ ALGOS = {
     "WeightedMovingMeanBGS": capi.WMM,
     "WeightedMovingVarianceBGS": capi.WMV,
     "AdaptiveBackgroundLearning": capi.ABL,
+    "AdaptiveSelectiveBackgroundLearning": capi.ASBL,
+    "MixtureOfGaussianV1BGS": capi.MOG1,
     "MixtureOfGaussianV2BGS": capi.MOG2,
 }
 STATE_TOL = 1e-4
@@ -51,12 +53,28 @@ def check_mog2_state(eng, orc, n, stream=0):
     assert np.array_equal(eng.get_state("nmodes", (n,), np.uint8, stream=stream), orc.get_state("nmodes", (n,), np.uint8))
 
 
+def check_mog1_state(eng, orc, n, C=3, stream=0):
+    for plane, shape in (("sortkey", (5, n)), ("w", (5, n)), ("mu", (5, C, n)), ("var", (5, C, n))):
+        a, b = eng.get_state(plane, shape, np.float32, stream=stream), orc.get_state(plane, shape, np.float32)
+        err = float(np.max(np.abs(a - b)))
+        assert err <= STATE_TOL, "%s: max |delta| %g > %g" % (plane, err, STATE_TOL)
+
+
+def check_state(name, eng, orc, n, stream=0):
+    if name == "MixtureOfGaussianV2BGS":
+        check_mog2_state(eng, orc, n, stream)
+    if name == "MixtureOfGaussianV1BGS":
+        check_mog1_state(eng, orc, n, 3, stream)
+    if name in ("AdaptiveBackgroundLearning", "AdaptiveSelectiveBackgroundLearning", "StaticFrameDifferenceBGS"):
+        c = 1 if name == "AdaptiveSelectiveBackgroundLearning" else 3
+        assert np.array_equal(eng.get_state("bg", (n * c,), np.uint8, stream=stream), orc.get_state("bg", (n * c,), np.uint8))
+
+
 @pytest.mark.parametrize("name", sorted(ALGOS))
 def test_golden_frames(name, golden_frames):
     """The reference's own frames/*.png crop, 24 consecutive frames."""
     eng, orc, _ = run_pair(ALGOS[name], golden_frames)
-    if name == "MixtureOfGaussianV2BGS":
-        check_mog2_state(eng, orc, golden_frames.shape[1] * golden_frames.shape[2])
+    check_state(name, eng, orc, golden_frames.shape[1] * golden_frames.shape[2])
 
 
 @pytest.mark.parametrize("name", sorted(ALGOS))
@@ -65,13 +83,15 @@ def test_seeded_random(name, shape):
     """vector (16 px/lane), dword (4 px/lane) and ragged (1 px/lane) kernels all hit: 64x256, 48x64 | 37x53 ..."""
     frames = synth.random_frames(10, shape[0], shape[1], 3, seed=hash((name, shape)) % 1000)
     eng, orc, _ = run_pair(ALGOS[name], frames)
-    if name == "MixtureOfGaussianV2BGS":
-        check_mog2_state(eng, orc, shape[0] * shape[1])
+    check_state(name, eng, orc, shape[0] * shape[1])
 
 
-@pytest.mark.parametrize("name", ["FrameDifferenceBGS", "StaticFrameDifferenceBGS", "WeightedMovingMeanBGS", "WeightedMovingVarianceBGS", "AdaptiveBackgroundLearning"])
+@pytest.mark.parametrize("name", ["FrameDifferenceBGS", "StaticFrameDifferenceBGS", "WeightedMovingMeanBGS", "WeightedMovingVarianceBGS", "AdaptiveBackgroundLearning",
+                                  "AdaptiveSelectiveBackgroundLearning", "MixtureOfGaussianV1BGS"])
 def test_single_channel(name, golden_gray):
-    run_pair(ALGOS[name], golden_gray)
+    eng, orc, _ = run_pair(ALGOS[name], golden_gray)
+    if name == "MixtureOfGaussianV1BGS":
+        check_mog1_state(eng, orc, golden_gray.shape[1] * golden_gray.shape[2], C=1)
 
 
 def test_mog2_rejects_gray(golden_gray):
@@ -97,7 +117,8 @@ def test_empty_input_is_a_noop(name):
 def test_warmup_outputs_untouched():
     """FD frame 1, WMM/WMV frames 1-2 return with outputs untouched; FD/WMV never write a background."""
     frames = synth.random_frames(4, 16, 32, 3, seed=5)
-    for algo, warm, has_bg in ((capi.FRAME_DIFF, 1, False), (capi.WMM, 2, True), (capi.WMV, 2, False), (capi.STATIC_FRAME_DIFF, 0, True), (capi.ABL, 0, True), (capi.MOG2, 0, True)):
+    for algo, warm, has_bg in ((capi.FRAME_DIFF, 1, False), (capi.WMM, 2, True), (capi.WMV, 2, False), (capi.STATIC_FRAME_DIFF, 0, True), (capi.ABL, 0, True),
+                               (capi.ASBL, 0, True), (capi.MOG1, 0, False), (capi.MOG2, 0, True)):
         eng = Engine(algo)
         for t, f in enumerate(frames):
             fg, bg = eng.process(f)
@@ -196,7 +217,7 @@ def test_params_can_change_between_frames(golden_frames):
 def test_streams_are_independent(golden_frames):
     """One engine, 3 streams fed different clips in interleaved order == 3 separate oracles."""
     clips = [golden_frames[0:8], golden_frames[8:16], golden_frames[16:24][::-1]]
-    for algo in (capi.MOG2, capi.WMV, capi.ABL):
+    for algo in (capi.MOG2, capi.WMV, capi.ABL, capi.ASBL, capi.MOG1):
         eng = Engine(algo, n_streams=3)
         orcs = [pyoracle.Oracle(algo) for _ in clips]
         for t in range(8):
@@ -239,23 +260,25 @@ def test_device_batch_matches_oracle(name, borrow):
         d_frames = torch.from_numpy(np.ascontiguousarray(clips[:, t])).cuda()
         keep.append(d_frames)  # borrowed history must stay alive
         d_fg = torch.full((S, H, W), 9, dtype=torch.uint8, device="cuda")
-        d_bg = torch.full((S, H, W, 3), 9, dtype=torch.uint8, device="cuda")
-        d_bits = torch.zeros((S, H * W // 64), dtype=torch.int64, device="cuda")
+        d_bg = torch.full((S, H, W, 1 if algo == capi.ASBL else 3), 9, dtype=torch.uint8, device="cuda")
+        has_bits = algo != capi.ASBL  # the stencil kernel writes the byte mask only
+        d_bits = torch.zeros((S, H * W // 64), dtype=torch.int64, device="cuda") if has_bits else None
         flags = eng.process_batch_device(d_frames, d_fg, d_bg, d_bits)
         torch.cuda.synchronize()
         fg, bg = d_fg.cpu().numpy(), d_bg.cpu().numpy()
-        bits = np.unpackbits(d_bits.cpu().numpy().view(np.uint8).reshape(S, -1), axis=1, bitorder="little").reshape(S, H, W)
+        bits = np.unpackbits(d_bits.cpu().numpy().view(np.uint8).reshape(S, -1), axis=1, bitorder="little").reshape(S, H, W) if has_bits else None
         for s in range(S):
             ofg, obg = orcs[s].process(clips[s, t])
             assert bool(flags & capi.FG_VALID) == (ofg is not None)
             assert bool(flags & capi.BG_VALID) == (obg is not None)
             if ofg is not None:
                 assert np.array_equal(fg[s], ofg), (t, s)
-                assert np.array_equal(bits[s] * 255, np.where(ofg != 0, 255, 0)), (t, s)
+                if has_bits:
+                    assert np.array_equal(bits[s] * 255, np.where(ofg != 0, 255, 0)), (t, s)
             else:
                 assert (fg[s] == 9).all()  # untouched
             if obg is not None:
-                assert np.array_equal(bg[s], obg), (t, s)
+                assert np.array_equal(bg[s].reshape(obg.shape), obg), (t, s)
     if algo == capi.MOG2:
         for s in range(S):
             check_mog2_state(eng, orcs[s], H * W, stream=s)
@@ -308,3 +331,93 @@ def test_full_size_1080p_mog2_sampled_parity():
     tot = np.where(live, w, 0).sum(0)  # == 1 after a renormalisation, < 1 right after a weakest-mode replacement
     assert (tot > 0.5).all() and (tot <= 1.0 + 1e-3).all()
     assert (var[live] >= 4.0).all() and (var[live] <= 75.0).all()
+
+
+# ----------------------------------------------------------------------------- MOG1 / ASBL variants
+
+@pytest.mark.parametrize("kw", [dict(alpha=0.005), dict(alpha=0.0), dict(alpha=-1.0), dict(alpha=1.0), dict(mog1_background_ratio=0.3),
+                                dict(mog1_var_threshold=1.0), dict(mog1_noise_sigma=2.0), dict(enable_threshold=0)])
+def test_mog1_param_variants(kw, golden_frames):
+    p = _params(capi.MOG1, **kw)
+    eng, orc, _ = run_pair(capi.MOG1, golden_frames[:12], params=p)
+    check_mog1_state(eng, orc, golden_frames.shape[1] * golden_frames.shape[2])
+
+
+def test_mog1_long_run():
+    frames = synth.numpy_frames("surv", 100, 48, 80, seed=77)
+    eng, orc, _ = run_pair(capi.MOG1, frames)
+    check_mog1_state(eng, orc, 48 * 80)
+
+
+@pytest.mark.parametrize("kw", [dict(learning_frames=3), dict(learning_frames=0), dict(learning_frames=-1), dict(threshold=5),
+                                dict(alpha_learn=0.3, alpha_detection=0.01), dict(alpha_detection=1.0)])
+def test_asbl_variants(kw, golden_frames):
+    """learningFrames <= 0 skips the learning phase; after it only pixels whose median-filtered mask is 0 are updated."""
+    run_pair(capi.ASBL, golden_frames[:12], params=_params(capi.ASBL, **kw))
+
+
+@pytest.mark.parametrize("shape", [(48, 64), (37, 53), (5, 7), (3, 3), (1, 9), (130, 70)])
+def test_asbl_ragged_sizes(shape):
+    frames = synth.random_frames(8, shape[0], shape[1], 3, seed=shape[0])
+    run_pair(capi.ASBL, frames, params=_params(capi.ASBL, learning_frames=2))
+
+
+# ----------------------------------------------------------------------------- LBSP descriptors (pinned by the reference's own code)
+
+def test_lbsp_matches_reference_fixture():
+    """tests/golden/lbsp_ref.npz was produced by the reference's LBSP_16bits_dbcross_*.i (oracle/_ref) in the build container."""
+    torch = _torch()
+    from tracking_amd.engine import lbsp_describe_device
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lbsp_ref.npz"))
+    frames = np.load(os.path.join(os.path.dirname(__file__), "golden", "frames_96x80.npz"))["frames"]
+    gray = np.load(os.path.join(os.path.dirname(__file__), "golden", "frames_gray_64x48.npz"))["frames"]
+    d3 = lbsp_describe_device(torch.from_numpy(frames[0]).cuda(), g["lut3"]).cpu().numpy().view(np.uint16)
+    assert np.array_equal(d3, g["desc3"])
+    d7 = lbsp_describe_device(torch.from_numpy(frames[7]).cuda(), g["lut3"]).cpu().numpy().view(np.uint16)
+    assert np.array_equal(d7, g["desc3_f7"])
+    d1 = lbsp_describe_device(torch.from_numpy(gray[0]).cuda(), g["lut1"]).cpu().numpy().view(np.uint16)
+    assert np.array_equal(d1[:, :, 0], g["desc1"])
+
+
+@pytest.mark.parametrize("shape", [(48, 64), (37, 53), (5, 5), (4, 9), (80, 200), (17, 131)])
+@pytest.mark.parametrize("ch", [1, 3])
+def test_lbsp_seeded_vs_oracle(shape, ch):
+    torch = _torch()
+    from tracking_amd.engine import lbsp_describe_device
+    rng = np.random.default_rng(shape[0] * 7 + ch)
+    img = rng.integers(0, 256, shape + ((3,) if ch == 3 else ()), dtype=np.uint8)
+    for rel, off in ((0.333, 0), (0.1, 3), (0.9, 0)):
+        lut = pyoracle.lbsp_lut(rel, off, ch)
+        want = pyoracle.lbsp_describe(img, lut)
+        got = lbsp_describe_device(torch.from_numpy(img).cuda(), lut).cpu().numpy().view(np.uint16)
+        assert np.array_equal(got, want)
+        if pyoracle.ref_lbsp_available():  # only in the build container; the GPU box has the prebuilt .so
+            assert np.array_equal(got, pyoracle.ref_lbsp_describe(img, lut))
+
+
+def test_lbsp_full_size_1080p():
+    torch = _torch()
+    from tracking_amd.engine import lbsp_describe_device
+    img = synth.s_surv(1, 1080, 1920, seed=3, device="cuda")[0]
+    lut = pyoracle.lbsp_lut(0.333, 0, 3)
+    got = lbsp_describe_device(img, lut).cpu().numpy().view(np.uint16)
+    want = pyoracle.lbsp_describe(img.cpu().numpy(), lut)
+    assert np.array_equal(got, want)
+
+
+# ----------------------------------------------------------------------------- mask post-processing primitives
+
+@pytest.mark.parametrize("shape", [(48, 64), (37, 53), (3, 3), (1, 1), (130, 200)])
+def test_mask_morphology_vs_oracle(shape):
+    torch = _torch()
+    from tracking_amd.engine import mask_morph_device, MORPH_ERODE, MORPH_DILATE, MORPH_MEDIAN
+    rng = np.random.default_rng(shape[1])
+    mask = np.where(rng.random(shape) < 0.45, 255, 0).astype(np.uint8)
+    gray = rng.integers(0, 256, shape, dtype=np.uint8)
+    d = torch.from_numpy(mask).cuda()
+    for it in (1, 2, 3):
+        assert np.array_equal(mask_morph_device(d, MORPH_ERODE, iterations=it).cpu().numpy(), pyoracle.erode3x3(mask, it))
+        assert np.array_equal(mask_morph_device(d, MORPH_DILATE, iterations=it).cpu().numpy(), pyoracle.dilate3x3(mask, it))
+    for k in (3, 9, 13):
+        assert np.array_equal(mask_morph_device(d, MORPH_MEDIAN, ksize=k).cpu().numpy(), pyoracle.median_blur(mask, k))
+    assert np.array_equal(mask_morph_device(torch.from_numpy(gray).cuda(), MORPH_MEDIAN, ksize=5).cpu().numpy(), pyoracle.median_blur(gray, 5))

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -18,8 +19,10 @@
 #include <string>
 #include <vector>
 
+#include "kernel_mog1.h"
 #include "kernel_mog2.h"
 #include "kernel_pointwise.h"
+#include "kernel_stencil.h"
 
 namespace {
 
@@ -63,6 +66,9 @@ struct bgs_engine {
   // byte state (SFD background, ABL/ASBL background): [S][n*state_ch]
   uint8_t* bgstate = nullptr;
   int state_ch = 0;
+  uint8_t* bgstate2 = nullptr;  // ASBL: second buffer of the ping-pong pair (the 3x3 median reads neighbours' OLD background)
+  std::vector<uint8_t> flip;    // ASBL: which buffer holds the current background, per stream
+  float* mog1_state = nullptr;  // MOG1 model (kernel_mog1.h, tiled)
   // MOG2 model (kernel_mog2.h: tiled AoSoA by default, planar kept for A/B runs)
   float* mog2_state = nullptr;
   uint8_t* mog2_nmodes = nullptr;  // planar layout only
@@ -89,10 +95,10 @@ namespace {
 void free_all(bgs_engine* e) {
   for (auto& r : e->ring)
     if (r) (void)hipFree(r), r = nullptr;
-  void* dev[] = {e->bgstate, e->mog2_state, e->mog2_nmodes, e->d_in, e->d_fg, e->d_bg};
+  void* dev[] = {e->bgstate, e->bgstate2, e->mog1_state, e->mog2_state, e->mog2_nmodes, e->d_in, e->d_fg, e->d_bg};
   for (void* d : dev)
     if (d) (void)hipFree(d);
-  e->bgstate = nullptr, e->mog2_state = nullptr, e->mog2_nmodes = nullptr, e->d_in = e->d_fg = e->d_bg = nullptr;
+  e->bgstate = e->bgstate2 = nullptr, e->mog1_state = nullptr, e->mog2_state = nullptr, e->mog2_nmodes = nullptr, e->d_in = e->d_fg = e->d_bg = nullptr;
   void* host[] = {e->h_in, e->h_fg, e->h_bg};
   for (void* h : host)
     if (h) (void)hipHostFree(h);
@@ -252,11 +258,19 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
     case BGS_WMV: e->nring = 3; break;
     case BGS_STATIC_FRAME_DIFF:
     case BGS_ABL: e->state_ch = ch; break;
+    case BGS_ASBL: e->state_ch = 1; break;
+    case BGS_MOG1:
     case BGS_MOG2: break;
     default: return fail(BGS_ERR_UNSUPPORTED, "algorithm %d is not implemented in this build", (int)e->algo);
   }
   for (int i = 0; i < e->nring; ++i) HIP_TRY(hipMalloc((void**)&e->ring[i], fb));
   if (e->state_ch) HIP_TRY(hipMalloc((void**)&e->bgstate, P * e->state_ch));
+  if (e->algo == BGS_ASBL) HIP_TRY(hipMalloc((void**)&e->bgstate2, P));
+  if (e->algo == BGS_MOG1) {
+    const size_t planes = ch == 3 ? bgs::mog1_planes<3>() : bgs::mog1_planes<1>();
+    const size_t tiles = (P + bgs::kMog1Tile - 1) / bgs::kMog1Tile;
+    HIP_TRY(hipMalloc((void**)&e->mog1_state, tiles * planes * bgs::kMog1Tile * sizeof(float)));
+  }
   if (!e->stream) HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   if (e->algo == BGS_MOG2) {
     int rc = mog2_allocate(e);
@@ -392,6 +406,74 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
       flags = BGS_FG_VALID | BGS_BG_VALID;
       break;
     }
+    case BGS_ASBL: {
+      const int cur = e->flip[first];
+      for (int i = first; i < first + count; ++i)
+        if (e->flip[i] != cur) return fail(BGS_ERR_INVALID, "streams %d and %d are not in lock-step", first, i);
+      uint8_t* bufs[2] = {e->bgstate, e->bgstate2};
+      if (t == 0) {  // img_input(gray).copyTo(img_background): a frame of threshold -1 ... simplest exact way is a tiny gray kernel
+        bgs::FrameArgs g{};
+        g.cur = d_frames, g.fg = bufs[cur] + off, g.npix = npix, g.enable_thr = 0;
+        const int G = 1;
+        bgs::FrameArgs a = g;  // LAUNCH_FRAME_KERNEL reads `a`
+        LAUNCH_FRAME_KERNEL(gray_kernel, "gray_kernel");
+      }
+      bgs::AsblArgs q{};
+      q.frame = d_frames, q.bg_in = bufs[cur] + off, q.bg_out = bufs[cur ^ 1] + off, q.fg = d_fg, q.bg_img = d_bg;
+      q.rows = e->rows, q.cols = e->cols, q.thr = p.threshold;
+      const int64_t cnt = e->counter[first];
+      q.learn = (p.learning_frames > 0 && cnt <= p.learning_frames) ? 1 : 0;
+      q.aL = p.alpha_learn, q.bL = 1 - p.alpha_learn, q.aD = p.alpha_detection, q.bD = 1 - p.alpha_detection;
+      {
+        Timed tm(e, s, "asbl_kernel");
+        const dim3 grid((e->cols + bgs::kAsblTW - 1) / bgs::kAsblTW, (e->rows + bgs::kAsblTH - 1) / bgs::kAsblTH, count);
+        if (C == 3)
+          hipLaunchKernelGGL((bgs::asbl_kernel<3>), grid, dim3(bgs::kBlock), 0, s, q);
+        else
+          hipLaunchKernelGGL((bgs::asbl_kernel<1>), grid, dim3(bgs::kBlock), 0, s, q);
+      }
+      for (int i = first; i < first + count; ++i) {
+        e->flip[i] = (uint8_t)(cur ^ 1);
+        if (q.learn) e->counter[i]++;
+      }
+      flags = BGS_FG_VALID | BGS_BG_VALID;
+      break;
+    }
+    case BGS_MOG1: {
+      double lr = p.alpha;
+      int64_t nframes = t;
+      bgs::Mog1Args m{};
+      m.state = e->mog1_state, m.state_off = off, m.npix = npix;
+      if (nframes == 0 || lr >= 1) {  // needToInitialize: bgmodel = zeros
+        if (C == 3)
+          hipLaunchKernelGGL((bgs::mog1_clear_kernel<3>), dim3(blocks_for(npix)), dim3(bgs::kBlock), 0, s, m);
+        else
+          hipLaunchKernelGGL((bgs::mog1_clear_kernel<1>), dim3(blocks_for(npix)), dim3(bgs::kBlock), 0, s, m);
+        nframes = 0;
+      }
+      ++nframes;
+      lr = (lr >= 0 && nframes > 1) ? lr : 1. / (double)std::min<int64_t>(nframes, p.mog1_history);
+      const double defaultNoiseSigma = 30 * 0.5;
+      m.frame = d_frames, m.fg = d_fg, m.fg_bits = d_bits;
+      m.alpha = (float)lr, m.T = (float)p.mog1_background_ratio, m.vT = (float)p.mog1_var_threshold;
+      m.w0 = (float)0.05;
+      m.sk0 = C == 3 ? (float)(m.w0 / (defaultNoiseSigma * 2 * std::sqrt(3.))) : (float)(m.w0 / (defaultNoiseSigma * 2));
+      m.var0 = (float)(defaultNoiseSigma * defaultNoiseSigma * 4);
+      m.minVar = (float)(p.mog1_noise_sigma * p.mog1_noise_sigma);
+      m.thr = p.threshold, m.enable_thr = p.enable_threshold, m.packed = d_bits != nullptr, m.xcd_swizzle = e->xcd_swizzle;
+      {
+        Timed tm(e, s, "mog1_update_kernel");
+        const bool px2 = npix % 2 == 0 && off % 2 == 0;
+        const dim3 grid(blocks_for(px2 ? npix / 2 : npix)), block(bgs::kBlock);
+        if (C == 3 && px2) hipLaunchKernelGGL((bgs::mog1_update_kernel<3, 2>), grid, block, 0, s, m);
+        if (C == 3 && !px2) hipLaunchKernelGGL((bgs::mog1_update_kernel<3, 1>), grid, block, 0, s, m);
+        if (C == 1 && px2) hipLaunchKernelGGL((bgs::mog1_update_kernel<1, 2>), grid, block, 0, s, m);
+        if (C == 1 && !px2) hipLaunchKernelGGL((bgs::mog1_update_kernel<1, 1>), grid, block, 0, s, m);
+      }
+      for (int i = first; i < first + count; ++i) e->seen[i] = nframes - 1;
+      flags = BGS_FG_VALID;  // BackgroundSubtractorMOG has no getBackgroundImage (MixtureOfGaussianV1BGS.cpp:53)
+      break;
+    }
     case BGS_MOG2: {
       double lr = p.alpha;
       int64_t nframes = t;
@@ -502,6 +584,7 @@ int bgs_create(bgs_algo algo, const bgs_params* params, int hip_device, int n_st
   e->S = n_streams;
   e->seen.assign(n_streams, 0);
   e->counter.assign(n_streams, 0);
+  e->flip.assign(n_streams, 0);
   if (const char* env = getenv("BGS_MOG2_PX")) e->mog2_px = atoi(env);
   if (const char* env = getenv("BGS_MOG2_LAYOUT")) e->mog2_tiled = strcmp(env, "planar") != 0;
   if (const char* env = getenv("BGS_XCD_SWIZZLE")) e->xcd_swizzle = atoi(env);
@@ -589,7 +672,7 @@ int bgs_process(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols
   rc = process_range(e, stream, 1, dst, fg ? e->d_fg : nullptr, bg ? e->d_bg : nullptr, nullptr, e->stream, &flags);
   e->borrow = saved_borrow;
   if (rc) return rc;
-  const int bg_ch = channels;
+  const int bg_ch = e->algo == BGS_ASBL ? 1 : channels;
   if (fg && (flags & BGS_FG_VALID)) HIP_TRY(hipMemcpyAsync(e->h_fg, e->d_fg, e->n, hipMemcpyDeviceToHost, e->stream));
   if (bg && (flags & BGS_BG_VALID)) HIP_TRY(hipMemcpyAsync(e->h_bg, e->d_bg, e->n * bg_ch, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
@@ -648,6 +731,29 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
       return (int64_t)need;
     }
   }
+  if (e->algo == BGS_MOG1) {
+    const int R = 2 + 2 * C, NP = bgs::kMog1K * R;
+    int f0 = -1, nf = 0;  // field offset inside a mode record, floats per mode
+    if (!strcmp(plane, "sortkey")) f0 = 0, nf = 1;
+    if (!strcmp(plane, "w")) f0 = 1, nf = 1;
+    if (!strcmp(plane, "mu")) f0 = 2, nf = C;
+    if (!strcmp(plane, "var")) f0 = 2 + C, nf = C;
+    if (f0 >= 0) {
+      const size_t need = (size_t)bgs::kMog1K * nf * n * 4;
+      if (cap < need) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
+      const size_t T = bgs::kMog1Tile, TF = (size_t)NP * T, t0 = off / T, t1 = (off + n + T - 1) / T;
+      std::vector<float> tiles((t1 - t0) * TF);
+      if (hipMemcpy(tiles.data(), e->mog1_state + t0 * TF, tiles.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+      for (size_t i = 0; i < n; ++i) {
+        const size_t sp = off + i;
+        const float* tb = tiles.data() + (sp / T - t0) * TF + sp % T;
+        for (int k = 0; k < bgs::kMog1K; ++k)
+          for (int c = 0; c < nf; ++c) ((float*)dst)[((size_t)k * nf + c) * n + i] = tb[(size_t)(k * R + f0 + c) * T];
+      }
+      return (int64_t)need;
+    }
+  }
+  if (!strcmp(plane, "bg") && e->algo == BGS_ASBL) return copy_bytes((e->flip[stream] ? e->bgstate2 : e->bgstate) + off, n);
   if (!strcmp(plane, "bg") && e->bgstate) return copy_bytes(e->bgstate + off * e->state_ch, n * e->state_ch);
   const int64_t t = e->seen[stream];
   if (!strcmp(plane, "prev1") && e->nring && t >= 1) return copy_bytes(e->ring[(t - 1) % e->nring] + off * C, n * C);
@@ -695,7 +801,48 @@ void bgs_destroy(bgs_engine* e) {
   delete e;
 }
 
-int bgs_lbsp_describe_device(int, const void*, int, int, int, const uint8_t*, void*, void*) { return fail(BGS_ERR_UNSUPPORTED, "not implemented in this build"); }
-int bgs_mask_morph_device(int, const void*, void*, int, int, int, int, int, void*) { return fail(BGS_ERR_UNSUPPORTED, "not implemented in this build"); }
+int bgs_lbsp_describe_device(int hip_device, const void* d_img, int rows, int cols, int channels, const uint8_t* t_lut, void* d_desc, void* hip_stream) {
+  if (!d_img || !d_desc || !t_lut || rows <= 0 || cols <= 0) return fail(BGS_ERR_INVALID, "bad argument");
+  if (channels != 1 && channels != 3) return fail(BGS_ERR_UNSUPPORTED, "channels must be 1 or 3");
+  if (!aligned(d_img, 4)) return fail(BGS_ERR_INVALID, "image must be 4-byte aligned");
+  HIP_TRY(hipSetDevice(hip_device));
+  bgs::LbspArgs a{};
+  a.img = (const uint8_t*)d_img, a.desc = (uint16_t*)d_desc, a.rows = rows, a.cols = cols;
+  std::memcpy(a.lut, t_lut, 256);
+  const dim3 grid((cols + bgs::kLbspTW - 1) / bgs::kLbspTW, (rows + bgs::kLbspTH - 1) / bgs::kLbspTH, 1);
+  if (channels == 3)
+    hipLaunchKernelGGL((bgs::lbsp_kernel<3>), grid, dim3(bgs::kBlock), 0, (hipStream_t)hip_stream, a);
+  else
+    hipLaunchKernelGGL((bgs::lbsp_kernel<1>), grid, dim3(bgs::kBlock), 0, (hipStream_t)hip_stream, a);
+  HIP_TRY(hipGetLastError());
+  return BGS_OK;
+}
+
+int bgs_mask_morph_device(int hip_device, const void* d_src, void* d_dst, int rows, int cols, int op, int ksize, int iterations, void* hip_stream) {
+  if (!d_src || !d_dst || rows <= 0 || cols <= 0 || op < 0 || op > 2 || iterations < 1) return fail(BGS_ERR_INVALID, "bad argument");
+  if (op == 2 && (ksize < 3 || ksize > 2 * bgs::kMorphMaxR + 1 || ksize % 2 == 0)) return fail(BGS_ERR_INVALID, "median ksize must be odd, 3..15");
+  if (d_src == d_dst) return fail(BGS_ERR_INVALID, "in-place morphology is not supported");
+  HIP_TRY(hipSetDevice(hip_device));
+  hipStream_t s = (hipStream_t)hip_stream;
+  const size_t n = (size_t)rows * cols;
+  uint8_t* tmp = nullptr;
+  if (iterations > 1) HIP_TRY(hipMalloc((void**)&tmp, n));
+  const dim3 grid((cols + bgs::kMorphTW - 1) / bgs::kMorphTW, (rows + bgs::kMorphTH - 1) / bgs::kMorphTH, 1);
+  const uint8_t* in = (const uint8_t*)d_src;
+  for (int i = 0; i < iterations; ++i) {
+    // alternate so that the last iteration lands in d_dst
+    uint8_t* out = ((iterations - 1 - i) % 2 == 0) ? (uint8_t*)d_dst : tmp;
+    bgs::MorphArgs a{in, out, rows, cols, op, ksize};
+    hipLaunchKernelGGL(bgs::morph_kernel, grid, dim3(bgs::kBlock), 0, s, a);
+    in = out;
+  }
+  hipError_t er = hipGetLastError();
+  if (tmp) {
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(tmp);
+  }
+  if (er != hipSuccess) return fail(BGS_ERR_HIP, "morph kernel launch failed: %s", hipGetErrorString(er));
+  return BGS_OK;
+}
 
 }  // extern "C"

@@ -1,0 +1,233 @@
+// kernel_mog1.h — K5: MixtureOfGaussianV1BGS (cv::BackgroundSubtractorMOG, KaewTraKulPong-Bowden) update + classify.
+//
+// Replaces  MixtureOfGaussianV1BGS::process  package_bgs/MixtureOfGaussianV1BGS.cpp:51-56
+// Algorithm: OpenCV 2.4 bgfg_gaussmix.cpp process8uC3 / process8uC1: scan the modes in sortKey
+// order until an empty one (w < FLT_EPSILON) or a match (d2 < vT * sum(var)); update the match and bubble it up by
+// sortKey = w_old / sqrt(sum var); otherwise replace the weakest; renormalise; foreground iff the hit lies past the
+// background prefix (cumulative weight > T).
+//
+// Layout: tiled AoSoA like MOG2 (kernel_mog2.h): tile = 256 pixels x NP planes, NP = K*(2+2C) floats per pixel
+// (40 for BGR, 20 for gray); plane index of mode k: sortKey = k*R, weight = k*R+1, mean[c] = k*R+2+c, var[c] = k*R+2+C+c.
+// One lane owns PX = 2 consecutive pixels (8-byte accesses; 40 floats x 2 px already fill 80 VGPRs).
+// Algorithmic traffic (BGR): r 3 + 160, w 160 + 1 = 324 B/pixel/frame — HBM-bound, no MFMA, no LDS.
+#pragma once
+#include <cfloat>
+
+#include "bgs_device.h"
+
+namespace bgs {
+
+constexpr int kMog1K = 5;
+constexpr int kMog1Tile = 256;
+
+struct Mog1Args {
+  const uint8_t* frame;  // [P][C]
+  uint8_t* fg;           // [P] or null
+  uint64_t* fg_bits;     // [P/64] or null
+  float* state;          // tiles of 256 px x NP planes
+  size_t state_off, npix;
+  float alpha, T, vT, w0, sk0, var0, minVar;
+  int thr, enable_thr, packed, xcd_swizzle;
+};
+
+template <int C>
+struct Mog1Px {
+  float sk[kMog1K], w[kMog1K], mu[kMog1K][C], var[kMog1K][C];
+};
+
+template <int C>
+__device__ __forceinline__ void mog1_swap(Mog1Px<C>& s, int i, int j) {
+  float t;
+  t = s.sk[i], s.sk[i] = s.sk[j], s.sk[j] = t;
+  t = s.w[i], s.w[i] = s.w[j], s.w[j] = t;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    t = s.mu[i][c], s.mu[i][c] = s.mu[j][c], s.mu[j][c] = t;
+    t = s.var[i][c], s.var[i][c] = s.var[j][c], s.var[j][c] = t;
+  }
+}
+
+template <int C>
+__device__ __forceinline__ float mog1_varsum(const Mog1Px<C>& s, int k) {
+  if constexpr (C == 3)
+    return s.var[k][0] + s.var[k][1] + s.var[k][2];
+  else
+    return s.var[k][0];
+}
+
+// one pixel, same statement order as process8uC3 so every float rounds identically; returns 0 / 255
+template <int C>
+__device__ __forceinline__ int mog1_pixel(Mog1Px<C>& s, const float (&pix)[C], const Mog1Args& a) {
+  constexpr int K = kMog1K;
+  int kHit = -1, kForeground = -1;
+  if (a.alpha > 0) {
+    float wsum = 0;
+    bool done = false;
+    int k_end = K;  // value of the scan index when the reference's first loop exits
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (!done) {
+        const float w = s.w[k];
+        wsum += w;
+        if (w < FLT_EPSILON) {
+          done = true, k_end = k;
+        } else {
+          float diff[C], d2 = 0;
+#pragma unroll
+          for (int c = 0; c < C; ++c) diff[c] = pix[c] - s.mu[k][c], d2 += diff[c] * diff[c];
+          if (d2 < a.vT * mog1_varsum<C>(s, k)) {
+            wsum -= w;
+            const float dw = a.alpha * (1.f - w);
+            s.w[k] = w + dw;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+              s.mu[k][c] = s.mu[k][c] + a.alpha * diff[c];
+              const float v = s.var[k][c] + a.alpha * (diff[c] * diff[c] - s.var[k][c]);
+              s.var[k][c] = v > a.minVar ? v : a.minVar;
+            }
+            s.sk[k] = div_rn(w, sqrt_rn(mog1_varsum<C>(s, k)));  // sic: the OLD weight
+            bool moving = true;
+            int pos = k;
+#pragma unroll
+            for (int k1 = k - 1; k1 >= 0; --k1) {
+              moving = moving && !(s.sk[k1] >= s.sk[k1 + 1]);
+              if (moving) mog1_swap<C>(s, k1, k1 + 1), pos = k1;
+            }
+            kHit = pos;
+            done = true, k_end = k;
+          }
+        }
+      }
+    }
+    if (kHit < 0) {  // no match: replace the first empty mode, else the last one
+      const int kk = k_end < K - 1 ? k_end : K - 1;
+      kHit = kk;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        if (k == kk) {
+          wsum += a.w0 - s.w[k];
+          s.w[k] = a.w0;
+#pragma unroll
+          for (int c = 0; c < C; ++c) s.mu[k][c] = pix[c], s.var[k][c] = a.var0;
+          s.sk[k] = a.sk0;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if (k >= k_end) wsum += s.w[k];
+    }
+    const float wscale = div_rn(1.f, wsum);
+    wsum = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      s.w[k] *= wscale;
+      wsum += s.w[k];
+      s.sk[k] *= wscale;
+      if (wsum > a.T && kForeground < 0) kForeground = k + 1;
+    }
+    return kHit >= kForeground ? 255 : 0;
+  }
+  // learning rate 0: classify only
+  bool done = false;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if (!done) {
+      if (s.w[k] < FLT_EPSILON) {
+        done = true;
+      } else {
+        float d2 = 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float d = pix[c] - s.mu[k][c];
+          d2 += d * d;
+        }
+        if (d2 < a.vT * mog1_varsum<C>(s, k)) kHit = k, done = true;
+      }
+    }
+  }
+  if (kHit >= 0) {
+    float wsum = 0;
+    bool stop = false;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (!stop) {
+        wsum += s.w[k];
+        if (wsum > a.T) kForeground = k + 1, stop = true;
+      }
+    }
+  }
+  return (kHit < 0 || kHit >= kForeground) ? 255 : 0;
+}
+
+template <int C>
+__host__ __device__ constexpr int mog1_planes() { return kMog1K * (2 + 2 * C); }
+
+template <int C>
+__device__ __forceinline__ size_t mog1_plane_off(int p, size_t sp) {
+  return (sp >> 8) * (size_t)(mog1_planes<C>() * kMog1Tile) + (size_t)p * kMog1Tile + (sp & 255);
+}
+
+// grid: ceil(npix / PX / kBlock); npix % PX == 0 and state_off % PX == 0 (host picks PX = 1 otherwise)
+template <int C, int PX>
+__global__ __launch_bounds__(kBlock) void mog1_update_kernel(const Mog1Args a) {
+  constexpr int K = kMog1K, R = 2 + 2 * C, NP = K * R;
+  size_t blk = blockIdx.x;
+  if (a.xcd_swizzle) {  // each XCD streams one contiguous eighth of the launch (see kernel_mog2.h)
+    const size_t per = gridDim.x >> 3, main = per << 3;
+    if (blk < main) blk = (blk & 7) * per + (blk >> 3);
+  }
+  const size_t p0 = (blk * kBlock + threadIdx.x) * PX;
+  const bool active = p0 < a.npix;
+  uint32_t bits = 0;
+  if (active) {
+    const size_t sp = a.state_off + p0;
+    float st[NP][PX];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) load_f<PX>(a.state + mog1_plane_off<C>(q, sp), st[q]);
+    uint8_t px[PX * C];
+#pragma unroll
+    for (int i = 0; i < PX * C; ++i) px[i] = a.frame[p0 * C + i];
+    uint32_t mword = 0;
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+      Mog1Px<C> s;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        s.sk[k] = st[k * R][j], s.w[k] = st[k * R + 1][j];
+#pragma unroll
+        for (int c = 0; c < C; ++c) s.mu[k][c] = st[k * R + 2 + c][j], s.var[k][c] = st[k * R + 2 + C + c][j];
+      }
+      float pix[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) pix[c] = (float)px[j * C + c];
+      const int m = thr_bin(mog1_pixel<C>(s, pix, a), a.thr, a.enable_thr);
+      mword |= (uint32_t)m << (8 * j);
+      bits |= (uint32_t)(m != 0) << j;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        st[k * R][j] = s.sk[k], st[k * R + 1][j] = s.w[k];
+#pragma unroll
+        for (int c = 0; c < C; ++c) st[k * R + 2 + c][j] = s.mu[k][c], st[k * R + 2 + C + c][j] = s.var[k][c];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NP; ++q) store_f<PX>(a.state + mog1_plane_off<C>(q, sp), st[q]);
+    if (a.fg) {
+#pragma unroll
+      for (int j = 0; j < PX; ++j) a.fg[p0 + j] = (uint8_t)(mword >> (8 * j));
+    }
+  }
+  if (a.packed) store_packed_mask<PX>(a.fg_bits, p0, bits, active);
+}
+
+template <int C>
+__global__ __launch_bounds__(kBlock) void mog1_clear_kernel(const Mog1Args a) {
+  const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= a.npix) return;
+  const size_t sp = a.state_off + p;
+#pragma unroll
+  for (int q = 0; q < mog1_planes<C>(); ++q) a.state[mog1_plane_off<C>(q, sp)] = 0.f;
+}
+
+}  // namespace bgs

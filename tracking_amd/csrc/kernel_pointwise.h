@@ -87,6 +87,16 @@ __global__ __launch_bounds__(kBlock) void framediff_kernel(const FrameArgs a) {
   gray_thr_store<G, C>(d, a, p0, active, a.fg_bits != nullptr);
 }
 
+// cv::cvtColor(BGR2GRAY) / copy of a 1-channel frame into a.fg (AdaptiveSelectiveBackgroundLearning.cpp:37-40, :47-48)
+template <int G, int C>
+__global__ __launch_bounds__(kBlock) void gray_kernel(const FrameArgs a) {
+  const size_t p0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * G;
+  const bool active = p0 < a.npix;
+  PxGroup<G, C> d;
+  if (active) d.load(a.cur + p0 * C);
+  gray_thr_store<G, C>(d, a, p0, active, false);
+}
+
 // the f32 image the reference builds with convertTo(CV_32F, 1./255.)
 __device__ __forceinline__ float to_unit(int v) { return (float)v * (float)(1. / 255.); }
 

@@ -1,0 +1,217 @@
+// kernel_stencil.h — the kernels with a spatial neighbourhood, staged through LDS.
+//
+//   K3b asbl_kernel   AdaptiveSelectiveBackgroundLearning::process  package_bgs/AdaptiveSelectiveBackgroundLearning.cpp:37-94
+//                     gray -> |I-B| -> threshold -> 3x3 median (BORDER_REPLICATE) -> selective running average, one launch.
+//   K7  lbsp_kernel   LBSP::computeRGBDescriptor / computeGrayscaleDescriptor  package_bgs/pl/LBSP.h:50-71
+//                     with the bit order of LBSP_16bits_dbcross_{3ch3t,1ch}.i:27-43 and the per-centre threshold LUT of
+//                     BackgroundSubtractorSuBSENSE.cpp:209-210, 227-228.
+//   K9  morph / median kernels  (cv::erode / cv::dilate 3x3, cv::medianBlur k) for the post-processing chain of
+//                     BackgroundSubtractorSuBSENSE.cpp:624-640.
+//
+// Mapping: one workgroup = one TW x TH output tile of one image (blockIdx.z = image of the batch); the tile plus its
+// halo is loaded once into LDS with coalesced dword loads, every output is then computed from LDS.
+#pragma once
+#include "bgs_device.h"
+
+namespace bgs {
+
+// ----------------------------------------------------------------------------------------------------- ASBL
+struct AsblArgs {
+  const uint8_t* frame;    // [S][rows][cols][C]
+  const uint8_t* bg_in;    // [S][rows][cols] gray background (previous)
+  uint8_t* bg_out;         // [S][rows][cols] updated background (other buffer of the ping-pong pair)
+  uint8_t* fg;             // [S][rows][cols] or null
+  uint8_t* bg_img;         // [S][rows][cols] or null (copy of bg_out for the caller)
+  int rows, cols, thr, learn;
+  double aL, bL, aD, bD;   // alphaLearn, 1-alphaLearn, alphaDetection, 1-alphaDetection
+};
+
+constexpr int kAsblTW = 64, kAsblTH = 4;  // one lane per pixel, 256 lanes
+
+template <int C>
+__device__ __forceinline__ int asbl_gray(const uint8_t* p) {
+  if constexpr (C == 3)
+    return gray_bgr(p[0], p[1], p[2]);
+  else
+    return p[0];
+}
+
+template <int C>
+__global__ __launch_bounds__(kBlock) void asbl_kernel(const AsblArgs a) {
+  __shared__ uint8_t raw[kAsblTH + 2][kAsblTW + 2 + 2];  // thresholded |I-B| of the tile + 1-pixel halo
+  const int x0 = blockIdx.x * kAsblTW, y0 = blockIdx.y * kAsblTH;
+  const size_t img = (size_t)blockIdx.z * a.rows * a.cols;
+  const uint8_t* frame = a.frame + img * C;
+  const uint8_t* bg = a.bg_in + img;
+  const float sf = (float)(1. / 255.);
+  // raw mask for the halo'd tile; out-of-image cells replicate the nearest pixel (BORDER_REPLICATE)
+  for (int i = threadIdx.x; i < (kAsblTH + 2) * (kAsblTW + 2); i += kBlock) {
+    const int ly = i / (kAsblTW + 2), lx = i - ly * (kAsblTW + 2);
+    int y = y0 + ly - 1, x = x0 + lx - 1;
+    y = min(max(y, 0), a.rows - 1), x = min(max(x, 0), a.cols - 1);
+    const size_t p = (size_t)y * a.cols + x;
+    const float d = fabsf((float)asbl_gray<C>(frame + p * C) * sf - (float)bg[p] * sf);  // :50-57
+    raw[ly][lx] = (uint8_t)(sat_u8(d * 255.f) > a.thr ? 255 : 0);                          // :59-62
+  }
+  __syncthreads();
+  const int lx = threadIdx.x % kAsblTW, ly = threadIdx.x / kAsblTW;
+  const int x = x0 + lx, y = y0 + ly;
+  if (x >= a.cols || y >= a.rows) return;
+  // cv::medianBlur(k=3) of a {0,255} image = majority of the 9 cells
+  int cnt = 0;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) cnt += raw[ly + dy][lx + dx] != 0;
+  const int m = cnt >= 5 ? 255 : 0;
+  const size_t p = (size_t)y * a.cols + x;
+  const float i_f = (float)asbl_gray<C>(frame + p * C) * sf;
+  float b_f = (float)bg[p] * sf;
+  if (a.learn)
+    b_f = add_weighted(i_f, a.aL, b_f, a.bL);  // :69  (MatExpr -> addWeighted)
+  else if (m == 0)
+    b_f = (float)__dadd_rn(__dmul_rn(a.aD, (double)i_f), __dmul_rn(a.bD, (double)b_f));  // :83-86 scalar double expression
+  const int b8 = sat_u8(b_f * 255.f);  // :92-94
+  a.bg_out[img + p] = (uint8_t)b8;
+  if (a.bg_img) a.bg_img[img + p] = (uint8_t)b8;
+  if (a.fg) a.fg[img + p] = (uint8_t)m;
+}
+
+// ----------------------------------------------------------------------------------------------------- LBSP
+struct LbspArgs {
+  const uint8_t* img;  // [S][rows][cols][C]
+  uint16_t* desc;      // [S][rows][cols][C]
+  int rows, cols;
+  uint8_t lut[256];    // absolute threshold per centre value
+};
+
+constexpr int kLbspTW = 64, kLbspTH = 16;  // output tile; 256 lanes, each 4 rows of one column
+
+// bit 15..0 -> (dx, dy) of LBSP_16bits_dbcross_3ch3t.i:27-43
+__device__ __constant__ const int8_t kLbspDx[16] = {-1, 1, 1, -1, 1, 0, -1, 0, -2, 2, 2, -2, 0, 0, 2, -2};
+__device__ __constant__ const int8_t kLbspDy[16] = {1, -1, 1, -1, 0, -1, 0, 1, -2, 2, -2, 2, 2, -2, 0, 0};
+
+template <int C>
+__global__ __launch_bounds__(kBlock) void lbsp_kernel(const LbspArgs a) {
+  constexpr int HW = kLbspTW + 4, HH = kLbspTH + 4;   // tile + 2-pixel halo
+  constexpr int ROWB = (HW * C + 3 + 3) / 4 * 4;       // LDS row pitch in bytes (room for the alignment shift)
+  __shared__ uint32_t tile[HH][ROWB / 4];
+  const int x0 = blockIdx.x * kLbspTW, y0 = blockIdx.y * kLbspTH;
+  const size_t imgsz = (size_t)a.rows * a.cols * C;
+  const uint8_t* img = a.img + (size_t)blockIdx.z * imgsz;
+  // byte range of one halo'd row inside the image row: [(x0-2)*C, (x0+TW+2)*C), loaded as aligned dwords
+  const long rb = (long)(x0 - 2) * C;
+  for (int i = threadIdx.x; i < HH * (ROWB / 4); i += kBlock) {
+    const int ry = i / (ROWB / 4), rd = i - ry * (ROWB / 4);
+    const int y = min(max(y0 + ry - 2, 0), a.rows - 1);
+    const long row0 = (long)y * a.cols * C;
+    const long a0 = (row0 + rb) & ~3L;  // aligned-down start of this row's span (may be < 0 only for the very first bytes)
+    const long off = a0 + 4L * rd;
+    uint32_t v = 0;
+    if (off >= 0 && off + 4 <= (long)imgsz)
+      v = *reinterpret_cast<const uint32_t*>(img + off);
+    else if (off < (long)imgsz && off + 4 > 0) {  // dword straddling the buffer edge: byte by byte
+      for (int b = 0; b < 4; ++b)
+        if (off + b >= 0 && off + b < (long)imgsz) v |= (uint32_t)img[off + b] << (8 * b);
+    }
+    tile[ry][rd] = v;
+  }
+  __syncthreads();
+  const int lx = threadIdx.x % kLbspTW, lyq = threadIdx.x / kLbspTW;  // lyq in 0..3: rows lyq*4 .. lyq*4+3
+  const int x = x0 + lx;
+  if (x >= a.cols) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ly = lyq * 4 + r, y = y0 + ly;
+    if (y >= a.rows) break;
+    uint16_t* out = a.desc + (size_t)blockIdx.z * imgsz + ((size_t)y * a.cols + x) * C;
+    const bool interior = x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2;  // LBSP::validateROI
+    if (!interior) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) out[c] = 0;
+      continue;
+    }
+    auto at = [&](int ry, int rx, int c) -> int {  // pixel (ry, rx) of the halo'd tile, channel c
+      const uint8_t* rowp = reinterpret_cast<const uint8_t*>(tile[ry]);
+      const long row0 = (long)(y0 + ry - 2) * a.cols * C;  // interior pixels only read unclamped rows
+      const int shift = (int)((row0 + rb) & 3L);
+      return rowp[shift + rx * C + c];
+    };
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int ref = at(ly + 2, lx + 2, c);
+      const int t = a.lut[ref];
+      unsigned res = 0;
+#pragma unroll
+      for (int b = 0; b < 16; ++b) {
+        const int v = at(ly + 2 + kLbspDy[b], lx + 2 + kLbspDx[b], c);
+        res |= (unsigned)(abs(v - ref) > t) << (15 - b);
+      }
+      out[c] = (uint16_t)res;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------- mask morphology
+struct MorphArgs {
+  const uint8_t* src;
+  uint8_t* dst;
+  int rows, cols, op, ksize;  // op 0 erode3x3, 1 dilate3x3, 2 median(ksize)
+};
+
+constexpr int kMorphTW = 64, kMorphTH = 4, kMorphMaxR = 7;  // median up to 15x15
+
+// 3x3 erode/dilate: border cells outside the image do not take part (morphologyDefaultBorderValue);
+// median: BORDER_REPLICATE.  Masks are {0,255} in the SuBSENSE chain but any u8 image is handled.
+__global__ __launch_bounds__(kBlock) void morph_kernel(const MorphArgs a) {
+  __shared__ uint8_t t[kMorphTH + 2 * kMorphMaxR][kMorphTW + 2 * kMorphMaxR + 2];
+  const int R = a.op == 2 ? a.ksize / 2 : 1;
+  const int x0 = blockIdx.x * kMorphTW, y0 = blockIdx.y * kMorphTH;
+  const size_t img = (size_t)blockIdx.z * a.rows * a.cols;
+  const int HW = kMorphTW + 2 * R, HH = kMorphTH + 2 * R;
+  for (int i = threadIdx.x; i < HW * HH; i += kBlock) {
+    const int ly = i / HW, lx = i - ly * HW;
+    const int y = y0 + ly - R, x = x0 + lx - R;
+    uint8_t v;
+    if (a.op == 2) {
+      v = a.src[img + (size_t)min(max(y, 0), a.rows - 1) * a.cols + min(max(x, 0), a.cols - 1)];
+    } else {
+      const bool in = y >= 0 && y < a.rows && x >= 0 && x < a.cols;
+      v = in ? a.src[img + (size_t)y * a.cols + x] : (a.op == 0 ? 255 : 0);
+    }
+    t[ly][lx] = v;
+  }
+  __syncthreads();
+  const int lx = threadIdx.x % kMorphTW, ly = threadIdx.x / kMorphTW;
+  const int x = x0 + lx, y = y0 + ly;
+  if (x >= a.cols || y >= a.rows) return;
+  int out;
+  if (a.op == 2) {
+    // exact median by counting: the value v such that #(<= v) first reaches (k*k)/2 + 1; binary search over 8 bits
+    const int need = (a.ksize * a.ksize) / 2 + 1;
+    int lo = 0, hi = 255;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      int cnt = 0;
+      for (int dy = 0; dy <= 2 * R; ++dy)
+        for (int dx = 0; dx <= 2 * R; ++dx) cnt += t[ly + dy][lx + dx] <= mid;
+      if (cnt >= need)
+        hi = mid;
+      else
+        lo = mid + 1;
+    }
+    out = lo;
+  } else {
+    out = a.op == 0 ? 255 : 0;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int v = t[ly + dy][lx + dx];
+        out = a.op == 0 ? min(out, v) : max(out, v);
+      }
+  }
+  a.dst[img + (size_t)y * a.cols + x] = (uint8_t)out;
+}
+
+}  // namespace bgs

@@ -113,3 +113,33 @@ class Engine:
         ms, n, name = C.c_double(0), C.c_int64(0), C.c_char_p()
         capi.check(capi.lib().bgs_kernel_timing(self._h, C.byref(ms), C.byref(n), C.byref(name)))
         return ms.value, n.value, (name.value or b"").decode()
+
+
+# -- stand-alone device primitives ---------------------------------------------------------------------------------
+def lbsp_describe_device(img, lut, out=None, device=0, hip_stream=None):
+    """img: torch CUDA uint8 [rows][cols][C] (or [rows][cols]); lut: 256 uint8 thresholds (numpy).  Returns uint16 descriptors."""
+    import torch
+    rows, cols = img.shape[:2]
+    ch = 1 if img.dim() == 2 else img.shape[2]
+    if out is None:
+        out = torch.empty((rows, cols, ch), dtype=torch.int16, device=img.device)
+    if hip_stream is None:
+        hip_stream = torch.cuda.current_stream().cuda_stream
+    lut = np.ascontiguousarray(lut, dtype=np.uint8)
+    capi.check(capi.lib().bgs_lbsp_describe_device(device, C.c_void_p(img.data_ptr()), rows, cols, ch, lut.ctypes.data_as(C.c_void_p),
+                                                   C.c_void_p(out.data_ptr()), C.c_void_p(hip_stream)))
+    return out
+
+
+MORPH_ERODE, MORPH_DILATE, MORPH_MEDIAN = 0, 1, 2
+
+
+def mask_morph_device(src, op, ksize=3, iterations=1, device=0, hip_stream=None):
+    """src: torch CUDA uint8 [rows][cols].  op: MORPH_ERODE / MORPH_DILATE (3x3, `iterations` times) or MORPH_MEDIAN (ksize)."""
+    import torch
+    rows, cols = src.shape
+    dst = torch.empty_like(src)
+    if hip_stream is None:
+        hip_stream = torch.cuda.current_stream().cuda_stream
+    capi.check(capi.lib().bgs_mask_morph_device(device, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), rows, cols, op, ksize, iterations, C.c_void_p(hip_stream)))
+    return dst
