@@ -1,0 +1,186 @@
+"""CPU tests of the oracle itself (no GPU): golden vectors, the reference-built checkers, the reference's quirks.
+
+What pins what:
+  * LBSP descriptors   — fixture produced by the REFERENCE'S OWN pattern files (oracle/_ref) -> pinned
+  * FrameDifference    — independent integer formula (numpy) written from FrameDifferenceBGS.cpp:45-51
+  * everything else    — regression vectors of the oracle (OpenCV is absent: parity unpinned), plus properties
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from tools import synth
+from tracking_amd import capi
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+UNTOUCHED = 7  # marker make_golden.py stores where the reference leaves the output untouched
+
+
+def test_lbsp_oracle_matches_reference_built_fixture(golden_frames, golden_gray):
+    g = np.load(os.path.join(GOLDEN, "lbsp_ref.npz"))
+    assert np.array_equal(pyoracle.lbsp_lut(0.333, 0, 3), g["lut3"])
+    assert np.array_equal(pyoracle.lbsp_lut(0.333, 0, 1), g["lut1"])
+    assert np.array_equal(pyoracle.lbsp_describe(golden_frames[0], g["lut3"]), g["desc3"])
+    assert np.array_equal(pyoracle.lbsp_describe(golden_frames[7], g["lut3"]), g["desc3_f7"])
+    assert np.array_equal(pyoracle.lbsp_describe(golden_gray[0], g["lut1"])[:, :, 0], g["desc1"])
+
+
+@pytest.mark.skipif(not pyoracle.ref_lbsp_available(), reason="oracle/_ref is built only where /root/reference exists")
+def test_lbsp_oracle_matches_live_reference_build():
+    rng = np.random.default_rng(1)
+    for ch in (1, 3):
+        img = rng.integers(0, 256, (40, 56) + ((3,) if ch == 3 else ()), dtype=np.uint8)
+        for rel, off in ((0.333, 0), (0.05, 9), (1.0, 0)):
+            lut = pyoracle.lbsp_lut(rel, off, ch)
+            assert np.array_equal(pyoracle.lbsp_describe(img, lut), pyoracle.ref_lbsp_describe(img, lut))
+
+
+def test_lbsp_lut_values():
+    lut3, lut1 = pyoracle.lbsp_lut(0.333, 0, 3), pyoracle.lbsp_lut(0.333, 0, 1)
+    assert lut3[0] == 0 and lut3[255] == 85 and lut3[100] == 33       # saturate_cast<uchar>(t*0.333f), half-to-even
+    assert lut1[255] == 28 and lut1[9] == 1                            # (t*0.333f)/3
+
+
+def test_framediff_matches_independent_formula(golden_frames):
+    want = np.load(os.path.join(GOLDEN, "framediff_indep.npz"))["masks"]
+    o = pyoracle.Oracle(capi.FRAME_DIFF)
+    assert o.process(golden_frames[0]) == (None, None)  # first frame: stored, outputs untouched
+    for t in range(1, len(golden_frames)):
+        fg, bg = o.process(golden_frames[t])
+        assert bg is None
+        assert np.array_equal(fg, want[t - 1])
+
+
+@pytest.mark.parametrize("name,algo", [("fd", capi.FRAME_DIFF), ("sfd", capi.STATIC_FRAME_DIFF), ("wmm", capi.WMM), ("wmv", capi.WMV),
+                                       ("abl", capi.ABL), ("asbl", capi.ASBL), ("mog2", capi.MOG2), ("mog1", capi.MOG1)])
+def test_oracle_regression_vectors(name, algo, golden_frames, oracle_regress):
+    o = pyoracle.Oracle(algo)
+    want = oracle_regress[name + "_fg"]
+    bg = None
+    for t, f in enumerate(golden_frames):
+        fg, b = o.process(f)
+        if fg is None:
+            assert (want[t] == UNTOUCHED).all()
+        else:
+            assert np.array_equal(fg, want[t]), (name, t)
+        bg = b if b is not None else bg
+    if name + "_bg_last" in oracle_regress.files:
+        assert np.array_equal(bg, oracle_regress[name + "_bg_last"])
+    if name == "mog2":
+        n = golden_frames.shape[1] * golden_frames.shape[2]
+        assert np.array_equal(o.get_state("w", (5, n), np.float32), oracle_regress["mog2_w"])
+        assert np.array_equal(o.get_state("var", (5, n), np.float32), oracle_regress["mog2_var"])
+        assert np.array_equal(o.get_state("mu", (5, 3, n), np.float32), oracle_regress["mog2_mu"])
+        assert np.array_equal(o.get_state("nmodes", (n,), np.uint8), oracle_regress["mog2_nmodes"])
+
+
+def test_gray_constants():
+    """cv::cvtColor(BGR2GRAY): (B*1868 + G*9617 + R*4899 + 8192) >> 14; weights sum to 2^14 so gray(v,v,v) == v."""
+    v = np.arange(256, dtype=np.uint8)
+    img = np.stack([v, v, v], -1)[None]
+    assert np.array_equal(pyoracle.bgr2gray(img)[0], v)
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255]]], np.uint8)
+    assert pyoracle.bgr2gray(px)[0].tolist() == [29, 150, 76]
+
+
+def test_mog2_first_frame_is_all_foreground(golden_frames):
+    """On frame 1 every pixel spawns its first mode: not background, a == 1 -> shadow(127) -> thresholded to 255."""
+    o = pyoracle.Oracle(capi.MOG2)
+    fg, bg = o.process(golden_frames[0])
+    assert (fg == 255).all()
+    assert np.array_equal(bg, golden_frames[0])  # single mode of weight 1 centred on the pixel
+    p = capi.default_params(capi.MOG2)
+    p.enable_threshold = 0
+    o = pyoracle.Oracle(capi.MOG2, params=p)
+    fg, _ = o.process(golden_frames[0])
+    black = (golden_frames[0] == 0).all(-1)  # detectShadowGMM: "no division by zero allowed" -> not a shadow -> 255
+    assert (fg[~black] == 127).all() and (fg[black] == 255).all()
+
+
+def test_mog2_invariants_on_saturating_clip():
+    frames = synth.numpy_frames("sat", 30, 24, 40, seed=1234)
+    o = pyoracle.Oracle(capi.MOG2)
+    for f in frames:
+        o.process(f, want_bg=False)
+    n = 24 * 40
+    w = o.get_state("w", (5, n), np.float32)
+    var = o.get_state("var", (5, n), np.float32)
+    nm = o.get_state("nmodes", (n,), np.uint8)
+    assert nm.min() == 5, "S_sat must keep all 5 modes alive (it defines the dense 206 B/px traffic model)"
+    assert (np.diff(w, axis=0) <= 0).all()
+    assert (var >= 4).all() and (var <= 75).all()
+
+
+def test_mog2_threads_do_not_change_results(golden_frames):
+    a, b = pyoracle.Oracle(capi.MOG2, threads=1), pyoracle.Oracle(capi.MOG2, threads=4)
+    for f in golden_frames[:8]:
+        fa, ba = a.process(f)
+        fb, bb = b.process(f)
+        assert np.array_equal(fa, fb) and np.array_equal(ba, bb)
+
+
+def test_mog1_first_frame_is_all_background(golden_frames):
+    o = pyoracle.Oracle(capi.MOG1)
+    fg, bg = o.process(golden_frames[0])
+    assert (fg == 0).all() and bg is None  # BackgroundSubtractorMOG has no getBackgroundImage
+
+
+def test_wrapper_quirks(golden_frames):
+    """warm-up outputs untouched; FD/WMV never write a background; ASBL thresholds at 25 and is single-channel."""
+    f = golden_frames
+    o = pyoracle.Oracle(capi.WMV)
+    assert o.process(f[0]) == (None, None) and o.process(f[1]) == (None, None)
+    fg, bg = o.process(f[2])
+    assert fg is not None and bg is None
+    o = pyoracle.Oracle(capi.WMM)
+    assert o.process(f[0]) == (None, None) and o.process(f[1]) == (None, None)
+    fg, bg = o.process(f[2])
+    assert fg is not None and bg.shape == f[0].shape
+    o = pyoracle.Oracle(capi.ASBL)
+    assert o.params.threshold == 25 and o.params.learning_frames == 90
+    fg, bg = o.process(f[0])
+    assert (fg == 0).all() and bg.ndim == 2 and np.array_equal(bg, pyoracle.bgr2gray(f[0]))
+    o = pyoracle.Oracle(capi.STATIC_FRAME_DIFF)
+    fg, bg = o.process(f[0])
+    assert (fg == 0).all() and np.array_equal(bg, f[0])
+    for t in range(1, 5):
+        _, bg = o.process(f[t])
+        assert np.array_equal(bg, f[0])  # frozen first frame
+
+
+def test_abl_state_is_requantised_uint8(golden_frames):
+    """AdaptiveBackgroundLearning keeps its background as uint8 (App. C 4): a constant scene is a fixed point."""
+    o = pyoracle.Oracle(capi.ABL)
+    for _ in range(5):
+        fg, bg = o.process(golden_frames[0])
+        assert np.array_equal(bg, golden_frames[0]) and (fg == 0).all()
+
+
+def test_empty_input_and_geometry_change():
+    o = pyoracle.Oracle(capi.FRAME_DIFF)
+    assert o.process(None) == (None, None)
+    a = synth.random_frames(2, 8, 8, 3, seed=1)
+    o.process(a[0])
+    with pytest.raises(RuntimeError):
+        o.process(a[1][:4])
+
+
+def test_morphology_primitives():
+    m = np.zeros((9, 9), np.uint8)
+    m[3:6, 3:6] = 255
+    assert pyoracle.erode3x3(m)[4, 4] == 255 and pyoracle.erode3x3(m).sum() == 255
+    assert pyoracle.dilate3x3(m)[2:7, 2:7].min() == 255 and pyoracle.dilate3x3(m).sum() == 25 * 255
+    ones = np.full((4, 4), 255, np.uint8)
+    assert (pyoracle.erode3x3(ones, 3) == 255).all()  # outside pixels do not take part in the erosion
+    hole = np.full((7, 7), 255, np.uint8)
+    hole[0, :] = 0
+    hole[3, 3] = 0
+    ff = pyoracle.floodfill_from_origin(hole, 255)
+    assert ff[0, 0] == 255 and ff[3, 3] == 0  # the enclosed hole is not reached from (0,0)
+    rng = np.random.default_rng(0)
+    g = rng.integers(0, 256, (12, 15), dtype=np.uint8)
+    p = np.pad(g, 1, mode="edge")
+    want = np.array([[np.median(p[y:y + 3, x:x + 3]) for x in range(15)] for y in range(12)]).astype(np.uint8)
+    assert np.array_equal(pyoracle.median_blur(g, 3), want)

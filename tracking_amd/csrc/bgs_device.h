@@ -35,6 +35,17 @@ __device__ __forceinline__ float add_weighted(float a, double alpha, float b, do
   return (float)__dadd_rn(__dmul_rn((double)a, alpha), __dmul_rn((double)b, beta));
 }
 
+// XCD-aware block order (speed only): workgroups are dealt round-robin over the 8 XCDs, so blockIdx % 8 says which blocks share
+// an XCD and its L2.  Remap so that each XCD walks ONE contiguous eighth of the launch instead of every 8th block.
+__device__ __forceinline__ size_t xcd_block(int enable) {
+  size_t blk = blockIdx.x;
+  if (enable) {
+    const size_t per = gridDim.x >> 3, main = per << 3;
+    if (blk < main) blk = (blk & 7) * per + (blk >> 3);
+  }
+  return blk;
+}
+
 // byte j (0..3) of a dword
 __device__ __forceinline__ int byte_of(uint32_t w, int j) { return (int)((w >> (8 * j)) & 0xffu); }
 

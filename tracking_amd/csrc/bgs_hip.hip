@@ -75,8 +75,8 @@ struct bgs_engine {
   bool mog2_tiled = true;
   int mog2_px = 0;                 // pixels per lane, 0 = widest the alignment allows
   int xcd_swizzle = 1;             // XCD-aware block order (kernel_mog2.h)
-  int probe_max = 6;               // placement probe: candidates tried at allocation (<= 1: off)
-  float probe_ms[8] = {0};         // what the probe measured (diagnostics)
+  int probe_max = 10;              // placement probe: candidates tried at allocation (<= 1: off)
+  float probe_ms[16] = {0};         // what the probe measured (diagnostics)
   int probe_n = 0, probe_pick = -1;
 
   // host staging (bgs_process)
@@ -185,7 +185,7 @@ int mog2_allocate(bgs_engine* e) {
     HIP_TRY(hipMalloc((void**)&e->mog2_nmodes, P));
     return BGS_OK;
   }
-  const int tries = std::min(e->probe_max, 8);
+  const int tries = std::min(e->probe_max, 16);
   if (tries <= 1 || bytes < ((size_t)768 << 20)) {
     HIP_TRY(hipMalloc((void**)&e->mog2_state, bytes));
     return BGS_OK;
@@ -196,7 +196,7 @@ int mog2_allocate(bgs_engine* e) {
   hipEvent_t ev0, ev1;
   HIP_TRY(hipEventCreate(&ev0));
   HIP_TRY(hipEventCreate(&ev1));
-  float* cand[8] = {nullptr};
+  float* cand[16] = {nullptr};
   int n = 0, best = 0;
   float tmin = 1e30f, tmax = 0.f;
   int rc = BGS_OK;
@@ -349,7 +349,7 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
 
   bgs::FrameArgs a{};
   a.cur = d_frames, a.fg = d_fg, a.bg = d_bg, a.fg_bits = d_bits, a.npix = npix;
-  a.thr = p.threshold, a.enable_thr = p.enable_threshold, a.enable_weight = p.enable_weight;
+  a.thr = p.threshold, a.enable_thr = p.enable_threshold, a.enable_weight = p.enable_weight, a.xcd_swizzle = e->xcd_swizzle;
 
   const bool whole = (first == 0 && count == e->S);
   if (e->borrow && !whole && e->nring) return fail(BGS_ERR_INVALID, "borrowed frame history needs whole-batch calls");

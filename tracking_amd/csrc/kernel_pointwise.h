@@ -24,7 +24,7 @@ struct FrameArgs {
   uint8_t* bg;          // [npix][C] or null
   uint64_t* fg_bits;    // [npix/64] or null
   size_t npix;
-  int thr, enable_thr, enable_weight, update;
+  int thr, enable_thr, enable_weight, update, xcd_swizzle;
   double alpha, beta;   // ABL: alpha, 1-alpha
 };
 
@@ -74,7 +74,7 @@ __device__ __forceinline__ void gray_thr_store(const PxGroup<G, C>& d, const Fra
 
 template <int G, int C>
 __global__ __launch_bounds__(kBlock) void framediff_kernel(const FrameArgs a) {
-  const size_t p0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * G;
+  const size_t p0 = (xcd_block(a.xcd_swizzle) * kBlock + threadIdx.x) * G;
   const bool active = p0 < a.npix;
   PxGroup<G, C> d;
   if (active) {
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kBlock) void framediff_kernel(const FrameArgs a) {
 // cv::cvtColor(BGR2GRAY) / copy of a 1-channel frame into a.fg (AdaptiveSelectiveBackgroundLearning.cpp:37-40, :47-48)
 template <int G, int C>
 __global__ __launch_bounds__(kBlock) void gray_kernel(const FrameArgs a) {
-  const size_t p0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * G;
+  const size_t p0 = (xcd_block(a.xcd_swizzle) * kBlock + threadIdx.x) * G;
   const bool active = p0 < a.npix;
   PxGroup<G, C> d;
   if (active) d.load(a.cur + p0 * C);
@@ -115,7 +115,7 @@ __device__ __forceinline__ float mean3(float i0, float i1, float i2, double w0, 
 
 template <int G, int C>
 __global__ __launch_bounds__(kBlock) void wmm_kernel(const FrameArgs a) {
-  const size_t p0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * G;
+  const size_t p0 = (xcd_block(a.xcd_swizzle) * kBlock + threadIdx.x) * G;
   const bool active = p0 < a.npix;
   PxGroup<G, C> d;
   if (active) {
@@ -148,7 +148,7 @@ __device__ __forceinline__ float wvar(float x, float mean, double w) {
 
 template <int G, int C>
 __global__ __launch_bounds__(kBlock) void wmv_kernel(const FrameArgs a) {
-  const size_t p0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * G;
+  const size_t p0 = (xcd_block(a.xcd_swizzle) * kBlock + threadIdx.x) * G;
   const bool active = p0 < a.npix;
   PxGroup<G, C> d;
   if (active) {
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kBlock) void wmv_kernel(const FrameArgs a) {
 
 template <int G, int C>
 __global__ __launch_bounds__(kBlock) void abl_kernel(const FrameArgs a) {
-  const size_t p0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * G;
+  const size_t p0 = (xcd_block(a.xcd_swizzle) * kBlock + threadIdx.x) * G;
   const bool active = p0 < a.npix;
   PxGroup<G, C> d;
   if (active) {

@@ -1,0 +1,107 @@
+// FrameProcessor.cpp — see FrameProcessor.h.  Statement order follows FrameProcessor.cpp of the reference.
+#include "FrameProcessor.h"
+
+#include <iomanip>
+
+namespace bgs_hip {
+
+FrameProcessor::FrameProcessor()
+    : frameToStop(0), firstTime(true), frameNumber(0), duration(0), tictoc(""), enablePreProcessor(true), frameDifference(nullptr),
+      enableFrameDifferenceBGS(false), staticFrameDifference(nullptr), enableStaticFrameDifferenceBGS(false), weightedMovingMean(nullptr),
+      enableWeightedMovingMeanBGS(false), weightedMovingVariance(nullptr), enableWeightedMovingVarianceBGS(false), mixtureOfGaussianV1BGS(nullptr),
+      enableMixtureOfGaussianV1BGS(false), mixtureOfGaussianV2BGS(nullptr), enableMixtureOfGaussianV2BGS(false), adaptiveBackgroundLearning(nullptr),
+      enableAdaptiveBackgroundLearning(false), adaptiveSelectiveBackgroundLearning(nullptr), enableAdaptiveSelectiveBackgroundLearning(false) {
+  std::cout << "FrameProcessor()" << std::endl;
+  loadConfig();  // FrameProcessor.cpp:26-27
+  saveConfig();
+}
+
+FrameProcessor::~FrameProcessor() { std::cout << "~FrameProcessor()" << std::endl; }
+
+void FrameProcessor::init() {  // FrameProcessor.cpp:35-155
+  if (enableFrameDifferenceBGS) frameDifference = new FrameDifferenceBGS;
+  if (enableStaticFrameDifferenceBGS) staticFrameDifference = new StaticFrameDifferenceBGS;
+  if (enableWeightedMovingMeanBGS) weightedMovingMean = new WeightedMovingMeanBGS;
+  if (enableWeightedMovingVarianceBGS) weightedMovingVariance = new WeightedMovingVarianceBGS;
+  if (enableMixtureOfGaussianV1BGS) mixtureOfGaussianV1BGS = new MixtureOfGaussianV1BGS;
+  if (enableMixtureOfGaussianV2BGS) mixtureOfGaussianV2BGS = new MixtureOfGaussianV2BGS;
+  if (enableAdaptiveBackgroundLearning) adaptiveBackgroundLearning = new AdaptiveBackgroundLearning;
+  if (enableAdaptiveSelectiveBackgroundLearning) adaptiveSelectiveBackgroundLearning = new AdaptiveSelectiveBackgroundLearning;
+}
+
+void FrameProcessor::process(std::string name, IBGS* bgs, const Image& img_input, Image& img_bgs) {  // :157-167
+  if (tictoc == name) tic(name);
+  Image img_bkgmodel;
+  bgs->process(img_input, img_bgs, img_bkgmodel);
+  if (tictoc == name) toc();
+}
+
+void FrameProcessor::process(const Image& img_input) {  // :169-340
+  frameNumber++;
+  if (enablePreProcessor) img_input.copyTo(img_prep);  // PreProcessor default: img_input.copyTo(img_output) (PreProcessor.cpp:56)
+  // with enablePreProcessor = 0 img_prep stays empty and every class returns at `if(img_input.empty()) return;`
+  if (enableFrameDifferenceBGS) process("FrameDifferenceBGS", frameDifference, img_prep, img_framediff);
+  if (enableStaticFrameDifferenceBGS) process("StaticFrameDifferenceBGS", staticFrameDifference, img_prep, img_staticfdiff);
+  if (enableWeightedMovingMeanBGS) process("WeightedMovingMeanBGS", weightedMovingMean, img_prep, img_wmovmean);
+  if (enableWeightedMovingVarianceBGS) process("WeightedMovingVarianceBGS", weightedMovingVariance, img_prep, img_movvar);
+  if (enableMixtureOfGaussianV1BGS) process("MixtureOfGaussianV1BGS", mixtureOfGaussianV1BGS, img_prep, img_mog1);
+  if (enableMixtureOfGaussianV2BGS) process("MixtureOfGaussianV2BGS", mixtureOfGaussianV2BGS, img_prep, img_mog2);
+  if (enableAdaptiveBackgroundLearning) process("AdaptiveBackgroundLearning", adaptiveBackgroundLearning, img_prep, img_bkgl_fgmask);
+  if (enableAdaptiveSelectiveBackgroundLearning)
+    process("AdaptiveSelectiveBackgroundLearning", adaptiveSelectiveBackgroundLearning, img_prep, img_asbl);
+  firstTime = false;
+}
+
+void FrameProcessor::finish() {  // :342-482 (reverse order of init)
+  delete adaptiveSelectiveBackgroundLearning, adaptiveSelectiveBackgroundLearning = nullptr;
+  delete adaptiveBackgroundLearning, adaptiveBackgroundLearning = nullptr;
+  delete mixtureOfGaussianV2BGS, mixtureOfGaussianV2BGS = nullptr;
+  delete mixtureOfGaussianV1BGS, mixtureOfGaussianV1BGS = nullptr;
+  delete weightedMovingVariance, weightedMovingVariance = nullptr;
+  delete weightedMovingMean, weightedMovingMean = nullptr;
+  delete staticFrameDifference, staticFrameDifference = nullptr;
+  delete frameDifference, frameDifference = nullptr;
+}
+
+void FrameProcessor::tic(std::string value) {  // :484-488
+  processname = value;
+  t0 = std::chrono::steady_clock::now();
+}
+
+void FrameProcessor::toc() {  // :490-494, same line format
+  duration = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  std::cout << processname << "\ttime(sec):" << std::fixed << std::setprecision(6) << duration << std::endl;
+}
+
+void FrameProcessor::saveConfig() {  // :496-552 (keys of the classes this build provides)
+  XmlConfig fs;
+  fs.beginWrite();
+  fs.writeString("tictoc", tictoc);
+  fs.writeInt("enablePreProcessor", enablePreProcessor);
+  fs.writeInt("enableFrameDifferenceBGS", enableFrameDifferenceBGS);
+  fs.writeInt("enableStaticFrameDifferenceBGS", enableStaticFrameDifferenceBGS);
+  fs.writeInt("enableWeightedMovingMeanBGS", enableWeightedMovingMeanBGS);
+  fs.writeInt("enableWeightedMovingVarianceBGS", enableWeightedMovingVarianceBGS);
+  fs.writeInt("enableMixtureOfGaussianV1BGS", enableMixtureOfGaussianV1BGS);
+  fs.writeInt("enableMixtureOfGaussianV2BGS", enableMixtureOfGaussianV2BGS);
+  fs.writeInt("enableAdaptiveBackgroundLearning", enableAdaptiveBackgroundLearning);
+  fs.writeInt("enableAdaptiveSelectiveBackgroundLearning", enableAdaptiveSelectiveBackgroundLearning);
+  fs.save("./config/FrameProcessor.xml");
+}
+
+void FrameProcessor::loadConfig() {  // :554-610 (defaults: PreProcessor and FrameDifferenceBGS on, everything else off)
+  XmlConfig fs;
+  fs.load("./config/FrameProcessor.xml");
+  tictoc = fs.readString("tictoc", "");
+  enablePreProcessor = fs.readInt("enablePreProcessor", true);
+  enableFrameDifferenceBGS = fs.readInt("enableFrameDifferenceBGS", true);
+  enableStaticFrameDifferenceBGS = fs.readInt("enableStaticFrameDifferenceBGS", false);
+  enableWeightedMovingMeanBGS = fs.readInt("enableWeightedMovingMeanBGS", false);
+  enableWeightedMovingVarianceBGS = fs.readInt("enableWeightedMovingVarianceBGS", false);
+  enableMixtureOfGaussianV1BGS = fs.readInt("enableMixtureOfGaussianV1BGS", false);
+  enableMixtureOfGaussianV2BGS = fs.readInt("enableMixtureOfGaussianV2BGS", false);
+  enableAdaptiveBackgroundLearning = fs.readInt("enableAdaptiveBackgroundLearning", false);
+  enableAdaptiveSelectiveBackgroundLearning = fs.readInt("enableAdaptiveSelectiveBackgroundLearning", false);
+}
+
+}  // namespace bgs_hip

@@ -1,0 +1,73 @@
+// FrameProcessor.h — host-side mirror of bgslibrary::FrameProcessor (FrameProcessor.{h,cpp}) for the classes on the hot path.
+//
+//   IFrameProcessor::process(const Image&)            IFrameProcessor.h:23-28
+//   FrameProcessor::init / process / finish           FrameProcessor.cpp:35-155, 169-340, 342-482
+//   per-algorithm helper with tic/toc                 FrameProcessor.cpp:157-167, 484-494
+//   ./config/FrameProcessor.xml (tictoc + enable*)    FrameProcessor.cpp:496-610
+//
+// Same control flow as the reference: one IBGS instance per enabled class, created in init(), fed the same
+// pre-processed frame in the reference's order, one mask per class kept in a member image.  The PreProcessor default
+// (a plain copy of the BGR input, PreProcessor.cpp:56) is the identity here; its optional filters are out of scope.
+#pragma once
+#include <chrono>
+#include <string>
+
+#include "bgs_host.h"
+
+namespace bgs_hip {
+
+class IFrameProcessor {  // IFrameProcessor.h:23-28
+ public:
+  virtual void process(const Image& input) = 0;
+  virtual ~IFrameProcessor() {}
+};
+
+class FrameProcessor : public IFrameProcessor {
+ public:
+  FrameProcessor();
+  ~FrameProcessor() override;
+  long frameToStop;
+  std::string imgref;
+
+  void init();
+  void process(const Image& img_input) override;
+  void finish();
+
+  // the masks the reference keeps as img_framediff, img_staticfdiff, ... (FrameProcessor.h:99-170)
+  Image img_prep, img_framediff, img_staticfdiff, img_wmovmean, img_movvar, img_mog1, img_mog2, img_bkgl_fgmask, img_asbl;
+  double lastDuration() const { return duration; }
+
+ private:
+  bool firstTime;
+  long frameNumber;
+  std::string processname;
+  double duration;
+  std::chrono::steady_clock::time_point t0;
+  std::string tictoc;
+
+  bool enablePreProcessor;
+  FrameDifferenceBGS* frameDifference;
+  bool enableFrameDifferenceBGS;
+  StaticFrameDifferenceBGS* staticFrameDifference;
+  bool enableStaticFrameDifferenceBGS;
+  WeightedMovingMeanBGS* weightedMovingMean;
+  bool enableWeightedMovingMeanBGS;
+  WeightedMovingVarianceBGS* weightedMovingVariance;
+  bool enableWeightedMovingVarianceBGS;
+  MixtureOfGaussianV1BGS* mixtureOfGaussianV1BGS;
+  bool enableMixtureOfGaussianV1BGS;
+  MixtureOfGaussianV2BGS* mixtureOfGaussianV2BGS;
+  bool enableMixtureOfGaussianV2BGS;
+  AdaptiveBackgroundLearning* adaptiveBackgroundLearning;
+  bool enableAdaptiveBackgroundLearning;
+  AdaptiveSelectiveBackgroundLearning* adaptiveSelectiveBackgroundLearning;  // not in the reference's FrameProcessor (Demo.cpp / USTC_BGS type 7 only)
+  bool enableAdaptiveSelectiveBackgroundLearning;
+
+  void process(std::string name, IBGS* bgs, const Image& img_input, Image& img_bgs);
+  void tic(std::string value);
+  void toc();
+  void saveConfig();
+  void loadConfig();
+};
+
+}  // namespace bgs_hip

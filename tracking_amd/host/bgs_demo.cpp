@@ -1,0 +1,58 @@
+// bgs_demo.cpp — the build's own small harness in the pattern of the reference's Demo2.cpp:142-168 (frames/N.png loop) and
+// Main.cpp:63-72 (hard failures surface as one std::exception).  OpenCV is absent, so frames come from a raw file:
+//     bgs_demo <frames.raw> <rows> <cols> <n_frames> <out_prefix>
+// frames.raw = n_frames x rows x cols x 3 bytes (BGR).  For every class enabled in ./config/FrameProcessor.xml the mask of
+// each frame is appended to <out_prefix>.<ClassName>.raw (frames whose output the class leaves untouched are written as 0x07).
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <vector>
+
+#include "FrameProcessor.h"
+
+using namespace bgs_hip;
+
+static void dump(std::ofstream& f, const Image& m, int rows, int cols) {
+  std::vector<uint8_t> untouched((size_t)rows * cols, 7);
+  if (m.empty()) {
+    f.write((const char*)untouched.data(), untouched.size());
+    return;
+  }
+  for (int y = 0; y < m.rows; ++y) f.write((const char*)m.ptr(y), m.cols);
+}
+
+int main(int argc, char** argv) {
+  if (argc < 6) {
+    std::fprintf(stderr, "usage: %s frames.raw rows cols n_frames out_prefix\n", argv[0]);
+    return 2;
+  }
+  const int rows = std::atoi(argv[2]), cols = std::atoi(argv[3]), n = std::atoi(argv[4]);
+  const std::string prefix = argv[5];
+  try {
+    std::ifstream in(argv[1], std::ios::binary);
+    if (!in) throw Exception(BGS_ERR_INVALID, std::string("cannot open ") + argv[1]);
+    FrameProcessor* fp = new FrameProcessor;
+    fp->init();
+    const char* names[] = {"FrameDifferenceBGS", "StaticFrameDifferenceBGS", "WeightedMovingMeanBGS", "WeightedMovingVarianceBGS",
+                           "MixtureOfGaussianV1BGS", "MixtureOfGaussianV2BGS", "AdaptiveBackgroundLearning", "AdaptiveSelectiveBackgroundLearning"};
+    Image* masks[] = {&fp->img_framediff, &fp->img_staticfdiff, &fp->img_wmovmean, &fp->img_movvar, &fp->img_mog1, &fp->img_mog2, &fp->img_bkgl_fgmask, &fp->img_asbl};
+    std::vector<std::ofstream> outs;
+    for (const char* nm : names) outs.emplace_back((prefix + "." + nm + ".raw").c_str(), std::ios::binary);
+    Image frame(rows, cols, 3);
+    for (int t = 0; t < n; ++t) {
+      in.read((char*)frame.data, (size_t)rows * cols * 3);
+      if (!in) throw Exception(BGS_ERR_INVALID, "short read on frame file");
+      fp->process(frame);
+      for (size_t i = 0; i < outs.size(); ++i) dump(outs[i], *masks[i], rows, cols);
+    }
+    fp->finish();
+    delete fp;
+  } catch (const std::exception& ex) {  // Main.cpp:63-72
+    std::cout << "std::exception:" << ex.what() << std::endl;
+    return 1;
+  } catch (...) {
+    std::cout << "Unknow error" << std::endl;
+    return 1;
+  }
+  return 0;
+}

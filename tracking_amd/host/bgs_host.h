@@ -206,6 +206,8 @@ class HipBGSBase : public IBGS {
   bgs_params params_;
 
  private:
+  void saveConfig() override = 0;  // private pure virtuals of IBGS, re-declared so process() above may call them
+  void loadConfig() override = 0;
   bgs_algo algo_;
   const char* name_;
   bool clears_bg_;
