@@ -49,6 +49,8 @@ struct orc_engine {
   uint8_t* modes;
   /* MOG1: MixData{sortKey, weight, mean[C], var[C]}[N*K] */
   float* mix;
+  /* SigmaDelta: Mt = bgimg, Vt */
+  uint8_t* vt;
   /* scratch */
   uint8_t *tmp8a, *tmp8b;
   float* tmpf;
@@ -261,6 +263,7 @@ void orc_destroy(orc_engine* e) {
   free(e->mean);
   free(e->modes);
   free(e->mix);
+  free(e->vt);
   free(e->tmp8a);
   free(e->tmp8b);
   free(e->tmpf);
@@ -786,6 +789,53 @@ static int mog1_process(orc_engine* e, uint8_t* fg, size_t fg_step, uint32_t* fl
   return BGS_OK;
 }
 
+/* ---------------------------------------------------------------- SigmaDelta (N4) */
+
+/* SigmaDeltaBGS::process (package_bgs/bl/SigmaDeltaBGS.cpp:20-55) over sdLaMa091 (package_bgs/bl/sdLaMa091.cpp).
+ * PINNED: tests compare this restatement with the reference's own sdLaMa091.cpp compiled into oracle/_ref.
+ * Quirks kept on purpose:
+ *  - AllocInit_8u_C3R initialises Vt through the C1R routine, i.e. only the first `cols` BYTES of every 3*cols-byte row get Vmin
+ *    (sdLaMa091.cpp:190-201, 211-212); the rest is whatever malloc returned - zero pages for the mmap-sized buffers of real
+ *    frames (>= 128 KB), which is what this restatement (and the GPU engine) uses;
+ *  - Ot = absVal((int8_t)(Mt - I)): the difference wraps to int8 before the absolute value (:66-68, :559);
+ *  - ++Vt / --Vt act on a uint8 (255 + 1 wraps to 0), then clamp with uint8-typed min/max (:576-583, :70-76). */
+static uint32_t sd_process(orc_engine* e, uint8_t* fg, size_t fg_step) {
+  const size_t nb = e->n * 3;
+  const uint32_t N = (uint32_t)e->p.sd_amp_factor;
+  const uint8_t vmin = (uint8_t)e->p.sd_min_var, vmax = (uint8_t)e->p.sd_max_var;
+  if (!e->have1) { /* SigmaDeltaBGS.cpp:33-39: first frame allocates + initialises, no output */
+    e->vt = (uint8_t*)malloc(nb);
+    memcpy(e->bgimg, e->cur, nb);
+    for (int y = 0; y < e->rows; ++y)
+      for (int j = 0; j < 3 * e->cols; ++j) e->vt[(size_t)y * 3 * e->cols + j] = j < e->cols ? vmin : 0;
+    e->have1 = 1;
+    return 0;
+  }
+  uint8_t* mask = e->tmp8b;
+  for (size_t px = 0; px < e->n; ++px) {
+    int isfg = 0;
+    for (int c = 0; c < 3; ++c) {
+      const size_t i = 3 * px + c;
+      uint8_t mt = e->bgimg[i];
+      const uint8_t im = e->cur[i];
+      if (mt < im) ++mt; else if (mt > im) --mt;                 /* :535-540 */
+      const int8_t d8 = (int8_t)(uint8_t)(mt - im);              /* :559 absVal(int8_t) */
+      const uint8_t ot = d8 < 0 ? (uint8_t)-d8 : (uint8_t)d8;
+      const uint32_t amp = N * ot;                               /* :576 */
+      uint8_t vt = e->vt[i];
+      if (vt < amp) ++vt; else if (vt > amp) --vt;               /* :578-581, uint8 wrap */
+      vt = vt < vmax ? vt : vmax;                                /* min(vt, Vmax) */
+      vt = vt > vmin ? vt : vmin;                                /* max(., Vmin) */
+      if (ot >= vt) isfg = 1;                                    /* :605 */
+      e->bgimg[i] = mt;
+      e->vt[i] = vt;
+    }
+    mask[px] = isfg ? 255 : 0;
+  }
+  write_mask(e, mask, fg, fg_step); /* SigmaDeltaBGS.cpp:44-52: first channel of the 3-channel map */
+  return BGS_FG_VALID;
+}
+
 /* ---------------------------------------------------------------- dispatch */
 
 int orc_process(orc_engine* e, const uint8_t* in, int rows, int cols, int channels, size_t in_step, uint8_t* fg, size_t fg_step, uint8_t* bg,
@@ -807,6 +857,10 @@ int orc_process(orc_engine* e, const uint8_t* in, int rows, int cols, int channe
     case BGS_ASBL: flags = asbl_process(e, fg, fg_step, bg, bg_step); break;
     case BGS_MOG2: rc = mog2_process(e, fg, fg_step, bg, bg_step, &flags); break;
     case BGS_MOG1: rc = mog1_process(e, fg, fg_step, &flags); break;
+    case BGS_SIGMA_DELTA:
+      if (channels != 3) return BGS_ERR_UNSUPPORTED;
+      flags = sd_process(e, fg, fg_step);
+      break;
     default: return BGS_ERR_UNSUPPORTED;
   }
   if (rc) return rc;
@@ -865,6 +919,11 @@ int64_t orc_get_state(orc_engine* e, const char* plane, void* dst, size_t cap) {
           for (size_t i = 0; i < n; ++i) f[((size_t)k * C + c) * n + i] = e->mix[(i * K + k) * R + off + c];
       return (int64_t)(n * K * C * 4);
     }
+  }
+  if (e->algo == BGS_SIGMA_DELTA && e->have1 && (!strcmp(plane, "mt") || !strcmp(plane, "vt"))) {
+    NEED(n * 3);
+    memcpy(dst, !strcmp(plane, "mt") ? e->bgimg : e->vt, n * 3);
+    return (int64_t)(n * 3);
   }
   if (!strcmp(plane, "bg") && (e->algo == BGS_STATIC_FRAME_DIFF || e->algo == BGS_ABL || e->algo == BGS_ASBL)) {
     const size_t nb = n * (e->algo == BGS_ASBL ? 1 : C);

@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libbgs_oracle.so")
 _REF_LBSP = os.path.join(_HERE, "_ref", "libref_lbsp.so")
-_REF_SDLAMA = os.path.join(_HERE, "_ref", "libref_sdlama.so")
+_REF_SDLAMA = os.path.join(_HERE, "_ref", "ref_sdlama_cli")
 
 _P = C.c_void_p
 _lib = None
@@ -188,3 +188,21 @@ def ref_lbsp_describe(img, lut):
     out = np.empty((rows, cols, ch), np.uint16)
     l.ref_lbsp_describe(_ptr(img), img.strides[0], rows, cols, ch, _ptr(lut), _ptr(out))
     return out
+
+
+def ref_sdlama_available():
+    return os.path.exists(_REF_SDLAMA)
+
+
+def ref_sigmadelta_clip(frames, amp=1, vmin=15, vmax=255):
+    """Masks of frames[1:] from the REFERENCE'S OWN package_bgs/bl/sdLaMa091.cpp (compiled as is into oracle/_ref/ref_sdlama_cli)
+    driven the way SigmaDeltaBGS::process drives it (SigmaDeltaBGS.cpp:20-55).  Runs in a process of its own so that the
+    part of Vt sdLaMa091 never initialises is untouched zero memory (see oracle/ref_sdlama_cli.cpp)."""
+    import tempfile
+    frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    n, rows, cols = frames.shape[:3]
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.raw"), os.path.join(d, "out.raw")
+        frames.tofile(fin)
+        subprocess.run([_REF_SDLAMA, fin, str(rows), str(cols), str(n), str(amp), str(vmin), str(vmax), fout], check=True)
+        return np.fromfile(fout, np.uint8).reshape(n - 1, rows, cols)

@@ -6,6 +6,8 @@ Inputs  : crops of the reference's own test data files  /root/reference/frames/1
 Outputs :
   frames_96x80.npz      'frames' uint8 [24][80][96][3]  (BGR, frames 1..24, crop y 60:140, x 110:206 — the busiest region)
   frames_gray_64x48.npz 'frames' uint8 [12][48][64]
+  sigmadelta_ref.npz    SigmaDeltaBGS masks of frames[1:] produced by THE REFERENCE'S OWN package_bgs/bl/sdLaMa091.cpp
+                        (oracle/_ref/ref_sdlama_cli), default parameters and (ampFactor 3, minVar 2, maxVar 200) -> pinned
   lbsp_ref.npz          LBSP descriptors of frames[0] produced by THE REFERENCE'S OWN pattern files
                         (oracle/_ref/libref_lbsp.so, built from package_bgs/pl/LBSP_16bits_dbcross_*.i) -> pinned
   framediff_indep.npz   FrameDifference masks computed by an independent numpy formula (integer only)
@@ -44,6 +46,13 @@ def main():
                         desc3=po.ref_lbsp_describe(frames[0], lut3), desc1=po.ref_lbsp_describe(gray[0], lut1)[:, :, 0],
                         desc3_f7=po.ref_lbsp_describe(frames[7], lut3))
 
+    # --- pinned: SigmaDelta masks from the reference's own sdLaMa091.cpp (oracle/_ref/ref_sdlama_cli)
+    assert po.ref_sdlama_available()
+    sd = {}
+    for tag, (amp, vmin, vmax) in {"default": (1, 15, 255), "amp3": (3, 2, 200)}.items():
+        sd[tag] = po.ref_sigmadelta_clip(frames, amp, vmin, vmax)
+    np.savez_compressed(os.path.join(HERE, "sigmadelta_ref.npz"), **sd)
+
     # --- independent integer formula for FrameDifference (FrameDifferenceBGS.cpp:45-51 with P1/P2 of DESIGN.md §5)
     masks = []
     for a, b in zip(frames[:-1], frames[1:]):
@@ -55,7 +64,7 @@ def main():
     # --- oracle regression vectors
     out = {}
     for name, algo in [("fd", capi.FRAME_DIFF), ("sfd", capi.STATIC_FRAME_DIFF), ("wmm", capi.WMM), ("wmv", capi.WMV),
-                       ("abl", capi.ABL), ("asbl", capi.ASBL), ("mog2", capi.MOG2), ("mog1", capi.MOG1)]:
+                       ("abl", capi.ABL), ("asbl", capi.ASBL), ("mog2", capi.MOG2), ("mog1", capi.MOG1), ("sd", capi.SIGMA_DELTA)]:
         o = po.Oracle(algo)
         fgs, bgs = [], []
         for f in frames:

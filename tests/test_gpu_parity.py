@@ -24,6 +24,7 @@ ALGOS = {
     "AdaptiveSelectiveBackgroundLearning": capi.ASBL,
     "MixtureOfGaussianV1BGS": capi.MOG1,
     "MixtureOfGaussianV2BGS": capi.MOG2,
+    "SigmaDeltaBGS": capi.SIGMA_DELTA,
 }
 STATE_TOL = 1e-4
 
@@ -65,6 +66,9 @@ def check_state(name, eng, orc, n, stream=0):
         check_mog2_state(eng, orc, n, stream)
     if name == "MixtureOfGaussianV1BGS":
         check_mog1_state(eng, orc, n, 3, stream)
+    if name == "SigmaDeltaBGS":
+        for plane in ("mt", "vt"):
+            assert np.array_equal(eng.get_state(plane, (n * 3,), np.uint8, stream=stream), orc.get_state(plane, (n * 3,), np.uint8)), plane
     if name in ("AdaptiveBackgroundLearning", "AdaptiveSelectiveBackgroundLearning", "StaticFrameDifferenceBGS"):
         c = 1 if name == "AdaptiveSelectiveBackgroundLearning" else 3
         assert np.array_equal(eng.get_state("bg", (n * c,), np.uint8, stream=stream), orc.get_state("bg", (n * c,), np.uint8))
@@ -94,6 +98,31 @@ def test_single_channel(name, golden_gray):
         check_mog1_state(eng, orc, golden_gray.shape[1] * golden_gray.shape[2], C=1)
 
 
+def test_sigmadelta_matches_reference_fixture(golden_frames):
+    """GPU vs masks produced by the reference's own sdLaMa091.cpp (tests/golden/sigmadelta_ref.npz): pinned parity."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sigmadelta_ref.npz"))
+    for tag, (amp, vmin, vmax) in {"default": (1, 15, 255), "amp3": (3, 2, 200)}.items():
+        eng = Engine(capi.SIGMA_DELTA, params=_params(capi.SIGMA_DELTA, sd_amp_factor=amp, sd_min_var=vmin, sd_max_var=vmax))
+        assert eng.process(golden_frames[0]) == (None, None)
+        for t in range(1, len(golden_frames)):
+            fg, bg = eng.process(golden_frames[t])
+            assert bg is None and np.array_equal(fg, g[tag][t - 1]), (tag, t)
+
+
+@pytest.mark.parametrize("kw", [dict(sd_amp_factor=2, sd_min_var=2), dict(sd_amp_factor=7, sd_min_var=3, sd_max_var=40), dict(sd_max_var=300), dict(sd_min_var=0)])
+def test_sigmadelta_variants(kw):
+    rng = np.random.default_rng(5)
+    frames = rng.integers(0, 256, (20, 33, 47, 3), dtype=np.uint8)
+    eng, orc, _ = run_pair(capi.SIGMA_DELTA, frames, params=_params(capi.SIGMA_DELTA, **kw))
+    check_state("SigmaDeltaBGS", eng, orc, 33 * 47)
+
+
+def test_sigmadelta_rejects_gray(golden_gray):
+    with pytest.raises(capi.BgsError) as ei:
+        Engine(capi.SIGMA_DELTA).process(golden_gray[0])
+    assert ei.value.code == capi.ERR_UNSUPPORTED
+
+
 def test_mog2_rejects_gray(golden_gray):
     """cv::BackgroundSubtractorMOG2::getBackgroundImage asserts nchannels == 3; the wrapper calls it every frame."""
     eng = Engine(capi.MOG2)
@@ -118,7 +147,7 @@ def test_warmup_outputs_untouched():
     """FD frame 1, WMM/WMV frames 1-2 return with outputs untouched; FD/WMV never write a background."""
     frames = synth.random_frames(4, 16, 32, 3, seed=5)
     for algo, warm, has_bg in ((capi.FRAME_DIFF, 1, False), (capi.WMM, 2, True), (capi.WMV, 2, False), (capi.STATIC_FRAME_DIFF, 0, True), (capi.ABL, 0, True),
-                               (capi.ASBL, 0, True), (capi.MOG1, 0, False), (capi.MOG2, 0, True)):
+                               (capi.ASBL, 0, True), (capi.MOG1, 0, False), (capi.MOG2, 0, True), (capi.SIGMA_DELTA, 1, False)):
         eng = Engine(algo)
         for t, f in enumerate(frames):
             fg, bg = eng.process(f)

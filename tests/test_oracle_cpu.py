@@ -37,6 +37,38 @@ def test_lbsp_oracle_matches_live_reference_build():
             assert np.array_equal(pyoracle.lbsp_describe(img, lut), pyoracle.ref_lbsp_describe(img, lut))
 
 
+def test_sigmadelta_oracle_matches_reference_built_fixture(golden_frames):
+    """tests/golden/sigmadelta_ref.npz = masks from the reference's own sdLaMa091.cpp (made in the build container)."""
+    g = np.load(os.path.join(GOLDEN, "sigmadelta_ref.npz"))
+    for tag, (amp, vmin, vmax) in {"default": (1, 15, 255), "amp3": (3, 2, 200)}.items():
+        p = capi.default_params(capi.SIGMA_DELTA)
+        p.sd_amp_factor, p.sd_min_var, p.sd_max_var = amp, vmin, vmax
+        o = pyoracle.Oracle(capi.SIGMA_DELTA, params=p)
+        assert o.process(golden_frames[0]) == (None, None)  # SigmaDeltaBGS.cpp:33-39
+        for t in range(1, len(golden_frames)):
+            fg, bg = o.process(golden_frames[t])
+            assert bg is None and np.array_equal(fg, g[tag][t - 1]), (tag, t)
+
+
+@pytest.mark.skipif(not pyoracle.ref_sdlama_available(), reason="oracle/_ref is built only where /root/reference exists")
+@pytest.mark.parametrize("amp,vmin,vmax", [(1, 15, 255), (2, 2, 255), (4, 10, 100), (1, 0, 255), (7, 3, 40), (2, 20, 300)])
+def test_sigmadelta_oracle_matches_live_reference_build(amp, vmin, vmax):
+    """Restatement vs the reference's own C file on adversarial clips: big jumps (int8 wrap of Mt - I), amplified
+    differences above 255 (uint8 wrap of ++Vt), maxVar > 255 (truncated to uint8 by sdLaMa091's min/max)."""
+    rng = np.random.default_rng(amp * 100 + vmin)
+    frames = rng.integers(0, 256, (30, 40, 52, 3), dtype=np.uint8)
+    frames[10:20] = (frames[10:20].astype(np.int32) // 8 + 200).astype(np.uint8)  # a long bright stretch
+    want_all = pyoracle.ref_sigmadelta_clip(frames, amp, vmin, vmax)
+    p = capi.default_params(capi.SIGMA_DELTA)
+    p.sd_amp_factor, p.sd_min_var, p.sd_max_var = amp, vmin, vmax
+    o = pyoracle.Oracle(capi.SIGMA_DELTA, params=p)
+    for t, f in enumerate(frames):
+        fg, _ = o.process(f)
+        assert (t == 0) == (fg is None)
+        if t:
+            assert np.array_equal(fg, want_all[t - 1]), t
+
+
 def test_lbsp_lut_values():
     lut3, lut1 = pyoracle.lbsp_lut(0.333, 0, 3), pyoracle.lbsp_lut(0.333, 0, 1)
     assert lut3[0] == 0 and lut3[255] == 85 and lut3[100] == 33       # saturate_cast<uchar>(t*0.333f), half-to-even
@@ -54,7 +86,7 @@ def test_framediff_matches_independent_formula(golden_frames):
 
 
 @pytest.mark.parametrize("name,algo", [("fd", capi.FRAME_DIFF), ("sfd", capi.STATIC_FRAME_DIFF), ("wmm", capi.WMM), ("wmv", capi.WMV),
-                                       ("abl", capi.ABL), ("asbl", capi.ASBL), ("mog2", capi.MOG2), ("mog1", capi.MOG1)])
+                                       ("abl", capi.ABL), ("asbl", capi.ASBL), ("mog2", capi.MOG2), ("mog1", capi.MOG1), ("sd", capi.SIGMA_DELTA)])
 def test_oracle_regression_vectors(name, algo, golden_frames, oracle_regress):
     o = pyoracle.Oracle(algo)
     want = oracle_regress[name + "_fg"]

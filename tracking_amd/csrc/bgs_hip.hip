@@ -259,6 +259,10 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
     case BGS_STATIC_FRAME_DIFF:
     case BGS_ABL: e->state_ch = ch; break;
     case BGS_ASBL: e->state_ch = 1; break;
+    case BGS_SIGMA_DELTA:
+      if (ch != 3) return fail(BGS_ERR_UNSUPPORTED, "SigmaDeltaBGS is 3-channel only (sdLaMa091AllocInit_8u_C3R, SigmaDeltaBGS.cpp:35)");
+      e->state_ch = 3;
+      break;
     case BGS_MOG1:
     case BGS_MOG2: break;
     default: return fail(BGS_ERR_UNSUPPORTED, "algorithm %d is not implemented in this build", (int)e->algo);
@@ -266,6 +270,7 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
   for (int i = 0; i < e->nring; ++i) HIP_TRY(hipMalloc((void**)&e->ring[i], fb));
   if (e->state_ch) HIP_TRY(hipMalloc((void**)&e->bgstate, P * e->state_ch));
   if (e->algo == BGS_ASBL) HIP_TRY(hipMalloc((void**)&e->bgstate2, P));
+  if (e->algo == BGS_SIGMA_DELTA) HIP_TRY(hipMalloc((void**)&e->bgstate2, P * 3));  // Vt
   if (e->algo == BGS_MOG1) {
     const size_t planes = ch == 3 ? bgs::mog1_planes<3>() : bgs::mog1_planes<1>();
     const size_t tiles = (P + bgs::kMog1Tile - 1) / bgs::kMog1Tile;
@@ -404,6 +409,27 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
           for (int i = first; i < first + count; ++i) e->counter[i]++;
       }
       flags = BGS_FG_VALID | BGS_BG_VALID;
+      break;
+    }
+    case BGS_SIGMA_DELTA: {
+      uint8_t *mt = e->bgstate + off * 3, *vt = e->bgstate2 + off * 3;
+      if (t == 0) {  // SigmaDeltaBGS.cpp:33-39: allocate + initialise, return without output
+        HIP_TRY(hipMemcpyAsync(mt, d_frames, fb, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(bgs::sigmadelta_init_vt_kernel, dim3(blocks_for(fb)), dim3(bgs::kBlock), 0, s, vt, fb, e->cols, (int)(uint8_t)p.sd_min_var);
+        break;
+      }
+      bgs::SigmaDeltaArgs q{};
+      q.cur = d_frames, q.mt = mt, q.vt = vt, q.fg = d_fg, q.fg_bits = d_bits, q.npix = npix;
+      q.N = (uint32_t)p.sd_amp_factor, q.vmin = (uint8_t)p.sd_min_var, q.vmax = (uint8_t)p.sd_max_var, q.xcd_swizzle = e->xcd_swizzle;
+      int G = 16;
+      if (npix % 16 || !aligned(d_frames, 16) || !aligned(mt, 16) || !aligned(vt, 16) || (d_fg && !aligned(d_fg, 16))) G = (npix % 4 || !aligned(d_frames, 4) || !aligned(mt, 4) || (d_fg && !aligned(d_fg, 4))) ? 1 : 4;
+      {
+        Timed tm(e, s, "sigmadelta_kernel");
+        if (G == 16) hipLaunchKernelGGL((bgs::sigmadelta_kernel<16>), dim3(blocks_for(npix / 16)), dim3(bgs::kBlock), 0, s, q);
+        if (G == 4) hipLaunchKernelGGL((bgs::sigmadelta_kernel<4>), dim3(blocks_for(npix / 4)), dim3(bgs::kBlock), 0, s, q);
+        if (G == 1) hipLaunchKernelGGL((bgs::sigmadelta_kernel<1>), dim3(blocks_for(npix)), dim3(bgs::kBlock), 0, s, q);
+      }
+      flags = BGS_FG_VALID;
       break;
     }
     case BGS_ASBL: {
@@ -753,6 +779,8 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
       return (int64_t)need;
     }
   }
+  if (e->algo == BGS_SIGMA_DELTA && e->seen[stream] >= 1 && (!strcmp(plane, "mt") || !strcmp(plane, "vt")))
+    return copy_bytes((!strcmp(plane, "mt") ? e->bgstate : e->bgstate2) + off * 3, n * 3);
   if (!strcmp(plane, "bg") && e->algo == BGS_ASBL) return copy_bytes((e->flip[stream] ? e->bgstate2 : e->bgstate) + off, n);
   if (!strcmp(plane, "bg") && e->bgstate) return copy_bytes(e->bgstate + off * e->state_ch, n * e->state_ch);
   const int64_t t = e->seen[stream];

@@ -191,4 +191,70 @@ __global__ __launch_bounds__(kBlock) void abl_kernel(const FrameArgs a) {
   gray_thr_store<G, C>(d, a, p0, active, a.fg_bits != nullptr);
 }
 
+// K-N4 SigmaDeltaBGS::process over sdLaMa091 (package_bgs/bl/SigmaDeltaBGS.cpp:41-52, sdLaMa091.cpp:529-633): pure byte arithmetic,
+// one fused pass instead of the reference's four.  p1/state_out = Mt (in place), p2w = Vt (in place).  16 B/pixel.
+struct SigmaDeltaArgs {
+  const uint8_t* cur;
+  uint8_t* mt;
+  uint8_t* vt;
+  uint8_t* fg;
+  uint64_t* fg_bits;
+  size_t npix;
+  uint32_t N;
+  int vmin, vmax, xcd_swizzle;
+};
+
+template <int G>
+__global__ __launch_bounds__(kBlock) void sigmadelta_kernel(const SigmaDeltaArgs a) {
+  const size_t p0 = (xcd_block(a.xcd_swizzle) * kBlock + threadIdx.x) * G;
+  const bool active = p0 < a.npix;
+  PxGroup<G, 1> m;
+#pragma unroll
+  for (int i = 0; i < PxGroup<G, 1>::NB / 4; ++i) m.b.w[i] = 0;
+  uint32_t bits = 0;
+  if (active) {
+    PxGroup<G, 3> x, mt, vt;
+    x.load(a.cur + p0 * 3);
+    mt.load(a.mt + p0 * 3);
+    vt.load(a.vt + p0 * 3);
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      bool isfg = false;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int i = 3 * j + c;
+        int mv = mt.b.get(i);
+        const int im = x.b.get(i);
+        mv += (mv < im) - (mv > im);                                   // sdLaMa091.cpp:535-540
+        const int d8 = (int)(int8_t)(uint8_t)(mv - im);                // :559 absVal(int8_t): the difference wraps to int8 first
+        const uint32_t ot = (uint32_t)(d8 < 0 ? -d8 : d8) & 0xffu;
+        const uint32_t amp = a.N * ot;                                 // :576
+        uint32_t v = (uint32_t)vt.b.get(i);
+        v = (v + (v < amp) - (v > amp)) & 0xffu;                       // :578-581 on a uint8: 255+1 wraps to 0
+        v = min(v, (uint32_t)a.vmax);                                  // :583 max(min(Vt, Vmax), Vmin) with uint8 operands
+        v = max(v, (uint32_t)a.vmin);
+        isfg = isfg || ot >= v;                                        // :605
+        mt.b.set(i, mv);
+        vt.b.set(i, (int)v);
+      }
+      m.b.set(j, isfg ? 255 : 0);
+      bits |= (uint32_t)isfg << j;
+    }
+    mt.store(a.mt + p0 * 3);
+    vt.store(a.vt + p0 * 3);
+    if (a.fg) m.store(a.fg + p0);
+  }
+  if (a.fg_bits) {
+    if constexpr (64 % G == 0) store_packed_mask<G>(a.fg_bits, p0, bits, active);
+  }
+}
+
+// Vt initialisation exactly as sdLaMa091AllocInit_8u_C3R leaves it (see the quirk note in DESIGN.md §5): byte j of every
+// 3*cols-byte row is Vmin for j < cols, 0 beyond.
+__global__ __launch_bounds__(kBlock) void sigmadelta_init_vt_kernel(uint8_t* vt, size_t nbytes, int cols, int vmin) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nbytes) return;
+  vt[i] = (int)(i % ((size_t)3 * cols)) < cols ? (uint8_t)vmin : (uint8_t)0;
+}
+
 }  // namespace bgs

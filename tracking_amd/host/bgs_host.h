@@ -431,6 +431,32 @@ class MixtureOfGaussianV1BGS : public HipBGSBase {
   }
 };
 
+// package_bgs/bl/SigmaDeltaBGS.{h,cpp}
+class SigmaDeltaBGS : public HipBGSBase {
+ public:
+  SigmaDeltaBGS() : HipBGSBase(BGS_SIGMA_DELTA, "SigmaDeltaBGS"), showOutput(true) {}
+  BGS_HIP_BANNER_DTOR(SigmaDeltaBGS)
+ private:
+  bool showOutput;
+  void saveConfig() override {  // SigmaDeltaBGS.cpp:57-66
+    XmlConfig fs;
+    fs.beginWrite();
+    fs.writeInt("ampFactor", params_.sd_amp_factor);
+    fs.writeInt("minVar", params_.sd_min_var);
+    fs.writeInt("maxVar", params_.sd_max_var);
+    fs.writeInt("showOutput", showOutput);
+    fs.save(configPath());
+  }
+  void loadConfig() override {  // :68-79
+    XmlConfig fs;
+    fs.load(configPath());
+    params_.sd_amp_factor = fs.readInt("ampFactor", 1);
+    params_.sd_min_var = fs.readInt("minVar", 15);
+    params_.sd_max_var = fs.readInt("maxVar", 255);
+    showOutput = fs.readInt("showOutput", true);
+  }
+};
+
 #undef BGS_HIP_BANNER_DTOR
 
 }  // namespace bgs_hip
