@@ -122,7 +122,9 @@ typedef struct bgs_params {
   int32_t sd_min_var;          /* 15 */
   int32_t sd_max_var;          /* 255 */
 
-  uint32_t reserved[16];
+  int32_t subsense_desc_dist_threshold_offset; /* 3 (BGSSUBSENSE_DEFAULT_DESC_DIST_THRESHOLD_OFFSET) */
+
+  uint32_t reserved[15];
 } bgs_params;
 
 int bgs_abi_version(void);
@@ -221,7 +223,8 @@ int bgs_lbsp_describe_device(int hip_device, const void* d_img, int rows, int co
                              const uint8_t* t_lut, void* d_desc, void* hip_stream);
 
 /* 3x3 morphology / median / hole-fill post-processing of a byte mask on device
- * (BackgroundSubtractorSuBSENSE.cpp:624-640). op: 0 erode3x3, 1 dilate3x3, 2 median(ksize). */
+ * (BackgroundSubtractorSuBSENSE.cpp:624-640). op: 0 erode3x3, 1 dilate3x3, 2 median(ksize),
+ * 3 median(ksize) of a {0,255} mask (majority count, same result, faster). */
 int bgs_mask_morph_device(int hip_device, const void* d_src, void* d_dst, int rows, int cols, int op, int ksize,
                           int iterations, void* hip_stream);
 

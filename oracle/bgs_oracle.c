@@ -27,6 +27,7 @@
  *   P9 medianBlur k : true median, BORDER_REPLICATE
  */
 #include "bgs_oracle.h"
+#include "subsense_oracle.h"
 
 #include <float.h>
 #include <math.h>
@@ -51,6 +52,7 @@ struct orc_engine {
   float* mix;
   /* SigmaDelta: Mt = bgimg, Vt */
   uint8_t* vt;
+  ss_state* ss; /* SuBSENSE (subsense_oracle.c) */
   /* scratch */
   uint8_t *tmp8a, *tmp8b;
   float* tmpf;
@@ -221,6 +223,7 @@ int orc_default_params(bgs_algo algo, bgs_params* p) {
   p->subsense_n_samples = 50;
   p->subsense_n_required = 2;
   p->subsense_samples_for_moving_avgs = 100;
+  p->subsense_desc_dist_threshold_offset = 3;
   p->sd_amp_factor = 1;
   p->sd_min_var = 15;
   p->sd_max_var = 255;
@@ -264,6 +267,7 @@ void orc_destroy(orc_engine* e) {
   free(e->modes);
   free(e->mix);
   free(e->vt);
+  ss_destroy(e->ss);
   free(e->tmp8a);
   free(e->tmp8b);
   free(e->tmpf);
@@ -857,6 +861,22 @@ int orc_process(orc_engine* e, const uint8_t* in, int rows, int cols, int channe
     case BGS_ASBL: flags = asbl_process(e, fg, fg_step, bg, bg_step); break;
     case BGS_MOG2: rc = mog2_process(e, fg, fg_step, bg, bg_step, &flags); break;
     case BGS_MOG1: rc = mog1_process(e, fg, fg_step, &flags); break;
+    case BGS_SUBSENSE: { /* SuBSENSEBGS::process, package_bgs/pl/SuBSENSE.cpp:21-45 */
+      if (channels != 3) return BGS_ERR_UNSUPPORTED;
+      if (!e->ss) { /* :27-36 first frame: construct + initialize(img, ROI = all 255), then fall through to operator() */
+        rc = ss_create(&e->p, e->cur, rows, cols, &e->ss);
+        if (rc) return rc;
+      }
+      uint8_t* bgc = bg ? (uint8_t*)malloc(e->n * 3) : NULL;
+      rc = ss_process(e->ss, e->cur, e->tmp8b, bgc);
+      write_mask(e, e->tmp8b, fg, fg_step);
+      if (bgc) {
+        write_img(e, bgc, 3, bg, bg_step);
+        free(bgc);
+      }
+      flags = BGS_FG_VALID | BGS_BG_VALID;
+      break;
+    }
     case BGS_SIGMA_DELTA:
       if (channels != 3) return BGS_ERR_UNSUPPORTED;
       flags = sd_process(e, fg, fg_step);
@@ -920,6 +940,7 @@ int64_t orc_get_state(orc_engine* e, const char* plane, void* dst, size_t cap) {
       return (int64_t)(n * K * C * 4);
     }
   }
+  if (e->algo == BGS_SUBSENSE && e->ss) return ss_get_state(e->ss, plane, dst, cap);
   if (e->algo == BGS_SIGMA_DELTA && e->have1 && (!strcmp(plane, "mt") || !strcmp(plane, "vt"))) {
     NEED(n * 3);
     memcpy(dst, !strcmp(plane, "mt") ? e->bgimg : e->vt, n * 3);

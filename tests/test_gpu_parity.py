@@ -450,3 +450,94 @@ def test_mask_morphology_vs_oracle(shape):
     for k in (3, 9, 13):
         assert np.array_equal(mask_morph_device(d, MORPH_MEDIAN, ksize=k).cpu().numpy(), pyoracle.median_blur(mask, k))
     assert np.array_equal(mask_morph_device(torch.from_numpy(gray).cuda(), MORPH_MEDIAN, ksize=5).cpu().numpy(), pyoracle.median_blur(gray, 5))
+
+
+# ----------------------------------------------------------------------------- SuBSENSE (BGR path)
+
+SS_F32 = ["R", "V", "T", "Dlast", "DminLT", "DminST", "RawLT", "RawST", "FinLT", "FinST"]
+SS_U8 = ["unstable", "blinks", "lastfg", "lastraw"]
+
+
+def check_subsense_state(eng, orc, rows, cols, nS=50, stream=0):
+    n = rows * cols
+    for pl in SS_F32:
+        a, b = eng.get_state(pl, (n,), np.float32, stream=stream), orc.get_state(pl, (n,), np.float32)
+        # inf/nan-free maps; tolerance as for every float state, observed difference 0
+        assert np.array_equal(np.isfinite(a), np.isfinite(b)), pl
+        err = float(np.max(np.abs(np.where(np.isfinite(a), a, 0) - np.where(np.isfinite(b), b, 0))))
+        assert err <= STATE_TOL, "%s: max |delta| %g" % (pl, err)
+    for pl in SS_U8:
+        assert np.array_equal(eng.get_state(pl, (n,), np.uint8, stream=stream), orc.get_state(pl, (n,), np.uint8)), pl
+    assert np.array_equal(eng.get_state("lastcolor", (n * 3,), np.uint8, stream=stream), orc.get_state("lastcolor", (n * 3,), np.uint8))
+    assert np.array_equal(eng.get_state("lastdesc", (n * 3,), np.uint16, stream=stream), orc.get_state("lastdesc", (n * 3,), np.uint16))
+    assert np.array_equal(eng.get_state("color", (nS, n, 3), np.uint8, stream=stream), orc.get_state("color", (nS, n, 3), np.uint8)), "colour samples"
+    assert np.array_equal(eng.get_state("desc", (nS, n, 3), np.uint16, stream=stream), orc.get_state("desc", (nS, n, 3), np.uint16)), "descriptor samples"
+    assert np.array_equal(eng.get_state("lut", (256,), np.uint8, stream=stream), orc.get_state("lut", (256,), np.uint8))
+    assert np.array_equal(eng.get_state("scalars", (7,), np.float64, stream=stream), orc.get_state("scalars", (7,), np.float64))
+
+
+def test_subsense_golden_frames(golden_frames):
+    """96x80 < QVGA: 3x3 diffusion, median 9, no frame-level learning-rate scaling."""
+    eng, orc, _ = run_pair(capi.SUBSENSE, golden_frames)
+    check_subsense_state(eng, orc, golden_frames.shape[1], golden_frames.shape[2])
+
+
+def test_subsense_qvga_with_frame_level_block():
+    """320x240 = QVGA: learning-rate scaling + auto model reset enabled; a scene cut at frame 12 triggers refreshModel(0.1)."""
+    a = synth.numpy_frames("surv", 12, 240, 320, seed=21)
+    b = synth.numpy_frames("surv", 10, 240, 320, seed=99)  # different background: large frame-level colour difference
+    frames = np.concatenate([a, b])
+    eng, orc, _ = run_pair(capi.SUBSENSE, frames)
+    check_subsense_state(eng, orc, 240, 320)
+    sc = eng.get_state("scalars", (7,), np.float64)
+    assert sc[2] > 0, "the scene cut should have started a model-reset cooldown"
+
+
+def test_subsense_large_frame_5x5_spread():
+    """> 2x QVGA: 5x5 diffusion, larger median kernel (400x392 -> k = 11)."""
+    frames = synth.numpy_frames("surv", 8, 392, 400, seed=5)
+    eng, orc, _ = run_pair(capi.SUBSENSE, frames)
+    check_subsense_state(eng, orc, 392, 400)
+
+
+@pytest.mark.parametrize("shape", [(48, 64), (37, 53), (5, 5), (9, 131)])
+def test_subsense_ragged_sizes(shape):
+    frames = synth.random_frames(8, shape[0], shape[1], 3, seed=shape[1])
+    eng, orc, _ = run_pair(capi.SUBSENSE, frames)
+    check_subsense_state(eng, orc, shape[0], shape[1])
+
+
+@pytest.mark.parametrize("kw", [dict(subsense_n_samples=20), dict(subsense_n_required=3), dict(subsense_min_color_dist_threshold=15),
+                                dict(subsense_desc_dist_threshold_offset=1), dict(lbsp_rel_threshold=0.2), dict(subsense_samples_for_moving_avgs=20)])
+def test_subsense_param_variants(kw, golden_frames):
+    p = _params(capi.SUBSENSE, **kw)
+    eng, orc, _ = run_pair(capi.SUBSENSE, golden_frames[:10], params=p)
+    check_subsense_state(eng, orc, golden_frames.shape[1], golden_frames.shape[2], nS=p.subsense_n_samples)
+
+
+def test_subsense_streams_and_device_batch():
+    torch = _torch()
+    S, T, H, W = 3, 6, 40, 72
+    clips = np.stack([synth.random_frames(T, H, W, 3, seed=300 + s) for s in range(S)])
+    eng = Engine(capi.SUBSENSE, n_streams=S)
+    eng.set_geometry(H, W, 3)
+    orcs = [pyoracle.Oracle(capi.SUBSENSE) for _ in range(S)]
+    for t in range(T):
+        d_frames = torch.from_numpy(np.ascontiguousarray(clips[:, t])).cuda()
+        d_fg = torch.empty((S, H, W), dtype=torch.uint8, device="cuda")
+        d_bg = torch.empty((S, H, W, 3), dtype=torch.uint8, device="cuda")
+        eng.process_batch_device(d_frames, d_fg, d_bg, None)
+        torch.cuda.synchronize()
+        for s in range(S):
+            ofg, obg = orcs[s].process(clips[s, t])
+            assert np.array_equal(d_fg[s].cpu().numpy(), ofg), (t, s)
+            assert np.array_equal(d_bg[s].cpu().numpy(), obg), (t, s)
+    for s in range(S):
+        check_subsense_state(eng, orcs[s], H, W, stream=s)
+
+
+def test_subsense_rejects_unsupported_inputs(golden_gray):
+    with pytest.raises(capi.BgsError):
+        Engine(capi.SUBSENSE).process(golden_gray[0])  # 1-channel path not built
+    with pytest.raises(capi.BgsError):
+        Engine(capi.SUBSENSE).process(np.zeros((243, 325, 3), np.uint8))  # >= QVGA and not a multiple of 8

@@ -216,3 +216,60 @@ def test_morphology_primitives():
     p = np.pad(g, 1, mode="edge")
     want = np.array([[np.median(p[y:y + 3, x:x + 3]) for x in range(15)] for y in range(12)]).astype(np.uint8)
     assert np.array_equal(pyoracle.median_blur(g, 3), want)
+
+
+def test_subsense_oracle_basics(golden_frames):
+    """SuBSENSE restatement: the first call initialises AND classifies (SuBSENSE.cpp:27-38), the 2-px border never fires,
+    the background image is the mean of the 50 colour samples, and the counter-based RNG makes runs reproducible."""
+    a, b = pyoracle.Oracle(capi.SUBSENSE), pyoracle.Oracle(capi.SUBSENSE)
+    for t, f in enumerate(golden_frames[:8]):
+        fa, ba = a.process(f)
+        fb, bb = b.process(f)
+        assert fa is not None and ba is not None
+        assert np.array_equal(fa, fb) and np.array_equal(ba, bb)
+        assert set(np.unique(fa)) <= {0, 255}
+    n = golden_frames.shape[1] * golden_frames.shape[2]
+    color = a.get_state("color", (50, n, 3), np.uint8).astype(np.float32)
+    acc = np.zeros((n, 3), np.float32)
+    for k in range(50):
+        acc += color[k] / np.float32(50)
+    assert np.array_equal(ba.reshape(n, 3), np.clip(np.rint(acc), 0, 255).astype(np.uint8))
+    R = a.get_state("R", (n,), np.float32)
+    assert R.min() >= 1.0
+    sc = a.get_state("scalars", (7,), np.float64)
+    assert sc[0] == 8 and sc[3] == 4.0 and sc[4] == 512.0  # below QVGA: caps doubled, no learning-rate scaling
+
+
+def test_subsense_static_scene_goes_quiet():
+    rng = np.random.default_rng(3)
+    base = rng.integers(40, 200, (40, 56, 3)).astype(np.int32)
+    o = pyoracle.Oracle(capi.SUBSENSE)
+    for t in range(15):
+        f = np.clip(base + rng.integers(-2, 3, base.shape), 0, 255).astype(np.uint8)
+        fg, _ = o.process(f)
+    assert (fg == 255).mean() < 0.01
+
+
+def test_counter_rng_is_shared_by_both_sides():
+    """ss_rand() is the whole stochastic contract: same function in oracle/subsense_oracle.c and kernel_subsense.h."""
+    import ctypes as C
+    l = pyoracle.lib()
+    l.ss_rand.restype = C.c_uint32
+    l.ss_rand.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+
+    def ref(frame, pixel, draw):
+        M = 0xFFFFFFFF
+        x = (frame * 0x9E3779B1) & M
+        x ^= (pixel + 0x85EBCA6B + ((x << 6) & M) + (x >> 2)) & M
+        x ^= ((draw + 1) * 0xC2B2AE35) & M
+        x ^= x >> 16
+        x = (x * 0x85EBCA6B) & M
+        x ^= x >> 13
+        x = (x * 0xC2B2AE35) & M
+        x ^= x >> 16
+        return x >> 1
+
+    for args in [(0, 0, 0), (1, 2, 3), (77, 123456, 6), (4000000000, 0xFFFFFFFF, 16)]:
+        assert l.ss_rand(*args) == ref(*args)
+    vals = np.array([l.ss_rand(5, p, 4) % 8 for p in range(8000)])
+    assert np.bincount(vals, minlength=8).min() > 800  # roughly uniform

@@ -56,7 +56,8 @@ class BgsParams(C.Structure):
         ("sd_amp_factor", C.c_int32),
         ("sd_min_var", C.c_int32),
         ("sd_max_var", C.c_int32),
-        ("reserved", C.c_uint32 * 16),
+        ("subsense_desc_dist_threshold_offset", C.c_int32),
+        ("reserved", C.c_uint32 * 15),
     ]
 
 

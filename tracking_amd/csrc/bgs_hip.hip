@@ -23,6 +23,7 @@
 #include "kernel_mog2.h"
 #include "kernel_pointwise.h"
 #include "kernel_stencil.h"
+#include "kernel_subsense.h"
 
 namespace {
 
@@ -49,6 +50,10 @@ inline unsigned blocks_for(size_t groups) { return (unsigned)((groups + bgs::kBl
 
 }  // namespace
 
+namespace {
+struct SsDevice;  // engine_subsense.h
+}
+
 struct bgs_engine {
   bgs_algo algo;
   bgs_params p;
@@ -69,6 +74,7 @@ struct bgs_engine {
   uint8_t* bgstate2 = nullptr;  // ASBL: second buffer of the ping-pong pair (the 3x3 median reads neighbours' OLD background)
   std::vector<uint8_t> flip;    // ASBL: which buffer holds the current background, per stream
   float* mog1_state = nullptr;  // MOG1 model (kernel_mog1.h, tiled)
+  SsDevice* ss = nullptr;       // SuBSENSE model (engine_subsense.h)
   // MOG2 model (kernel_mog2.h: tiled AoSoA by default, planar kept for A/B runs)
   float* mog2_state = nullptr;
   uint8_t* mog2_nmodes = nullptr;  // planar layout only
@@ -92,6 +98,8 @@ struct bgs_engine {
 
 namespace {
 
+void ss_free(bgs_engine* e);  // engine_subsense.h
+
 void free_all(bgs_engine* e) {
   for (auto& r : e->ring)
     if (r) (void)hipFree(r), r = nullptr;
@@ -105,6 +113,7 @@ void free_all(bgs_engine* e) {
   e->h_in = e->h_fg = e->h_bg = nullptr;
   for (auto& ev : e->events) (void)hipEventDestroy(ev.first), (void)hipEventDestroy(ev.second);
   e->events.clear();
+  ss_free(e);
 }
 
 int check_params(bgs_algo algo, const bgs_params& p) {
@@ -244,6 +253,8 @@ int mog2_allocate(bgs_engine* e) {
   return rc;
 }
 
+#include "engine_subsense.h"
+
 int allocate(bgs_engine* e, int rows, int cols, int ch) {
   if (rows <= 0 || cols <= 0) return fail(BGS_ERR_INVALID, "bad geometry %dx%d", rows, cols);
   if (ch != 1 && ch != 3) return fail(BGS_ERR_UNSUPPORTED, "channels must be 1 or 3, got %d", ch);
@@ -264,7 +275,8 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
       e->state_ch = 3;
       break;
     case BGS_MOG1:
-    case BGS_MOG2: break;
+    case BGS_MOG2:
+    case BGS_SUBSENSE: break;
     default: return fail(BGS_ERR_UNSUPPORTED, "algorithm %d is not implemented in this build", (int)e->algo);
   }
   for (int i = 0; i < e->nring; ++i) HIP_TRY(hipMalloc((void**)&e->ring[i], fb));
@@ -279,6 +291,10 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
   if (!e->stream) HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   if (e->algo == BGS_MOG2) {
     int rc = mog2_allocate(e);
+    if (rc) return rc;
+  }
+  if (e->algo == BGS_SUBSENSE) {
+    int rc = ss_allocate(e);
     if (rc) return rc;
   }
   if (!e->stream) HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
@@ -408,6 +424,13 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
         if (a.update && p.limit > 0 && p.limit < cnt)
           for (int i = first; i < first + count; ++i) e->counter[i]++;
       }
+      flags = BGS_FG_VALID | BGS_BG_VALID;
+      break;
+    }
+    case BGS_SUBSENSE: {
+      if (d_bits) return fail(BGS_ERR_UNSUPPORTED, "SuBSENSE writes the byte mask only");
+      int rc = ss_process(e, first, count, d_frames, d_fg, d_bg, s, t);
+      if (rc) return rc;
       flags = BGS_FG_VALID | BGS_BG_VALID;
       break;
     }
@@ -573,6 +596,7 @@ int bgs_default_params(bgs_algo algo, bgs_params* p) {
   p->subsense_n_samples = 50;
   p->subsense_n_required = 2;
   p->subsense_samples_for_moving_avgs = 100;
+  p->subsense_desc_dist_threshold_offset = 3;
   p->sd_amp_factor = 1;
   p->sd_min_var = 15;
   p->sd_max_var = 255;
@@ -757,6 +781,7 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
       return (int64_t)need;
     }
   }
+  if (e->algo == BGS_SUBSENSE && e->ss) return ss_get_state(e, stream, plane, dst, cap);
   if (e->algo == BGS_MOG1) {
     const int R = 2 + 2 * C, NP = bgs::kMog1K * R;
     int f0 = -1, nf = 0;  // field offset inside a mode record, floats per mode
@@ -847,8 +872,8 @@ int bgs_lbsp_describe_device(int hip_device, const void* d_img, int rows, int co
 }
 
 int bgs_mask_morph_device(int hip_device, const void* d_src, void* d_dst, int rows, int cols, int op, int ksize, int iterations, void* hip_stream) {
-  if (!d_src || !d_dst || rows <= 0 || cols <= 0 || op < 0 || op > 2 || iterations < 1) return fail(BGS_ERR_INVALID, "bad argument");
-  if (op == 2 && (ksize < 3 || ksize > 2 * bgs::kMorphMaxR + 1 || ksize % 2 == 0)) return fail(BGS_ERR_INVALID, "median ksize must be odd, 3..15");
+  if (!d_src || !d_dst || rows <= 0 || cols <= 0 || op < 0 || op > 3 || iterations < 1) return fail(BGS_ERR_INVALID, "bad argument");
+  if (op >= 2 && (ksize < 3 || ksize > 2 * bgs::kMorphMaxR + 1 || ksize % 2 == 0)) return fail(BGS_ERR_INVALID, "median ksize must be odd, 3..15");
   if (d_src == d_dst) return fail(BGS_ERR_INVALID, "in-place morphology is not supported");
   HIP_TRY(hipSetDevice(hip_device));
   hipStream_t s = (hipStream_t)hip_stream;

@@ -1,0 +1,264 @@
+// engine_subsense.h — host-side orchestration of the SuBSENSE kernels (kernel_subsense.h).  Included by bgs_hip.hip inside
+// its anonymous namespace, after bgs_engine / fail() / HIP_TRY / Timed are defined.
+// One ss_process() call = SuBSENSEBGS::process (package_bgs/pl/SuBSENSE.cpp:21-45) for streams [first, first+count).
+//
+// Everything runs on the launch stream; the frame-level block (BackgroundSubtractorSuBSENSE.cpp:643-699) runs on the device
+// so there is no host round trip except the flood fill's convergence flag (:630).
+
+enum { SS_R, SS_V, SS_T, SS_DLAST0, SS_DLAST1, SS_DMINLT, SS_DMINST, SS_RAWLT, SS_RAWST0, SS_RAWST1, SS_FINLT, SS_FINST, SS_NF32 };
+enum { SS_UNSTABLE, SS_BLINKS, SS_LASTFG, SS_LASTRAW, SS_LASTRAWBLINK, SS_LASTDILINV, SS_RAW, SS_T1, SS_T2, SS_T3, SS_T4, SS_NU8 };
+
+struct SsDevice {
+  uint8_t *color = nullptr, *lut = nullptr, *lastColor = nullptr;
+  uint16_t *desc = nullptr, *lastDesc = nullptr, *req = nullptr;
+  float* f32[SS_NF32] = {nullptr};
+  uint8_t* u8[SS_NU8] = {nullptr};
+  float *dsLT = nullptr, *dsST = nullptr;
+  bgs::SsScalars* sc = nullptr;
+  int* changed = nullptr;
+  int* h_changed = nullptr;  // pinned
+  std::vector<uint8_t> pp;   // per stream: which copy of Dlast / RawST is current
+  int use3x3 = 1, lrScaling = 0, medK = 9;
+  float capLo0 = 4.f, capHi0 = 512.f;
+  void release() {
+    void* p[] = {color, lut, lastColor, desc, lastDesc, req, dsLT, dsST, sc, changed};
+    for (void* q : p)
+      if (q) (void)hipFree(q);
+    for (auto& q : f32)
+      if (q) (void)hipFree(q), q = nullptr;
+    for (auto& q : u8)
+      if (q) (void)hipFree(q), q = nullptr;
+    if (h_changed) (void)hipHostFree(h_changed);
+    color = lut = lastColor = nullptr, desc = lastDesc = req = nullptr, dsLT = dsST = nullptr, sc = nullptr, changed = h_changed = nullptr;
+  }
+};
+
+int ss_allocate(bgs_engine* e) {
+  if (e->ch != 3) return fail(BGS_ERR_UNSUPPORTED, "SuBSENSE: only the 3-channel (BGR) path is built");
+  if (e->rows < 5 || e->cols < 5) return fail(BGS_ERR_UNSUPPORTED, "SuBSENSE needs at least 5x5 pixels (LBSP::validateROI)");
+  const bgs_params& p = e->p;
+  if (p.subsense_n_samples < 1 || p.subsense_n_samples > 63 || p.subsense_n_required > p.subsense_n_samples)
+    return fail(BGS_ERR_UNSUPPORTED, "SuBSENSE: nBGSamples must be 1..63 and nRequiredBGSamples <= nBGSamples");
+  SsDevice* d = new SsDevice();
+  e->ss = d;
+  // geometry-dependent switches of BackgroundSubtractorSuBSENSE::initialize (:121-140), ROI = whole frame (SuBSENSE.cpp:36)
+  const int total = e->rows * e->cols, qvga = 320 * 240;
+  if (total >= qvga) {
+    d->lrScaling = 1;
+    d->use3x3 = !(total > qvga * 2);
+    int k = (int)std::floor((float)total / qvga + 0.5f) + 9;
+    k = std::min(k, 14);
+    d->medK = (k % 2) ? k : k - 1;
+    d->capLo0 = 2.f, d->capHi0 = 256.f;
+    if (e->rows % 8 || e->cols % 8)
+      return fail(BGS_ERR_UNSUPPORTED, "SuBSENSE frame-level analysis: rows and cols must be multiples of 8 (cv::resize INTER_AREA with an integer ratio)");
+  }
+  const size_t N = e->n, P = N * e->S, nS = (size_t)p.subsense_n_samples;
+  HIP_TRY(hipMalloc((void**)&d->color, P * nS * 3));
+  HIP_TRY(hipMalloc((void**)&d->desc, P * nS * 3 * 2));
+  HIP_TRY(hipMalloc((void**)&d->lastColor, P * 3));
+  HIP_TRY(hipMalloc((void**)&d->lastDesc, P * 3 * 2));
+  HIP_TRY(hipMalloc((void**)&d->req, P * 2 * 2));
+  HIP_TRY(hipMalloc((void**)&d->lut, (size_t)e->S * 256));
+  HIP_TRY(hipMalloc((void**)&d->sc, (size_t)e->S * sizeof(bgs::SsScalars)));
+  HIP_TRY(hipMalloc((void**)&d->changed, sizeof(int)));
+  HIP_TRY(hipHostMalloc((void**)&d->h_changed, sizeof(int), hipHostMallocDefault));
+  for (auto& q : d->f32) HIP_TRY(hipMalloc((void**)&q, P * sizeof(float)));
+  for (auto& q : d->u8) HIP_TRY(hipMalloc((void**)&q, P));
+  const size_t ds = (size_t)(e->rows / 8) * (e->cols / 8) * 3 * e->S + 4;
+  HIP_TRY(hipMalloc((void**)&d->dsLT, ds * sizeof(float)));
+  HIP_TRY(hipMalloc((void**)&d->dsST, ds * sizeof(float)));
+  d->pp.assign(e->S, 0);
+  return BGS_OK;
+}
+
+void ss_fill_args(const bgs_engine* e, bgs::SsArgs& a, int first, int cur_pp, unsigned frameIndex) {
+  const SsDevice* d = e->ss;
+  const bgs_params& p = e->p;
+  a.color = d->color, a.desc = d->desc, a.lastColor = d->lastColor, a.lastDesc = d->lastDesc, a.req = d->req, a.lut = d->lut, a.sc = d->sc;
+  a.R = d->f32[SS_R], a.V = d->f32[SS_V], a.T = d->f32[SS_T];
+  a.DlastOld = d->f32[cur_pp ? SS_DLAST1 : SS_DLAST0], a.DlastNew = d->f32[cur_pp ? SS_DLAST0 : SS_DLAST1];
+  a.RawSTOld = d->f32[cur_pp ? SS_RAWST1 : SS_RAWST0], a.RawSTNew = d->f32[cur_pp ? SS_RAWST0 : SS_RAWST1];
+  a.DminLT = d->f32[SS_DMINLT], a.DminST = d->f32[SS_DMINST], a.RawLT = d->f32[SS_RAWLT], a.FinLT = d->f32[SS_FINLT], a.FinST = d->f32[SS_FINST];
+  a.unstable = d->u8[SS_UNSTABLE], a.blinks = d->u8[SS_BLINKS], a.lastFG = d->u8[SS_LASTFG], a.lastRaw = d->u8[SS_LASTRAW];
+  a.lastRawBlink = d->u8[SS_LASTRAWBLINK], a.lastDilInv = d->u8[SS_LASTDILINV], a.raw = d->u8[SS_RAW];
+  a.t1 = d->u8[SS_T1], a.t2 = d->u8[SS_T2], a.t3 = d->u8[SS_T3];
+  a.dsLT = d->dsLT, a.dsST = d->dsST;
+  a.rows = e->rows, a.cols = e->cols, a.nS = p.subsense_n_samples, a.nReq = p.subsense_n_required, a.nMinColor = p.subsense_min_color_dist_threshold;
+  a.nDescOff = p.subsense_desc_dist_threshold_offset, a.nMov = p.subsense_samples_for_moving_avgs, a.lbspOff = p.lbsp_threshold_offset;
+  a.use3x3 = d->use3x3, a.lrScaling = d->lrScaling, a.medK = d->medK, a.relT = p.lbsp_rel_threshold;
+  a.frameIndex = frameIndex, a.first = first;
+  const int64_t fi = frameIndex ? frameIndex : 1;
+  a.fLT = 1.0f / (float)std::min<int64_t>(fi, p.subsense_samples_for_moving_avgs);
+  a.fST = 1.0f / (float)std::min<int64_t>(fi, p.subsense_samples_for_moving_avgs / 4);
+}
+
+void ss_morph(const uint8_t* src, uint8_t* dst, int rows, int cols, int count, int op, int ksize, hipStream_t s) {
+  bgs::MorphArgs m{src, dst, rows, cols, op, ksize};
+  hipLaunchKernelGGL(bgs::morph_kernel, dim3((cols + bgs::kMorphTW - 1) / bgs::kMorphTW, (rows + bgs::kMorphTH - 1) / bgs::kMorphTH, count), dim3(bgs::kBlock), 0, s, m);
+}
+
+// cv::saturate_cast<uchar>(offset + t * rel) per entry (BackgroundSubtractorSuBSENSE.cpp:227-228); host-side, once per stream
+void ss_initial_lut(const bgs_params& p, uint8_t lut[256]) {
+  for (int t = 0; t < 256; ++t) {
+    const float v = (float)(size_t)p.lbsp_threshold_offset + (float)(size_t)t * p.lbsp_rel_threshold;
+    long r = std::lrint((double)v);
+    lut[t] = (uint8_t)std::min<long>(std::max<long>(r, 0), 255);
+  }
+}
+
+int ss_init_streams(bgs_engine* e, int first, int count, const uint8_t* d_frames, hipStream_t s) {
+  SsDevice* d = e->ss;
+  const size_t N = e->n, off = N * first, npix = N * count, nS = (size_t)e->p.subsense_n_samples;
+  uint8_t lut[256];
+  ss_initial_lut(e->p, lut);
+  bgs::SsScalars sc0{};
+  sc0.autoReset = d->lrScaling, sc0.capLo = d->capLo0, sc0.capHi = d->capHi0;
+  for (int i = first; i < first + count; ++i) {
+    HIP_TRY(hipMemcpyAsync(d->lut + (size_t)i * 256, lut, 256, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d->sc + i, &sc0, sizeof(sc0), hipMemcpyHostToDevice, s));
+    d->pp[i] = 0;
+  }
+  HIP_TRY(hipStreamSynchronize(s));  // lut / sc0 live on this stack frame
+  auto fillf = [&](int idx, float v) -> hipError_t {
+    uint32_t bits;
+    std::memcpy(&bits, &v, 4);
+    return hipMemsetD32Async((hipDeviceptr_t)(d->f32[idx] + off), (int)bits, npix, s);
+  };
+  HIP_TRY(fillf(SS_T, d->capLo0));  // m_oUpdateRateFrame = lower cap (:142)
+  HIP_TRY(fillf(SS_R, 1.0f));
+  HIP_TRY(fillf(SS_V, 10.0f));
+  for (int idx : {SS_DLAST0, SS_DLAST1, SS_DMINLT, SS_DMINST, SS_RAWLT, SS_RAWST0, SS_RAWST1, SS_FINLT, SS_FINST}) HIP_TRY(fillf(idx, 0.0f));
+  for (int idx : {SS_UNSTABLE, SS_BLINKS, SS_LASTFG, SS_LASTRAW, SS_LASTRAWBLINK, SS_LASTDILINV}) HIP_TRY(hipMemsetAsync(d->u8[idx] + off, 0, npix, s));
+  const size_t dsn = (size_t)(e->rows / 8) * (e->cols / 8) * 3;
+  if (dsn) {
+    HIP_TRY(hipMemsetAsync(d->dsLT + dsn * first, 0, dsn * count * sizeof(float), s));
+    HIP_TRY(hipMemsetAsync(d->dsST + dsn * first, 0, dsn * count * sizeof(float), s));
+  }
+  HIP_TRY(hipMemsetAsync(d->color + off * nS * 3, 0, npix * nS * 3, s));
+  HIP_TRY(hipMemsetAsync(d->desc + off * nS * 3, 0, npix * nS * 3 * 2, s));
+  // first-frame descriptors (:229-243) with the initial LUT, border = 0; LastColor interior = frame
+  bgs::LbspArgs la{};
+  la.img = d_frames, la.desc = d->lastDesc + off * 3, la.rows = e->rows, la.cols = e->cols;
+  std::memcpy(la.lut, lut, 256);
+  hipLaunchKernelGGL((bgs::lbsp_kernel<3>), dim3((e->cols + bgs::kLbspTW - 1) / bgs::kLbspTW, (e->rows + bgs::kLbspTH - 1) / bgs::kLbspTH, count), dim3(bgs::kBlock), 0, s, la);
+  bgs::SsArgs a{};
+  ss_fill_args(e, a, first, 0, 0);
+  a.frame = d_frames;
+  hipLaunchKernelGGL(bgs::ss_init_lastcolor_kernel, dim3(blocks_for(N), 1, count), dim3(bgs::kBlock), 0, s, a);
+  hipLaunchKernelGGL(bgs::ss_refresh_kernel, dim3(blocks_for(N), 1, count), dim3(bgs::kBlock), 0, s, a, 0);  // refreshModel(1.0f) (:246)
+  HIP_TRY(hipGetLastError());
+  return BGS_OK;
+}
+
+int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uint8_t* d_fg, uint8_t* d_bg, hipStream_t s, int64_t t) {
+  SsDevice* d = e->ss;
+  const size_t N = e->n, off = N * first, npix = N * count;
+  if (!aligned(d_frames, 4)) return fail(BGS_ERR_INVALID, "SuBSENSE: frames must be 4-byte aligned");
+  if (t == 0) {  // SuBSENSE.cpp:27-36: construct + initialize on the first frame, then fall through to operator()
+    int rc = ss_init_streams(e, first, count, d_frames, s);
+    if (rc) return rc;
+  }
+  const int cur = d->pp[first];
+  for (int i = first; i < first + count; ++i)
+    if (d->pp[i] != cur) return fail(BGS_ERR_INVALID, "streams %d and %d are not in lock-step", first, i);
+  bgs::SsArgs a{};
+  ss_fill_args(e, a, first, cur, (unsigned)(t + 1));
+  a.frame = d_frames, a.fg = d_fg, a.bgimg = d_bg;
+  const dim3 tiles((e->cols + bgs::kSsTW - 1) / bgs::kSsTW, (e->rows + bgs::kSsTH - 1) / bgs::kSsTH, count), block(bgs::kBlock);
+  {
+    Timed tm(e, s, "ss_phase_a_kernel");
+    hipLaunchKernelGGL(bgs::ss_phase_a_kernel, tiles, block, 0, s, a);
+  }
+  hipLaunchKernelGGL(bgs::ss_phase_b_kernel, tiles, block, 0, s, a);
+  hipLaunchKernelGGL(bgs::ss_blink_kernel, dim3(blocks_for(npix)), block, 0, s, a, npix);
+  uint8_t *raw = d->u8[SS_RAW] + off, *t1 = d->u8[SS_T1] + off, *t2 = d->u8[SS_T2] + off, *t3 = d->u8[SS_T3] + off, *t4 = d->u8[SS_T4] + off;
+  uint8_t* lastFG = d->u8[SS_LASTFG] + off;
+  // morphologyEx(MORPH_CLOSE) :628  -> t1 = PreFlood
+  ss_morph(raw, t3, e->rows, e->cols, count, 1, 3, s);
+  ss_morph(t3, t1, e->rows, e->cols, count, 0, 3, s);
+  // floodFill(PreFlood copy, (0,0), 255) :629-630 -> t2 = reached set
+  HIP_TRY(hipMemsetAsync(t2, 0, npix, s));
+  hipLaunchKernelGGL(bgs::ss_flood_seed_kernel, dim3((count + 63) / 64), dim3(64), 0, s, t2, N, count);
+  const dim3 ftiles((e->cols + bgs::kFloodT - 1) / bgs::kFloodT, (e->rows + bgs::kFloodT - 1) / bgs::kFloodT, count);
+  for (int it = 0; it < e->rows + e->cols + 8; ++it) {
+    HIP_TRY(hipMemsetAsync(d->changed, 0, sizeof(int), s));
+    hipLaunchKernelGGL(bgs::ss_flood_kernel, ftiles, block, 0, s, (const uint8_t*)t1, t2, e->rows, e->cols, d->changed);
+    HIP_TRY(hipMemcpyAsync(d->h_changed, d->changed, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (!*d->h_changed) break;
+  }
+  // erode x3 :632 -> t3
+  ss_morph(t1, t3, e->rows, e->cols, count, 0, 3, s);
+  ss_morph(t3, t4, e->rows, e->cols, count, 0, 3, s);
+  ss_morph(t4, t3, e->rows, e->cols, count, 0, 3, s);
+  hipLaunchKernelGGL(bgs::ss_combine_kernel, dim3(blocks_for(npix)), block, 0, s, a, (const uint8_t*)t1, (const uint8_t*)t2, (const uint8_t*)t3, t4, npix);  // :631-634
+  ss_morph(t4, lastFG, e->rows, e->cols, count, 3, d->medK, s);  // medianBlur :635 (the input is a {0,255} mask)
+  ss_morph(lastFG, t1, e->rows, e->cols, count, 1, 3, s);        // dilate x3 :636
+  ss_morph(t1, t3, e->rows, e->cols, count, 1, 3, s);
+  ss_morph(t3, t1, e->rows, e->cols, count, 1, 3, s);
+  hipLaunchKernelGGL(bgs::ss_finish_kernel, dim3(blocks_for(npix)), block, 0, s, a, (const uint8_t*)t1, npix);  // :637-642
+  if (d->lrScaling) {
+    const int dsn = (e->rows / 8) * (e->cols / 8);
+    hipLaunchKernelGGL(bgs::ss_downsample_kernel, dim3(blocks_for(dsn), 1, count), block, 0, s, a);
+  }
+  hipLaunchKernelGGL(bgs::ss_frame_level_kernel, dim3(count), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(bgs::ss_refresh_kernel, dim3(blocks_for(N), 1, count), block, 0, s, a, 1);  // refreshModel(0.1f) if asked (:680)
+  if (d_bg) hipLaunchKernelGGL(bgs::ss_background_kernel, dim3(blocks_for(N * 3), 1, count), block, 0, s, a);
+  HIP_TRY(hipGetLastError());
+  for (int i = first; i < first + count; ++i) d->pp[i] = (uint8_t)(cur ^ 1);
+  return BGS_OK;
+}
+
+int64_t ss_get_state(bgs_engine* e, int stream, const char* plane, void* dst, size_t cap) {
+  SsDevice* d = e->ss;
+  const size_t N = e->n, off = N * stream, nS = (size_t)e->p.subsense_n_samples;
+  const int cur = d->pp[stream];
+  struct Ent {
+    const char* name;
+    const void* p;
+    size_t bytes;
+  };
+  const Ent tab[] = {{"R", d->f32[SS_R] + off, N * 4},
+                     {"V", d->f32[SS_V] + off, N * 4},
+                     {"T", d->f32[SS_T] + off, N * 4},
+                     {"Dlast", d->f32[cur ? SS_DLAST1 : SS_DLAST0] + off, N * 4},
+                     {"DminLT", d->f32[SS_DMINLT] + off, N * 4},
+                     {"DminST", d->f32[SS_DMINST] + off, N * 4},
+                     {"RawLT", d->f32[SS_RAWLT] + off, N * 4},
+                     {"RawST", d->f32[cur ? SS_RAWST1 : SS_RAWST0] + off, N * 4},
+                     {"FinLT", d->f32[SS_FINLT] + off, N * 4},
+                     {"FinST", d->f32[SS_FINST] + off, N * 4},
+                     {"unstable", d->u8[SS_UNSTABLE] + off, N},
+                     {"blinks", d->u8[SS_BLINKS] + off, N},
+                     {"lastfg", d->u8[SS_LASTFG] + off, N},
+                     {"lastraw", d->u8[SS_LASTRAW] + off, N},
+                     {"lastcolor", d->lastColor + off * 3, N * 3},
+                     {"lastdesc", d->lastDesc + off * 3, N * 6},
+                     {"color", d->color + off * nS * 3, N * nS * 3},
+                     {"desc", d->desc + off * nS * 3, N * nS * 6},
+                     {"lut", d->lut + (size_t)stream * 256, 256}};
+  for (const Ent& t : tab)
+    if (!strcmp(plane, t.name)) {
+      if (cap < t.bytes) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
+      if (hipMemcpy(dst, t.p, t.bytes, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+      return (int64_t)t.bytes;
+    }
+  if (!strcmp(plane, "scalars")) {
+    if (cap < 7 * sizeof(double)) return fail(BGS_ERR_STATE, "buffer too small for plane scalars");
+    bgs::SsScalars sc;
+    if (hipMemcpy(&sc, d->sc + stream, sizeof(sc), hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+    double* o = (double*)dst;
+    o[0] = (double)e->seen[stream], o[1] = sc.framesSinceReset, o[2] = sc.cooldown, o[3] = sc.capLo, o[4] = sc.capHi, o[5] = sc.autoReset, o[6] = sc.lastNZ;
+    return 7 * sizeof(double);
+  }
+  return fail(BGS_ERR_STATE, "unknown state plane '%s' for SuBSENSE", plane);
+}
+
+void ss_free(bgs_engine* e) {
+  if (e->ss) {
+    e->ss->release();
+    delete e->ss;
+    e->ss = nullptr;
+  }
+}

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(kBlock) void lbsp_kernel(const LbspArgs a) {
 struct MorphArgs {
   const uint8_t* src;
   uint8_t* dst;
-  int rows, cols, op, ksize;  // op 0 erode3x3, 1 dilate3x3, 2 median(ksize)
+  int rows, cols, op, ksize;  // op 0 erode3x3, 1 dilate3x3, 2 median(ksize), 3 median(ksize) of a {0,255} mask (majority count)
 };
 
 constexpr int kMorphTW = 64, kMorphTH = 4, kMorphMaxR = 7;  // median up to 15x15
@@ -165,7 +165,7 @@ constexpr int kMorphTW = 64, kMorphTH = 4, kMorphMaxR = 7;  // median up to 15x1
 // median: BORDER_REPLICATE.  Masks are {0,255} in the SuBSENSE chain but any u8 image is handled.
 __global__ __launch_bounds__(kBlock) void morph_kernel(const MorphArgs a) {
   __shared__ uint8_t t[kMorphTH + 2 * kMorphMaxR][kMorphTW + 2 * kMorphMaxR + 2];
-  const int R = a.op == 2 ? a.ksize / 2 : 1;
+  const int R = a.op >= 2 ? a.ksize / 2 : 1;
   const int x0 = blockIdx.x * kMorphTW, y0 = blockIdx.y * kMorphTH;
   const size_t img = (size_t)blockIdx.z * a.rows * a.cols;
   const int HW = kMorphTW + 2 * R, HH = kMorphTH + 2 * R;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void morph_kernel(const MorphArgs a) {
     const int ly = i / HW, lx = i - ly * HW;
     const int y = y0 + ly - R, x = x0 + lx - R;
     uint8_t v;
-    if (a.op == 2) {
+    if (a.op >= 2) {
       v = a.src[img + (size_t)min(max(y, 0), a.rows - 1) * a.cols + min(max(x, 0), a.cols - 1)];
     } else {
       const bool in = y >= 0 && y < a.rows && x >= 0 && x < a.cols;
@@ -186,7 +186,13 @@ __global__ __launch_bounds__(kBlock) void morph_kernel(const MorphArgs a) {
   const int x = x0 + lx, y = y0 + ly;
   if (x >= a.cols || y >= a.rows) return;
   int out;
-  if (a.op == 2) {
+  if (a.op == 3) {
+    // binary mask: the median is 255 iff more than half of the k*k cells are non-zero
+    int cnt = 0;
+    for (int dy = 0; dy <= 2 * R; ++dy)
+      for (int dx = 0; dx <= 2 * R; ++dx) cnt += t[ly + dy][lx + dx] != 0;
+    out = cnt >= (a.ksize * a.ksize) / 2 + 1 ? 255 : 0;
+  } else if (a.op == 2) {
     // exact median by counting: the value v such that #(<= v) first reaches (k*k)/2 + 1; binary search over 8 bits
     const int need = (a.ksize * a.ksize) / 2 + 1;
     int lo = 0, hi = 255;

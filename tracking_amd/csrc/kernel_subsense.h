@@ -1,0 +1,551 @@
+// kernel_subsense.h — K7/K8/K9 for SuBSENSEBGS (package_bgs/pl/SuBSENSE.cpp:21-45 over BackgroundSubtractorSuBSENSE.cpp), BGR path.
+//
+//   ss_phase_a_kernel    per-pixel loop of operator()            BackgroundSubtractorSuBSENSE.cpp:437-584
+//                        (thresholds :459-463, LBSP intra :465-466, sample consensus :469-497, rolling means :498-522,
+//                         update decisions :508-551, feedback T/v/R :553-576, non-zero-desc count :577-578, last frame :579-582)
+//   ss_phase_b_kernel    the sample writes decided in phase A (self update + neighbour diffusion), applied in raster order
+//   ss_refresh_kernel    refreshModel                             :249-291   (also the model initialisation, :246)
+//   ss_blink_kernel / ss_combine_kernel / ss_finish_kernel / flood kernels   post-processing chain :624-642
+//   ss_downsample_kernel + ss_frame_level_kernel                  frame-level block :643-699 (runs on the device: no host sync)
+//   ss_background_kernel getBackgroundImage                       :702-718
+//
+// Parallel-safe contract (the CPU restatement the tests compare against follows the same one): random draws are ss_rand(frame, pixel, slot)
+// instead of the reference's sequential libc rand(); a frame is two phases (classify everything against the model as it
+// stood at the start of the frame, then apply all sample writes, the highest source pixel index winning a conflict);
+// a pixel reads its random neighbour's D_last / raw-segmentation means from the previous frame's copy.
+//
+// Layout per stream: colour samples u8 [nS][N][3], descriptor samples u16 [nS][N][3] (one contiguous plane per sample index,
+// so the early-exit sample loop reads one coalesced row of each plane per iteration), ten f32 maps [N] (+2 second copies),
+// byte maps [N].  The current frame's 5x5 neighbourhood is staged through LDS once per workgroup (64x4 pixel tile + halo 2).
+#pragma once
+#include "bgs_device.h"
+
+namespace bgs {
+
+constexpr int kSsTW = 64, kSsTH = 4;  // one lane per pixel
+
+// per-stream scalars that the frame-level block updates ON THE DEVICE
+struct SsScalars {
+  int framesSinceReset, cooldown, autoReset, doRefresh;
+  float capLo, capHi, lastNZ;
+  unsigned nzCount, totDiff;
+  int pad[7];
+};
+
+struct SsArgs {
+  const uint8_t* frame;  // [S][N][3]
+  uint8_t* color;        // [S][nS][N][3]
+  uint16_t* desc;        // [S][nS][N][3]
+  float *R, *V, *T, *DlastOld, *DlastNew, *DminLT, *DminST, *RawLT, *RawSTOld, *RawSTNew, *FinLT, *FinST;  // [S][N]
+  uint8_t *unstable, *blinks, *lastFG, *lastRaw, *lastRawBlink, *lastDilInv, *lastColor;                  // [S][N] ([S][N][3])
+  uint16_t* lastDesc;    // [S][N][3]
+  uint8_t *raw, *t1, *t2, *t3;  // [S][N] scratch masks
+  uint16_t* req;         // [S][N][2]
+  uint8_t* lut;          // [S][256]
+  SsScalars* sc;         // [S]
+  float *dsLT, *dsST;    // [S][dsh][dsw][3]
+  uint8_t* fg;           // [S][N] output mask (may be null)
+  uint8_t* bgimg;        // [S][N][3] output background (may be null)
+  int rows, cols, nS, nReq, nMinColor, nDescOff, nMov, lbspOff, use3x3, lrScaling, medK;
+  float relT, fLT, fST;
+  unsigned frameIndex;
+  int first;             // first stream of this launch (blockIdx.z is relative to it)
+};
+
+__host__ __device__ __forceinline__ uint32_t ss_rand(uint32_t frame, uint32_t pixel, uint32_t draw) {
+  uint32_t x = frame * 0x9E3779B1u;
+  x ^= pixel + 0x85EBCA6Bu + (x << 6) + (x >> 2);
+  x ^= (draw + 1u) * 0xC2B2AE35u;
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x >> 1;
+}
+
+__device__ __constant__ const int8_t kSsPattern[7][7] = {{2, 4, 6, 7, 6, 4, 2},     {4, 8, 12, 14, 12, 8, 4},  {6, 12, 21, 25, 21, 12, 6}, {7, 14, 25, 28, 25, 14, 7},
+                                                         {6, 12, 21, 25, 21, 12, 6}, {4, 8, 12, 14, 12, 8, 4}, {2, 4, 6, 7, 6, 4, 2}};  // RandUtils.h:13-25
+__device__ __constant__ const int8_t kSsN3[8][2] = {{-1, 1}, {0, 1}, {1, 1}, {-1, 0}, {1, 0}, {-1, -1}, {0, -1}, {1, -1}};  // RandUtils.h:51-56
+__device__ __constant__ const int8_t kSsN5[24][2] = {{-2, 2},  {-1, 2},  {0, 2},  {1, 2},  {2, 2},  {-2, 1},  {-1, 1},  {0, 1},  {1, 1},  {2, 1},  {-2, 0},  {-1, 0},
+                                                     {1, 0},   {2, 0},   {-2, -1}, {-1, -1}, {0, -1}, {1, -1}, {2, -1}, {-2, -2}, {-1, -2}, {0, -2}, {1, -2}, {2, -2}};
+
+#define SS_REQ_VALID 0x8000u
+__device__ __forceinline__ uint16_t ss_req(unsigned slot, int code) { return (uint16_t)(SS_REQ_VALID | (slot << 8) | (unsigned)code); }
+
+// 16 neighbours of one channel packed 4 per dword, in LBSP bit order (bit 15 first); descriptor of `ref` against them
+__device__ __forceinline__ unsigned ss_lbsp(const uint32_t (&nb)[4], int ref, int t) {
+  unsigned r = 0;
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    const int v = (int)((nb[b >> 2] >> (8 * (b & 3))) & 0xffu);
+    r |= (unsigned)(abs(v - ref) > t) << (15 - b);
+  }
+  return r;
+}
+
+// ----------------------------------------------------------------------------------------------- phase A
+__global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
+  constexpr int HW = kSsTW + 4, HH = kSsTH + 4;
+  constexpr int ROWB = (HW * 3 + 3 + 3) / 4 * 4;
+  __shared__ uint32_t tile[HH][ROWB / 4];
+  __shared__ uint8_t lut[256];
+  __shared__ unsigned nz_block;
+  const int stream = a.first + blockIdx.z;
+  const size_t N = (size_t)a.rows * a.cols, sN = (size_t)stream * N;
+  const uint8_t* img = a.frame + (size_t)blockIdx.z * N * 3;
+  const int x0 = blockIdx.x * kSsTW, y0 = blockIdx.y * kSsTH;
+  const long imgsz = (long)N * 3, rb = (long)(x0 - 2) * 3;
+  for (int i = threadIdx.x; i < HH * (ROWB / 4); i += kBlock) {
+    const int ry = i / (ROWB / 4), rd = i - ry * (ROWB / 4);
+    const int y = min(max(y0 + ry - 2, 0), a.rows - 1);
+    const long off = (((long)y * a.cols * 3 + rb) & ~3L) + 4L * rd;
+    uint32_t v = 0;
+    if (off >= 0 && off + 4 <= imgsz)
+      v = *reinterpret_cast<const uint32_t*>(img + off);
+    else if (off < imgsz && off + 4 > 0)
+      for (int b = 0; b < 4; ++b)
+        if (off + b >= 0 && off + b < imgsz) v |= (uint32_t)img[off + b] << (8 * b);
+    tile[ry][rd] = v;
+  }
+  lut[threadIdx.x] = a.lut[(size_t)stream * 256 + threadIdx.x];
+  if (threadIdx.x == 0) nz_block = 0;
+  __syncthreads();
+  const int lx = threadIdx.x % kSsTW, ly = threadIdx.x / kSsTW;
+  const int x = x0 + lx, y = y0 + ly;
+  const bool interior = x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2;  // LBSP::validateROI; border pixels are never touched
+  bool nzflag = false;
+  if (interior) {
+    const SsScalars sc = a.sc[stream];
+    const size_t p = (size_t)y * a.cols + x, i = sN + p;
+    const uint32_t fr = a.frameIndex, pi = (uint32_t)p;
+    auto at = [&](int ry, int rx, int c) -> int {
+      const uint8_t* rowp = reinterpret_cast<const uint8_t*>(tile[ry]);
+      const int shift = (int)(((long)(y0 + ry - 2) * a.cols * 3 + rb) & 3L);
+      return rowp[shift + rx * 3 + c];
+    };
+    const int8_t dxs[16] = {-1, 1, 1, -1, 1, 0, -1, 0, -2, 2, 2, -2, 0, 0, 2, -2}, dys[16] = {1, -1, 1, -1, 0, -1, 0, 1, -2, 2, -2, 2, 2, -2, 0, 0};
+    int cur[3];
+    uint32_t nb[3][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      cur[c] = at(ly + 2, lx + 2, c);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) nb[c][q] = 0;
+#pragma unroll
+      for (int b = 0; b < 16; ++b) nb[c][b >> 2] |= (uint32_t)at(ly + 2 + dys[b], lx + 2 + dxs[b], c) << (8 * (b & 3));
+    }
+    float Rv = a.R[i], Vv = a.V[i], Tv = a.T[i];
+    const int unst_old = a.unstable[i];
+    const int stabOff = a.nMinColor / 5;
+    const size_t colorThr = (size_t)((Rv * (float)a.nMinColor) - (float)((!unst_old) * stabOff));                                     // :459
+    const size_t descThr = ((size_t)1 << ((size_t)floorf(Rv + 0.5f))) + (size_t)a.nDescOff + (size_t)(unst_old * a.nDescOff);        // :460
+    const size_t totColorThr = colorThr * 3, totDescThr = descThr * 3, scColorThr = totColorThr / 2;
+    unsigned intra[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) intra[c] = ss_lbsp(nb[c], cur[c], lut[cur[c]]);  // :465-466
+    const float rawST_old = a.RawSTOld[i];
+    const int unst = (Rv > 3.0f || (a.RawLT[i] - a.FinLT[i]) > 0.1f || (rawST_old - a.FinST[i]) > 0.1f) ? 1 : 0;  // :467
+    a.unstable[i] = (uint8_t)unst;
+    size_t minDesc = 48, minSum = 765;
+    int good = 0, idx = 0;
+    const size_t sbase = (size_t)stream * a.nS * N;
+    while (good < a.nReq && idx < a.nS) {  // :469-497
+      const uint8_t* bc = a.color + (sbase + (size_t)idx * N + p) * 3;
+      const uint16_t* bd = a.desc + (sbase + (size_t)idx * N + p) * 3;
+      size_t totDesc = 0, totSum = 0;
+      bool ok = true;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (ok) {
+          const int bcc = bc[c];
+          const size_t cd = (size_t)abs(cur[c] - bcc);
+          if (cd > scColorThr) {
+            ok = false;
+          } else {
+            const unsigned bdc = bd[c];
+            const size_t intraD = (size_t)__popc(intra[c] ^ bdc);
+            const unsigned inter = ss_lbsp(nb[c], bcc, lut[bcc]);
+            const size_t interD = (size_t)__popc(inter ^ bdc);
+            const size_t dd = (intraD + interD) / 2;
+            size_t sd = (dd / 2) * (255 / 16) + cd;
+            sd = sd < 255 ? sd : 255;
+            if (sd > scColorThr)
+              ok = false;
+            else
+              totDesc += dd, totSum += sd;
+          }
+        }
+      }
+      if (ok && !(totDesc > totDescThr || totSum > totColorThr)) {
+        minDesc = minDesc > totDesc ? totDesc : minDesc;
+        minSum = minSum > totSum ? totSum : minSum;
+        good++;
+      }
+      idx++;
+    }
+    size_t l1 = 0, hd = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      l1 += (size_t)abs((int)a.lastColor[i * 3 + c] - cur[c]);
+      hd += (size_t)__popc(((unsigned)a.lastDesc[i * 3 + c] ^ intra[c]) & 0xffffu);
+    }
+    const float fLT = a.fLT, fST = a.fST;
+    const float normLast = ((float)l1 / 765 + (float)hd / 48) / 2;  // :498
+    a.DlastNew[i] = a.DlastOld[i] * (1.0f - fST) + normLast * fST;
+    float dminLT = a.DminLT[i], dminST = a.DminST[i], rawLT = a.RawLT[i], rawST = rawST_old;
+    bool isfg;
+    uint16_t reqSelf = 0, reqNbr = 0;
+    if (good < a.nReq) {  // foreground :500-515
+      float nm = ((float)minSum / 765 + (float)minDesc / 48) / 2 + (float)(a.nReq - good) / a.nReq;
+      nm = nm > 1.0f ? 1.0f : nm;
+      dminLT = dminLT * (1.0f - fLT) + nm * fLT;
+      dminST = dminST * (1.0f - fST) + nm * fST;
+      rawLT = rawLT * (1.0f - fLT) + fLT;
+      rawST = rawST * (1.0f - fST) + fST;
+      isfg = true;
+      if (sc.cooldown && (ss_rand(fr, pi, 0) % 2u) == 0) reqSelf = ss_req(ss_rand(fr, pi, 1) % (uint32_t)a.nS, 12);
+    } else {  // background :516-552
+      const float nm = ((float)minSum / 765 + (float)minDesc / 48) / 2;
+      dminLT = dminLT * (1.0f - fLT) + nm * fLT;
+      dminST = dminST * (1.0f - fST) + nm * fST;
+      rawLT = rawLT * (1.0f - fLT);
+      rawST = rawST * (1.0f - fST);
+      isfg = false;
+      const size_t lr = (size_t)ceilf(Tv);
+      if ((ss_rand(fr, pi, 2) % lr) == 0) reqSelf = ss_req(ss_rand(fr, pi, 3) % (uint32_t)a.nS, 12);
+      const bool use3 = a.use3x3 && !unst;
+      int xn, yn;
+      if (use3) {
+        const int r = (int)(ss_rand(fr, pi, 4) % 8u);
+        xn = x + kSsN3[r][0], yn = y + kSsN3[r][1];
+      } else {
+        const int r = (int)(ss_rand(fr, pi, 4) % 24u);
+        xn = x + kSsN5[r][0], yn = y + kSsN5[r][1];
+      }
+      xn = min(max(xn, 2), a.cols - 3), yn = min(max(yn, 2), a.rows - 3);
+      const size_t nrand = ss_rand(fr, pi, 5);
+      const size_t j = sN + (size_t)yn * a.cols + xn;
+      const float nbrLast = a.DlastOld[j], nbrRaw = a.RawSTOld[j];  // previous frame's copy (contract)
+      if ((nrand % (use3 ? lr : (lr / 2 + 1))) == 0 || (nbrRaw > 0.995f && nbrLast < 0.010f && (nrand % ((size_t)sc.capLo)) == 0))
+        reqNbr = ss_req(ss_rand(fr, pi, 6) % (uint32_t)a.nS, (yn - y + 2) * 5 + (xn - x + 2));
+    }
+    a.DminLT[i] = dminLT, a.DminST[i] = dminST, a.RawLT[i] = rawLT, a.RawSTNew[i] = rawST;
+    a.raw[i] = isfg ? 255 : 0;
+    a.req[i * 2] = reqSelf, a.req[i * 2 + 1] = reqNbr;
+    // feedback :553-576
+    const float dmin_min = dminLT < dminST ? dminLT : dminST, dmin_max = dminLT > dminST ? dminLT : dminST;
+    const int lastfg = a.lastFG[i];
+    if (lastfg || (dmin_min < 0.1f && isfg)) {
+      if (Tv < sc.capHi) Tv += div_rn(0.5f, dmin_max * Vv);
+    } else if (Tv > sc.capLo)
+      Tv -= div_rn(0.25f * Vv, dmin_max);
+    if (Tv < sc.capLo)
+      Tv = sc.capLo;
+    else if (Tv > sc.capHi)
+      Tv = sc.capHi;
+    if (dmin_max > 0.1f && a.blinks[i])
+      Vv += 1.0f;
+    else if (Vv > 0.1f) {
+      Vv -= lastfg ? 0.1f / 4 : unst ? 0.1f / 2 : 0.1f;
+      if (Vv < 0.1f) Vv = 0.1f;
+    }
+    const float pw = 1.0f + dmin_min * 2;
+    if ((double)Rv < __dmul_rn((double)pw, (double)pw))  // std::pow(float, int) is a double in C++11; the square is exact
+      Rv += 0.01f * (Vv - 0.1f);
+    else {
+      Rv -= div_rn(0.01f, Vv);
+      if (Rv < 1.0f) Rv = 1.0f;
+    }
+    a.R[i] = Rv, a.V[i] = Vv, a.T[i] = Tv;
+    nzflag = (__popc(intra[0]) + __popc(intra[1]) + __popc(intra[2])) >= 4;  // :577-578
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {  // :579-582
+      a.lastDesc[i * 3 + c] = (uint16_t)intra[c];
+      a.lastColor[i * 3 + c] = (uint8_t)cur[c];
+    }
+  } else if (x < a.cols && y < a.rows) {
+    const size_t i = sN + (size_t)y * a.cols + x;
+    a.raw[i] = 0;
+    a.req[i * 2] = 0, a.req[i * 2 + 1] = 0;
+    a.DlastNew[i] = a.DlastOld[i], a.RawSTNew[i] = a.RawSTOld[i];
+  }
+  const unsigned long long bal = __ballot(nzflag);
+  if ((threadIdx.x & (kWave - 1)) == 0 && bal) atomicAdd(&nz_block, (unsigned)__popcll(bal));
+  __syncthreads();
+  if (threadIdx.x == 0 && nz_block) atomicAdd(&a.sc[stream].nzCount, nz_block);
+}
+
+// ----------------------------------------------------------------------------------------------- phase B
+__global__ __launch_bounds__(kBlock) void ss_phase_b_kernel(const SsArgs a) {
+  __shared__ uint32_t rq[kSsTH + 4][kSsTW + 4];  // both requests of a pixel in one dword
+  const int stream = a.first + blockIdx.z;
+  const size_t N = (size_t)a.rows * a.cols, sN = (size_t)stream * N;
+  const int x0 = blockIdx.x * kSsTW, y0 = blockIdx.y * kSsTH;
+  for (int i = threadIdx.x; i < (kSsTH + 4) * (kSsTW + 4); i += kBlock) {
+    const int ly = i / (kSsTW + 4), lx = i - ly * (kSsTW + 4);
+    const int y = y0 + ly - 2, x = x0 + lx - 2;
+    uint32_t v = 0;
+    if (y >= 2 && y < a.rows - 2 && x >= 2 && x < a.cols - 2) v = *reinterpret_cast<const uint32_t*>(a.req + (sN + (size_t)y * a.cols + x) * 2);
+    rq[ly][lx] = v;
+  }
+  __syncthreads();
+  const int lx = threadIdx.x % kSsTW, ly = threadIdx.x / kSsTW;
+  const int x = x0 + lx, y = y0 + ly;
+  if (!(x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2)) return;
+  const size_t p = (size_t)y * a.cols + x;
+  const size_t sbase = (size_t)stream * a.nS * N;
+  for (int dy = -2; dy <= 2; ++dy)
+    for (int dx = -2; dx <= 2; ++dx) {  // sources in raster order: a later source overwrites an earlier one, as in the reference's loop
+      const uint32_t both = rq[ly + 2 + dy][lx + 2 + dx];
+      if (!both) continue;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {  // self request first, then the neighbour request
+        const unsigned r = (both >> (16 * q)) & 0xffffu;
+        if (!(r & SS_REQ_VALID)) continue;
+        const int code = (int)(r & 0x1f), slot = (int)((r >> 8) & 0x3f);
+        if (dy + code / 5 - 2 != 0 || dx + code % 5 - 2 != 0) continue;  // not aimed at this pixel
+        const size_t src = sN + (size_t)(y + dy) * a.cols + (x + dx);
+        const size_t dst = (sbase + (size_t)slot * N + p) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          a.color[dst + c] = a.lastColor[src * 3 + c];  // phase A stored the source's current colour / intra descriptor there
+          a.desc[dst + c] = a.lastDesc[src * 3 + c];
+        }
+      }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------- refreshModel :249-291
+// mode 0: unconditional full refresh (initialisation, frac = 1); mode 1: 10 % refresh if the frame-level block asked for it
+__global__ __launch_bounds__(kBlock) void ss_refresh_kernel(const SsArgs a, int mode) {
+  const int stream = a.first + blockIdx.z;
+  const size_t N = (size_t)a.rows * a.cols, sN = (size_t)stream * N;
+  if (mode == 1 && !a.sc[stream].doRefresh) return;
+  const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= N) return;
+  if (mode == 1) a.T[sN + p] = 1.0f;  // m_oUpdateRateFrame = cv::Scalar(1.0f), every pixel (:682)
+  const int x = (int)(p % a.cols), y = (int)(p / a.cols);
+  if (!(x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2)) return;
+  if (a.lastFG[sN + p]) return;  // bForceFGUpdate = false
+  const int nRefresh = mode == 1 ? (int)(0.1f * a.nS) : a.nS;
+  const uint32_t fr = a.frameIndex;
+  const int start = mode == 1 ? (int)(ss_rand(fr, 0xFFFFFFFFu, 0) % (uint32_t)a.nS) : 0;
+  const size_t sbase = (size_t)stream * a.nS * N;
+  for (int m = 0; m < nRefresh; ++m) {
+    int r = 1 + (int)(ss_rand(fr, (uint32_t)p, 16u + (uint32_t)m) % 512u), xs, ys = 0;  // RandUtils.h:28-48
+    bool stop = false;
+    for (xs = 0; xs < 7 && !stop; ++xs)
+      for (ys = 0; ys < 7; ++ys) {
+        r -= kSsPattern[ys][xs];
+        if (r <= 0) {
+          stop = true;
+          break;
+        }
+      }
+    if (stop) --xs;  // the goto leaves x_sample un-incremented
+    xs = min(max(xs + x - 3, 2), a.cols - 3), ys = min(max(ys + y - 3, 2), a.rows - 3);
+    const size_t j = sN + (size_t)ys * a.cols + xs;
+    if (!a.lastFG[j]) {
+      const size_t dst = (sbase + (size_t)((start + m) % a.nS) * N + p) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a.color[dst + c] = a.lastColor[j * 3 + c], a.desc[dst + c] = a.lastDesc[j * 3 + c];
+    }
+  }
+}
+
+// LastColor of the first frame: interior pixels only (:229-243); lastDesc comes from lbsp_kernel
+__global__ __launch_bounds__(kBlock) void ss_init_lastcolor_kernel(const SsArgs a) {
+  const int stream = a.first + blockIdx.z;
+  const size_t N = (size_t)a.rows * a.cols;
+  const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= N) return;
+  const int x = (int)(p % a.cols), y = (int)(p / a.cols);
+  const bool in = x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) a.lastColor[((size_t)stream * N + p) * 3 + c] = in ? a.frame[((size_t)blockIdx.z * N + p) * 3 + c] : 0;
+}
+
+// ----------------------------------------------------------------------------------------------- post-processing :624-642
+// blink maps :624-627
+__global__ __launch_bounds__(kBlock) void ss_blink_kernel(const SsArgs a, size_t count) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= count) return;
+  const size_t g = (size_t)a.first * a.rows * a.cols + i;
+  const uint8_t raw = a.raw[g], blink = raw ^ a.lastRaw[g];
+  a.blinks[g] = blink | a.lastRawBlink[g];
+  a.lastRawBlink[g] = blink;
+  a.lastRaw[g] = raw;
+}
+
+// flood fill from (0,0) (:630): `reach` marks pixels 4-connected to the origin through pixels equal to the seed value.
+// One workgroup relaxes a 32x32 tile in LDS until it is stable; the host repeats the launch until no tile changed.
+constexpr int kFloodT = 32;
+__global__ __launch_bounds__(kBlock) void ss_flood_kernel(const uint8_t* mask, uint8_t* reach, int rows, int cols, int* changed) {
+  __shared__ uint8_t m[kFloodT + 2][kFloodT + 2], r[kFloodT + 2][kFloodT + 2];
+  __shared__ int again, any;
+  const size_t img = (size_t)blockIdx.z * rows * cols;
+  const uint8_t seed = mask[img];
+  const int x0 = blockIdx.x * kFloodT, y0 = blockIdx.y * kFloodT;
+  for (int i = threadIdx.x; i < (kFloodT + 2) * (kFloodT + 2); i += kBlock) {
+    const int ly = i / (kFloodT + 2), lx = i - ly * (kFloodT + 2);
+    const int y = y0 + ly - 1, x = x0 + lx - 1;
+    const bool in = y >= 0 && y < rows && x >= 0 && x < cols;
+    m[ly][lx] = in && mask[img + (size_t)y * cols + x] == seed;
+    r[ly][lx] = in ? reach[img + (size_t)y * cols + x] : 0;
+  }
+  if (threadIdx.x == 0) any = 0;
+  __syncthreads();
+  do {
+    __syncthreads();
+    if (threadIdx.x == 0) again = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < kFloodT * kFloodT; i += kBlock) {
+      const int ly = 1 + i / kFloodT, lx = 1 + i % kFloodT;
+      if (m[ly][lx] && !r[ly][lx] && (r[ly - 1][lx] | r[ly + 1][lx] | r[ly][lx - 1] | r[ly][lx + 1])) r[ly][lx] = 1, again = 1, any = 1;
+    }
+    __syncthreads();
+  } while (again);
+  if (any) {
+    for (int i = threadIdx.x; i < kFloodT * kFloodT; i += kBlock) {
+      const int ly = 1 + i / kFloodT, lx = 1 + i % kFloodT;
+      const int y = y0 + ly - 1, x = x0 + lx - 1;
+      if (y < rows && x < cols && r[ly][lx]) reach[img + (size_t)y * cols + x] = 1;
+    }
+    if (threadIdx.x == 0) *changed = 1;
+  }
+}
+__global__ void ss_flood_seed_kernel(uint8_t* reach, size_t n_per_image, int images) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < images) reach[(size_t)s * n_per_image] = 1;  // floodFill always repaints the seed pixel itself
+}
+
+// cur = raw | ~flooded | eroded(pre)  (:631-634): holes = pixels of `pre` equal to the seed value that the fill did not reach... in
+// mask terms: flooded image = 255 where reached or where pre != seed... written out explicitly below.
+__global__ __launch_bounds__(kBlock) void ss_combine_kernel(const SsArgs a, const uint8_t* pre, const uint8_t* reach, const uint8_t* eroded, uint8_t* out, size_t count) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= count) return;
+  const size_t N = (size_t)a.rows * a.cols, g = (size_t)a.first * N + i;
+  const uint8_t flooded = reach[i] ? 255 : pre[i];  // floodFill paints the reached region with 255, leaves the rest
+  out[i] = a.raw[g] | (uint8_t)~flooded | eroded[i];
+}
+
+// :637-642: blink mask clean-up against the dilated final mask (old then new), final-segmentation running means, output
+__global__ __launch_bounds__(kBlock) void ss_finish_kernel(const SsArgs a, const uint8_t* dilated, size_t count) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= count) return;
+  const size_t g = (size_t)a.first * a.rows * a.cols + i;
+  uint8_t b = a.blinks[g] & a.lastDilInv[g];
+  const uint8_t inv = (uint8_t)~dilated[i];
+  a.lastDilInv[g] = inv;
+  a.blinks[g] = b & inv;
+  const uint8_t m = a.lastFG[g];
+  if (a.fg) a.fg[i] = m;
+  // cv::addWeighted(f32, 1-f, u8, (1/255)*f, 0, dst, CV_32F): both operands as float, arithmetic in double
+  const double aLT = (double)(1.0f - a.fLT), bLT = __dmul_rn(1.0 / 255, (double)a.fLT), aST = (double)(1.0f - a.fST), bST = __dmul_rn(1.0 / 255, (double)a.fST);
+  a.FinLT[g] = (float)__dadd_rn(__dmul_rn((double)a.FinLT[g], aLT), __dmul_rn((double)(float)m, bLT));
+  a.FinST[g] = (float)__dadd_rn(__dmul_rn((double)a.FinST[g], aST), __dmul_rn((double)(float)m, bST));
+}
+
+// ----------------------------------------------------------------------------------------------- frame-level block :656-665
+__global__ __launch_bounds__(kBlock) void ss_downsample_kernel(const SsArgs a) {
+  const int stream = a.first + blockIdx.z;
+  const int dsw = a.cols / 8, dsh = a.rows / 8;
+  const int idx = blockIdx.x * kBlock + threadIdx.x;
+  unsigned diff = 0;
+  if (idx < dsw * dsh) {
+    const int x = idx % dsw, y = idx / dsw;
+    const uint8_t* img = a.frame + (size_t)blockIdx.z * a.rows * a.cols * 3;
+    float d[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      int sum = 0;
+      for (int yy = 0; yy < 8; ++yy)
+        for (int xx = 0; xx < 8; ++xx) sum += img[((size_t)(y * 8 + yy) * a.cols + (x * 8 + xx)) * 3 + c];
+      const float v = (float)sat_u8((float)sum * (1.f / 64));  // cv::resize INTER_AREA, integer ratio
+      float* lt = a.dsLT + ((size_t)stream * dsw * dsh + idx) * 3 + c;
+      float* st = a.dsST + ((size_t)stream * dsw * dsh + idx) * 3 + c;
+      const float nlt = v * a.fLT + *lt * (1 - a.fLT), nst = v * a.fST + *st * (1 - a.fST);  // cv::accumulateWeighted
+      *lt = nlt, *st = nst;
+      d[c] = fabsf(nst - nlt);
+    }
+    diff = max((unsigned)d[0], max((unsigned)d[1], (unsigned)d[2]));
+  }
+  // block reduction -> one atomic per block
+  __shared__ unsigned part[kBlock / kWave];
+  unsigned v = diff;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned t = 0;
+    for (int w = 0; w < kBlock / kWave; ++w) t += part[w];
+    if (t) atomicAdd(&a.sc[stream].totDiff, t);
+  }
+}
+
+// LUT auto-adjustment :643-655 (one lane per LUT entry) and the scalar logic :666-699 (lane 0), one workgroup per stream
+__global__ __launch_bounds__(256) void ss_frame_level_kernel(const SsArgs a) {
+  const int stream = a.first + blockIdx.x;
+  SsScalars* sc = a.sc + stream;
+  __shared__ float ratio_s, last_s;
+  if (threadIdx.x == 0) {
+    const size_t relevant = (size_t)(a.rows - 4) * (a.cols - 4);
+    ratio_s = (float)sc->nzCount / relevant;
+    last_s = sc->lastNZ;
+  }
+  __syncthreads();
+  const float ratio = ratio_s, last = last_s;
+  uint8_t* lut = a.lut + (size_t)stream * 256;
+  const int t = threadIdx.x;
+  if (ratio < 0.1f && last < 0.1f) {
+    const double lim = (double)a.lbspOff + ceil((double)((float)t * a.relT / 4));
+    if (lut[t] > sat_u8((float)lim)) --lut[t];
+  } else if (ratio > 0.5f && last > 0.5f) {
+    if (lut[t] < sat_u8((float)a.lbspOff + 255 * a.relT)) ++lut[t];
+  }
+  if (threadIdx.x != 0) return;
+  sc->lastNZ = ratio;
+  sc->nzCount = 0;
+  sc->doRefresh = 0;
+  if (a.lrScaling) {
+    const float diffRatio = (float)sc->totDiff / ((a.rows / 8) * (a.cols / 8));
+    sc->totDiff = 0;
+    const int thr = a.nMinColor / 2;
+    if (sc->autoReset) {
+      if (sc->framesSinceReset > 1000)
+        sc->autoReset = 0;
+      else if (diffRatio >= thr && sc->cooldown == 0) {
+        sc->framesSinceReset = 0;
+        sc->doRefresh = 1;  // refreshModel(0.1f) + UpdateRate = 1 run in ss_refresh_kernel(mode 1), next in the stream
+        sc->cooldown = a.nMov / 4;
+      } else
+        ++sc->framesSinceReset;
+    } else if (diffRatio >= thr * 2) {
+      sc->framesSinceReset = 0;
+      sc->autoReset = 1;
+    }
+    if (diffRatio >= thr / 2) {
+      const int lo = 2 >> (int)(diffRatio / 2), hi = 256 >> (int)(diffRatio / 2);
+      sc->capLo = (float)max(lo, 1), sc->capHi = (float)max(hi, 1);
+    } else {
+      sc->capLo = 2.0f, sc->capHi = 256.0f;
+    }
+    if (sc->cooldown > 0) --sc->cooldown;
+  }
+}
+
+// getBackgroundImage :702-718
+__global__ __launch_bounds__(kBlock) void ss_background_kernel(const SsArgs a) {
+  const int stream = a.first + blockIdx.z;
+  const size_t N = (size_t)a.rows * a.cols;
+  const size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x;  // byte index inside one [N][3] image
+  if (e >= N * 3) return;
+  const uint8_t* base = a.color + (size_t)stream * a.nS * N * 3 + e;
+  float acc = 0;
+  for (int k = 0; k < a.nS; ++k) acc += div_rn((float)base[(size_t)k * N * 3], (float)a.nS);
+  a.bgimg[(size_t)blockIdx.z * N * 3 + e] = (uint8_t)sat_u8(acc);
+}
+
+}  // namespace bgs

@@ -457,6 +457,38 @@ class SigmaDeltaBGS : public HipBGSBase {
   }
 };
 
+// package_bgs/pl/SuBSENSE.{h,cpp} (the class USTC_BGS type 36 instantiates, ustc_src/ustc_bgs.cpp:68)
+class SuBSENSEBGS : public HipBGSBase {
+ public:
+  SuBSENSEBGS() : HipBGSBase(BGS_SUBSENSE, "SuBSENSEBGS"), showOutput(true) {}
+  ~SuBSENSEBGS() override {}
+ private:
+  bool showOutput;
+  void saveConfig() override {  // SuBSENSE.cpp:47-60
+    XmlConfig fs;
+    fs.beginWrite();
+    fs.writeReal("fRelLBSPThreshold", params_.lbsp_rel_threshold);
+    fs.writeInt("nDescDistThresholdOffset", params_.subsense_desc_dist_threshold_offset);
+    fs.writeInt("nMinColorDistThreshold", params_.subsense_min_color_dist_threshold);
+    fs.writeInt("nBGSamples", params_.subsense_n_samples);
+    fs.writeInt("nRequiredBGSamples", params_.subsense_n_required);
+    fs.writeInt("nSamplesForMovingAvgs", params_.subsense_samples_for_moving_avgs);
+    fs.writeInt("showOutput", showOutput);
+    fs.save(configPath());
+  }
+  void loadConfig() override {  // SuBSENSE.cpp:62-75 (read every frame; the model itself is built once, on the first frame)
+    XmlConfig fs;
+    fs.load(configPath());
+    params_.lbsp_rel_threshold = (float)fs.readReal("fRelLBSPThreshold", 0.333f);
+    params_.subsense_desc_dist_threshold_offset = fs.readInt("nDescDistThresholdOffset", 3);
+    params_.subsense_min_color_dist_threshold = fs.readInt("nMinColorDistThreshold", 30);
+    params_.subsense_n_samples = fs.readInt("nBGSamples", 50);
+    params_.subsense_n_required = fs.readInt("nRequiredBGSamples", 2);
+    params_.subsense_samples_for_moving_avgs = fs.readInt("nSamplesForMovingAvgs", 100);
+    showOutput = fs.readInt("showOutput", true);
+  }
+};
+
 #undef BGS_HIP_BANNER_DTOR
 
 }  // namespace bgs_hip
