@@ -484,8 +484,8 @@ def test_subsense_golden_frames(golden_frames):
 
 def test_subsense_qvga_with_frame_level_block():
     """320x240 = QVGA: learning-rate scaling + auto model reset enabled; a scene cut at frame 12 triggers refreshModel(0.1)."""
-    a = synth.numpy_frames("surv", 12, 240, 320, seed=21)
-    b = synth.numpy_frames("surv", 10, 240, 320, seed=99)  # different background: large frame-level colour difference
+    a = synth.numpy_frames("surv", 30, 240, 320, seed=21) // 6          # dark scene, long enough for ST (1/25) and LT (1/30) to part
+    b = 255 - synth.numpy_frames("surv", 12, 240, 320, seed=99) // 6    # bright scene: large frame-level colour difference
     frames = np.concatenate([a, b])
     eng, orc, _ = run_pair(capi.SUBSENSE, frames)
     check_subsense_state(eng, orc, 240, 320)
