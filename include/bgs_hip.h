@@ -224,7 +224,7 @@ int bgs_lbsp_describe_device(int hip_device, const void* d_img, int rows, int co
 
 /* 3x3 morphology / median / hole-fill post-processing of a byte mask on device
  * (BackgroundSubtractorSuBSENSE.cpp:624-640). op: 0 erode3x3, 1 dilate3x3, 2 median(ksize),
- * 3 median(ksize) of a {0,255} mask (majority count, same result, faster). */
+ * 3 median(ksize) of a {0,255} mask (majority count, same result, faster), 4 cv::floodFill(img, Point(0,0), 255). */
 int bgs_mask_morph_device(int hip_device, const void* d_src, void* d_dst, int rows, int cols, int op, int ksize,
                           int iterations, void* hip_stream);
 

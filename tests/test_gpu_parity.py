@@ -541,3 +541,23 @@ def test_subsense_rejects_unsupported_inputs(golden_gray):
         Engine(capi.SUBSENSE).process(golden_gray[0])  # 1-channel path not built
     with pytest.raises(capi.BgsError):
         Engine(capi.SUBSENSE).process(np.zeros((243, 325, 3), np.uint8))  # >= QVGA and not a multiple of 8
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (37, 53), (1, 1), (3, 200), (130, 257), (200, 70)])
+def test_floodfill_from_origin_vs_oracle(shape):
+    """cv::floodFill(mask, Point(0,0), 255): mazes with long snaking corridors, enclosed holes, origin on either value,
+    sizes that are not multiples of the 64x64 bit-packed tile."""
+    torch = _torch()
+    from tracking_amd.engine import mask_morph_device, MORPH_FLOODFILL_ORIGIN, MORPH_MEDIAN_BINARY
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    for density, origin in ((0.3, 0), (0.45, 0), (0.6, 255), (0.0, 0)):
+        m = np.where(rng.random(shape) < density, 255, 0).astype(np.uint8)
+        if shape[0] > 8 and shape[1] > 8:  # a serpentine wall: forces a long path
+            m[4:-4:8, :-3] = 255
+            m[8:-4:8, 3:] = 255
+        m[0, 0] = origin
+        got = mask_morph_device(torch.from_numpy(m).cuda(), MORPH_FLOODFILL_ORIGIN).cpu().numpy()
+        assert np.array_equal(got, pyoracle.floodfill_from_origin(m, 255)), (density, origin)
+    b = np.where(rng.random(shape) < 0.5, 255, 0).astype(np.uint8)
+    for k in (3, 9, 13):
+        assert np.array_equal(mask_morph_device(torch.from_numpy(b).cuda(), MORPH_MEDIAN_BINARY, ksize=k).cpu().numpy(), pyoracle.median_blur(b, k))

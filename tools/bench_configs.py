@@ -46,6 +46,32 @@ def run(algo, name, rows, cols, S, bpp, steps=60, borrow=True, want_bg=False):
     e.close()
 
 
+def run_subsense(S, steps=30):
+    """BASELINE configs[3]: SuBSENSE at 1920x1080 (per-frame wall time: ~20 launches incl. the flood-fill host loop)."""
+    dev = torch.device("cuda", 0)
+    rows, cols, T = 1080, 1920, 8
+    pool = torch.empty((T, S, rows, cols, 3), dtype=torch.uint8, device=dev)
+    for s in range(S):
+        pool[:, s] = synth.s_surv(T, rows, cols, seed=4321 + s, device=dev)
+    e = Engine(capi.SUBSENSE, n_streams=S)
+    e.set_geometry(rows, cols, 3)
+    fg = torch.empty((S, rows, cols), dtype=torch.uint8, device=dev)
+    for t in range(6):
+        e.process_batch_device(pool[t % T], fg, None, None)
+    torch.cuda.synchronize()
+    e.enable_kernel_timing(True)
+    t0 = time.perf_counter()
+    for t in range(steps):
+        e.process_batch_device(pool[(6 + t) % T], fg, None, None)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps
+    ms, n, kname = e.kernel_timing()
+    px = S * rows * cols
+    print("%-34s %dx%d x%d streams: %.3f ms/frame-step wall -> %8.1f Mpix/s (%.1f 1080p frames/s); %s %.3f ms; fg ratio %.3f"
+          % ("SuBSENSEBGS", cols, rows, S, wall * 1e3, px / wall / 1e6, S / wall, kname, ms, float((fg != 0).float().mean())))
+    e.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=8)
@@ -56,6 +82,7 @@ def main():
     run(capi.WMM, "WeightedMovingMeanBGS (+bg)", 2160, 3840, S, 13, want_bg=True)
     run(capi.FRAME_DIFF, "FrameDifferenceBGS", 2160, 3840, S, 7)
     run(capi.MOG1, "MixtureOfGaussianV1BGS", 1080, 1920, 16, 324, borrow=False)
+    run_subsense(2)
     # LBSP descriptors, 1080p
     img = synth.s_surv(1, 1080, 1920, seed=9, device="cuda")[0]
     from oracle import pyoracle

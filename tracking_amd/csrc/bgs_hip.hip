@@ -872,11 +872,33 @@ int bgs_lbsp_describe_device(int hip_device, const void* d_img, int rows, int co
 }
 
 int bgs_mask_morph_device(int hip_device, const void* d_src, void* d_dst, int rows, int cols, int op, int ksize, int iterations, void* hip_stream) {
-  if (!d_src || !d_dst || rows <= 0 || cols <= 0 || op < 0 || op > 3 || iterations < 1) return fail(BGS_ERR_INVALID, "bad argument");
-  if (op >= 2 && (ksize < 3 || ksize > 2 * bgs::kMorphMaxR + 1 || ksize % 2 == 0)) return fail(BGS_ERR_INVALID, "median ksize must be odd, 3..15");
+  if (!d_src || !d_dst || rows <= 0 || cols <= 0 || op < 0 || op > 4 || iterations < 1) return fail(BGS_ERR_INVALID, "bad argument");
+  if ((op == 2 || op == 3) && (ksize < 3 || ksize > 2 * bgs::kMorphMaxR + 1 || ksize % 2 == 0)) return fail(BGS_ERR_INVALID, "median ksize must be odd, 3..15");
   if (d_src == d_dst) return fail(BGS_ERR_INVALID, "in-place morphology is not supported");
   HIP_TRY(hipSetDevice(hip_device));
   hipStream_t s = (hipStream_t)hip_stream;
+  if (op == 4) {  // cv::floodFill(img, Point(0,0), 255)
+    const int W64 = (cols + 63) / 64, tilesY = (rows + 63) / 64;
+    uint64_t *mb = nullptr, *rb = nullptr;
+    int* ch = nullptr;
+    HIP_TRY(hipMalloc((void**)&mb, (size_t)rows * W64 * 8));
+    HIP_TRY(hipMalloc((void**)&rb, (size_t)rows * W64 * 8));
+    HIP_TRY(hipMalloc((void**)&ch, sizeof(int)));
+    hipLaunchKernelGGL(bgs::ss_flood_pack_kernel, dim3(blocks_for((size_t)rows * W64 * bgs::kWave)), dim3(bgs::kBlock), 0, s, (const uint8_t*)d_src, mb, rb, rows, cols, W64);
+    hipLaunchKernelGGL(bgs::ss_flood_seed_kernel, dim3(1), dim3(bgs::kBlock), 0, s, (const uint64_t*)mb, rb, rows, cols, W64);
+    int h = 1;
+    for (long it = 0; it < (long)rows * W64 + 8 && h; ++it) {  // every launch that changes anything reaches at least one new word
+      (void)hipMemsetAsync(ch, 0, sizeof(int), s);
+      hipLaunchKernelGGL(bgs::ss_flood_kernel, dim3(blocks_for((size_t)tilesY * W64 * bgs::kWave)), dim3(bgs::kBlock), 0, s, (const uint64_t*)mb, rb, rows, W64, ch);
+      (void)hipMemcpyAsync(&h, ch, sizeof(int), hipMemcpyDeviceToHost, s);
+      (void)hipStreamSynchronize(s);
+    }
+    hipLaunchKernelGGL(bgs::ss_flood_paint_kernel, dim3(blocks_for((size_t)rows * cols)), dim3(bgs::kBlock), 0, s, (const uint8_t*)d_src, (const uint64_t*)rb, (uint8_t*)d_dst, rows, cols, W64);
+    hipError_t er = hipStreamSynchronize(s);
+    (void)hipFree(mb), (void)hipFree(rb), (void)hipFree(ch);
+    if (er != hipSuccess) return fail(BGS_ERR_HIP, "flood fill failed: %s", hipGetErrorString(er));
+    return BGS_OK;
+  }
   const size_t n = (size_t)rows * cols;
   uint8_t* tmp = nullptr;
   if (iterations > 1) HIP_TRY(hipMalloc((void**)&tmp, n));

@@ -17,11 +17,12 @@ struct SsDevice {
   bgs::SsScalars* sc = nullptr;
   int* changed = nullptr;
   int* h_changed = nullptr;  // pinned
+  uint64_t *mbits = nullptr, *rbits = nullptr;  // flood fill: bit-packed mask / reached set, [S][rows][W64]
   std::vector<uint8_t> pp;   // per stream: which copy of Dlast / RawST is current
   int use3x3 = 1, lrScaling = 0, medK = 9;
   float capLo0 = 4.f, capHi0 = 512.f;
   void release() {
-    void* p[] = {color, lut, lastColor, desc, lastDesc, req, dsLT, dsST, sc, changed};
+    void* p[] = {color, lut, lastColor, desc, lastDesc, req, dsLT, dsST, sc, changed, mbits, rbits};
     for (void* q : p)
       if (q) (void)hipFree(q);
     for (auto& q : f32)
@@ -29,7 +30,7 @@ struct SsDevice {
     for (auto& q : u8)
       if (q) (void)hipFree(q), q = nullptr;
     if (h_changed) (void)hipHostFree(h_changed);
-    color = lut = lastColor = nullptr, desc = lastDesc = req = nullptr, dsLT = dsST = nullptr, sc = nullptr, changed = h_changed = nullptr;
+    color = lut = lastColor = nullptr, desc = lastDesc = req = nullptr, dsLT = dsST = nullptr, sc = nullptr, changed = h_changed = nullptr, mbits = rbits = nullptr;
   }
 };
 
@@ -62,6 +63,9 @@ int ss_allocate(bgs_engine* e) {
   HIP_TRY(hipMalloc((void**)&d->lut, (size_t)e->S * 256));
   HIP_TRY(hipMalloc((void**)&d->sc, (size_t)e->S * sizeof(bgs::SsScalars)));
   HIP_TRY(hipMalloc((void**)&d->changed, sizeof(int)));
+  const size_t words = (size_t)e->S * e->rows * ((e->cols + 63) / 64);
+  HIP_TRY(hipMalloc((void**)&d->mbits, words * 8));
+  HIP_TRY(hipMalloc((void**)&d->rbits, words * 8));
   HIP_TRY(hipHostMalloc((void**)&d->h_changed, sizeof(int), hipHostMallocDefault));
   for (auto& q : d->f32) HIP_TRY(hipMalloc((void**)&q, P * sizeof(float)));
   for (auto& q : d->u8) HIP_TRY(hipMalloc((void**)&q, P));
@@ -172,18 +176,21 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
   }
   hipLaunchKernelGGL(bgs::ss_phase_b_kernel, tiles, block, 0, s, a);
   hipLaunchKernelGGL(bgs::ss_blink_kernel, dim3(blocks_for(npix)), block, 0, s, a, npix);
-  uint8_t *raw = d->u8[SS_RAW] + off, *t1 = d->u8[SS_T1] + off, *t2 = d->u8[SS_T2] + off, *t3 = d->u8[SS_T3] + off, *t4 = d->u8[SS_T4] + off;
+  uint8_t *raw = d->u8[SS_RAW] + off, *t1 = d->u8[SS_T1] + off, *t3 = d->u8[SS_T3] + off, *t4 = d->u8[SS_T4] + off;
   uint8_t* lastFG = d->u8[SS_LASTFG] + off;
   // morphologyEx(MORPH_CLOSE) :628  -> t1 = PreFlood
   ss_morph(raw, t3, e->rows, e->cols, count, 1, 3, s);
   ss_morph(t3, t1, e->rows, e->cols, count, 0, 3, s);
-  // floodFill(PreFlood copy, (0,0), 255) :629-630 -> t2 = reached set
-  HIP_TRY(hipMemsetAsync(t2, 0, npix, s));
-  hipLaunchKernelGGL(bgs::ss_flood_seed_kernel, dim3((count + 63) / 64), dim3(64), 0, s, t2, N, count);
-  const dim3 ftiles((e->cols + bgs::kFloodT - 1) / bgs::kFloodT, (e->rows + bgs::kFloodT - 1) / bgs::kFloodT, count);
-  for (int it = 0; it < e->rows + e->cols + 8; ++it) {
+  // floodFill(PreFlood copy, (0,0), 255) :629-630 on bit-packed rows -> rbits = reached set
+  const int W64 = (e->cols + 63) / 64, tilesY = (e->rows + 63) / 64;
+  uint64_t* mbits = d->mbits + (size_t)first * e->rows * W64;
+  uint64_t* rbits = d->rbits + (size_t)first * e->rows * W64;
+  hipLaunchKernelGGL(bgs::ss_flood_pack_kernel, dim3(blocks_for((size_t)e->rows * W64 * bgs::kWave), 1, count), block, 0, s, (const uint8_t*)t1, mbits, rbits, e->rows, e->cols, W64);
+  hipLaunchKernelGGL(bgs::ss_flood_seed_kernel, dim3(count), block, 0, s, (const uint64_t*)mbits, rbits, e->rows, e->cols, W64);
+  const dim3 fgrid(blocks_for((size_t)tilesY * W64 * bgs::kWave), 1, count);
+  for (long it = 0; it < (long)e->rows * W64 + 8; it += 4) {  // runs until no tile changed; 4 launches per flag check (typical masks: 1-3 checks)
     HIP_TRY(hipMemsetAsync(d->changed, 0, sizeof(int), s));
-    hipLaunchKernelGGL(bgs::ss_flood_kernel, ftiles, block, 0, s, (const uint8_t*)t1, t2, e->rows, e->cols, d->changed);
+    for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(bgs::ss_flood_kernel, fgrid, block, 0, s, (const uint64_t*)mbits, rbits, e->rows, W64, d->changed);
     HIP_TRY(hipMemcpyAsync(d->h_changed, d->changed, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (!*d->h_changed) break;
@@ -192,7 +199,7 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
   ss_morph(t1, t3, e->rows, e->cols, count, 0, 3, s);
   ss_morph(t3, t4, e->rows, e->cols, count, 0, 3, s);
   ss_morph(t4, t3, e->rows, e->cols, count, 0, 3, s);
-  hipLaunchKernelGGL(bgs::ss_combine_kernel, dim3(blocks_for(npix)), block, 0, s, a, (const uint8_t*)t1, (const uint8_t*)t2, (const uint8_t*)t3, t4, npix);  // :631-634
+  hipLaunchKernelGGL(bgs::ss_combine_kernel, dim3(blocks_for(npix)), block, 0, s, a, (const uint8_t*)t1, (const uint64_t*)rbits, W64, (const uint8_t*)t3, t4, npix);  // :631-634
   ss_morph(t4, lastFG, e->rows, e->cols, count, 3, d->medK, s);  // medianBlur :635 (the input is a {0,255} mask)
   ss_morph(lastFG, t1, e->rows, e->cols, count, 1, 3, s);        // dilate x3 :636
   ss_morph(t1, t3, e->rows, e->cols, count, 1, 3, s);

@@ -378,55 +378,121 @@ __global__ __launch_bounds__(kBlock) void ss_blink_kernel(const SsArgs a, size_t
   a.lastRaw[g] = raw;
 }
 
-// flood fill from (0,0) (:630): `reach` marks pixels 4-connected to the origin through pixels equal to the seed value.
-// One workgroup relaxes a 32x32 tile in LDS until it is stable; the host repeats the launch until no tile changed.
-constexpr int kFloodT = 32;
-__global__ __launch_bounds__(kBlock) void ss_flood_kernel(const uint8_t* mask, uint8_t* reach, int rows, int cols, int* changed) {
-  __shared__ uint8_t m[kFloodT + 2][kFloodT + 2], r[kFloodT + 2][kFloodT + 2];
-  __shared__ int again, any;
-  const size_t img = (size_t)blockIdx.z * rows * cols;
-  const uint8_t seed = mask[img];
-  const int x0 = blockIdx.x * kFloodT, y0 = blockIdx.y * kFloodT;
-  for (int i = threadIdx.x; i < (kFloodT + 2) * (kFloodT + 2); i += kBlock) {
-    const int ly = i / (kFloodT + 2), lx = i - ly * (kFloodT + 2);
-    const int y = y0 + ly - 1, x = x0 + lx - 1;
-    const bool in = y >= 0 && y < rows && x >= 0 && x < cols;
-    m[ly][lx] = in && mask[img + (size_t)y * cols + x] == seed;
-    r[ly][lx] = in ? reach[img + (size_t)y * cols + x] : 0;
-  }
-  if (threadIdx.x == 0) any = 0;
-  __syncthreads();
-  do {
-    __syncthreads();
-    if (threadIdx.x == 0) again = 0;
-    __syncthreads();
-    for (int i = threadIdx.x; i < kFloodT * kFloodT; i += kBlock) {
-      const int ly = 1 + i / kFloodT, lx = 1 + i % kFloodT;
-      if (m[ly][lx] && !r[ly][lx] && (r[ly - 1][lx] | r[ly + 1][lx] | r[ly][lx - 1] | r[ly][lx + 1])) r[ly][lx] = 1, again = 1, any = 1;
-    }
-    __syncthreads();
-  } while (again);
-  if (any) {
-    for (int i = threadIdx.x; i < kFloodT * kFloodT; i += kBlock) {
-      const int ly = 1 + i / kFloodT, lx = 1 + i % kFloodT;
-      const int y = y0 + ly - 1, x = x0 + lx - 1;
-      if (y < rows && x < cols && r[ly][lx]) reach[img + (size_t)y * cols + x] = 1;
-    }
-    if (threadIdx.x == 0) *changed = 1;
+// flood fill from (0,0) (:630) on BIT-PACKED rows: one 64-bit word = 64 pixels, one wave = one 64x64 tile, lane = row.
+//   mbits[y][w] bit i = (mask(y, 64w+i) == seed value)      rbits = pixels reached so far
+// Inside a row the fill is carry arithmetic ((m + r) ripples a seed through its run of 1s); between rows it is a wave
+// shuffle; a tile relaxes to its fixed point in registers, the host relaunches until no tile changed (the wavefront
+// crosses one tile per launch, from every side at once when the whole outer ring is background - always the case after
+// the morphological close of a mask whose 2-pixel border is empty).
+__device__ __forceinline__ uint64_t ss_hfill(uint64_t r, uint64_t m) {
+  r &= m;
+  const uint64_t up = m & ~(m + r);  // run bits at and above each seed
+  const uint64_t rr = __brevll(r), mr = __brevll(m);
+  const uint64_t dn = __brevll(mr & ~(mr + rr));
+  return r | up | dn;
+}
+
+__global__ __launch_bounds__(kBlock) void ss_flood_pack_kernel(const uint8_t* mask, uint64_t* mbits, uint64_t* rbits, int rows, int cols, int W64) {
+  // one wave per word: lane = pixel; padded pixels (x >= cols) are 0 in mbits
+  const int img = blockIdx.z;
+  const size_t wid = (size_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;  // word index inside the image
+  if (wid >= (size_t)rows * W64) return;
+  const int y = (int)(wid / W64), w = (int)(wid % W64), x = w * 64 + (threadIdx.x & (kWave - 1));
+  const uint8_t* im = mask + (size_t)img * rows * cols;
+  const uint8_t seed = im[0];
+  const bool bit = x < cols && im[(size_t)y * cols + x] == seed;
+  const unsigned long long b = __ballot(bit);
+  if ((threadIdx.x & (kWave - 1)) == 0) {
+    mbits[(size_t)img * rows * W64 + wid] = b;
+    rbits[(size_t)img * rows * W64 + wid] = 0;
   }
 }
-__global__ void ss_flood_seed_kernel(uint8_t* reach, size_t n_per_image, int images) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < images) reach[(size_t)s * n_per_image] = 1;  // floodFill always repaints the seed pixel itself
+
+// seeds: the origin; or the whole outer ring when every ring pixel has the seed value (then all of it is 4-connected to the origin)
+__global__ __launch_bounds__(kBlock) void ss_flood_seed_kernel(const uint64_t* mbits, uint64_t* rbits, int rows, int cols, int W64) {
+  const size_t base = (size_t)blockIdx.x * rows * W64;
+  const uint64_t* m = mbits + base;
+  uint64_t* r = rbits + base;
+  const uint64_t lastmask = (cols % 64) ? ((1ull << (cols % 64)) - 1) : ~0ull;
+  const int lastbit = (cols - 1) % 64;
+  int bad = 0;
+  for (int i = threadIdx.x; i < W64; i += kBlock) {
+    const uint64_t full = (i == W64 - 1) ? lastmask : ~0ull;
+    bad |= (m[i] & full) != full || (m[(size_t)(rows - 1) * W64 + i] & full) != full;
+  }
+  for (int y = threadIdx.x; y < rows; y += kBlock) bad |= !(m[(size_t)y * W64] & 1ull) || !((m[(size_t)y * W64 + W64 - 1] >> lastbit) & 1ull);
+  const int ring_ok = !__syncthreads_or(bad);
+  if (!ring_ok) {
+    if (threadIdx.x == 0) r[0] = 1ull;  // floodFill always repaints the seed pixel itself
+    return;
+  }
+  for (int i = threadIdx.x; i < W64; i += kBlock) {
+    const uint64_t full = (i == W64 - 1) ? lastmask : ~0ull;
+    r[i] = full;
+    r[(size_t)(rows - 1) * W64 + i] = full;
+  }
+  __syncthreads();
+  for (int y = threadIdx.x + 1; y < rows - 1; y += kBlock) {
+    atomicOr((unsigned long long*)&r[(size_t)y * W64], 1ull);
+    atomicOr((unsigned long long*)&r[(size_t)y * W64 + W64 - 1], 1ull << lastbit);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void ss_flood_kernel(const uint64_t* mbits, uint64_t* rbits, int rows, int W64, int* changed) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int tilesY = (rows + 63) / 64;
+  const size_t tile = (size_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+  if (tile >= (size_t)tilesY * W64) return;  // whole wave
+  const int ty = (int)(tile / W64), w = (int)(tile % W64), y = ty * 64 + lane;
+  const size_t base = (size_t)blockIdx.z * rows * W64;
+  const uint64_t* mb = mbits + base;
+  uint64_t* rb = rbits + base;
+  const bool in = y < rows;
+  const uint64_t m = in ? mb[(size_t)y * W64 + w] : 0;
+  const uint64_t r0 = in ? rb[(size_t)y * W64 + w] : 0;
+  // halos from the neighbouring tiles as they stand in memory (constant during this launch)
+  uint64_t side = 0;
+  if (in && w > 0 && (rb[(size_t)y * W64 + w - 1] >> 63)) side |= 1ull;
+  if (in && w < W64 - 1 && (rb[(size_t)y * W64 + w + 1] & 1ull)) side |= 1ull << 63;
+  uint64_t vert = 0;
+  if (lane == 0 && y > 0 && in) vert = rb[(size_t)(y - 1) * W64 + w];
+  if (lane == 63 && y + 1 < rows) vert = rb[(size_t)(y + 1) * W64 + w];
+  uint64_t r = ss_hfill(r0 | ((side | vert) & m), m);
+  for (;;) {
+    const uint32_t lo = (uint32_t)r, hi = (uint32_t)(r >> 32);
+    uint64_t up = ((uint64_t)__shfl_up(hi, 1, kWave) << 32) | __shfl_up(lo, 1, kWave);
+    uint64_t dn = ((uint64_t)__shfl_down(hi, 1, kWave) << 32) | __shfl_down(lo, 1, kWave);
+    if (lane == 0) up = 0;
+    if (lane == 63) dn = 0;
+    const uint64_t rn = ss_hfill(r | ((up | dn) & m), m);
+    const bool ch = rn != r;
+    r = rn;
+    if (!__any(ch)) break;
+  }
+  if (in && r != r0) {
+    rb[(size_t)y * W64 + w] = r;
+    *changed = 1;
+  }
+}
+
+// cv::floodFill(img, Point(0,0), 255) as an image: reached pixels become 255, the rest keep their value
+__global__ __launch_bounds__(kBlock) void ss_flood_paint_kernel(const uint8_t* src, const uint64_t* rbits, uint8_t* dst, int rows, int cols, int W64) {
+  const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= (size_t)rows * cols) return;
+  const int y = (int)(p / cols), x = (int)(p % cols);
+  dst[p] = ((rbits[(size_t)y * W64 + (x >> 6)] >> (x & 63)) & 1ull) ? 255 : src[p];
 }
 
 // cur = raw | ~flooded | eroded(pre)  (:631-634): holes = pixels of `pre` equal to the seed value that the fill did not reach... in
 // mask terms: flooded image = 255 where reached or where pre != seed... written out explicitly below.
-__global__ __launch_bounds__(kBlock) void ss_combine_kernel(const SsArgs a, const uint8_t* pre, const uint8_t* reach, const uint8_t* eroded, uint8_t* out, size_t count) {
+__global__ __launch_bounds__(kBlock) void ss_combine_kernel(const SsArgs a, const uint8_t* pre, const uint64_t* rbits, int W64, const uint8_t* eroded, uint8_t* out, size_t count) {
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= count) return;
   const size_t N = (size_t)a.rows * a.cols, g = (size_t)a.first * N + i;
-  const uint8_t flooded = reach[i] ? 255 : pre[i];  // floodFill paints the reached region with 255, leaves the rest
+  const size_t img = i / N, p = i % N;
+  const int y = (int)(p / a.cols), x = (int)(p % a.cols);
+  const bool reached = (rbits[(img * a.rows + y) * W64 + (x >> 6)] >> (x & 63)) & 1ull;
+  const uint8_t flooded = reached ? 255 : pre[i];  // floodFill paints the reached region with 255, leaves the rest
   out[i] = a.raw[g] | (uint8_t)~flooded | eroded[i];
 }
 

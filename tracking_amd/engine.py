@@ -131,7 +131,7 @@ def lbsp_describe_device(img, lut, out=None, device=0, hip_stream=None):
     return out
 
 
-MORPH_ERODE, MORPH_DILATE, MORPH_MEDIAN = 0, 1, 2
+MORPH_ERODE, MORPH_DILATE, MORPH_MEDIAN, MORPH_MEDIAN_BINARY, MORPH_FLOODFILL_ORIGIN = 0, 1, 2, 3, 4
 
 
 def mask_morph_device(src, op, ksize=3, iterations=1, device=0, hip_stream=None):
