@@ -862,16 +862,15 @@ int orc_process(orc_engine* e, const uint8_t* in, int rows, int cols, int channe
     case BGS_MOG2: rc = mog2_process(e, fg, fg_step, bg, bg_step, &flags); break;
     case BGS_MOG1: rc = mog1_process(e, fg, fg_step, &flags); break;
     case BGS_SUBSENSE: { /* SuBSENSEBGS::process, package_bgs/pl/SuBSENSE.cpp:21-45 */
-      if (channels != 3) return BGS_ERR_UNSUPPORTED;
       if (!e->ss) { /* :27-36 first frame: construct + initialize(img, ROI = all 255), then fall through to operator() */
-        rc = ss_create(&e->p, e->cur, rows, cols, &e->ss);
+        rc = ss_create(&e->p, e->cur, rows, cols, channels, &e->ss);
         if (rc) return rc;
       }
-      uint8_t* bgc = bg ? (uint8_t*)malloc(e->n * 3) : NULL;
+      uint8_t* bgc = bg ? (uint8_t*)malloc(e->n * channels) : NULL;
       rc = ss_process(e->ss, e->cur, e->tmp8b, bgc);
       write_mask(e, e->tmp8b, fg, fg_step);
       if (bgc) {
-        write_img(e, bgc, 3, bg, bg_step);
+        write_img(e, bgc, channels, bg, bg_step);
         free(bgc);
       }
       flags = BGS_FG_VALID | BGS_BG_VALID;

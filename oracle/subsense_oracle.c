@@ -1,6 +1,6 @@
 /*
  * subsense_oracle.c — CPU restatement of SuBSENSEBGS (package_bgs/pl/SuBSENSE.cpp:21-45 over
- * package_bgs/pl/BackgroundSubtractorSuBSENSE.cpp), 3-channel path.  TEST INFRASTRUCTURE ONLY (see bgs_oracle.h).
+ * package_bgs/pl/BackgroundSubtractorSuBSENSE.cpp), 3-channel (:437-584) and 1-channel (:306-434) paths.  TEST INFRASTRUCTURE ONLY (see bgs_oracle.h).
  *
  * PARITY UNPINNED, and by construction only partly comparable with the reference:
  *   (1) the reference consumes libc rand() sequentially in raster order (no srand anywhere) — not reproducible by any
@@ -75,10 +75,10 @@ static inline uint8_t sat_u8_f(float v) {
 static const int8_t LB_DX[16] = {-1, 1, 1, -1, 1, 0, -1, 0, -2, 2, 2, -2, 0, 0, 2, -2};
 static const int8_t LB_DY[16] = {1, -1, 1, -1, 0, -1, 0, 1, -2, 2, -2, 2, 2, -2, 0, 0};
 
-static inline unsigned lbsp1(const uint8_t* img, int cols, int x, int y, int c, int ref, int t) {
+static inline unsigned lbsp1(const uint8_t* img, int cols, int C, int x, int y, int c, int ref, int t) {
   unsigned r = 0;
   for (int b = 0; b < 16; ++b) {
-    const int v = img[((size_t)(y + LB_DY[b]) * cols + (x + LB_DX[b])) * 3 + c];
+    const int v = img[((size_t)(y + LB_DY[b]) * cols + (x + LB_DX[b])) * C + c];
     r |= (unsigned)(abs(v - ref) > t) << (15 - b);
   }
   return r;
@@ -87,7 +87,7 @@ static inline unsigned lbsp1(const uint8_t* img, int cols, int x, int y, int c, 
 /* ------------------------------------------------------------------------------------------------ state */
 
 struct ss_state {
-  int rows, cols;
+  int rows, cols, C;
   size_t n;
   int nS, nReq, nMinColor, nDescOff, nMov; /* N samples, required, min colour dist thr, desc dist thr offset, samples for moving avgs */
   float relT;
@@ -145,9 +145,9 @@ static void ss_refresh(ss_state* s, float frac, int force) {
         const size_t j = (size_t)ys * s->cols + xs;
         if (force || !s->lastFG[j]) {
           const int k = m % nS;
-          for (int c = 0; c < 3; ++c) {
-            s->color[((size_t)k * s->n + i) * 3 + c] = s->lastColor[j * 3 + c];
-            s->desc[((size_t)k * s->n + i) * 3 + c] = s->lastDesc[j * 3 + c];
+          for (int c = 0; c < s->C; ++c) {
+            s->color[((size_t)k * s->n + i) * s->C + c] = s->lastColor[j * s->C + c];
+            s->desc[((size_t)k * s->n + i) * s->C + c] = s->lastDesc[j * s->C + c];
           }
         }
       }
@@ -155,10 +155,11 @@ static void ss_refresh(ss_state* s, float frac, int force) {
 }
 
 /* BackgroundSubtractorSuBSENSE::initialize (:82-247) with ROI = all 255 (SuBSENSE.cpp:36) */
-int ss_create(const bgs_params* p, const uint8_t* img, int rows, int cols, ss_state** out) {
+int ss_create(const bgs_params* p, const uint8_t* img, int rows, int cols, int C, ss_state** out) {
   if (rows < 5 || cols < 5) return BGS_ERR_UNSUPPORTED; /* LBSP::validateROI leaves nothing */
+  if (C != 1 && C != 3) return BGS_ERR_UNSUPPORTED;
   ss_state* s = (ss_state*)calloc(1, sizeof(*s));
-  s->rows = rows, s->cols = cols, s->n = (size_t)rows * cols;
+  s->rows = rows, s->cols = cols, s->C = C, s->n = (size_t)rows * cols;
   s->nS = p->subsense_n_samples, s->nReq = p->subsense_n_required, s->nMinColor = p->subsense_min_color_dist_threshold;
   s->nDescOff = p->subsense_desc_dist_threshold_offset;
   s->nMov = p->subsense_samples_for_moving_avgs;
@@ -184,21 +185,21 @@ int ss_create(const bgs_params* p, const uint8_t* img, int rows, int cols, ss_st
   s->Dlast[0] = fmap(n, 0), s->Dlast[1] = fmap(n, 0), s->DminLT = fmap(n, 0), s->DminST = fmap(n, 0);
   s->RawLT = fmap(n, 0), s->RawST[0] = fmap(n, 0), s->RawST[1] = fmap(n, 0), s->FinLT = fmap(n, 0), s->FinST = fmap(n, 0);
   s->dsw = cols / 8, s->dsh = rows / 8;
-  s->dsLT = fmap((size_t)s->dsw * s->dsh * 3 + 1, 0), s->dsST = fmap((size_t)s->dsw * s->dsh * 3 + 1, 0);
+  s->dsLT = fmap((size_t)s->dsw * s->dsh * C + 1, 0), s->dsST = fmap((size_t)s->dsw * s->dsh * C + 1, 0);
   s->unstable = (uint8_t*)calloc(n, 1), s->blinks = (uint8_t*)calloc(n, 1), s->lastFG = (uint8_t*)calloc(n, 1), s->lastRaw = (uint8_t*)calloc(n, 1);
   s->lastRawBlink = (uint8_t*)calloc(n, 1), s->lastDilInv = (uint8_t*)calloc(n, 1);
-  s->lastColor = (uint8_t*)calloc(n, 3), s->lastDesc = (uint16_t*)calloc(n * 3, 2);
-  s->color = (uint8_t*)calloc((size_t)s->nS * n, 3), s->desc = (uint16_t*)calloc((size_t)s->nS * n * 3, 2);
+  s->lastColor = (uint8_t*)calloc(n, C), s->lastDesc = (uint16_t*)calloc(n * C, 2);
+  s->color = (uint8_t*)calloc((size_t)s->nS * n, C), s->desc = (uint16_t*)calloc((size_t)s->nS * n * C, 2);
   s->raw = (uint8_t*)calloc(n, 1), s->t1 = (uint8_t*)calloc(n, 1), s->t2 = (uint8_t*)calloc(n, 1), s->t3 = (uint8_t*)calloc(n, 1);
   s->req = (uint16_t*)calloc(n * 2, 2);
-  orc_lbsp_lut(s->relT, s->lbspOff, 3, s->lut); /* :227-228 */
+  orc_lbsp_lut(s->relT, s->lbspOff, C, s->lut); /* :209-210 (1ch: /3), :227-228 */
   for (int y = 2; y < rows - 2; ++y)
     for (int x = 2; x < cols - 2; ++x) { /* :229-243 */
       const size_t i = (size_t)y * cols + x;
-      for (int c = 0; c < 3; ++c) {
-        const int v = img[i * 3 + c];
-        s->lastColor[i * 3 + c] = (uint8_t)v;
-        s->lastDesc[i * 3 + c] = (uint16_t)lbsp1(img, cols, x, y, c, v, s->lut[v]);
+      for (int c = 0; c < C; ++c) {
+        const int v = img[i * C + c];
+        s->lastColor[i * C + c] = (uint8_t)v;
+        s->lastDesc[i * C + c] = (uint16_t)lbsp1(img, cols, C, x, y, c, v, s->lut[v]);
       }
     }
   ss_refresh(s, 1.0f, 0); /* :246 */
@@ -209,10 +210,11 @@ int ss_create(const bgs_params* p, const uint8_t* img, int rows, int cols, ss_st
 /* ------------------------------------------------------------------------------------------------ one frame */
 
 static void ss_phase_a(ss_state* s, const uint8_t* img, size_t* nonzero_desc) {
-  const int cols = s->cols, rows = s->rows, nS = s->nS, nReq = s->nReq;
+  const int cols = s->cols, rows = s->rows, nS = s->nS, nReq = s->nReq, C = s->C;
   const size_t n = s->n;
   const uint32_t fr = (uint32_t)s->frameIndex;
   const int64_t fi = s->frameIndex;
+  const size_t maxColor = 255 * (size_t)C, maxDesc = 16 * (size_t)C; /* s_nColorMaxDataRange_*, s_nDescMaxDataRange_* */
   const float fLT = 1.0f / (float)(fi < s->nMov ? fi : s->nMov), fST = 1.0f / (float)(fi < s->nMov / 4 ? fi : s->nMov / 4); /* :303-304 */
   const float* DlastOld = s->Dlast[s->pp];
   float* DlastNew = s->Dlast[s->pp ^ 1];
@@ -227,64 +229,82 @@ static void ss_phase_a(ss_state* s, const uint8_t* img, size_t* nonzero_desc) {
   for (int y = 2; y < rows - 2; ++y)
     for (int x = 2; x < cols - 2; ++x) {
       const size_t i = (size_t)y * cols + x;
-      const uint8_t* cur = img + i * 3;
+      const uint8_t* cur = img + i * C;
       float Rv = s->R[i], Vv = s->V[i], Tv = s->T[i];
       const int unst_old = s->unstable[i];
       /* thresholds :459-463 */
-      const size_t colorThr = (size_t)((Rv * (float)s->nMinColor) - (float)((!unst_old) * stabOff));
+      const size_t colorThr = (size_t)((Rv * (float)s->nMinColor) - (float)((!unst_old) * stabOff)) / (C == 1 ? 2 : 1); /* :328 has a trailing /2 */
       const size_t descThr = ((size_t)1 << ((size_t)floorf(Rv + 0.5f))) + (size_t)s->nDescOff + (size_t)(unst_old * s->nDescOff);
       const size_t totColorThr = colorThr * 3, totDescThr = descThr * 3, scColorThr = totColorThr / 2;
-      unsigned intra[3];
-      for (int c = 0; c < 3; ++c) intra[c] = lbsp1(img, cols, x, y, c, cur[c], s->lut[cur[c]]); /* :465-466 */
+      unsigned intra[3] = {0, 0, 0};
+      for (int c = 0; c < C; ++c) intra[c] = lbsp1(img, cols, C, x, y, c, cur[c], s->lut[cur[c]]); /* :465-466 / :331 */
       const int unst = (Rv > 3.0f || (s->RawLT[i] - s->FinLT[i]) > 0.1f || (RawSTOld[i] - s->FinST[i]) > 0.1f) ? 1 : 0; /* :467 */
       s->unstable[i] = (uint8_t)unst;
-      size_t minDesc = 48, minSum = 765; /* s_nDescMaxDataRange_3ch, s_nColorMaxDataRange_3ch */
+      size_t minDesc = maxDesc, minSum = maxColor;
       int good = 0, idx = 0;
-      while (good < nReq && idx < nS) { /* :469-497 */
-        const uint8_t* bc = s->color + ((size_t)idx * n + i) * 3;
-        const uint16_t* bd = s->desc + ((size_t)idx * n + i) * 3;
-        size_t totDesc = 0, totSum = 0;
-        int ok = 1;
-        for (int c = 0; c < 3 && ok; ++c) {
-          const size_t cd = (size_t)abs((int)cur[c] - (int)bc[c]);
-          if (cd > scColorThr) {
-            ok = 0;
-            break;
+      while (good < nReq && idx < nS) { /* :469-497 (3ch) / :334-357 (1ch) */
+        const uint8_t* bc = s->color + ((size_t)idx * n + i) * C;
+        const uint16_t* bd = s->desc + ((size_t)idx * n + i) * C;
+        if (C == 1) {
+          const size_t cd = (size_t)abs((int)cur[0] - (int)bc[0]);
+          if (cd <= colorThr) {
+            const size_t intraD = (size_t)popc16(intra[0] ^ bd[0]);
+            const unsigned inter = lbsp1(img, cols, 1, x, y, 0, bc[0], s->lut[bc[0]]);
+            const size_t dd = (intraD + (size_t)popc16(inter ^ bd[0])) / 2;
+            if (dd <= descThr) {
+              size_t sd = (dd / 4) * (255 / 16) + cd;
+              if (sd > 255) sd = 255;
+              if (sd <= colorThr) {
+                if (minDesc > dd) minDesc = dd;
+                if (minSum > sd) minSum = sd;
+                good++;
+              }
+            }
           }
-          const size_t intraD = (size_t)popc16(intra[c] ^ bd[c]);
-          const unsigned inter = lbsp1(img, cols, x, y, c, bc[c], s->lut[bc[c]]);
-          const size_t interD = (size_t)popc16(inter ^ bd[c]);
-          const size_t dd = (intraD + interD) / 2;
-          size_t sd = (dd / 2) * (255 / 16) + cd;
-          if (sd > 255) sd = 255;
-          if (sd > scColorThr) {
-            ok = 0;
-            break;
+        } else {
+          size_t totDesc = 0, totSum = 0;
+          int ok = 1;
+          for (int c = 0; c < 3 && ok; ++c) {
+            const size_t cd = (size_t)abs((int)cur[c] - (int)bc[c]);
+            if (cd > scColorThr) {
+              ok = 0;
+              break;
+            }
+            const size_t intraD = (size_t)popc16(intra[c] ^ bd[c]);
+            const unsigned inter = lbsp1(img, cols, 3, x, y, c, bc[c], s->lut[bc[c]]);
+            const size_t interD = (size_t)popc16(inter ^ bd[c]);
+            const size_t dd = (intraD + interD) / 2;
+            size_t sd = (dd / 2) * (255 / 16) + cd;
+            if (sd > 255) sd = 255;
+            if (sd > scColorThr) {
+              ok = 0;
+              break;
+            }
+            totDesc += dd;
+            totSum += sd;
           }
-          totDesc += dd;
-          totSum += sd;
-        }
-        if (ok && !(totDesc > totDescThr || totSum > totColorThr)) {
-          if (minDesc > totDesc) minDesc = totDesc;
-          if (minSum > totSum) minSum = totSum;
-          good++;
+          if (ok && !(totDesc > totDescThr || totSum > totColorThr)) {
+            if (minDesc > totDesc) minDesc = totDesc;
+            if (minSum > totSum) minSum = totSum;
+            good++;
+          }
         }
         idx++;
       }
       /* :498-499 */
       size_t l1 = 0, hd = 0;
-      for (int c = 0; c < 3; ++c) {
-        l1 += (size_t)abs((int)s->lastColor[i * 3 + c] - (int)cur[c]);
-        hd += (size_t)popc16(s->lastDesc[i * 3 + c] ^ intra[c]);
+      for (int c = 0; c < C; ++c) {
+        l1 += (size_t)abs((int)s->lastColor[i * C + c] - (int)cur[c]);
+        hd += (size_t)popc16(s->lastDesc[i * C + c] ^ intra[c]);
       }
-      const float normLast = ((float)l1 / 765 + (float)hd / 48) / 2;
+      const float normLast = ((float)l1 / maxColor + (float)hd / maxDesc) / 2;
       const float dlast = DlastOld[i] * (1.0f - fST) + normLast * fST;
       DlastNew[i] = dlast;
       float dminLT = s->DminLT[i], dminST = s->DminST[i], rawLT = s->RawLT[i], rawST = RawSTOld[i];
       int isfg;
       uint16_t reqSelf = 0, reqNbr = 0;
       if (good < nReq) { /* foreground :500-515 */
-        float nm = ((float)minSum / 765 + (float)minDesc / 48) / 2 + (float)(nReq - good) / nReq;
+        float nm = ((float)minSum / maxColor + (float)minDesc / maxDesc) / 2 + (float)(nReq - good) / nReq;
         if (nm > 1.0f) nm = 1.0f;
         dminLT = dminLT * (1.0f - fLT) + nm * fLT;
         dminST = dminST * (1.0f - fST) + nm * fST;
@@ -293,7 +313,7 @@ static void ss_phase_a(ss_state* s, const uint8_t* img, size_t* nonzero_desc) {
         isfg = 1;
         if (s->cooldown && (ss_rand(fr, (uint32_t)i, 0) % 2u) == 0) reqSelf = REQ(ss_rand(fr, (uint32_t)i, 1) % (uint32_t)nS, 12);
       } else { /* background :516-552 */
-        const float nm = ((float)minSum / 765 + (float)minDesc / 48) / 2;
+        const float nm = ((float)minSum / maxColor + (float)minDesc / maxDesc) / 2;
         dminLT = dminLT * (1.0f - fLT) + nm * fLT;
         dminST = dminST * (1.0f - fST) + nm * fST;
         rawLT = rawLT * (1.0f - fLT);
@@ -345,10 +365,10 @@ static void ss_phase_a(ss_state* s, const uint8_t* img, size_t* nonzero_desc) {
         if (Rv < 1.0f) Rv = 1.0f;
       }
       s->R[i] = Rv, s->V[i] = Vv, s->T[i] = Tv;
-      if (popc16(intra[0]) + popc16(intra[1]) + popc16(intra[2]) >= 4) ++nz; /* :577-578 */
-      for (int c = 0; c < 3; ++c) {                                          /* :579-582 */
-        s->lastDesc[i * 3 + c] = (uint16_t)intra[c];
-        s->lastColor[i * 3 + c] = cur[c];
+      if (C == 3 ? (popc16(intra[0]) + popc16(intra[1]) + popc16(intra[2]) >= 4) : (popc16(intra[0]) >= 2)) ++nz; /* :577-578 / :430-431 */
+      for (int c = 0; c < C; ++c) {                                                                            /* :579-582 */
+        s->lastDesc[i * C + c] = (uint16_t)intra[c];
+        s->lastColor[i * C + c] = cur[c];
       }
     }
   s->pp ^= 1;
@@ -373,9 +393,9 @@ static void ss_phase_b(ss_state* s) {
             const int code = (int)(r & 0x1f), slot = (int)((r >> 8) & 0x3f);
             const int ty = ys + code / 5 - 2, tx = xs + code % 5 - 2;
             if (ty != y || tx != x) continue;
-            for (int c = 0; c < 3; ++c) {
-              s->color[((size_t)slot * n + j) * 3 + c] = s->lastColor[i * 3 + c]; /* = current frame colour of the source */
-              s->desc[((size_t)slot * n + j) * 3 + c] = s->lastDesc[i * 3 + c];   /* = its current intra descriptor */
+            for (int c = 0; c < s->C; ++c) {
+              s->color[((size_t)slot * n + j) * s->C + c] = s->lastColor[i * s->C + c]; /* = current frame colour of the source */
+              s->desc[((size_t)slot * n + j) * s->C + c] = s->lastDesc[i * s->C + c];   /* = its current intra descriptor */
             }
           }
         }
@@ -438,24 +458,29 @@ int ss_process(ss_state* s, const uint8_t* img, uint8_t* fg /* [n] */, uint8_t* 
   s->lastNZ = ratio;
   if (s->lrScaling) { /* :656-699 */
     size_t totDiff = 0;
+    const int C = s->C;
     for (int y = 0; y < s->dsh; ++y)
       for (int x = 0; x < s->dsw; ++x) {
-        float d[3];
-        for (int c = 0; c < 3; ++c) {
+        float d[3] = {0, 0, 0};
+        for (int c = 0; c < C; ++c) {
           int sum = 0;
           for (int yy = 0; yy < 8; ++yy)
-            for (int xx = 0; xx < 8; ++xx) sum += img[((size_t)(y * 8 + yy) * s->cols + (x * 8 + xx)) * 3 + c];
+            for (int xx = 0; xx < 8; ++xx) sum += img[((size_t)(y * 8 + yy) * s->cols + (x * 8 + xx)) * C + c];
           const float v = (float)sat_u8_f((float)sum * (1.f / 64)); /* INTER_AREA, integer ratio */
-          float* lt = s->dsLT + ((size_t)y * s->dsw + x) * 3 + c;
-          float* st = s->dsST + ((size_t)y * s->dsw + x) * 3 + c;
+          float* lt = s->dsLT + ((size_t)y * s->dsw + x) * C + c;
+          float* st = s->dsST + ((size_t)y * s->dsw + x) * C + c;
           *lt = v * fLT + *lt * (1 - fLT); /* accumulateWeighted: src*a + dst*(1-a) */
           *st = v * fST + *st * (1 - fST);
           d[c] = fabsf(*st - *lt);
         }
-        size_t m = (size_t)d[0];
-        if ((size_t)d[1] > m) m = (size_t)d[1];
-        if ((size_t)d[2] > m) m = (size_t)d[2];
-        totDiff += m;
+        if (C == 1)
+          totDiff += (size_t)d[0] / 2; /* :664 */
+        else {
+          size_t m = (size_t)d[0];
+          if ((size_t)d[1] > m) m = (size_t)d[1];
+          if ((size_t)d[2] > m) m = (size_t)d[2];
+          totDiff += m;
+        }
       }
     const float diffRatio = (float)totDiff / (s->dsh * s->dsw);
     const int thr = s->nMinColor / 2; /* FRAMELEVEL_MIN_COLOR_DIFF_THRESHOLD */
@@ -484,10 +509,10 @@ int ss_process(ss_state* s, const uint8_t* img, uint8_t* fg /* [n] */, uint8_t* 
   }
   if (bg) { /* getBackgroundImage :702-718 */
     for (size_t i = 0; i < n; ++i)
-      for (int c = 0; c < 3; ++c) {
+      for (int c = 0; c < s->C; ++c) {
         float acc = 0;
-        for (int k = 0; k < s->nS; ++k) acc += ((float)s->color[((size_t)k * n + i) * 3 + c]) / s->nS;
-        bg[i * 3 + c] = sat_u8_f(acc);
+        for (int k = 0; k < s->nS; ++k) acc += ((float)s->color[((size_t)k * n + i) * s->C + c]) / s->nS;
+        bg[i * s->C + c] = sat_u8_f(acc);
       }
   }
   return BGS_OK;
@@ -502,8 +527,8 @@ int64_t ss_get_state(ss_state* s, const char* plane, void* dst, size_t cap) {
   } tab[] = {{"R", s->R, n * 4},          {"V", s->V, n * 4},           {"T", s->T, n * 4},           {"Dlast", s->Dlast[s->pp], n * 4},
              {"DminLT", s->DminLT, n * 4}, {"DminST", s->DminST, n * 4}, {"RawLT", s->RawLT, n * 4},   {"RawST", s->RawST[s->pp], n * 4},
              {"FinLT", s->FinLT, n * 4},   {"FinST", s->FinST, n * 4},   {"unstable", s->unstable, n}, {"blinks", s->blinks, n},
-             {"lastfg", s->lastFG, n},     {"lastraw", s->lastRaw, n},   {"lastcolor", s->lastColor, n * 3}, {"lastdesc", s->lastDesc, n * 6},
-             {"color", s->color, (size_t)s->nS * n * 3}, {"desc", s->desc, (size_t)s->nS * n * 6}, {"lut", s->lut, 256}};
+             {"lastfg", s->lastFG, n},     {"lastraw", s->lastRaw, n},   {"lastcolor", s->lastColor, n * s->C}, {"lastdesc", s->lastDesc, n * 2 * s->C},
+             {"color", s->color, (size_t)s->nS * n * s->C}, {"desc", s->desc, (size_t)s->nS * n * 2 * s->C}, {"lut", s->lut, 256}};
   for (size_t k = 0; k < sizeof(tab) / sizeof(tab[0]); ++k)
     if (!strcmp(plane, tab[k].name)) {
       if (cap < tab[k].bytes) return BGS_ERR_STATE;

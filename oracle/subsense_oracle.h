@@ -9,7 +9,7 @@ extern "C" {
 #endif
 typedef struct ss_state ss_state;
 uint32_t ss_rand(uint32_t frame, uint32_t pixel, uint32_t draw);
-int ss_create(const bgs_params* p, const uint8_t* first_frame, int rows, int cols, ss_state** out);
+int ss_create(const bgs_params* p, const uint8_t* first_frame, int rows, int cols, int channels, ss_state** out);
 int ss_process(ss_state* s, const uint8_t* img, uint8_t* fg, uint8_t* bg);
 int64_t ss_get_state(ss_state* s, const char* plane, void* dst, size_t cap);
 void ss_destroy(ss_state* s);

@@ -458,7 +458,7 @@ SS_F32 = ["R", "V", "T", "Dlast", "DminLT", "DminST", "RawLT", "RawST", "FinLT",
 SS_U8 = ["unstable", "blinks", "lastfg", "lastraw"]
 
 
-def check_subsense_state(eng, orc, rows, cols, nS=50, stream=0):
+def check_subsense_state(eng, orc, rows, cols, nS=50, stream=0, C=3):
     n = rows * cols
     for pl in SS_F32:
         a, b = eng.get_state(pl, (n,), np.float32, stream=stream), orc.get_state(pl, (n,), np.float32)
@@ -468,10 +468,10 @@ def check_subsense_state(eng, orc, rows, cols, nS=50, stream=0):
         assert err <= STATE_TOL, "%s: max |delta| %g" % (pl, err)
     for pl in SS_U8:
         assert np.array_equal(eng.get_state(pl, (n,), np.uint8, stream=stream), orc.get_state(pl, (n,), np.uint8)), pl
-    assert np.array_equal(eng.get_state("lastcolor", (n * 3,), np.uint8, stream=stream), orc.get_state("lastcolor", (n * 3,), np.uint8))
-    assert np.array_equal(eng.get_state("lastdesc", (n * 3,), np.uint16, stream=stream), orc.get_state("lastdesc", (n * 3,), np.uint16))
-    assert np.array_equal(eng.get_state("color", (nS, n, 3), np.uint8, stream=stream), orc.get_state("color", (nS, n, 3), np.uint8)), "colour samples"
-    assert np.array_equal(eng.get_state("desc", (nS, n, 3), np.uint16, stream=stream), orc.get_state("desc", (nS, n, 3), np.uint16)), "descriptor samples"
+    assert np.array_equal(eng.get_state("lastcolor", (n * C,), np.uint8, stream=stream), orc.get_state("lastcolor", (n * C,), np.uint8))
+    assert np.array_equal(eng.get_state("lastdesc", (n * C,), np.uint16, stream=stream), orc.get_state("lastdesc", (n * C,), np.uint16))
+    assert np.array_equal(eng.get_state("color", (nS, n, C), np.uint8, stream=stream), orc.get_state("color", (nS, n, C), np.uint8)), "colour samples"
+    assert np.array_equal(eng.get_state("desc", (nS, n, C), np.uint16, stream=stream), orc.get_state("desc", (nS, n, C), np.uint16)), "descriptor samples"
     assert np.array_equal(eng.get_state("lut", (256,), np.uint8, stream=stream), orc.get_state("lut", (256,), np.uint8))
     assert np.array_equal(eng.get_state("scalars", (7,), np.float64, stream=stream), orc.get_state("scalars", (7,), np.float64))
 
@@ -536,9 +536,21 @@ def test_subsense_streams_and_device_batch():
         check_subsense_state(eng, orcs[s], H, W, stream=s)
 
 
-def test_subsense_rejects_unsupported_inputs(golden_gray):
-    with pytest.raises(capi.BgsError):
-        Engine(capi.SUBSENSE).process(golden_gray[0])  # 1-channel path not built
+def test_subsense_grayscale_path(golden_gray):
+    """CV_8UC1 input: the 1-channel branch of operator() (BackgroundSubtractorSuBSENSE.cpp:306-434), LUT / 3, halved colour threshold."""
+    eng, orc, _ = run_pair(capi.SUBSENSE, golden_gray)
+    check_subsense_state(eng, orc, golden_gray.shape[1], golden_gray.shape[2], C=1)
+
+
+def test_subsense_grayscale_qvga_scene_cut():
+    a = synth.numpy_frames("surv", 30, 240, 320, seed=8)[..., 1] // 6
+    b = 255 - synth.numpy_frames("surv", 12, 240, 320, seed=9)[..., 1] // 6
+    frames = np.ascontiguousarray(np.concatenate([a, b]))
+    eng, orc, _ = run_pair(capi.SUBSENSE, frames)
+    check_subsense_state(eng, orc, 240, 320, C=1)
+
+
+def test_subsense_rejects_unsupported_inputs():
     with pytest.raises(capi.BgsError):
         Engine(capi.SUBSENSE).process(np.zeros((243, 325, 3), np.uint8))  # >= QVGA and not a multiple of 8
 
@@ -561,3 +573,21 @@ def test_floodfill_from_origin_vs_oracle(shape):
     b = np.where(rng.random(shape) < 0.5, 255, 0).astype(np.uint8)
     for k in (3, 9, 13):
         assert np.array_equal(mask_morph_device(torch.from_numpy(b).cuda(), MORPH_MEDIAN_BINARY, ksize=k).cpu().numpy(), pyoracle.median_blur(b, k))
+
+
+@pytest.mark.parametrize("thr", [1, 2, 15, 40, 127, 200])
+def test_wmv_quiet_pixel_shortcut_is_exact(thr):
+    """wmv_kernel skips the float pipeline when every channel's temporal range is < 2*thr (proof in kernel_pointwise.h).
+    Probe the boundary: ranges 2*thr-2 .. 2*thr+1 in every 0.5|0.5-like split, all three history slots, plus random data."""
+    rng = np.random.default_rng(thr)
+    H, W = 32, 64
+    base = rng.integers(0, max(1, 255 - 2 * thr - 2), (H, W, 3))
+    frames = []
+    for t in range(9):
+        delta = rng.integers(2 * thr - 2, 2 * thr + 2, (H, W, 3))
+        on = rng.random((H, W, 3)) < 0.5
+        frames.append(np.clip(base + np.where(on, delta, 0), 0, 255).astype(np.uint8))
+    frames = np.stack(frames)
+    run_pair(capi.WMV, frames, params=_params(capi.WMV, threshold=thr))
+    run_pair(capi.WMV, frames[:, :, :, 0], params=_params(capi.WMV, threshold=thr))
+    run_pair(capi.WMV, frames, params=_params(capi.WMV, threshold=thr, enable_weight=0))

@@ -273,3 +273,12 @@ def test_counter_rng_is_shared_by_both_sides():
         assert l.ss_rand(*args) == ref(*args)
     vals = np.array([l.ss_rand(5, p, 4) % 8 for p in range(8000)])
     assert np.bincount(vals, minlength=8).min() > 800  # roughly uniform
+
+
+def test_subsense_oracle_grayscale(golden_gray):
+    o = pyoracle.Oracle(capi.SUBSENSE)
+    for f in golden_gray:
+        fg, bg = o.process(f)
+        assert fg.shape == f.shape and bg.shape == f.shape
+    lut = o.get_state("lut", (256,), np.uint8)
+    assert lut[255] <= 28  # (t * 0.333f) / 3, possibly auto-decremented since

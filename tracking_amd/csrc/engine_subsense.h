@@ -8,6 +8,15 @@
 enum { SS_R, SS_V, SS_T, SS_DLAST0, SS_DLAST1, SS_DMINLT, SS_DMINST, SS_RAWLT, SS_RAWST0, SS_RAWST1, SS_FINLT, SS_FINST, SS_NF32 };
 enum { SS_UNSTABLE, SS_BLINKS, SS_LASTFG, SS_LASTRAW, SS_LASTRAWBLINK, SS_LASTDILINV, SS_RAW, SS_T1, SS_T2, SS_T3, SS_T4, SS_NU8 };
 
+// launch the C = 3 or C = 1 instantiation of a SuBSENSE kernel template
+#define SS_LAUNCH(KERNEL, grid, block, stream, ...)                                             \
+  do {                                                                                          \
+    if (e->ch == 3)                                                                             \
+      hipLaunchKernelGGL((bgs::KERNEL<3>), grid, block, 0, stream, __VA_ARGS__);                \
+    else                                                                                        \
+      hipLaunchKernelGGL((bgs::KERNEL<1>), grid, block, 0, stream, __VA_ARGS__);                \
+  } while (0)
+
 struct SsDevice {
   uint8_t *color = nullptr, *lut = nullptr, *lastColor = nullptr;
   uint16_t *desc = nullptr, *lastDesc = nullptr, *req = nullptr;
@@ -35,7 +44,6 @@ struct SsDevice {
 };
 
 int ss_allocate(bgs_engine* e) {
-  if (e->ch != 3) return fail(BGS_ERR_UNSUPPORTED, "SuBSENSE: only the 3-channel (BGR) path is built");
   if (e->rows < 5 || e->cols < 5) return fail(BGS_ERR_UNSUPPORTED, "SuBSENSE needs at least 5x5 pixels (LBSP::validateROI)");
   const bgs_params& p = e->p;
   if (p.subsense_n_samples < 1 || p.subsense_n_samples > 63 || p.subsense_n_required > p.subsense_n_samples)
@@ -54,11 +62,11 @@ int ss_allocate(bgs_engine* e) {
     if (e->rows % 8 || e->cols % 8)
       return fail(BGS_ERR_UNSUPPORTED, "SuBSENSE frame-level analysis: rows and cols must be multiples of 8 (cv::resize INTER_AREA with an integer ratio)");
   }
-  const size_t N = e->n, P = N * e->S, nS = (size_t)p.subsense_n_samples;
-  HIP_TRY(hipMalloc((void**)&d->color, P * nS * 3));
-  HIP_TRY(hipMalloc((void**)&d->desc, P * nS * 3 * 2));
-  HIP_TRY(hipMalloc((void**)&d->lastColor, P * 3));
-  HIP_TRY(hipMalloc((void**)&d->lastDesc, P * 3 * 2));
+  const size_t N = e->n, P = N * e->S, nS = (size_t)p.subsense_n_samples, C = (size_t)e->ch;
+  HIP_TRY(hipMalloc((void**)&d->color, P * nS * C));
+  HIP_TRY(hipMalloc((void**)&d->desc, P * nS * C * 2));
+  HIP_TRY(hipMalloc((void**)&d->lastColor, P * C));
+  HIP_TRY(hipMalloc((void**)&d->lastDesc, P * C * 2));
   HIP_TRY(hipMalloc((void**)&d->req, P * 2 * 2));
   HIP_TRY(hipMalloc((void**)&d->lut, (size_t)e->S * 256));
   HIP_TRY(hipMalloc((void**)&d->sc, (size_t)e->S * sizeof(bgs::SsScalars)));
@@ -69,7 +77,7 @@ int ss_allocate(bgs_engine* e) {
   HIP_TRY(hipHostMalloc((void**)&d->h_changed, sizeof(int), hipHostMallocDefault));
   for (auto& q : d->f32) HIP_TRY(hipMalloc((void**)&q, P * sizeof(float)));
   for (auto& q : d->u8) HIP_TRY(hipMalloc((void**)&q, P));
-  const size_t ds = (size_t)(e->rows / 8) * (e->cols / 8) * 3 * e->S + 4;
+  const size_t ds = (size_t)(e->rows / 8) * (e->cols / 8) * C * e->S + 4;
   HIP_TRY(hipMalloc((void**)&d->dsLT, ds * sizeof(float)));
   HIP_TRY(hipMalloc((void**)&d->dsST, ds * sizeof(float)));
   d->pp.assign(e->S, 0);
@@ -103,9 +111,10 @@ void ss_morph(const uint8_t* src, uint8_t* dst, int rows, int cols, int count, i
 }
 
 // cv::saturate_cast<uchar>(offset + t * rel) per entry (BackgroundSubtractorSuBSENSE.cpp:227-228); host-side, once per stream
-void ss_initial_lut(const bgs_params& p, uint8_t lut[256]) {
+void ss_initial_lut(const bgs_params& p, int channels, uint8_t lut[256]) {
   for (int t = 0; t < 256; ++t) {
-    const float v = (float)(size_t)p.lbsp_threshold_offset + (float)(size_t)t * p.lbsp_rel_threshold;
+    float v = (float)(size_t)p.lbsp_threshold_offset + (float)(size_t)t * p.lbsp_rel_threshold;
+    if (channels == 1) v = v / 3;  // :209-210
     long r = std::lrint((double)v);
     lut[t] = (uint8_t)std::min<long>(std::max<long>(r, 0), 255);
   }
@@ -113,9 +122,9 @@ void ss_initial_lut(const bgs_params& p, uint8_t lut[256]) {
 
 int ss_init_streams(bgs_engine* e, int first, int count, const uint8_t* d_frames, hipStream_t s) {
   SsDevice* d = e->ss;
-  const size_t N = e->n, off = N * first, npix = N * count, nS = (size_t)e->p.subsense_n_samples;
+  const size_t N = e->n, off = N * first, npix = N * count, nS = (size_t)e->p.subsense_n_samples, C = (size_t)e->ch;
   uint8_t lut[256];
-  ss_initial_lut(e->p, lut);
+  ss_initial_lut(e->p, e->ch, lut);
   bgs::SsScalars sc0{};
   sc0.autoReset = d->lrScaling, sc0.capLo = d->capLo0, sc0.capHi = d->capHi0;
   for (int i = first; i < first + count; ++i) {
@@ -134,23 +143,27 @@ int ss_init_streams(bgs_engine* e, int first, int count, const uint8_t* d_frames
   HIP_TRY(fillf(SS_V, 10.0f));
   for (int idx : {SS_DLAST0, SS_DLAST1, SS_DMINLT, SS_DMINST, SS_RAWLT, SS_RAWST0, SS_RAWST1, SS_FINLT, SS_FINST}) HIP_TRY(fillf(idx, 0.0f));
   for (int idx : {SS_UNSTABLE, SS_BLINKS, SS_LASTFG, SS_LASTRAW, SS_LASTRAWBLINK, SS_LASTDILINV}) HIP_TRY(hipMemsetAsync(d->u8[idx] + off, 0, npix, s));
-  const size_t dsn = (size_t)(e->rows / 8) * (e->cols / 8) * 3;
+  const size_t dsn = (size_t)(e->rows / 8) * (e->cols / 8) * C;
   if (dsn) {
     HIP_TRY(hipMemsetAsync(d->dsLT + dsn * first, 0, dsn * count * sizeof(float), s));
     HIP_TRY(hipMemsetAsync(d->dsST + dsn * first, 0, dsn * count * sizeof(float), s));
   }
-  HIP_TRY(hipMemsetAsync(d->color + off * nS * 3, 0, npix * nS * 3, s));
-  HIP_TRY(hipMemsetAsync(d->desc + off * nS * 3, 0, npix * nS * 3 * 2, s));
+  HIP_TRY(hipMemsetAsync(d->color + off * nS * C, 0, npix * nS * C, s));
+  HIP_TRY(hipMemsetAsync(d->desc + off * nS * C, 0, npix * nS * C * 2, s));
   // first-frame descriptors (:229-243) with the initial LUT, border = 0; LastColor interior = frame
   bgs::LbspArgs la{};
-  la.img = d_frames, la.desc = d->lastDesc + off * 3, la.rows = e->rows, la.cols = e->cols;
+  la.img = d_frames, la.desc = d->lastDesc + off * C, la.rows = e->rows, la.cols = e->cols;
   std::memcpy(la.lut, lut, 256);
-  hipLaunchKernelGGL((bgs::lbsp_kernel<3>), dim3((e->cols + bgs::kLbspTW - 1) / bgs::kLbspTW, (e->rows + bgs::kLbspTH - 1) / bgs::kLbspTH, count), dim3(bgs::kBlock), 0, s, la);
+  const dim3 lgrid((e->cols + bgs::kLbspTW - 1) / bgs::kLbspTW, (e->rows + bgs::kLbspTH - 1) / bgs::kLbspTH, count);
+  if (e->ch == 3)
+    hipLaunchKernelGGL((bgs::lbsp_kernel<3>), lgrid, dim3(bgs::kBlock), 0, s, la);
+  else
+    hipLaunchKernelGGL((bgs::lbsp_kernel<1>), lgrid, dim3(bgs::kBlock), 0, s, la);
   bgs::SsArgs a{};
   ss_fill_args(e, a, first, 0, 0);
   a.frame = d_frames;
-  hipLaunchKernelGGL(bgs::ss_init_lastcolor_kernel, dim3(blocks_for(N), 1, count), dim3(bgs::kBlock), 0, s, a);
-  hipLaunchKernelGGL(bgs::ss_refresh_kernel, dim3(blocks_for(N), 1, count), dim3(bgs::kBlock), 0, s, a, 0);  // refreshModel(1.0f) (:246)
+  SS_LAUNCH(ss_init_lastcolor_kernel, dim3(blocks_for(N), 1, count), dim3(bgs::kBlock), s, a);
+  SS_LAUNCH(ss_refresh_kernel, dim3(blocks_for(N), 1, count), dim3(bgs::kBlock), s, a, 0);  // refreshModel(1.0f) (:246)
   HIP_TRY(hipGetLastError());
   return BGS_OK;
 }
@@ -172,9 +185,9 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
   const dim3 tiles((e->cols + bgs::kSsTW - 1) / bgs::kSsTW, (e->rows + bgs::kSsTH - 1) / bgs::kSsTH, count), block(bgs::kBlock);
   {
     Timed tm(e, s, "ss_phase_a_kernel");
-    hipLaunchKernelGGL(bgs::ss_phase_a_kernel, tiles, block, 0, s, a);
+    SS_LAUNCH(ss_phase_a_kernel, tiles, block, s, a);
   }
-  hipLaunchKernelGGL(bgs::ss_phase_b_kernel, tiles, block, 0, s, a);
+  SS_LAUNCH(ss_phase_b_kernel, tiles, block, s, a);
   hipLaunchKernelGGL(bgs::ss_blink_kernel, dim3(blocks_for(npix)), block, 0, s, a, npix);
   uint8_t *raw = d->u8[SS_RAW] + off, *t1 = d->u8[SS_T1] + off, *t3 = d->u8[SS_T3] + off, *t4 = d->u8[SS_T4] + off;
   uint8_t* lastFG = d->u8[SS_LASTFG] + off;
@@ -207,11 +220,11 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
   hipLaunchKernelGGL(bgs::ss_finish_kernel, dim3(blocks_for(npix)), block, 0, s, a, (const uint8_t*)t1, npix);  // :637-642
   if (d->lrScaling) {
     const int dsn = (e->rows / 8) * (e->cols / 8);
-    hipLaunchKernelGGL(bgs::ss_downsample_kernel, dim3(blocks_for(dsn), 1, count), block, 0, s, a);
+    SS_LAUNCH(ss_downsample_kernel, dim3(blocks_for(dsn), 1, count), block, s, a);
   }
   hipLaunchKernelGGL(bgs::ss_frame_level_kernel, dim3(count), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(bgs::ss_refresh_kernel, dim3(blocks_for(N), 1, count), block, 0, s, a, 1);  // refreshModel(0.1f) if asked (:680)
-  if (d_bg) hipLaunchKernelGGL(bgs::ss_background_kernel, dim3(blocks_for(N * 3), 1, count), block, 0, s, a);
+  SS_LAUNCH(ss_refresh_kernel, dim3(blocks_for(N), 1, count), block, s, a, 1);  // refreshModel(0.1f) if asked (:680)
+  if (d_bg) SS_LAUNCH(ss_background_kernel, dim3(blocks_for(N * e->ch), 1, count), block, s, a);
   HIP_TRY(hipGetLastError());
   for (int i = first; i < first + count; ++i) d->pp[i] = (uint8_t)(cur ^ 1);
   return BGS_OK;
@@ -219,7 +232,7 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
 
 int64_t ss_get_state(bgs_engine* e, int stream, const char* plane, void* dst, size_t cap) {
   SsDevice* d = e->ss;
-  const size_t N = e->n, off = N * stream, nS = (size_t)e->p.subsense_n_samples;
+  const size_t N = e->n, off = N * stream, nS = (size_t)e->p.subsense_n_samples, C = (size_t)e->ch;
   const int cur = d->pp[stream];
   struct Ent {
     const char* name;
@@ -240,10 +253,10 @@ int64_t ss_get_state(bgs_engine* e, int stream, const char* plane, void* dst, si
                      {"blinks", d->u8[SS_BLINKS] + off, N},
                      {"lastfg", d->u8[SS_LASTFG] + off, N},
                      {"lastraw", d->u8[SS_LASTRAW] + off, N},
-                     {"lastcolor", d->lastColor + off * 3, N * 3},
-                     {"lastdesc", d->lastDesc + off * 3, N * 6},
-                     {"color", d->color + off * nS * 3, N * nS * 3},
-                     {"desc", d->desc + off * nS * 3, N * nS * 6},
+                     {"lastcolor", d->lastColor + off * C, N * C},
+                     {"lastdesc", d->lastDesc + off * C, N * 2 * C},
+                     {"color", d->color + off * nS * C, N * nS * C},
+                     {"desc", d->desc + off * nS * C, N * nS * 2 * C},
                      {"lut", d->lut + (size_t)stream * 256, 256}};
   for (const Ent& t : tab)
     if (!strcmp(plane, t.name)) {

@@ -146,6 +146,11 @@ __device__ __forceinline__ float wvar(float x, float mean, double w) {
   return p * (float)w;
 }
 
+// Exact shortcut for quiet pixels.  With the default weights (0.5, 0.3, 0.2; they sum to 1) the byte the reference produces for a
+// channel is round(255 * weighted std-dev of the three frame values), and a weighted std-dev of values spanning a range r is at
+// most r/2 (two-point distribution with the closest achievable split 0.5 | 0.5); the float pipeline's error is ~1e-5.  So if
+// every channel of a pixel has range(b0,b1,b2) < 2*thr, every channel byte is <= thr, hence gray <= thr and the thresholded
+// mask is 0 - no float work needed.  Only pixels with real temporal change take the full path (which stays bit-exact).
 template <int G, int C>
 __global__ __launch_bounds__(kBlock) void wmv_kernel(const FrameArgs a) {
   const size_t p0 = (xcd_block(a.xcd_swizzle) * kBlock + threadIdx.x) * G;
@@ -157,13 +162,31 @@ __global__ __launch_bounds__(kBlock) void wmv_kernel(const FrameArgs a) {
     y.load(a.p1 + p0 * C);
     z.load(a.p2 + p0 * C);
     const double w0 = a.enable_weight ? 0.5 : 0.3, w1 = 0.3, w2 = a.enable_weight ? 0.2 : 0.3;  // :68-70 (unweighted = 0.3 x3, sic)
+    const bool shortcut = a.enable_weight && a.enable_thr && a.thr >= 1;
 #pragma unroll
-    for (int i = 0; i < G * C; ++i) {
-      const float i0 = to_unit(x.b.get(i)), i1 = to_unit(y.b.get(i)), i2 = to_unit(z.b.get(i));
-      const float m = mean3<false>(i0, i1, i2, w0, w1, w2);
-      const float v = (wvar(i0, m, w0) + wvar(i1, m, w1)) + wvar(i2, m, w2);  // :83
-      const float sd = sqrt_rn(v);                                        // :95
-      d.b.set(i, sat_u8(sd * 255.f));                                         // :99
+    for (int j = 0; j < G; ++j) {
+      bool quiet = shortcut;
+      if (shortcut) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const int b0 = x.b.get(j * C + c), b1 = y.b.get(j * C + c), b2 = z.b.get(j * C + c);
+          quiet = quiet && (max(b0, max(b1, b2)) - min(b0, min(b1, b2)) < 2 * a.thr);
+        }
+      }
+      if (quiet) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) d.b.set(j * C + c, 0);  // any value <= thr gives the same mask
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const int i = j * C + c;
+          const float i0 = to_unit(x.b.get(i)), i1 = to_unit(y.b.get(i)), i2 = to_unit(z.b.get(i));
+          const float m = mean3<false>(i0, i1, i2, w0, w1, w2);
+          const float v = (wvar(i0, m, w0) + wvar(i1, m, w1)) + wvar(i2, m, w2);  // :83
+          const float sd = sqrt_rn(v);                                            // :95
+          d.b.set(i, sat_u8(sd * 255.f));                                         // :99
+        }
+      }
     }
   }
   gray_thr_store<G, C>(d, a, p0, active, a.fg_bits != nullptr);

@@ -1,4 +1,5 @@
-// kernel_subsense.h — K7/K8/K9 for SuBSENSEBGS (package_bgs/pl/SuBSENSE.cpp:21-45 over BackgroundSubtractorSuBSENSE.cpp), BGR path.
+// kernel_subsense.h — K7/K8/K9 for SuBSENSEBGS (package_bgs/pl/SuBSENSE.cpp:21-45 over BackgroundSubtractorSuBSENSE.cpp),
+// BGR (C = 3, :437-584) and grayscale (C = 1, :306-434) paths.
 //
 //   ss_phase_a_kernel    per-pixel loop of operator()            BackgroundSubtractorSuBSENSE.cpp:437-584
 //                        (thresholds :459-463, LBSP intra :465-466, sample consensus :469-497, rolling means :498-522,
@@ -85,21 +86,23 @@ __device__ __forceinline__ unsigned ss_lbsp(const uint32_t (&nb)[4], int ref, in
 }
 
 // ----------------------------------------------------------------------------------------------- phase A
+template <int C>
 __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
   constexpr int HW = kSsTW + 4, HH = kSsTH + 4;
-  constexpr int ROWB = (HW * 3 + 3 + 3) / 4 * 4;
+  constexpr int ROWB = (HW * C + 3 + 3) / 4 * 4;
+  constexpr size_t maxColor = 255 * C, maxDesc = 16 * C;  // s_nColorMaxDataRange_*, s_nDescMaxDataRange_*
   __shared__ uint32_t tile[HH][ROWB / 4];
   __shared__ uint8_t lut[256];
   __shared__ unsigned nz_block;
   const int stream = a.first + blockIdx.z;
   const size_t N = (size_t)a.rows * a.cols, sN = (size_t)stream * N;
-  const uint8_t* img = a.frame + (size_t)blockIdx.z * N * 3;
+  const uint8_t* img = a.frame + (size_t)blockIdx.z * N * C;
   const int x0 = blockIdx.x * kSsTW, y0 = blockIdx.y * kSsTH;
-  const long imgsz = (long)N * 3, rb = (long)(x0 - 2) * 3;
+  const long imgsz = (long)N * C, rb = (long)(x0 - 2) * C;
   for (int i = threadIdx.x; i < HH * (ROWB / 4); i += kBlock) {
     const int ry = i / (ROWB / 4), rd = i - ry * (ROWB / 4);
     const int y = min(max(y0 + ry - 2, 0), a.rows - 1);
-    const long off = (((long)y * a.cols * 3 + rb) & ~3L) + 4L * rd;
+    const long off = (((long)y * a.cols * C + rb) & ~3L) + 4L * rd;
     uint32_t v = 0;
     if (off >= 0 && off + 4 <= imgsz)
       v = *reinterpret_cast<const uint32_t*>(img + off);
@@ -121,14 +124,14 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
     const uint32_t fr = a.frameIndex, pi = (uint32_t)p;
     auto at = [&](int ry, int rx, int c) -> int {
       const uint8_t* rowp = reinterpret_cast<const uint8_t*>(tile[ry]);
-      const int shift = (int)(((long)(y0 + ry - 2) * a.cols * 3 + rb) & 3L);
-      return rowp[shift + rx * 3 + c];
+      const int shift = (int)(((long)(y0 + ry - 2) * a.cols * C + rb) & 3L);
+      return rowp[shift + rx * C + c];
     };
     const int8_t dxs[16] = {-1, 1, 1, -1, 1, 0, -1, 0, -2, 2, 2, -2, 0, 0, 2, -2}, dys[16] = {1, -1, 1, -1, 0, -1, 0, 1, -2, 2, -2, 2, 2, -2, 0, 0};
-    int cur[3];
-    uint32_t nb[3][4];
+    int cur[C];
+    uint32_t nb[C][4];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < C; ++c) {
       cur[c] = at(ly + 2, lx + 2, c);
 #pragma unroll
       for (int q = 0; q < 4; ++q) nb[c][q] = 0;
@@ -138,66 +141,86 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
     float Rv = a.R[i], Vv = a.V[i], Tv = a.T[i];
     const int unst_old = a.unstable[i];
     const int stabOff = a.nMinColor / 5;
-    const size_t colorThr = (size_t)((Rv * (float)a.nMinColor) - (float)((!unst_old) * stabOff));                                     // :459
+    const size_t colorThr = (size_t)((Rv * (float)a.nMinColor) - (float)((!unst_old) * stabOff)) / (C == 1 ? 2 : 1);                  // :459 / :328 (trailing /2)
     const size_t descThr = ((size_t)1 << ((size_t)floorf(Rv + 0.5f))) + (size_t)a.nDescOff + (size_t)(unst_old * a.nDescOff);        // :460
     const size_t totColorThr = colorThr * 3, totDescThr = descThr * 3, scColorThr = totColorThr / 2;
-    unsigned intra[3];
+    unsigned intra[C];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) intra[c] = ss_lbsp(nb[c], cur[c], lut[cur[c]]);  // :465-466
+    for (int c = 0; c < C; ++c) intra[c] = ss_lbsp(nb[c], cur[c], lut[cur[c]]);  // :465-466 / :331
     const float rawST_old = a.RawSTOld[i];
     const int unst = (Rv > 3.0f || (a.RawLT[i] - a.FinLT[i]) > 0.1f || (rawST_old - a.FinST[i]) > 0.1f) ? 1 : 0;  // :467
     a.unstable[i] = (uint8_t)unst;
-    size_t minDesc = 48, minSum = 765;
+    size_t minDesc = maxDesc, minSum = maxColor;
     int good = 0, idx = 0;
     const size_t sbase = (size_t)stream * a.nS * N;
-    while (good < a.nReq && idx < a.nS) {  // :469-497
-      const uint8_t* bc = a.color + (sbase + (size_t)idx * N + p) * 3;
-      const uint16_t* bd = a.desc + (sbase + (size_t)idx * N + p) * 3;
-      size_t totDesc = 0, totSum = 0;
-      bool ok = true;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        if (ok) {
-          const int bcc = bc[c];
-          const size_t cd = (size_t)abs(cur[c] - bcc);
-          if (cd > scColorThr) {
-            ok = false;
-          } else {
-            const unsigned bdc = bd[c];
-            const size_t intraD = (size_t)__popc(intra[c] ^ bdc);
-            const unsigned inter = ss_lbsp(nb[c], bcc, lut[bcc]);
-            const size_t interD = (size_t)__popc(inter ^ bdc);
-            const size_t dd = (intraD + interD) / 2;
-            size_t sd = (dd / 2) * (255 / 16) + cd;
+    while (good < a.nReq && idx < a.nS) {  // :469-497 (BGR) / :334-357 (gray)
+      const uint8_t* bc = a.color + (sbase + (size_t)idx * N + p) * C;
+      const uint16_t* bd = a.desc + (sbase + (size_t)idx * N + p) * C;
+      if constexpr (C == 1) {
+        const int bcc = bc[0];
+        const size_t cd = (size_t)abs(cur[0] - bcc);
+        if (cd <= colorThr) {
+          const unsigned bdc = bd[0];
+          const size_t intraD = (size_t)__popc(intra[0] ^ bdc);
+          const unsigned inter = ss_lbsp(nb[0], bcc, lut[bcc]);
+          const size_t dd = (intraD + (size_t)__popc(inter ^ bdc)) / 2;
+          if (dd <= descThr) {
+            size_t sd = (dd / 4) * (255 / 16) + cd;
             sd = sd < 255 ? sd : 255;
-            if (sd > scColorThr)
-              ok = false;
-            else
-              totDesc += dd, totSum += sd;
+            if (sd <= colorThr) {
+              minDesc = minDesc > dd ? dd : minDesc;
+              minSum = minSum > sd ? sd : minSum;
+              good++;
+            }
           }
         }
-      }
-      if (ok && !(totDesc > totDescThr || totSum > totColorThr)) {
-        minDesc = minDesc > totDesc ? totDesc : minDesc;
-        minSum = minSum > totSum ? totSum : minSum;
-        good++;
+      } else {
+        size_t totDesc = 0, totSum = 0;
+        bool ok = true;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          if (ok) {
+            const int bcc = bc[c];
+            const size_t cd = (size_t)abs(cur[c] - bcc);
+            if (cd > scColorThr) {
+              ok = false;
+            } else {
+              const unsigned bdc = bd[c];
+              const size_t intraD = (size_t)__popc(intra[c] ^ bdc);
+              const unsigned inter = ss_lbsp(nb[c], bcc, lut[bcc]);
+              const size_t interD = (size_t)__popc(inter ^ bdc);
+              const size_t dd = (intraD + interD) / 2;
+              size_t sd = (dd / 2) * (255 / 16) + cd;
+              sd = sd < 255 ? sd : 255;
+              if (sd > scColorThr)
+                ok = false;
+              else
+                totDesc += dd, totSum += sd;
+            }
+          }
+        }
+        if (ok && !(totDesc > totDescThr || totSum > totColorThr)) {
+          minDesc = minDesc > totDesc ? totDesc : minDesc;
+          minSum = minSum > totSum ? totSum : minSum;
+          good++;
+        }
       }
       idx++;
     }
     size_t l1 = 0, hd = 0;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      l1 += (size_t)abs((int)a.lastColor[i * 3 + c] - cur[c]);
-      hd += (size_t)__popc(((unsigned)a.lastDesc[i * 3 + c] ^ intra[c]) & 0xffffu);
+    for (int c = 0; c < C; ++c) {
+      l1 += (size_t)abs((int)a.lastColor[i * C + c] - cur[c]);
+      hd += (size_t)__popc(((unsigned)a.lastDesc[i * C + c] ^ intra[c]) & 0xffffu);
     }
     const float fLT = a.fLT, fST = a.fST;
-    const float normLast = ((float)l1 / 765 + (float)hd / 48) / 2;  // :498
+    const float normLast = ((float)l1 / maxColor + (float)hd / maxDesc) / 2;  // :498
     a.DlastNew[i] = a.DlastOld[i] * (1.0f - fST) + normLast * fST;
     float dminLT = a.DminLT[i], dminST = a.DminST[i], rawLT = a.RawLT[i], rawST = rawST_old;
     bool isfg;
     uint16_t reqSelf = 0, reqNbr = 0;
     if (good < a.nReq) {  // foreground :500-515
-      float nm = ((float)minSum / 765 + (float)minDesc / 48) / 2 + (float)(a.nReq - good) / a.nReq;
+      float nm = ((float)minSum / maxColor + (float)minDesc / maxDesc) / 2 + (float)(a.nReq - good) / a.nReq;
       nm = nm > 1.0f ? 1.0f : nm;
       dminLT = dminLT * (1.0f - fLT) + nm * fLT;
       dminST = dminST * (1.0f - fST) + nm * fST;
@@ -206,7 +229,7 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
       isfg = true;
       if (sc.cooldown && (ss_rand(fr, pi, 0) % 2u) == 0) reqSelf = ss_req(ss_rand(fr, pi, 1) % (uint32_t)a.nS, 12);
     } else {  // background :516-552
-      const float nm = ((float)minSum / 765 + (float)minDesc / 48) / 2;
+      const float nm = ((float)minSum / maxColor + (float)minDesc / maxDesc) / 2;
       dminLT = dminLT * (1.0f - fLT) + nm * fLT;
       dminST = dminST * (1.0f - fST) + nm * fST;
       rawLT = rawLT * (1.0f - fLT);
@@ -258,11 +281,14 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
       if (Rv < 1.0f) Rv = 1.0f;
     }
     a.R[i] = Rv, a.V[i] = Vv, a.T[i] = Tv;
-    nzflag = (__popc(intra[0]) + __popc(intra[1]) + __popc(intra[2])) >= 4;  // :577-578
+    if constexpr (C == 3)
+      nzflag = (__popc(intra[0]) + __popc(intra[1]) + __popc(intra[2])) >= 4;  // :577-578
+    else
+      nzflag = __popc(intra[0]) >= 2;  // :430-431
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {  // :579-582
-      a.lastDesc[i * 3 + c] = (uint16_t)intra[c];
-      a.lastColor[i * 3 + c] = (uint8_t)cur[c];
+    for (int c = 0; c < C; ++c) {  // :579-582
+      a.lastDesc[i * C + c] = (uint16_t)intra[c];
+      a.lastColor[i * C + c] = (uint8_t)cur[c];
     }
   } else if (x < a.cols && y < a.rows) {
     const size_t i = sN + (size_t)y * a.cols + x;
@@ -277,6 +303,7 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------------- phase B
+template <int C>
 __global__ __launch_bounds__(kBlock) void ss_phase_b_kernel(const SsArgs a) {
   __shared__ uint32_t rq[kSsTH + 4][kSsTW + 4];  // both requests of a pixel in one dword
   const int stream = a.first + blockIdx.z;
@@ -306,11 +333,11 @@ __global__ __launch_bounds__(kBlock) void ss_phase_b_kernel(const SsArgs a) {
         const int code = (int)(r & 0x1f), slot = (int)((r >> 8) & 0x3f);
         if (dy + code / 5 - 2 != 0 || dx + code % 5 - 2 != 0) continue;  // not aimed at this pixel
         const size_t src = sN + (size_t)(y + dy) * a.cols + (x + dx);
-        const size_t dst = (sbase + (size_t)slot * N + p) * 3;
+        const size_t dst = (sbase + (size_t)slot * N + p) * C;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          a.color[dst + c] = a.lastColor[src * 3 + c];  // phase A stored the source's current colour / intra descriptor there
-          a.desc[dst + c] = a.lastDesc[src * 3 + c];
+        for (int c = 0; c < C; ++c) {
+          a.color[dst + c] = a.lastColor[src * C + c];  // phase A stored the source's current colour / intra descriptor there
+          a.desc[dst + c] = a.lastDesc[src * C + c];
         }
       }
     }
@@ -318,6 +345,7 @@ __global__ __launch_bounds__(kBlock) void ss_phase_b_kernel(const SsArgs a) {
 
 // ----------------------------------------------------------------------------------------------- refreshModel :249-291
 // mode 0: unconditional full refresh (initialisation, frac = 1); mode 1: 10 % refresh if the frame-level block asked for it
+template <int C>
 __global__ __launch_bounds__(kBlock) void ss_refresh_kernel(const SsArgs a, int mode) {
   const int stream = a.first + blockIdx.z;
   const size_t N = (size_t)a.rows * a.cols, sN = (size_t)stream * N;
@@ -347,14 +375,15 @@ __global__ __launch_bounds__(kBlock) void ss_refresh_kernel(const SsArgs a, int 
     xs = min(max(xs + x - 3, 2), a.cols - 3), ys = min(max(ys + y - 3, 2), a.rows - 3);
     const size_t j = sN + (size_t)ys * a.cols + xs;
     if (!a.lastFG[j]) {
-      const size_t dst = (sbase + (size_t)((start + m) % a.nS) * N + p) * 3;
+      const size_t dst = (sbase + (size_t)((start + m) % a.nS) * N + p) * C;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) a.color[dst + c] = a.lastColor[j * 3 + c], a.desc[dst + c] = a.lastDesc[j * 3 + c];
+      for (int c = 0; c < C; ++c) a.color[dst + c] = a.lastColor[j * C + c], a.desc[dst + c] = a.lastDesc[j * C + c];
     }
   }
 }
 
 // LastColor of the first frame: interior pixels only (:229-243); lastDesc comes from lbsp_kernel
+template <int C>
 __global__ __launch_bounds__(kBlock) void ss_init_lastcolor_kernel(const SsArgs a) {
   const int stream = a.first + blockIdx.z;
   const size_t N = (size_t)a.rows * a.cols;
@@ -363,7 +392,7 @@ __global__ __launch_bounds__(kBlock) void ss_init_lastcolor_kernel(const SsArgs 
   const int x = (int)(p % a.cols), y = (int)(p / a.cols);
   const bool in = x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) a.lastColor[((size_t)stream * N + p) * 3 + c] = in ? a.frame[((size_t)blockIdx.z * N + p) * 3 + c] : 0;
+  for (int c = 0; c < C; ++c) a.lastColor[((size_t)stream * N + p) * C + c] = in ? a.frame[((size_t)blockIdx.z * N + p) * C + c] : 0;
 }
 
 // ----------------------------------------------------------------------------------------------- post-processing :624-642
@@ -514,6 +543,7 @@ __global__ __launch_bounds__(kBlock) void ss_finish_kernel(const SsArgs a, const
 }
 
 // ----------------------------------------------------------------------------------------------- frame-level block :656-665
+template <int C>
 __global__ __launch_bounds__(kBlock) void ss_downsample_kernel(const SsArgs a) {
   const int stream = a.first + blockIdx.z;
   const int dsw = a.cols / 8, dsh = a.rows / 8;
@@ -521,21 +551,24 @@ __global__ __launch_bounds__(kBlock) void ss_downsample_kernel(const SsArgs a) {
   unsigned diff = 0;
   if (idx < dsw * dsh) {
     const int x = idx % dsw, y = idx / dsw;
-    const uint8_t* img = a.frame + (size_t)blockIdx.z * a.rows * a.cols * 3;
-    float d[3];
+    const uint8_t* img = a.frame + (size_t)blockIdx.z * a.rows * a.cols * C;
+    float d[C];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < C; ++c) {
       int sum = 0;
       for (int yy = 0; yy < 8; ++yy)
-        for (int xx = 0; xx < 8; ++xx) sum += img[((size_t)(y * 8 + yy) * a.cols + (x * 8 + xx)) * 3 + c];
+        for (int xx = 0; xx < 8; ++xx) sum += img[((size_t)(y * 8 + yy) * a.cols + (x * 8 + xx)) * C + c];
       const float v = (float)sat_u8((float)sum * (1.f / 64));  // cv::resize INTER_AREA, integer ratio
-      float* lt = a.dsLT + ((size_t)stream * dsw * dsh + idx) * 3 + c;
-      float* st = a.dsST + ((size_t)stream * dsw * dsh + idx) * 3 + c;
+      float* lt = a.dsLT + ((size_t)stream * dsw * dsh + idx) * C + c;
+      float* st = a.dsST + ((size_t)stream * dsw * dsh + idx) * C + c;
       const float nlt = v * a.fLT + *lt * (1 - a.fLT), nst = v * a.fST + *st * (1 - a.fST);  // cv::accumulateWeighted
       *lt = nlt, *st = nst;
       d[c] = fabsf(nst - nlt);
     }
-    diff = max((unsigned)d[0], max((unsigned)d[1], (unsigned)d[2]));
+    if constexpr (C == 3)
+      diff = max((unsigned)d[0], max((unsigned)d[1], (unsigned)d[2]));
+    else
+      diff = (unsigned)d[0] / 2;  // :664
   }
   // block reduction -> one atomic per block
   __shared__ unsigned part[kBlock / kWave];
@@ -603,15 +636,16 @@ __global__ __launch_bounds__(256) void ss_frame_level_kernel(const SsArgs a) {
 }
 
 // getBackgroundImage :702-718
+template <int C>
 __global__ __launch_bounds__(kBlock) void ss_background_kernel(const SsArgs a) {
   const int stream = a.first + blockIdx.z;
   const size_t N = (size_t)a.rows * a.cols;
-  const size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x;  // byte index inside one [N][3] image
-  if (e >= N * 3) return;
-  const uint8_t* base = a.color + (size_t)stream * a.nS * N * 3 + e;
+  const size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x;  // byte index inside one [N][C] image
+  if (e >= N * C) return;
+  const uint8_t* base = a.color + (size_t)stream * a.nS * N * C + e;
   float acc = 0;
-  for (int k = 0; k < a.nS; ++k) acc += div_rn((float)base[(size_t)k * N * 3], (float)a.nS);
-  a.bgimg[(size_t)blockIdx.z * N * 3 + e] = (uint8_t)sat_u8(acc);
+  for (int k = 0; k < a.nS; ++k) acc += div_rn((float)base[(size_t)k * N * C], (float)a.nS);
+  a.bgimg[(size_t)blockIdx.z * N * C + e] = (uint8_t)sat_u8(acc);
 }
 
 }  // namespace bgs
