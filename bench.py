@@ -86,6 +86,38 @@ def cpu_baseline(pool, kind, budget_s=16.0):
     }
 
 
+def surv_leg(local, S, fg, steps=200, sparse=1):
+    """Same engine on S_surv (static background + sensor noise + moving boxes, SURVEY.md §8d headline-streams input): the
+    kernel skips model planes no pixel of a wave uses or changed, so throughput rises with scene sparsity.  Reported beside
+    `value` (which stays the dense S_sat roofline workload)."""
+    from tracking_amd import Engine, capi
+    dev = torch.device("cuda", local)
+    period = 16
+    pool = make_pool("surv", S, period, dev, 4321)
+    eng = Engine(capi.MOG2, device=local, n_streams=S)
+    eng.set_option(capi.OPT_MOG2_SPARSE, sparse)
+    eng.set_geometry(ROWS, COLS, CH)
+    for t in range(150):
+        eng.process_batch_device(pool[t % period], fg, None, None)
+    torch.cuda.synchronize()
+    eng.enable_kernel_timing(True)
+    t0 = time.perf_counter()
+    for t in range(steps):
+        eng.process_batch_device(pool[(150 + t) % period], fg, None, None)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms, _, _ = eng.kernel_timing()
+    nm = eng.get_state("nmodes", (ROWS * COLS,), np.uint8, stream=0)
+    mpix = steps * S * ROWS * COLS / dt / 1e6
+    out = {"mpixels_per_s": round(mpix, 1), "streams_1080p30": round(mpix / (ROWS * COLS / 1e6) / 30.0, 1), "kernel_ms": round(ms, 4),
+           "mean_live_modes_stream0": round(float(nm.mean()), 3), "foreground_ratio": round(float((fg != 0).float().mean()), 4),
+           "sparse_mode": sparse,
+           "note": "S_surv input, %d streams; BGS_OPT_MOG2_SPARSE=%d (1 = unchanged planes not written back [default], 2 = also planes of absent modes not read)" % (S, sparse)}
+    eng.close()
+    del pool
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,6 +198,7 @@ def main():
     live_modes = None
     single = None
     cpu = None
+    surv = None
     if rank == 0:
         nm = eng.get_state("nmodes", (ROWS * COLS,), np.uint8, stream=0)
         live_modes = float(nm.mean())
@@ -189,6 +222,8 @@ def main():
                   "kernel_algorithmic_GBps": round(BYTES_PER_PIXEL * ROWS * COLS / (ms1 * 1e-3) / 1e9, 1),
                   "note": "single stream: 207 MB of model state fits the 256 MiB Infinity Cache (not an HBM figure)"}
         e1.close()
+        if args.input == "sat":
+            surv = {"default": surv_leg(local, S, fg, sparse=1), "sparse_reads": surv_leg(local, S, fg, sparse=2)}
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(pool, args.input)
 
@@ -222,6 +257,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "frac_of_achievable_6290": round(achieved / 6290.0, 4)},
             "cpu_baseline": cpu,
             "single_stream": single,
+            "s_surv": surv,
         }
         print(json.dumps(out), flush=True)
     eng.close()

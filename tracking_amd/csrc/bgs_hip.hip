@@ -81,6 +81,7 @@ struct bgs_engine {
   bool mog2_tiled = true;
   int mog2_px = 0;                 // pixels per lane, 0 = widest the alignment allows
   int xcd_swizzle = 1;             // XCD-aware block order (kernel_mog2.h)
+  int mog2_sparse = 1;             // data-dependent plane skipping (kernel_mog2.h)
   int probe_max = 10;              // placement probe: candidates tried at allocation (<= 1: off)
   float probe_ms[16] = {0};         // what the probe measured (diagnostics)
   int probe_n = 0, probe_pick = -1;
@@ -142,7 +143,7 @@ int launch_mog2(bgs_engine* e, bgs::Mog2Args& a, hipStream_t s, bool timed = tru
   // shadow test only when it can change the delivered mask: not thresholded, or the threshold separates shadow from foreground
   a.shadow = p.mog2_detect_shadows && (!p.enable_threshold || ((p.mog2_shadow_value > p.threshold) != (255 > p.threshold)));
   a.want_bg = a.bgimg != nullptr, a.packed = a.fg_bits != nullptr;
-  a.xcd_swizzle = e->xcd_swizzle;
+  a.xcd_swizzle = e->xcd_swizzle, a.sparse = e->mog2_sparse;
   int PX = 4;
   if (a.npix % 4 || a.state_off % 4 || !aligned(a.frame, 4) || (a.fg && !aligned(a.fg, 4)) || (a.bgimg && !aligned(a.bgimg, 4))) PX = 1;
   if (e->mog2_px == 1 || e->mog2_px == 2) {
@@ -206,6 +207,8 @@ int mog2_allocate(bgs_engine* e) {
   HIP_TRY(hipEventCreate(&ev0));
   HIP_TRY(hipEventCreate(&ev1));
   float* cand[16] = {nullptr};
+  const int saved_sparse = e->mog2_sparse;
+  e->mog2_sparse = 0;  // probe with the dense traffic pattern: that is what a busy scene produces
   int n = 0, best = 0;
   float tmin = 1e30f, tmax = 0.f;
   int rc = BGS_OK;
@@ -238,6 +241,7 @@ int mog2_allocate(bgs_engine* e) {
       break;
     }
   }
+  e->mog2_sparse = saved_sparse;
   e->probe_n = n, e->probe_pick = best;
   for (int i = 0; i < n; ++i)
     if (i != best || rc) (void)hipFree(cand[i]);
@@ -638,6 +642,7 @@ int bgs_create(bgs_algo algo, const bgs_params* params, int hip_device, int n_st
   if (const char* env = getenv("BGS_MOG2_PX")) e->mog2_px = atoi(env);
   if (const char* env = getenv("BGS_MOG2_LAYOUT")) e->mog2_tiled = strcmp(env, "planar") != 0;
   if (const char* env = getenv("BGS_XCD_SWIZZLE")) e->xcd_swizzle = atoi(env);
+  if (const char* env = getenv("BGS_MOG2_SPARSE")) e->mog2_sparse = atoi(env);
   if (const char* env = getenv("BGS_PLACEMENT_PROBE")) e->probe_max = atoi(env);
   *out = e;
   return BGS_OK;
@@ -678,6 +683,7 @@ int bgs_set_option(bgs_engine* e, int option, int64_t value) {
       e->mog2_tiled = value != 0;
       return BGS_OK;
     case 4: e->xcd_swizzle = value != 0; return BGS_OK;
+    case 6: e->mog2_sparse = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return BGS_OK;
     case 5:
       if (e->n) return fail(BGS_ERR_INVALID, "the placement probe runs when the geometry is set");
       e->probe_max = (int)value;
