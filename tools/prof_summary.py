@@ -4,7 +4,8 @@
 HBM traffic per launch follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are reported in
 KiB-units of 1024 B by rocprofv3 (hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024), collected in separate --pmc passes, and
 on gfx950 FETCH_SIZE counts exactly half of the bytes of a wide coalesced streaming read -> doubled.
-usage: prof_summary.py <prof_dir> <kernel-substring> <min_grid> [algorithmic_bytes_per_launch]
+usage: prof_summary.py <prof_dir> <kernel-substring> <min_grid> [algorithmic_bytes_per_launch] [last_n]
+last_n: keep only the last n matching dispatches of every run (= bench.py's timed region when it runs with --main-only)
 """
 import collections
 import csv
@@ -24,9 +25,13 @@ def grid(r):
 def main():
     d, sub, min_grid = sys.argv[1], sys.argv[2], int(sys.argv[3])
     algo = float(sys.argv[4]) if len(sys.argv) > 4 else None
-    out = {"kernel": sub, "min_grid": min_grid}
+    last_n = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    out = {"kernel": sub, "min_grid": min_grid, "last_n_dispatches": last_n}
     kt = [r for r in rows(os.path.join(d, "stats", "stats_kernel_trace.csv")) if sub in r["Kernel_Name"] and grid(r) >= min_grid]
     if kt:
+        kt.sort(key=lambda r: int(r["Start_Timestamp"]))
+        if last_n:
+            kt = kt[-last_n:]
         dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in kt]
         out.update(launches=len(dur), avg_us=sum(dur) / len(dur) / 1e3, min_us=min(dur) / 1e3, max_us=max(dur) / 1e3,
                    grid=grid(kt[0]), vgpr=int(kt[0]["VGPR_Count"]), sgpr=int(kt[0]["SGPR_Count"]), name=kt[0]["Kernel_Name"])
@@ -38,10 +43,12 @@ def main():
         for f in os.listdir(p):
             if f.endswith("counter_collection.csv"):
                 agg = collections.defaultdict(list)
-                for r in rows(os.path.join(p, f)):
-                    if sub in r["Kernel_Name"] and grid(r) >= min_grid:
-                        agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                rs = [r for r in rows(os.path.join(p, f)) if sub in r["Kernel_Name"] and grid(r) >= min_grid]
+                rs.sort(key=lambda r: int(r["Dispatch_Id"]))
+                for r in rs:
+                    agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 for k, v in agg.items():
+                    v = v[-last_n:] if last_n else v
                     ctr[k] = sum(v) / len(v)
     out["counters_avg_per_launch"] = ctr
     if "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:

@@ -82,7 +82,7 @@ struct bgs_engine {
   int mog2_px = 0;                 // pixels per lane, 0 = widest the alignment allows
   int xcd_swizzle = 1;             // XCD-aware block order (kernel_mog2.h)
   int mog2_sparse = 1;             // data-dependent plane skipping (kernel_mog2.h)
-  int probe_max = 10;              // placement probe: candidates tried at allocation (<= 1: off)
+  int probe_max = 8;               // placement probe: candidates tried at allocation (<= 1: off)
   float probe_ms[16] = {0};         // what the probe measured (diagnostics)
   int probe_n = 0, probe_pick = -1;
 
@@ -186,8 +186,8 @@ size_t mog2_state_bytes(const bgs_engine* e) {
 // Model allocation with a PLACEMENT PROBE.  Measured on MI355X: the same kernel on the same layout runs in
 // one of two modes, ~5.5 TB/s or ~6.1 TB/s, depending only on which physical VRAM pages hipMalloc handed out (a physically
 // contiguous block always lands in the slow mode).  The model lives for the life of the stream, so it pays to look: allocate
-// a few candidates, time the real update kernel on each (zero model, zero frame: traffic is data-independent), keep the
-// fastest, free the rest.  Costs well under a second; skipped for models too small to be HBM-bound.
+// 8 candidates, time the real update kernel on each (zero model, zero frame, dense traffic), keep the fastest, free the
+// rest.  Costs ~0.2 s and, transiently, 8x the model's memory; skipped for models too small to be HBM-bound.
 int mog2_allocate(bgs_engine* e) {
   const size_t P = e->n * e->S, bytes = mog2_state_bytes(e);
   if (!e->mog2_tiled) {
@@ -236,10 +236,8 @@ int mog2_allocate(bgs_engine* e) {
     e->probe_ms[n] = ms / 4;
     if (ms < tmin) tmin = ms, best = n;
     tmax = std::max(tmax, ms);
-    if (n >= 1 && tmin < 0.95f * tmax) {  // both modes seen: the fast one is in hand
-      ++n;
-      break;
-    }
+    // no early exit: there are more than two speed classes (2.83 / 2.55 / 2.30 ms have been seen side by side), so every
+    // candidate is measured and the fastest kept
   }
   e->mog2_sparse = saved_sparse;
   e->probe_n = n, e->probe_pick = best;
