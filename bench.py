@@ -112,7 +112,7 @@ def surv_leg(local, S, fg, steps=200, sparse=1):
     out = {"mpixels_per_s": round(mpix, 1), "streams_1080p30": round(mpix / (ROWS * COLS / 1e6) / 30.0, 1), "kernel_ms": round(ms, 4),
            "mean_live_modes_stream0": round(float(nm.mean()), 3), "foreground_ratio": round(float((fg != 0).float().mean()), 4),
            "sparse_mode": sparse,
-           "note": "S_surv input, %d streams; BGS_OPT_MOG2_SPARSE=%d (1 = unchanged planes not written back [default], 2 = also planes of absent modes not read)" % (S, sparse)}
+           "note": "S_surv input, %d streams; BGS_OPT_MOG2_SPARSE=%d (1 = unchanged planes not written back, 2 = also planes of absent modes not read, 3 = automatic choice [default])" % (S, sparse)}
     eng.close()
     del pool
     return out
@@ -225,7 +225,7 @@ def main():
                   "note": "single stream: 207 MB of model state fits the 256 MiB Infinity Cache (not an HBM figure)"}
         e1.close()
         if args.input == "sat":
-            surv = {"default": surv_leg(local, S, fg, sparse=1), "sparse_reads": surv_leg(local, S, fg, sparse=2)}
+            surv = {"default": surv_leg(local, S, fg, sparse=3), "stores_only": surv_leg(local, S, fg, sparse=1)}
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(pool, args.input)
 

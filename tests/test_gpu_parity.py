@@ -591,3 +591,51 @@ def test_wmv_quiet_pixel_shortcut_is_exact(thr):
     run_pair(capi.WMV, frames, params=_params(capi.WMV, threshold=thr))
     run_pair(capi.WMV, frames[:, :, :, 0], params=_params(capi.WMV, threshold=thr))
     run_pair(capi.WMV, frames, params=_params(capi.WMV, threshold=thr, enable_weight=0))
+
+
+# ----------------------------------------------------------------------------- BASELINE configs[2], configs[3] at full size
+
+def test_full_size_4k_wmv_and_abl_sampled_parity():
+    """BASELINE configs[2]: WeightedMovingVarianceBGS + AdaptiveBackgroundLearning at 3840x2160, frames generated in HBM.
+    Both are pointwise, so the oracle replays a 65 536-pixel random sample of the same 6-frame clip and must agree bit for bit;
+    the whole frame is covered by a cross-check between the two device paths (byte mask vs bit-packed mask)."""
+    torch = _torch()
+    H, W, T = 2160, 3840, 6
+    frames = synth.s_surv(T, H, W, seed=4321, device="cuda")
+    rng = np.random.default_rng(7)
+    idx = np.sort(rng.choice(H * W, 65536, replace=False))
+    tidx = torch.from_numpy(idx).cuda()
+    sample = frames.reshape(T, H * W, 3)[:, tidx].cpu().numpy().reshape(T, 256, 256, 3)
+    for algo in (capi.WMV, capi.ABL):
+        eng = Engine(algo)
+        eng.set_geometry(H, W, 3)
+        orc = pyoracle.Oracle(algo)
+        d_fg = torch.empty((1, H, W), dtype=torch.uint8, device="cuda")
+        d_bg = torch.empty((1, H, W, 3), dtype=torch.uint8, device="cuda")
+        d_bits = torch.zeros((1, H * W // 64), dtype=torch.int64, device="cuda")
+        for t in range(T):
+            flags = eng.process_batch_device(frames[t:t + 1], d_fg, d_bg, d_bits)
+            torch.cuda.synchronize()
+            ofg, obg = orc.process(sample[t])
+            assert bool(flags & capi.FG_VALID) == (ofg is not None)
+            if ofg is not None:
+                assert np.array_equal(d_fg.reshape(-1)[tidx].cpu().numpy().reshape(256, 256), ofg), (algo, t)
+                bits = np.unpackbits(d_bits.cpu().numpy().view(np.uint8).reshape(-1), bitorder="little")
+                assert np.array_equal(bits.astype(bool), d_fg.reshape(-1).cpu().numpy() != 0)
+            if obg is not None:
+                assert np.array_equal(d_bg.reshape(-1, 3)[tidx].cpu().numpy().reshape(256, 256, 3), obg), (algo, t)
+
+
+def test_full_size_1080p_subsense_three_frames():
+    """BASELINE configs[3]: SuBSENSE at 1920x1080 (5x5 diffusion, median 13, frame-level block on): three frames against the
+    oracle (which needs ~6 s per frame at this size), mask + background + the learning-rate / threshold maps."""
+    frames = synth.numpy_frames("surv", 3, 1080, 1920, seed=4321)
+    eng, orc = Engine(capi.SUBSENSE), pyoracle.Oracle(capi.SUBSENSE)
+    for f in frames:
+        fg, bg = eng.process(f)
+        ofg, obg = orc.process(f)
+        assert np.array_equal(fg, ofg) and np.array_equal(bg, obg)
+    n = 1080 * 1920
+    for pl in ("R", "T", "V", "DminLT"):
+        assert np.array_equal(eng.get_state(pl, (n,), np.float32), orc.get_state(pl, (n,), np.float32)), pl
+    assert np.array_equal(eng.get_state("scalars", (7,), np.float64), orc.get_state("scalars", (7,), np.float64))

@@ -46,13 +46,13 @@ def run(algo, name, rows, cols, S, bpp, steps=60, borrow=True, want_bg=False):
     e.close()
 
 
-def run_subsense(S, steps=30):
+def run_subsense(S, steps=30, kind="surv"):
     """BASELINE configs[3]: SuBSENSE at 1920x1080 (per-frame wall time: ~20 launches incl. the flood-fill host loop)."""
     dev = torch.device("cuda", 0)
     rows, cols, T = 1080, 1920, 8
     pool = torch.empty((T, S, rows, cols, 3), dtype=torch.uint8, device=dev)
     for s in range(S):
-        pool[:, s] = synth.s_surv(T, rows, cols, seed=4321 + s, device=dev)
+        pool[:, s] = (synth.s_surv if kind == "surv" else synth.s_smooth)(T, rows, cols, seed=4321 + s, device=dev)
     e = Engine(capi.SUBSENSE, n_streams=S)
     e.set_geometry(rows, cols, 3)
     fg = torch.empty((S, rows, cols), dtype=torch.uint8, device=dev)
@@ -68,7 +68,7 @@ def run_subsense(S, steps=30):
     ms, n, kname = e.kernel_timing()
     px = S * rows * cols
     print("%-34s %dx%d x%d streams: %.3f ms/frame-step wall -> %8.1f Mpix/s (%.1f 1080p frames/s); %s %.3f ms; fg ratio %.3f"
-          % ("SuBSENSEBGS", cols, rows, S, wall * 1e3, px / wall / 1e6, S / wall, kname, ms, float((fg != 0).float().mean())))
+          % ("SuBSENSEBGS (%s input)" % kind, cols, rows, S, wall * 1e3, px / wall / 1e6, S / wall, kname, ms, float((fg != 0).float().mean())))
     e.close()
 
 
@@ -83,6 +83,7 @@ def main():
     run(capi.FRAME_DIFF, "FrameDifferenceBGS", 2160, 3840, S, 7)
     run(capi.MOG1, "MixtureOfGaussianV1BGS", 1080, 1920, 16, 324, borrow=False)
     run_subsense(2)
+    run_subsense(2, kind="smooth")
     # LBSP descriptors, 1080p
     img = synth.s_surv(1, 1080, 1920, seed=9, device="cuda")[0]
     from oracle import pyoracle

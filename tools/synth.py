@@ -43,8 +43,32 @@ def s_surv(n_frames, rows, cols, seed=4321, device="cpu", t0=0, box=(120, 200), 
     return out
 
 
+def s_smooth(n_frames, rows, cols, seed=777, device="cpu", t0=0, n_boxes=6, speed=4):
+    """Like s_surv but with a smooth (low-frequency) static background instead of per-pixel random texture: closer to real video,
+    where SuBSENSE's sample-consensus loop exits after 2-3 samples."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    low = torch.rand((1, 3, max(2, rows // 32), max(2, cols // 32)), generator=g, device=device) * 200 + 20
+    bg = torch.nn.functional.interpolate(low, size=(rows, cols), mode="bilinear", align_corners=False)[0].permute(1, 2, 0).round().to(torch.int16)
+    cg = torch.Generator(device="cpu").manual_seed(seed + 1)
+    bh, bw = min(120, max(1, rows // 3)), min(200, max(1, cols // 3))
+    pos = torch.stack([torch.randint(0, max(1, rows - bh), (n_boxes,), generator=cg), torch.randint(0, max(1, cols - bw), (n_boxes,), generator=cg)], 1)
+    vel = torch.randint(0, 2, (n_boxes, 2), generator=cg) * 2 - 1
+    col = torch.randint(0, 256, (n_boxes, 3), generator=cg).to(torch.int16)
+    out = torch.empty((n_frames, rows, cols, 3), dtype=torch.uint8, device=device)
+    for t in range(n_frames):
+        noise = (torch.randn((rows, cols, 3), generator=g, device=device) * 2.0).round().to(torch.int16)
+        f = (bg + noise).clamp_(0, 255)
+        for b in range(n_boxes):
+            step = (t0 + t) * speed
+            y = int((pos[b, 0] + vel[b, 0] * step) % max(1, rows - bh))
+            x = int((pos[b, 1] + vel[b, 1] * step) % max(1, cols - bw))
+            f[y:y + bh, x:x + bw] = col[b].to(device)
+        out[t] = f.to(torch.uint8)
+    return out
+
+
 def numpy_frames(kind, n_frames, rows, cols, seed):
-    fn = {"sat": s_sat, "surv": s_surv}[kind]
+    fn = {"sat": s_sat, "surv": s_surv, "smooth": s_smooth}[kind]
     return fn(n_frames, rows, cols, seed=seed).numpy()
 
 

@@ -81,7 +81,12 @@ struct bgs_engine {
   bool mog2_tiled = true;
   int mog2_px = 0;                 // pixels per lane, 0 = widest the alignment allows
   int xcd_swizzle = 1;             // XCD-aware block order (kernel_mog2.h)
-  int mog2_sparse = 1;             // data-dependent plane skipping (kernel_mog2.h)
+  int mog2_sparse = 3;             // data-dependent plane skipping (kernel_mog2.h): 0 dense, 1 stores, 2 stores+loads, 3 = choose 1 or 2 from the scene
+  int mog2_sparse_now = 1;         // what auto mode currently runs
+  unsigned* d_stat = nullptr;      // device: {sampled waves, sparse waves}
+  unsigned* h_stat = nullptr;      // pinned copy
+  hipEvent_t stat_ev = nullptr;
+  bool stat_pending = false;
   int probe_max = 8;               // placement probe: candidates tried at allocation (<= 1: off)
   float probe_ms[16] = {0};         // what the probe measured (diagnostics)
   int probe_n = 0, probe_pick = -1;
@@ -115,6 +120,9 @@ void free_all(bgs_engine* e) {
   for (auto& ev : e->events) (void)hipEventDestroy(ev.first), (void)hipEventDestroy(ev.second);
   e->events.clear();
   ss_free(e);
+  if (e->d_stat) (void)hipFree(e->d_stat), e->d_stat = nullptr;
+  if (e->h_stat) (void)hipHostFree(e->h_stat), e->h_stat = nullptr;
+  if (e->stat_ev) (void)hipEventDestroy(e->stat_ev), e->stat_ev = nullptr;
 }
 
 int check_params(bgs_algo algo, const bgs_params& p) {
@@ -143,7 +151,9 @@ int launch_mog2(bgs_engine* e, bgs::Mog2Args& a, hipStream_t s, bool timed = tru
   // shadow test only when it can change the delivered mask: not thresholded, or the threshold separates shadow from foreground
   a.shadow = p.mog2_detect_shadows && (!p.enable_threshold || ((p.mog2_shadow_value > p.threshold) != (255 > p.threshold)));
   a.want_bg = a.bgimg != nullptr, a.packed = a.fg_bits != nullptr;
-  a.xcd_swizzle = e->xcd_swizzle, a.sparse = e->mog2_sparse;
+  a.xcd_swizzle = e->xcd_swizzle;
+  a.sparse = e->mog2_sparse == 3 ? e->mog2_sparse_now : e->mog2_sparse;
+  a.stat = (timed && e->mog2_sparse == 3) ? e->d_stat : nullptr;
   int PX = 4;
   if (a.npix % 4 || a.state_off % 4 || !aligned(a.frame, 4) || (a.fg && !aligned(a.fg, 4)) || (a.bgimg && !aligned(a.bgimg, 4))) PX = 1;
   if (e->mog2_px == 1 || e->mog2_px == 2) {
@@ -158,6 +168,27 @@ int launch_mog2(bgs_engine* e, bgs::Mog2Args& a, hipStream_t s, bool timed = tru
   if (PX == PXV && tiled == TL) hipLaunchKernelGGL((bgs::mog2_update_kernel<PXV, TL>), grid, block, 0, s, a);
   MOG2_CASE(4, true) MOG2_CASE(2, true) MOG2_CASE(1, true) MOG2_CASE(4, false) MOG2_CASE(2, false) MOG2_CASE(1, false)
 #undef MOG2_CASE
+  if (a.stat) {
+    // Automatic sparse level (results are identical either way, only speed differs): skipping the loads of absent modes
+    // makes the plane loads wait for the nmodes load, which pays only when a good part of the waves can skip something.
+    // The kernel samples "largest nmodes in the wave < K-1" on every 64th block; the host reads the two counters back
+    // without ever blocking (event query) and switches with hysteresis.
+    if (e->stat_pending && hipEventQuery(e->stat_ev) == hipSuccess) {
+      e->stat_pending = false;
+      const unsigned total = e->h_stat[0], sparse_waves = e->h_stat[1];
+      if (total >= 64) {
+        const float frac = (float)sparse_waves / (float)total;
+        if (frac > 0.30f) e->mog2_sparse_now = 2;
+        if (frac < 0.15f) e->mog2_sparse_now = 1;
+      }
+    }
+    if (!e->stat_pending) {
+      (void)hipMemcpyAsync(e->h_stat, e->d_stat, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s);
+      (void)hipMemsetAsync(e->d_stat, 0, 2 * sizeof(unsigned), s);
+      (void)hipEventRecord(e->stat_ev, s);
+      e->stat_pending = true;
+    }
+  }
   return BGS_OK;
 }
 
@@ -190,6 +221,10 @@ size_t mog2_state_bytes(const bgs_engine* e) {
 // rest.  Costs ~0.2 s and, transiently, 8x the model's memory; skipped for models too small to be HBM-bound.
 int mog2_allocate(bgs_engine* e) {
   const size_t P = e->n * e->S, bytes = mog2_state_bytes(e);
+  HIP_TRY(hipMalloc((void**)&e->d_stat, 2 * sizeof(unsigned)));
+  HIP_TRY(hipMemset(e->d_stat, 0, 2 * sizeof(unsigned)));
+  HIP_TRY(hipHostMalloc((void**)&e->h_stat, 2 * sizeof(unsigned), hipHostMallocDefault));
+  HIP_TRY(hipEventCreateWithFlags(&e->stat_ev, hipEventDisableTiming));
   if (!e->mog2_tiled) {
     HIP_TRY(hipMalloc((void**)&e->mog2_state, bytes));
     HIP_TRY(hipMalloc((void**)&e->mog2_nmodes, P));
@@ -681,7 +716,7 @@ int bgs_set_option(bgs_engine* e, int option, int64_t value) {
       e->mog2_tiled = value != 0;
       return BGS_OK;
     case 4: e->xcd_swizzle = value != 0; return BGS_OK;
-    case 6: e->mog2_sparse = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return BGS_OK;
+    case 6: e->mog2_sparse = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 3); return BGS_OK;
     case 5:
       if (e->n) return fail(BGS_ERR_INVALID, "the placement probe runs when the geometry is set");
       e->probe_max = (int)value;

@@ -34,6 +34,7 @@ struct Mog2Args {
   float Tb, TB, Tg, varInit, varMin, varMax, tau;
   int thr, enable_thr, shadow_val;
   int shadow, want_bg, packed;  // wave-uniform feature switches
+  unsigned* stat;               // null, or 2 counters: sampled waves, sampled waves whose largest nmodes is below K-1 (auto mode)
   int sparse;                   // 0 dense; 1 skip the stores of planes nothing changed in; 2 also skip the loads of modes no pixel of the wave has
   int xcd_swizzle;              // workgroups that share an XCD walk one contiguous eighth of the launch
 };
@@ -273,6 +274,16 @@ __global__ __launch_bounds__(kBlock) void mog2_update_kernel(const Mog2Args a) {
       for (int n = 1; n <= kMog2K; ++n)
         if (__any(lane_max >= n)) M = n;
       nload = min(M + 1, kMog2K);
+    }
+    if (a.stat && (blockIdx.x & 63) == 0) {  // scene-sparsity sample for the engine's automatic choice between sparse 1 and 2
+      int lane_max = 0;
+#pragma unroll
+      for (int j = 0; j < PX; ++j) lane_max = max(lane_max, (int)((nmw >> (8 * j)) & 0xffu));
+      const bool dense_wave = __any(lane_max >= kMog2K - 1);
+      if ((threadIdx.x & (kWave - 1)) == 0) {
+        atomicAdd(a.stat, 1u);
+        if (!dense_wave) atomicAdd(a.stat + 1, 1u);
+      }
     }
 #pragma unroll
     for (int k = 1; k < kMog2K; ++k) {
