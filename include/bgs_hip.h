@@ -124,7 +124,18 @@ typedef struct bgs_params {
 
   int32_t subsense_desc_dist_threshold_offset; /* 3 (BGSSUBSENSE_DEFAULT_DESC_DIST_THRESHOLD_OFFSET) */
 
-  uint32_t reserved[15];
+  /* cv::BackgroundSubtractorGMG as GMG::process configures it (package_bgs/GMG.cpp:44-45) */
+  int32_t gmg_max_features;        /* 64 (compile-time bound of the kernel: <= 64) */
+  int32_t gmg_init_frames;         /* 20  GMG.cpp:19, :44 (OpenCV default 120) */
+  int32_t gmg_quantization_levels; /* 16 */
+  int32_t gmg_smoothing_radius;    /* 7 (cv::medianBlur kernel size; 0 = off) */
+  int32_t gmg_update_background_model; /* 1 */
+  int32_t gmg_pad_;
+  double gmg_learning_rate;        /* 0.025 */
+  double gmg_background_prior;     /* 0.8 */
+  double gmg_decision_threshold;   /* 0.7  GMG.cpp:19, :45 (OpenCV default 0.8) */
+
+  uint32_t reserved[3];
 } bgs_params;
 
 int bgs_abi_version(void);

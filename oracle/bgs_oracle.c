@@ -53,6 +53,10 @@ struct orc_engine {
   /* SigmaDelta: Mt = bgimg, Vt */
   uint8_t* vt;
   ss_state* ss; /* SuBSENSE (subsense_oracle.c) */
+  /* GMG: per pixel up to maxFeatures {colour, weight} + count */
+  int32_t* gmg_colors;
+  float* gmg_weights;
+  int32_t* gmg_nfeat;
   /* scratch */
   uint8_t *tmp8a, *tmp8b;
   float* tmpf;
@@ -224,6 +228,14 @@ int orc_default_params(bgs_algo algo, bgs_params* p) {
   p->subsense_n_required = 2;
   p->subsense_samples_for_moving_avgs = 100;
   p->subsense_desc_dist_threshold_offset = 3;
+  p->gmg_max_features = 64;
+  p->gmg_init_frames = 20;
+  p->gmg_quantization_levels = 16;
+  p->gmg_smoothing_radius = 7;
+  p->gmg_update_background_model = 1;
+  p->gmg_learning_rate = 0.025;
+  p->gmg_background_prior = 0.8;
+  p->gmg_decision_threshold = 0.7;
   p->sd_amp_factor = 1;
   p->sd_min_var = 15;
   p->sd_max_var = 255;
@@ -268,6 +280,9 @@ void orc_destroy(orc_engine* e) {
   free(e->mix);
   free(e->vt);
   ss_destroy(e->ss);
+  free(e->gmg_colors);
+  free(e->gmg_weights);
+  free(e->gmg_nfeat);
   free(e->tmp8a);
   free(e->tmp8b);
   free(e->tmpf);
@@ -793,6 +808,102 @@ static int mog1_process(orc_engine* e, uint8_t* fg, size_t fg_step, uint32_t* fl
   return BGS_OK;
 }
 
+/* ---------------------------------------------------------------- a9 GMG */
+
+/* cv::BackgroundSubtractorGMG (OpenCV 2.4 modules/video/src/bgfg_gmg.cpp) as GMG::process drives it
+ * (package_bgs/GMG.cpp:35-77: initializationFrames = 20, decisionThreshold = 0.7).  PARITY UNPINNED, and the LOWEST-confidence
+ * recall in this file; assumptions that matter, written down so they can be re-pinned:
+ *   G1 quantisation      : feature = OR_c ( (int)((v_c - 0.0) * levels / (255.0 - 0.0)) << 8c )           [double, truncation]
+ *   G2 decay             : weights[i] *= 1.0f - learningRate  with a double learningRate -> (float)((double)w * (1.0 - lr))
+ *   G3 insertFeature     : found -> weight += weights[i], move to front (memmove of the i entries before it);
+ *                          list full -> drop the last entry, new one in front; else append, ++nfeatures, return true
+ *   G4 training frames   : insertFeature(colour, 1.0f) and THE FEATURE COUNT PERSISTS (int& nfeatures); normalise on frame init-1
+ *   G5 decision          : posterior = w*prior / (w*prior + (1-w)*(1-prior)) in double; foreground iff (1 - posterior) > threshold
+ *   G6 after the pixel loop: cv::medianBlur(fgmask, smoothingRadius); ++frameNum
+ *   G7 BackgroundSubtractorGMG has no getBackgroundImage -> img_bgmodel ends up empty (GMG.cpp:59, :74) */
+static void gmg_normalize(float* w, int n) {
+  float total = 0.0f;
+  for (int i = 0; i < n; ++i) total += w[i];
+  if (total != 0.0f)
+    for (int i = 0; i < n; ++i) w[i] /= total;
+}
+static int gmg_insert(int color, float weight, int* colors, float* weights, int* nfeatures, int maxFeatures) {
+  int idx = -1;
+  for (int i = 0; i < *nfeatures; ++i)
+    if (color == colors[i]) {
+      weight += weights[i];
+      idx = i;
+      break;
+    }
+  if (idx >= 0) {
+    memmove(colors + 1, colors, (size_t)idx * sizeof(int));
+    memmove(weights + 1, weights, (size_t)idx * sizeof(float));
+    colors[0] = color;
+    weights[0] = weight;
+  } else if (*nfeatures == maxFeatures) {
+    memmove(colors + 1, colors, (size_t)(*nfeatures - 1) * sizeof(int));
+    memmove(weights + 1, weights, (size_t)(*nfeatures - 1) * sizeof(float));
+    colors[0] = color;
+    weights[0] = weight;
+  } else {
+    colors[*nfeatures] = color;
+    weights[*nfeatures] = weight;
+    ++*nfeatures;
+    return 1;
+  }
+  return 0;
+}
+
+static int gmg_process(orc_engine* e, uint8_t* fg, size_t fg_step, uint32_t* flags) {
+  const bgs_params* p = &e->p;
+  const int F = p->gmg_max_features, C = e->ch;
+  if (F < 1 || F > 64) return BGS_ERR_UNSUPPORTED;
+  if (!e->gmg_colors) {
+    e->gmg_colors = (int32_t*)calloc(e->n * F, sizeof(int32_t));
+    e->gmg_weights = (float*)calloc(e->n * F, sizeof(float));
+    e->gmg_nfeat = (int32_t*)calloc(e->n, sizeof(int32_t));
+  }
+  const int64_t frameNum = e->nframes; /* frames processed before this one */
+  const double lr = p->gmg_learning_rate, prior = p->gmg_background_prior, thr = p->gmg_decision_threshold;
+  uint8_t* mask = e->tmp8a;
+  for (size_t i = 0; i < e->n; ++i) {
+    int* colors = e->gmg_colors + i * F;
+    float* weights = e->gmg_weights + i * F;
+    int nf = e->gmg_nfeat[i];
+    unsigned feat = 0;
+    for (int c = 0, shift = 0; c < C; ++c, shift += 8) feat |= (unsigned)(int)(((double)e->cur[i * C + c] - 0.0) * p->gmg_quantization_levels / (255.0 - 0.0)) << shift; /* G1 */
+    const int color = (int)feat;
+    int isfg = 0;
+    if (frameNum >= p->gmg_init_frames) {
+      double weight = 0.0;
+      for (int k = 0; k < nf; ++k)
+        if (color == colors[k]) {
+          weight = weights[k];
+          break;
+        }
+      const double posterior = (weight * prior) / (weight * prior + (1.0 - weight) * (1.0 - prior)); /* G5 */
+      isfg = (1.0 - posterior) > thr;
+      if (p->gmg_update_background_model) {
+        for (int k = 0; k < nf; ++k) weights[k] = (float)((double)weights[k] * (1.0 - lr)); /* G2 */
+        if (gmg_insert(color, (float)lr, colors, weights, &nf, F)) gmg_normalize(weights, nf);
+      }
+    } else if (p->gmg_update_background_model) {
+      gmg_insert(color, 1.0f, colors, weights, &nf, F); /* G4 */
+      if (frameNum == p->gmg_init_frames - 1) gmg_normalize(weights, nf);
+    }
+    e->gmg_nfeat[i] = nf;
+    mask[i] = isfg ? 255 : 0;
+  }
+  const uint8_t* out = mask;
+  if (p->gmg_smoothing_radius > 0) { /* G6 */
+    orc_median_blur_u8(mask, e->tmp8b, e->rows, e->cols, p->gmg_smoothing_radius);
+    out = e->tmp8b;
+  }
+  write_mask(e, out, fg, fg_step);
+  *flags = BGS_FG_VALID; /* G7 */
+  return BGS_OK;
+}
+
 /* ---------------------------------------------------------------- SigmaDelta (N4) */
 
 /* SigmaDeltaBGS::process (package_bgs/bl/SigmaDeltaBGS.cpp:20-55) over sdLaMa091 (package_bgs/bl/sdLaMa091.cpp).
@@ -861,6 +972,7 @@ int orc_process(orc_engine* e, const uint8_t* in, int rows, int cols, int channe
     case BGS_ASBL: flags = asbl_process(e, fg, fg_step, bg, bg_step); break;
     case BGS_MOG2: rc = mog2_process(e, fg, fg_step, bg, bg_step, &flags); break;
     case BGS_MOG1: rc = mog1_process(e, fg, fg_step, &flags); break;
+    case BGS_GMG: rc = gmg_process(e, fg, fg_step, &flags); break;
     case BGS_SUBSENSE: { /* SuBSENSEBGS::process, package_bgs/pl/SuBSENSE.cpp:21-45 */
       if (!e->ss) { /* :27-36 first frame: construct + initialize(img, ROI = all 255), then fall through to operator() */
         rc = ss_create(&e->p, e->cur, rows, cols, channels, &e->ss);
@@ -940,6 +1052,27 @@ int64_t orc_get_state(orc_engine* e, const char* plane, void* dst, size_t cap) {
     }
   }
   if (e->algo == BGS_SUBSENSE && e->ss) return ss_get_state(e->ss, plane, dst, cap);
+  if (e->algo == BGS_GMG && e->gmg_colors) { /* canonical: colors int32 [F][n], weights f32 [F][n], nfeatures int32 [n] */
+    const int F = e->p.gmg_max_features;
+    if (!strcmp(plane, "nfeatures")) {
+      NEED(n * 4);
+      memcpy(dst, e->gmg_nfeat, n * 4);
+      return (int64_t)(n * 4);
+    }
+    if (!strcmp(plane, "colors") || !strcmp(plane, "weights")) {
+      NEED(n * F * 4);
+      const int isw = !strcmp(plane, "weights");
+      for (int f = 0; f < F; ++f)
+        for (size_t i = 0; i < n; ++i) {
+          const int live = f < e->gmg_nfeat[i]; /* entries past the count are dead storage: exported as 0 */
+          if (isw)
+            ((float*)dst)[(size_t)f * n + i] = live ? e->gmg_weights[i * F + f] : 0.f;
+          else
+            ((int32_t*)dst)[(size_t)f * n + i] = live ? e->gmg_colors[i * F + f] : 0;
+        }
+      return (int64_t)(n * F * 4);
+    }
+  }
   if (e->algo == BGS_SIGMA_DELTA && e->have1 && (!strcmp(plane, "mt") || !strcmp(plane, "vt"))) {
     NEED(n * 3);
     memcpy(dst, !strcmp(plane, "mt") ? e->bgimg : e->vt, n * 3);

@@ -25,6 +25,7 @@ ALGOS = {
     "MixtureOfGaussianV1BGS": capi.MOG1,
     "MixtureOfGaussianV2BGS": capi.MOG2,
     "SigmaDeltaBGS": capi.SIGMA_DELTA,
+    "GMG": capi.GMG,
 }
 STATE_TOL = 1e-4
 
@@ -66,6 +67,11 @@ def check_state(name, eng, orc, n, stream=0):
         check_mog2_state(eng, orc, n, stream)
     if name == "MixtureOfGaussianV1BGS":
         check_mog1_state(eng, orc, n, 3, stream)
+    if name == "GMG":
+        assert np.array_equal(eng.get_state("nfeatures", (n,), np.int32, stream=stream), orc.get_state("nfeatures", (n,), np.int32))
+        assert np.array_equal(eng.get_state("colors", (64, n), np.int32, stream=stream), orc.get_state("colors", (64, n), np.int32))
+        a, b = eng.get_state("weights", (64, n), np.float32, stream=stream), orc.get_state("weights", (64, n), np.float32)
+        assert float(np.max(np.abs(a - b))) <= STATE_TOL
     if name == "SigmaDeltaBGS":
         for plane in ("mt", "vt"):
             assert np.array_equal(eng.get_state(plane, (n * 3,), np.uint8, stream=stream), orc.get_state(plane, (n * 3,), np.uint8)), plane
@@ -147,7 +153,7 @@ def test_warmup_outputs_untouched():
     """FD frame 1, WMM/WMV frames 1-2 return with outputs untouched; FD/WMV never write a background."""
     frames = synth.random_frames(4, 16, 32, 3, seed=5)
     for algo, warm, has_bg in ((capi.FRAME_DIFF, 1, False), (capi.WMM, 2, True), (capi.WMV, 2, False), (capi.STATIC_FRAME_DIFF, 0, True), (capi.ABL, 0, True),
-                               (capi.ASBL, 0, True), (capi.MOG1, 0, False), (capi.MOG2, 0, True), (capi.SIGMA_DELTA, 1, False)):
+                               (capi.ASBL, 0, True), (capi.MOG1, 0, False), (capi.MOG2, 0, True), (capi.SIGMA_DELTA, 1, False), (capi.GMG, 0, False)):
         eng = Engine(algo)
         for t, f in enumerate(frames):
             fg, bg = eng.process(f)
@@ -246,7 +252,7 @@ def test_params_can_change_between_frames(golden_frames):
 def test_streams_are_independent(golden_frames):
     """One engine, 3 streams fed different clips in interleaved order == 3 separate oracles."""
     clips = [golden_frames[0:8], golden_frames[8:16], golden_frames[16:24][::-1]]
-    for algo in (capi.MOG2, capi.WMV, capi.ABL, capi.ASBL, capi.MOG1):
+    for algo in (capi.MOG2, capi.WMV, capi.ABL, capi.ASBL, capi.MOG1, capi.GMG):
         eng = Engine(algo, n_streams=3)
         orcs = [pyoracle.Oracle(algo) for _ in clips]
         for t in range(8):
@@ -290,7 +296,7 @@ def test_device_batch_matches_oracle(name, borrow):
         keep.append(d_frames)  # borrowed history must stay alive
         d_fg = torch.full((S, H, W), 9, dtype=torch.uint8, device="cuda")
         d_bg = torch.full((S, H, W, 1 if algo == capi.ASBL else 3), 9, dtype=torch.uint8, device="cuda")
-        has_bits = algo != capi.ASBL  # the stencil kernel writes the byte mask only
+        has_bits = algo not in (capi.ASBL, capi.GMG)  # the stencil / median paths write the byte mask only
         d_bits = torch.zeros((S, H * W // 64), dtype=torch.int64, device="cuda") if has_bits else None
         flags = eng.process_batch_device(d_frames, d_fg, d_bg, d_bits)
         torch.cuda.synchronize()
@@ -639,3 +645,38 @@ def test_full_size_1080p_subsense_three_frames():
     for pl in ("R", "T", "V", "DminLT"):
         assert np.array_equal(eng.get_state(pl, (n,), np.float32), orc.get_state(pl, (n,), np.float32)), pl
     assert np.array_equal(eng.get_state("scalars", (7,), np.float64), orc.get_state("scalars", (7,), np.float64))
+
+
+# ----------------------------------------------------------------------------- GMG
+
+def test_gmg_through_training_and_operation(golden_frames):
+    """48 frames: 20 training frames (histogram build-up, normalisation on frame 19), then decisions + move-to-front updates."""
+    frames = np.concatenate([golden_frames, golden_frames[::-1]])
+    eng, orc, _ = run_pair(capi.GMG, frames)
+    check_state("GMG", eng, orc, frames.shape[1] * frames.shape[2])
+
+
+@pytest.mark.parametrize("kw", [dict(gmg_init_frames=3), dict(gmg_max_features=4, gmg_init_frames=5), dict(gmg_quantization_levels=64, gmg_init_frames=4),
+                                dict(gmg_smoothing_radius=0, gmg_init_frames=4), dict(gmg_smoothing_radius=3, gmg_decision_threshold=0.9, gmg_init_frames=4),
+                                dict(gmg_learning_rate=0.2, gmg_background_prior=0.5, gmg_init_frames=2), dict(gmg_update_background_model=0, gmg_init_frames=1)])
+def test_gmg_variants(kw, golden_frames):
+    """small maxFeatures forces the drop-the-oldest path; 64 quantisation levels makes new features (and appends) frequent."""
+    p = _params(capi.GMG, **kw)
+    eng = Engine(capi.GMG, params=p)
+    orc = pyoracle.Oracle(capi.GMG, params=p)
+    for t, f in enumerate(golden_frames[:16]):
+        fg, bg = eng.process(f)
+        ofg, obg = orc.process(f)
+        assert bg is None and obg is None and np.array_equal(fg, ofg), t
+    n = golden_frames.shape[1] * golden_frames.shape[2]
+    assert np.array_equal(eng.get_state("nfeatures", (n,), np.int32), orc.get_state("nfeatures", (n,), np.int32))
+    F = 64
+    a, b = eng.get_state("weights", (p.gmg_max_features, n), np.float32), orc.get_state("weights", (p.gmg_max_features, n), np.float32)
+    assert float(np.max(np.abs(a - b))) <= STATE_TOL
+    assert np.array_equal(eng.get_state("colors", (p.gmg_max_features, n), np.int32), orc.get_state("colors", (p.gmg_max_features, n), np.int32))
+
+
+def test_gmg_gray_and_ragged(golden_gray):
+    run_pair(capi.GMG, np.concatenate([golden_gray, golden_gray]), params=_params(capi.GMG, gmg_init_frames=6))
+    frames = synth.random_frames(12, 37, 53, 3, seed=4)
+    run_pair(capi.GMG, frames, params=_params(capi.GMG, gmg_init_frames=5))

@@ -86,7 +86,7 @@ def test_framediff_matches_independent_formula(golden_frames):
 
 
 @pytest.mark.parametrize("name,algo", [("fd", capi.FRAME_DIFF), ("sfd", capi.STATIC_FRAME_DIFF), ("wmm", capi.WMM), ("wmv", capi.WMV),
-                                       ("abl", capi.ABL), ("asbl", capi.ASBL), ("mog2", capi.MOG2), ("mog1", capi.MOG1), ("sd", capi.SIGMA_DELTA)])
+                                       ("abl", capi.ABL), ("asbl", capi.ASBL), ("mog2", capi.MOG2), ("mog1", capi.MOG1), ("sd", capi.SIGMA_DELTA), ("gmg", capi.GMG), ("subsense", capi.SUBSENSE)])
 def test_oracle_regression_vectors(name, algo, golden_frames, oracle_regress):
     o = pyoracle.Oracle(algo)
     want = oracle_regress[name + "_fg"]
@@ -282,3 +282,20 @@ def test_subsense_oracle_grayscale(golden_gray):
         assert fg.shape == f.shape and bg.shape == f.shape
     lut = o.get_state("lut", (256,), np.uint8)
     assert lut[255] <= 28  # (t * 0.333f) / 3, possibly auto-decremented since
+
+
+def test_gmg_oracle_phases(golden_frames):
+    """GMG: 20 training frames without any foreground (GMG.cpp:44), then Bayesian decisions; no background image ever."""
+    o = pyoracle.Oracle(capi.GMG)
+    frames = np.concatenate([golden_frames, golden_frames[::-1]])
+    for t, f in enumerate(frames):
+        fg, bg = o.process(f)
+        assert bg is None
+        if t < 20:
+            assert (fg == 0).all()
+    assert 0.0 < (fg == 255).mean() < 0.6
+    n = f.shape[0] * f.shape[1]
+    nf = o.get_state("nfeatures", (n,), np.int32)
+    w = o.get_state("weights", (64, n), np.float32)
+    assert nf.min() >= 1 and nf.max() <= 64
+    assert np.allclose(w.sum(0), 1.0, atol=0.05)  # histograms stay (nearly) normalised

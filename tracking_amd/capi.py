@@ -57,7 +57,16 @@ class BgsParams(C.Structure):
         ("sd_min_var", C.c_int32),
         ("sd_max_var", C.c_int32),
         ("subsense_desc_dist_threshold_offset", C.c_int32),
-        ("reserved", C.c_uint32 * 15),
+        ("gmg_max_features", C.c_int32),
+        ("gmg_init_frames", C.c_int32),
+        ("gmg_quantization_levels", C.c_int32),
+        ("gmg_smoothing_radius", C.c_int32),
+        ("gmg_update_background_model", C.c_int32),
+        ("gmg_pad_", C.c_int32),
+        ("gmg_learning_rate", C.c_double),
+        ("gmg_background_prior", C.c_double),
+        ("gmg_decision_threshold", C.c_double),
+        ("reserved", C.c_uint32 * 3),
     ]
 
 

@@ -19,6 +19,7 @@
 #include <string>
 #include <vector>
 
+#include "kernel_gmg.h"
 #include "kernel_mog1.h"
 #include "kernel_mog2.h"
 #include "kernel_pointwise.h"
@@ -75,6 +76,9 @@ struct bgs_engine {
   std::vector<uint8_t> flip;    // ASBL: which buffer holds the current background, per stream
   float* mog1_state = nullptr;  // MOG1 model (kernel_mog1.h, tiled)
   SsDevice* ss = nullptr;       // SuBSENSE model (engine_subsense.h)
+  int32_t* gmg_colors = nullptr;  // GMG histograms (kernel_gmg.h)
+  float* gmg_weights = nullptr;
+  uint8_t* gmg_nfeat = nullptr;
   // MOG2 model (kernel_mog2.h: tiled AoSoA by default, planar kept for A/B runs)
   float* mog2_state = nullptr;
   uint8_t* mog2_nmodes = nullptr;  // planar layout only
@@ -109,10 +113,10 @@ void ss_free(bgs_engine* e);  // engine_subsense.h
 void free_all(bgs_engine* e) {
   for (auto& r : e->ring)
     if (r) (void)hipFree(r), r = nullptr;
-  void* dev[] = {e->bgstate, e->bgstate2, e->mog1_state, e->mog2_state, e->mog2_nmodes, e->d_in, e->d_fg, e->d_bg};
+  void* dev[] = {e->gmg_colors, e->gmg_weights, e->gmg_nfeat, e->bgstate, e->bgstate2, e->mog1_state, e->mog2_state, e->mog2_nmodes, e->d_in, e->d_fg, e->d_bg};
   for (void* d : dev)
     if (d) (void)hipFree(d);
-  e->bgstate = e->bgstate2 = nullptr, e->mog1_state = nullptr, e->mog2_state = nullptr, e->mog2_nmodes = nullptr, e->d_in = e->d_fg = e->d_bg = nullptr;
+  e->gmg_colors = nullptr, e->gmg_weights = nullptr, e->gmg_nfeat = nullptr, e->bgstate = e->bgstate2 = nullptr, e->mog1_state = nullptr, e->mog2_state = nullptr, e->mog2_nmodes = nullptr, e->d_in = e->d_fg = e->d_bg = nullptr;
   void* host[] = {e->h_in, e->h_fg, e->h_bg};
   for (void* h : host)
     if (h) (void)hipHostFree(h);
@@ -126,6 +130,9 @@ void free_all(bgs_engine* e) {
 }
 
 int check_params(bgs_algo algo, const bgs_params& p) {
+  if (algo == BGS_GMG && (p.gmg_max_features < 1 || p.gmg_max_features > 64)) return fail(BGS_ERR_UNSUPPORTED, "GMG maxFeatures must be 1..64, got %d", p.gmg_max_features);
+  if (algo == BGS_GMG && p.gmg_smoothing_radius != 0 && (p.gmg_smoothing_radius < 3 || p.gmg_smoothing_radius > 15 || p.gmg_smoothing_radius % 2 == 0))
+    return fail(BGS_ERR_UNSUPPORTED, "GMG smoothingRadius (cv::medianBlur kernel) must be 0 or odd 3..15, got %d", p.gmg_smoothing_radius);
   if (algo == BGS_MOG2 && p.mog2_nmixtures != bgs::kMog2K) return fail(BGS_ERR_UNSUPPORTED, "MOG2 kernel is built for K=%d mixtures, got %d", bgs::kMog2K, p.mog2_nmixtures);
   return BGS_OK;
 }
@@ -311,6 +318,7 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
       if (ch != 3) return fail(BGS_ERR_UNSUPPORTED, "SigmaDeltaBGS is 3-channel only (sdLaMa091AllocInit_8u_C3R, SigmaDeltaBGS.cpp:35)");
       e->state_ch = 3;
       break;
+    case BGS_GMG: e->state_ch = 1; break;  // bgstate = the unsmoothed mask
     case BGS_MOG1:
     case BGS_MOG2:
     case BGS_SUBSENSE: break;
@@ -320,6 +328,12 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
   if (e->state_ch) HIP_TRY(hipMalloc((void**)&e->bgstate, P * e->state_ch));
   if (e->algo == BGS_ASBL) HIP_TRY(hipMalloc((void**)&e->bgstate2, P));
   if (e->algo == BGS_SIGMA_DELTA) HIP_TRY(hipMalloc((void**)&e->bgstate2, P * 3));  // Vt
+  if (e->algo == BGS_GMG) {
+    const size_t F = (size_t)e->p.gmg_max_features;
+    HIP_TRY(hipMalloc((void**)&e->gmg_colors, P * F * sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void**)&e->gmg_weights, P * F * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&e->gmg_nfeat, P));
+  }
   if (e->algo == BGS_MOG1) {
     const size_t planes = ch == 3 ? bgs::mog1_planes<3>() : bgs::mog1_planes<1>();
     const size_t tiles = (P + bgs::kMog1Tile - 1) / bgs::kMog1Tile;
@@ -462,6 +476,30 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
           for (int i = first; i < first + count; ++i) e->counter[i]++;
       }
       flags = BGS_FG_VALID | BGS_BG_VALID;
+      break;
+    }
+    case BGS_GMG: {
+      if (d_bits) return fail(BGS_ERR_UNSUPPORTED, "GMG writes the byte mask only");
+      const size_t P = e->n * e->S;
+      if (t == 0) hipLaunchKernelGGL(bgs::gmg_clear_kernel, dim3(blocks_for(npix)), dim3(bgs::kBlock), 0, s, e->gmg_nfeat + off, npix);  // initialize(): nfeatures = 0
+      bgs::GmgArgs g{};
+      g.frame = d_frames, g.raw = e->bgstate + off, g.colors = e->gmg_colors, g.weights = e->gmg_weights, g.nfeat = e->gmg_nfeat;
+      g.plane = P, g.state_off = off, g.npix = npix, g.F = p.gmg_max_features, g.C = C, g.levels = p.gmg_quantization_levels;
+      g.typical = t >= p.gmg_init_frames, g.update = p.gmg_update_background_model != 0, g.normalize_now = t == (int64_t)p.gmg_init_frames - 1;
+      g.lr = p.gmg_learning_rate, g.prior = p.gmg_background_prior, g.thr = p.gmg_decision_threshold;
+      {
+        Timed tm(e, s, "gmg_kernel");
+        hipLaunchKernelGGL(bgs::gmg_kernel, dim3(blocks_for(npix)), dim3(bgs::kBlock), 0, s, g);
+      }
+      if (d_fg) {
+        if (p.gmg_smoothing_radius > 0) {  // cv::medianBlur(fgmask, smoothingRadius) of a {0,255} mask
+          bgs::MorphArgs m{e->bgstate + off, d_fg, e->rows, e->cols, 3, p.gmg_smoothing_radius};
+          hipLaunchKernelGGL(bgs::morph_kernel, dim3((e->cols + bgs::kMorphTW - 1) / bgs::kMorphTW, (e->rows + bgs::kMorphTH - 1) / bgs::kMorphTH, count), dim3(bgs::kBlock), 0, s, m);
+        } else {
+          HIP_TRY(hipMemcpyAsync(d_fg, e->bgstate + off, npix, hipMemcpyDeviceToDevice, s));
+        }
+      }
+      flags = BGS_FG_VALID;  // no getBackgroundImage for GMG (GMG.cpp:59): img_bgmodel ends up empty
       break;
     }
     case BGS_SUBSENSE: {
@@ -634,6 +672,14 @@ int bgs_default_params(bgs_algo algo, bgs_params* p) {
   p->subsense_n_required = 2;
   p->subsense_samples_for_moving_avgs = 100;
   p->subsense_desc_dist_threshold_offset = 3;
+  p->gmg_max_features = 64;
+  p->gmg_init_frames = 20;
+  p->gmg_quantization_levels = 16;
+  p->gmg_smoothing_radius = 7;
+  p->gmg_update_background_model = 1;
+  p->gmg_learning_rate = 0.025;
+  p->gmg_background_prior = 0.8;
+  p->gmg_decision_threshold = 0.7;
   p->sd_amp_factor = 1;
   p->sd_min_var = 15;
   p->sd_max_var = 255;
@@ -821,6 +867,26 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
     }
   }
   if (e->algo == BGS_SUBSENSE && e->ss) return ss_get_state(e, stream, plane, dst, cap);
+  if (e->algo == BGS_GMG && e->gmg_colors) {  // canonical: colors int32 [F][n], weights f32 [F][n] (entries past the count exported as 0), nfeatures int32 [n]
+    const size_t F = (size_t)e->p.gmg_max_features;
+    std::vector<uint8_t> nf(n);
+    if (hipMemcpy(nf.data(), e->gmg_nfeat + off, n, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+    if (!strcmp(plane, "nfeatures")) {
+      if (cap < n * 4) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
+      for (size_t i = 0; i < n; ++i) ((int32_t*)dst)[i] = nf[i];
+      return (int64_t)(n * 4);
+    }
+    if (!strcmp(plane, "colors") || !strcmp(plane, "weights")) {
+      if (cap < n * F * 4) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
+      const void* base = !strcmp(plane, "colors") ? (const void*)e->gmg_colors : (const void*)e->gmg_weights;
+      for (size_t f = 0; f < F; ++f) {
+        if (hipMemcpy((uint32_t*)dst + f * n, (const uint32_t*)base + f * P + off, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+        for (size_t i = 0; i < n; ++i)
+          if (f >= nf[i]) ((uint32_t*)dst)[f * n + i] = 0;
+      }
+      return (int64_t)(n * F * 4);
+    }
+  }
   if (e->algo == BGS_MOG1) {
     const int R = 2 + 2 * C, NP = bgs::kMog1K * R;
     int f0 = -1, nf = 0;  // field offset inside a mode record, floats per mode

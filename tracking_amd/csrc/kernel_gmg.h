@@ -1,0 +1,114 @@
+// kernel_gmg.h — K6: GMG (cv::BackgroundSubtractorGMG per-pixel histogram update + Bayesian decision).
+//
+// Replaces  GMG::process  package_bgs/GMG.cpp:56  ((*fgbg)(img_input, img_foreground) with initializationFrames = 20,
+// decisionThreshold = 0.7); algorithm: OpenCV 2.4 bgfg_gmg.cpp GMG_LoopBody (SURVEY.md App. B.4 — the least certain recall of
+// the whole path; the assumptions G1..G7 are listed in DESIGN.md §5.2).  The median smoothing that follows is morph_kernel.
+//
+// Layout: SoA planes  colors int32 [F][P], weights f32 [F][P], nfeatures u8 [P]  (F = maxFeatures <= 64); entry f of every
+// pixel lives in plane f, so each step of the per-pixel list walk is one coalesced 256-byte access per wave.  One lane owns
+// one pixel; all list walks run to the largest count in the wave (wave-uniform trip counts via __any).
+// Traffic is data-dependent: ~ (8 B read + 8 B written) x features of the pixel, up to 1 KiB/pixel; HBM-bound.
+#pragma once
+#include "bgs_device.h"
+
+namespace bgs {
+
+struct GmgArgs {
+  const uint8_t* frame;  // [npix][C]
+  uint8_t* raw;          // [npix] unsmoothed mask
+  int32_t* colors;       // [F][plane]
+  float* weights;        // [F][plane]
+  uint8_t* nfeat;        // [plane]
+  size_t plane, state_off, npix;
+  int F, C, levels, typical, update, normalize_now;  // typical = frameNum >= init; normalize_now = frameNum == init - 1
+  double lr, prior, thr;
+};
+
+__global__ __launch_bounds__(kBlock) void gmg_kernel(const GmgArgs a) {
+  const size_t p0 = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool active = p0 < a.npix;
+  const size_t sp = a.state_off + (active ? p0 : 0);
+  int nf = active ? (int)a.nfeat[sp] : 0;
+  int color = 0;
+  if (active) {
+    unsigned feat = 0;
+    for (int c = 0; c < a.C; ++c)  // G1: (int)((v - 0.0) * levels / (255.0 - 0.0)) << 8c, in double
+      feat |= (unsigned)(int)__ddiv_rn(__dmul_rn((double)a.frame[p0 * a.C + c], (double)a.levels), 255.0) << (8 * c);
+    color = (int)feat;
+  }
+  // pass 1: findFeature
+  int idx = -1;
+  float wfound = 0.f;
+  for (int i = 0;; ++i) {
+    const bool look = active && i < nf && idx < 0;
+    if (!__any(look)) break;
+    if (look && a.colors[(size_t)i * a.plane + sp] == color) idx = i, wfound = a.weights[(size_t)i * a.plane + sp];
+  }
+  bool isfg = false;
+  bool appended = false;
+  if (a.typical) {
+    const double w = (double)wfound;  // 0 when the colour is not in the histogram
+    const double num = __dmul_rn(w, a.prior);
+    const double den = __dadd_rn(num, __dmul_rn(__dsub_rn(1.0, w), __dsub_rn(1.0, a.prior)));
+    const double posterior = __ddiv_rn(num, den);  // G5
+    isfg = __dsub_rn(1.0, posterior) > a.thr;
+  }
+  if (a.update) {
+    const double decay = a.typical ? __dsub_rn(1.0, a.lr) : 1.0;  // G2 (training frames do not decay)
+    const float ins = a.typical ? (float)a.lr : 1.0f;
+    const bool found = idx >= 0, full = !found && nf == a.F;
+    const float front_w = found ? ins + (a.typical ? (float)__dmul_rn((double)wfound, decay) : wfound) : ins;
+    const int shift_end = found ? idx : (full ? nf - 1 : -1);  // entries 0..shift_end move down by one (G3)
+    int prev_c = 0;
+    float prev_w = 0.f;
+    for (int i = 0;; ++i) {
+      const bool act = active && i < nf && (a.typical || i <= shift_end);  // training frames touch only what moves
+      if (!__any(act)) break;
+      if (act) {
+        const size_t o = (size_t)i * a.plane + sp;
+        const int c = a.colors[o];
+        float w = a.weights[o];
+        if (a.typical) w = (float)__dmul_rn((double)w, decay);
+        if (i <= shift_end) {
+          a.colors[o] = i == 0 ? color : prev_c;
+          a.weights[o] = i == 0 ? front_w : prev_w;
+          prev_c = c, prev_w = w;
+        } else {
+          a.weights[o] = w;
+        }
+      }
+    }
+    if (active && !found && !full) {  // append
+      const size_t o = (size_t)nf * a.plane + sp;
+      a.colors[o] = color;
+      a.weights[o] = ins;
+      ++nf;
+      appended = true;
+    }
+    // normalizeHistogram: after an append in normal operation; for every pixel on the last training frame
+    const bool norm = active && (a.typical ? appended : (a.normalize_now != 0));
+    float total = 0.0f;
+    for (int i = 0;; ++i) {
+      const bool act = norm && i < nf;
+      if (!__any(act)) break;
+      if (act) total += a.weights[(size_t)i * a.plane + sp];
+    }
+    for (int i = 0;; ++i) {
+      const bool act = norm && total != 0.0f && i < nf;
+      if (!__any(act)) break;
+      if (act) {
+        const size_t o = (size_t)i * a.plane + sp;
+        a.weights[o] = div_rn(a.weights[o], total);
+      }
+    }
+    if (active) a.nfeat[sp] = (uint8_t)nf;  // G4: the count persists on training frames too
+  }
+  if (active) a.raw[p0] = isfg ? 255 : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void gmg_clear_kernel(uint8_t* nfeat, size_t n) {
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) nfeat[i] = 0;
+}
+
+}  // namespace bgs

@@ -431,6 +431,30 @@ class MixtureOfGaussianV1BGS : public HipBGSBase {
   }
 };
 
+// package_bgs/GMG.{h,cpp}
+class GMG : public HipBGSBase {
+ public:
+  GMG() : HipBGSBase(BGS_GMG, "GMG", /*clears_bg=*/true), showOutput(true) {}
+  BGS_HIP_BANNER_DTOR(GMG)
+ private:
+  bool showOutput;
+  void saveConfig() override {  // GMG.cpp:79-88
+    XmlConfig fs;
+    fs.beginWrite();
+    fs.writeInt("initializationFrames", params_.gmg_init_frames);
+    fs.writeReal("decisionThreshold", params_.gmg_decision_threshold);
+    fs.writeInt("showOutput", showOutput);
+    fs.save(configPath());
+  }
+  void loadConfig() override {  // :90-99
+    XmlConfig fs;
+    fs.load(configPath());
+    params_.gmg_init_frames = fs.readInt("initializationFrames", 20);
+    params_.gmg_decision_threshold = fs.readReal("decisionThreshold", 0.7);
+    showOutput = fs.readInt("showOutput", true);
+  }
+};
+
 // package_bgs/bl/SigmaDeltaBGS.{h,cpp}
 class SigmaDeltaBGS : public HipBGSBase {
  public:
