@@ -18,13 +18,36 @@ from tracking_amd import Engine, capi
 from tracking_amd.engine import lbsp_describe_device
 
 
-def run(algo, name, rows, cols, S, bpp, steps=60, borrow=True, want_bg=False):
+def cpu_rate(algo, frames_np, warm=3, params=None):
+    """The oracle (CPU restatement, 1 thread; rows split over the box's quota for the MOG loops) on a few frames of the same size."""
+    from oracle import pyoracle
+    import os
+    threads = 1
+    if algo in (capi.MOG2, capi.MOG1):
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            threads = min(len(os.sched_getaffinity(0)), int(int(q) / int(per))) if q != "max" else 16
+        except Exception:
+            threads = 16
+    o = pyoracle.Oracle(algo, params=params, threads=threads)
+    for f in frames_np[:warm]:
+        o.process(f, want_bg=False)
+    t0 = time.perf_counter()
+    n = 0
+    for f in frames_np[warm:]:
+        o.process(f, want_bg=False)
+        n += 1
+    dt = time.perf_counter() - t0
+    return n * frames_np.shape[1] * frames_np.shape[2] / dt / 1e6, threads
+
+
+def run(algo, name, rows, cols, S, bpp, steps=60, borrow=True, want_bg=False, cpu_frames=6, cpu_warm=3, params=None):
     dev = torch.device("cuda", 0)
     T = 8
     pool = torch.empty((T, S, rows, cols, 3), dtype=torch.uint8, device=dev)
     for s in range(S):
         pool[:, s] = synth.s_surv(T, rows, cols, seed=4321 + s, device=dev)
-    e = Engine(algo, n_streams=S)
+    e = Engine(algo, n_streams=S, params=params)
     e.set_geometry(rows, cols, 3)
     if borrow:
         e.set_option(capi.OPT_BORROW_FRAMES, 1)
@@ -41,8 +64,13 @@ def run(algo, name, rows, cols, S, bpp, steps=60, borrow=True, want_bg=False):
     wall = time.perf_counter() - t0
     ms, n, kname = e.kernel_timing()
     px = S * rows * cols
-    print("%-34s %dx%d x%d streams: kernel %-18s %.4f ms  -> %8.1f Mpix/s  %7.1f GB/s algorithmic (%d B/px) = %.1f%% of 8 TB/s | wall %.1f Mpix/s"
-          % (name, cols, rows, S, kname, ms, px / ms / 1e3, bpp * px / ms / 1e6, bpp, bpp * px / ms / 1e6 / 80.0, px * steps / wall / 1e6))
+    cpu = ""
+    if cpu_frames:
+        sample = pool[:cpu_frames, 0].cpu().numpy() if T >= cpu_frames else torch.cat([pool[:, 0]] * (cpu_frames // T + 1))[:cpu_frames].cpu().numpy()
+        rate, th = cpu_rate(algo, sample, warm=cpu_warm, params=params)
+        cpu = " | CPU oracle %.1f Mpix/s (%d thread%s)" % (rate, th, "s" if th > 1 else "")
+    print("%-34s %dx%d x%d streams: kernel %-18s %.4f ms  -> %8.1f Mpix/s  %7.1f GB/s algorithmic (%d B/px) = %.1f%% of 8 TB/s | wall %.1f Mpix/s%s"
+          % (name, cols, rows, S, kname, ms, px / ms / 1e3, bpp * px / ms / 1e6, bpp, bpp * px / ms / 1e6 / 80.0, px * steps / wall / 1e6, cpu))
     e.close()
 
 
@@ -81,7 +109,13 @@ def main():
     run(capi.ABL, "AdaptiveBackgroundLearning", 2160, 3840, S, 10, borrow=False)
     run(capi.WMM, "WeightedMovingMeanBGS (+bg)", 2160, 3840, S, 13, want_bg=True)
     run(capi.FRAME_DIFF, "FrameDifferenceBGS", 2160, 3840, S, 7)
+    run(capi.STATIC_FRAME_DIFF, "StaticFrameDifferenceBGS", 2160, 3840, S, 7, borrow=False)
+    run(capi.SIGMA_DELTA, "SigmaDeltaBGS", 2160, 3840, S, 16, borrow=False)
+    run(capi.ASBL, "AdaptiveSelectiveBackgroundLearning", 2160, 3840, S, 6, borrow=False)
     run(capi.MOG1, "MixtureOfGaussianV1BGS", 1080, 1920, 16, 324, borrow=False)
+    pg = capi.default_params(capi.GMG)
+    pg.gmg_init_frames = 4  # so the timed frames are normal-operation frames
+    run(capi.GMG, "GMG (data-dependent traffic)", 1080, 1920, 8, 16, borrow=False, cpu_frames=8, cpu_warm=5, params=pg)
     run_subsense(2)
     run_subsense(2, kind="smooth")
     # LBSP descriptors, 1080p
