@@ -47,6 +47,9 @@ static const int SS_N3[8][2] = {{-1, 1}, {0, 1}, {1, 1}, {-1, 0}, {1, 0}, {-1, -
 static const int SS_N5[24][2] = {{-2, 2},  {-1, 2},  {0, 2},  {1, 2},  {2, 2},  {-2, 1},  {-1, 1},  {0, 1},  {1, 1},  {2, 1},  {-2, 0},  {-1, 0},
                                  {1, 0},   {2, 0},   {-2, -1}, {-1, -1}, {0, -1}, {1, -1}, {2, -1}, {-2, -2}, {-1, -2}, {0, -2}, {1, -2}, {2, -2}};
 
+/* test instrumentation: when set (n bytes), phase A stores each pixel's sample-loop trip count there */
+uint8_t* ss_debug_iters = 0;
+
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
 
 /* RandUtils.h:28-48 getRandSamplePosition with r = 1 + rnd % 512 */
@@ -291,6 +294,7 @@ static void ss_phase_a(ss_state* s, const uint8_t* img, size_t* nonzero_desc) {
         }
         idx++;
       }
+      if (ss_debug_iters) ss_debug_iters[i] = (uint8_t)idx;
       /* :498-499 */
       size_t l1 = 0, hd = 0;
       for (int c = 0; c < C; ++c) {

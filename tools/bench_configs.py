@@ -103,8 +103,13 @@ def run_subsense(S, steps=30, kind="surv"):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=8)
+    ap.add_argument("--only", default="", help="subsense: just the SuBSENSE lines")
     args = ap.parse_args()
     S = args.streams
+    if args.only == "subsense":
+        run_subsense(2)
+        run_subsense(2, kind="smooth")
+        return
     run(capi.WMV, "WeightedMovingVarianceBGS", 2160, 3840, S, 10)
     run(capi.ABL, "AdaptiveBackgroundLearning", 2160, 3840, S, 10, borrow=False)
     run(capi.WMM, "WeightedMovingMeanBGS (+bg)", 2160, 3840, S, 13, want_bg=True)

@@ -494,7 +494,7 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
       if (d_fg) {
         if (p.gmg_smoothing_radius > 0) {  // cv::medianBlur(fgmask, smoothingRadius) of a {0,255} mask
           bgs::MorphArgs m{e->bgstate + off, d_fg, e->rows, e->cols, 3, p.gmg_smoothing_radius};
-          hipLaunchKernelGGL(bgs::morph_kernel, dim3((e->cols + bgs::kMorphTW - 1) / bgs::kMorphTW, (e->rows + bgs::kMorphTH - 1) / bgs::kMorphTH, count), dim3(bgs::kBlock), 0, s, m);
+          bgs::morph_launch(m, (int)count, s);
         } else {
           HIP_TRY(hipMemcpyAsync(d_fg, e->bgstate + off, npix, hipMemcpyDeviceToDevice, s));
         }
@@ -1005,15 +1005,20 @@ int bgs_mask_morph_device(int hip_device, const void* d_src, void* d_dst, int ro
     return BGS_OK;
   }
   const size_t n = (size_t)rows * cols;
+  // n iterations of the 3x3 erode/dilate are one (2n+1)^2 box (kernel_stencil.h); a launch covers up to kMorphMaxR of them
+  int passes = iterations, per_pass = 1;
+  if (op <= 1) per_pass = bgs::kMorphMaxR, passes = (iterations + per_pass - 1) / per_pass;
   uint8_t* tmp = nullptr;
-  if (iterations > 1) HIP_TRY(hipMalloc((void**)&tmp, n));
-  const dim3 grid((cols + bgs::kMorphTW - 1) / bgs::kMorphTW, (rows + bgs::kMorphTH - 1) / bgs::kMorphTH, 1);
+  if (passes > 1) HIP_TRY(hipMalloc((void**)&tmp, n));
   const uint8_t* in = (const uint8_t*)d_src;
-  for (int i = 0; i < iterations; ++i) {
-    // alternate so that the last iteration lands in d_dst
-    uint8_t* out = ((iterations - 1 - i) % 2 == 0) ? (uint8_t*)d_dst : tmp;
-    bgs::MorphArgs a{in, out, rows, cols, op, ksize};
-    hipLaunchKernelGGL(bgs::morph_kernel, grid, dim3(bgs::kBlock), 0, s, a);
+  int left = iterations;
+  for (int i = 0; i < passes; ++i) {
+    // alternate so that the last pass lands in d_dst
+    uint8_t* out = ((passes - 1 - i) % 2 == 0) ? (uint8_t*)d_dst : tmp;
+    const int it = op <= 1 ? std::min(left, per_pass) : 1;
+    bgs::MorphArgs a{in, out, rows, cols, op, op <= 1 ? 2 * it + 1 : ksize};
+    bgs::morph_launch(a, 1, s);
+    left -= it;
     in = out;
   }
   hipError_t er = hipGetLastError();

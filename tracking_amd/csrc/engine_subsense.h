@@ -107,7 +107,7 @@ void ss_fill_args(const bgs_engine* e, bgs::SsArgs& a, int first, int cur_pp, un
 
 void ss_morph(const uint8_t* src, uint8_t* dst, int rows, int cols, int count, int op, int ksize, hipStream_t s) {
   bgs::MorphArgs m{src, dst, rows, cols, op, ksize};
-  hipLaunchKernelGGL(bgs::morph_kernel, dim3((cols + bgs::kMorphTW - 1) / bgs::kMorphTW, (rows + bgs::kMorphTH - 1) / bgs::kMorphTH, count), dim3(bgs::kBlock), 0, s, m);
+  bgs::morph_launch(m, count, s);
 }
 
 // cv::saturate_cast<uchar>(offset + t * rel) per entry (BackgroundSubtractorSuBSENSE.cpp:227-228); host-side, once per stream
@@ -209,14 +209,10 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
     if (!*d->h_changed) break;
   }
   // erode x3 :632 -> t3
-  ss_morph(t1, t3, e->rows, e->cols, count, 0, 3, s);
-  ss_morph(t3, t4, e->rows, e->cols, count, 0, 3, s);
-  ss_morph(t4, t3, e->rows, e->cols, count, 0, 3, s);
+  ss_morph(t1, t3, e->rows, e->cols, count, 0, 7, s);  // erode x3 = one 7x7 box
   hipLaunchKernelGGL(bgs::ss_combine_kernel, dim3(blocks_for(npix)), block, 0, s, a, (const uint8_t*)t1, (const uint64_t*)rbits, W64, (const uint8_t*)t3, t4, npix);  // :631-634
   ss_morph(t4, lastFG, e->rows, e->cols, count, 3, d->medK, s);  // medianBlur :635 (the input is a {0,255} mask)
-  ss_morph(lastFG, t1, e->rows, e->cols, count, 1, 3, s);        // dilate x3 :636
-  ss_morph(t1, t3, e->rows, e->cols, count, 1, 3, s);
-  ss_morph(t3, t1, e->rows, e->cols, count, 1, 3, s);
+  ss_morph(lastFG, t1, e->rows, e->cols, count, 1, 7, s);        // dilate x3 :636 = one 7x7 box
   hipLaunchKernelGGL(bgs::ss_finish_kernel, dim3(blocks_for(npix)), block, 0, s, a, (const uint8_t*)t1, npix);  // :637-642
   if (d->lrScaling) {
     const int dsn = (e->rows / 8) * (e->cols / 8);

@@ -156,68 +156,112 @@ __global__ __launch_bounds__(kBlock) void lbsp_kernel(const LbspArgs a) {
 struct MorphArgs {
   const uint8_t* src;
   uint8_t* dst;
-  int rows, cols, op, ksize;  // op 0 erode3x3, 1 dilate3x3, 2 median(ksize), 3 median(ksize) of a {0,255} mask (majority count)
+  int rows, cols, op, ksize;  // op 0 erode, 1 dilate (ksize x ksize box = (ksize-1)/2 iterations of 3x3), 2 median(ksize), 3 median(ksize) of a {0,255} mask
 };
 
 constexpr int kMorphTW = 64, kMorphTH = 4, kMorphMaxR = 7;  // median up to 15x15
+constexpr int kBoxTW = 64, kBoxTH = 16;
 
-// 3x3 erode/dilate: border cells outside the image do not take part (morphologyDefaultBorderValue);
-// median: BORDER_REPLICATE.  Masks are {0,255} in the SuBSENSE chain but any u8 image is handled.
-__global__ __launch_bounds__(kBlock) void morph_kernel(const MorphArgs a) {
+// Box operations are separable: erode = min over the box, dilate = max, the median of a binary mask = (number of non-zero
+// cells > half).  One vertical pass into LDS, one horizontal pass out of it: 2(2R+1) LDS reads per pixel instead of (2R+1)^2.
+// n iterations of the 3x3 erode/dilate equal one (2n+1)x(2n+1) box: cells outside the image never take part
+// (morphologyDefaultBorderValue) and the image is convex, so the iterated and the one-shot minimum run over the same cells
+// (OpenCV itself folds iterations of a rectangular element into one larger element).  Median: BORDER_REPLICATE.
+__global__ __launch_bounds__(kBlock) void morph_box_kernel(const MorphArgs a) {
+  constexpr int LW = kBoxTW + 2 * kMorphMaxR + 2;
+  __shared__ uint8_t t[kBoxTH + 2 * kMorphMaxR][LW];
+  __shared__ uint8_t v[kBoxTH][LW];
+  const int R = a.ksize / 2, op = a.op;
+  const int x0 = blockIdx.x * kBoxTW, y0 = blockIdx.y * kBoxTH;
+  const size_t img = (size_t)blockIdx.z * a.rows * a.cols;
+  const int HW = kBoxTW + 2 * R, HH = kBoxTH + 2 * R;
+  for (int i = threadIdx.x; i < HW * HH; i += kBlock) {
+    const int ly = i / HW, lx = i - ly * HW;
+    const int y = y0 + ly - R, x = x0 + lx - R;
+    uint8_t c;
+    if (op == 3) {
+      c = a.src[img + (size_t)min(max(y, 0), a.rows - 1) * a.cols + min(max(x, 0), a.cols - 1)] != 0;
+    } else {
+      const bool in = y >= 0 && y < a.rows && x >= 0 && x < a.cols;
+      c = in ? a.src[img + (size_t)y * a.cols + x] : (op == 0 ? 255 : 0);
+    }
+    t[ly][lx] = c;
+  }
+  __syncthreads();
+  for (int task = threadIdx.x; task < HW * (kBoxTH / 4); task += kBlock) {  // vertical pass: one column, four output rows
+    const int strip = task / HW, cx = task - strip * HW;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ry = strip * 4 + r;
+      int acc = op == 0 ? 255 : 0;
+      for (int dy = 0; dy <= 2 * R; ++dy) {
+        const int c = t[ry + dy][cx];
+        acc = op == 0 ? min(acc, c) : op == 1 ? max(acc, c) : acc + c;
+      }
+      v[ry][cx] = (uint8_t)acc;
+    }
+  }
+  __syncthreads();
+  const int ly = threadIdx.x / (kBoxTW / 4), xs = (threadIdx.x % (kBoxTW / 4)) * 4;  // horizontal pass: four pixels of one row
+  const int y = y0 + ly, x = x0 + xs;
+  if (y >= a.rows || x >= a.cols) return;
+  const int need = (a.ksize * a.ksize) / 2 + 1;
+  uint32_t packed = 0;
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    int acc = op == 0 ? 255 : 0;
+    for (int dx = 0; dx <= 2 * R; ++dx) {
+      const int c = v[ly][xs + o + dx];
+      acc = op == 0 ? min(acc, c) : op == 1 ? max(acc, c) : acc + c;
+    }
+    if (op == 3) acc = acc >= need ? 255 : 0;
+    packed |= (uint32_t)acc << (8 * o);
+  }
+  uint8_t* out = a.dst + img + (size_t)y * a.cols + x;
+  if (x + 3 < a.cols && ((img + (size_t)y * a.cols + x) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.dst) & 3) == 0) {
+    *reinterpret_cast<uint32_t*>(out) = packed;
+  } else {
+    for (int o = 0; o < 4 && x + o < a.cols; ++o) out[o] = (uint8_t)(packed >> (8 * o));
+  }
+}
+
+// exact median of a u8 image by counting (BORDER_REPLICATE): the value v such that #(<= v) first reaches (k*k)/2 + 1
+__global__ __launch_bounds__(kBlock) void median_kernel(const MorphArgs a) {
   __shared__ uint8_t t[kMorphTH + 2 * kMorphMaxR][kMorphTW + 2 * kMorphMaxR + 2];
-  const int R = a.op >= 2 ? a.ksize / 2 : 1;
+  const int R = a.ksize / 2;
   const int x0 = blockIdx.x * kMorphTW, y0 = blockIdx.y * kMorphTH;
   const size_t img = (size_t)blockIdx.z * a.rows * a.cols;
   const int HW = kMorphTW + 2 * R, HH = kMorphTH + 2 * R;
   for (int i = threadIdx.x; i < HW * HH; i += kBlock) {
     const int ly = i / HW, lx = i - ly * HW;
     const int y = y0 + ly - R, x = x0 + lx - R;
-    uint8_t v;
-    if (a.op >= 2) {
-      v = a.src[img + (size_t)min(max(y, 0), a.rows - 1) * a.cols + min(max(x, 0), a.cols - 1)];
-    } else {
-      const bool in = y >= 0 && y < a.rows && x >= 0 && x < a.cols;
-      v = in ? a.src[img + (size_t)y * a.cols + x] : (a.op == 0 ? 255 : 0);
-    }
-    t[ly][lx] = v;
+    t[ly][lx] = a.src[img + (size_t)min(max(y, 0), a.rows - 1) * a.cols + min(max(x, 0), a.cols - 1)];
   }
   __syncthreads();
   const int lx = threadIdx.x % kMorphTW, ly = threadIdx.x / kMorphTW;
   const int x = x0 + lx, y = y0 + ly;
   if (x >= a.cols || y >= a.rows) return;
-  int out;
-  if (a.op == 3) {
-    // binary mask: the median is 255 iff more than half of the k*k cells are non-zero
+  const int need = (a.ksize * a.ksize) / 2 + 1;
+  int lo = 0, hi = 255;
+  while (lo < hi) {  // binary search over the 8 bits
+    const int mid = (lo + hi) >> 1;
     int cnt = 0;
     for (int dy = 0; dy <= 2 * R; ++dy)
-      for (int dx = 0; dx <= 2 * R; ++dx) cnt += t[ly + dy][lx + dx] != 0;
-    out = cnt >= (a.ksize * a.ksize) / 2 + 1 ? 255 : 0;
-  } else if (a.op == 2) {
-    // exact median by counting: the value v such that #(<= v) first reaches (k*k)/2 + 1; binary search over 8 bits
-    const int need = (a.ksize * a.ksize) / 2 + 1;
-    int lo = 0, hi = 255;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      int cnt = 0;
-      for (int dy = 0; dy <= 2 * R; ++dy)
-        for (int dx = 0; dx <= 2 * R; ++dx) cnt += t[ly + dy][lx + dx] <= mid;
-      if (cnt >= need)
-        hi = mid;
-      else
-        lo = mid + 1;
-    }
-    out = lo;
-  } else {
-    out = a.op == 0 ? 255 : 0;
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int v = t[ly + dy][lx + dx];
-        out = a.op == 0 ? min(out, v) : max(out, v);
-      }
+      for (int dx = 0; dx <= 2 * R; ++dx) cnt += t[ly + dy][lx + dx] <= mid;
+    if (cnt >= need)
+      hi = mid;
+    else
+      lo = mid + 1;
   }
-  a.dst[img + (size_t)y * a.cols + x] = (uint8_t)out;
+  a.dst[img + (size_t)y * a.cols + x] = (uint8_t)lo;
+}
+
+// host side: one launch over `count` images stored back to back
+inline void morph_launch(const MorphArgs& a, int count, hipStream_t s) {
+  if (a.op == 2)
+    hipLaunchKernelGGL(median_kernel, dim3((a.cols + kMorphTW - 1) / kMorphTW, (a.rows + kMorphTH - 1) / kMorphTH, count), dim3(kBlock), 0, s, a);
+  else
+    hipLaunchKernelGGL(morph_box_kernel, dim3((a.cols + kBoxTW - 1) / kBoxTW, (a.rows + kBoxTH - 1) / kBoxTH, count), dim3(kBlock), 0, s, a);
 }
 
 }  // namespace bgs

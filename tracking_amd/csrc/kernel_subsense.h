@@ -74,15 +74,23 @@ __device__ __constant__ const int8_t kSsN5[24][2] = {{-2, 2},  {-1, 2},  {0, 2},
 #define SS_REQ_VALID 0x8000u
 __device__ __forceinline__ uint16_t ss_req(unsigned slot, int code) { return (uint16_t)(SS_REQ_VALID | (slot << 8) | (unsigned)code); }
 
-// 16 neighbours of one channel packed 4 per dword, in LBSP bit order (bit 15 first); descriptor of `ref` against them
-__device__ __forceinline__ unsigned ss_lbsp(const uint32_t (&nb)[4], int ref, int t) {
-  unsigned r = 0;
+// LBSP descriptor of `ref` (threshold t) against the 16 neighbours of one channel, two neighbours per dword as 16-bit
+// lanes: dword k = neighbour k (LBSP bit 15-k) in the high half, neighbour 8+k (bit 7-k) in the low half.
+// |v - ref| > t  <=>  v outside [lo, hi] = [max(ref-t,0), min(ref+t,255)]  <=>  (v - lo) mod 2^16 > hi - lo, so one packed
+// wrap-around subtract, one packed saturating subtract and a packed min give the two flags of a dword (v_pk_* on CDNA).
+__device__ __forceinline__ unsigned ss_lbsp(const uint32_t (&nb)[8], int ref, int t) {
+  const unsigned lo = (unsigned)max(ref - t, 0), w = (unsigned)min(ref + t, 255) - lo;
+  const unsigned lo2 = lo * 0x10001u, w2 = w * 0x10001u, one = 0x10001u;
+  unsigned acc = 0;
 #pragma unroll
-  for (int b = 0; b < 16; ++b) {
-    const int v = (int)((nb[b >> 2] >> (8 * (b & 3))) & 0xffu);
-    r |= (unsigned)(abs(v - ref) > t) << (15 - b);
+  for (int k = 0; k < 8; ++k) {
+    unsigned u, d, f;  // (the compiler turns the portable form of this into compare + select per half: twice the instructions)
+    asm("v_pk_sub_u16 %0, %1, %2" : "=v"(u) : "v"(nb[k]), "v"(lo2));
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(u), "v"(w2));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(f) : "v"(d), "v"(one));
+    acc = (acc << 1) | f;
   }
-  return r;
+  return (acc & 0xffu) | ((acc >> 8) & 0xff00u);
 }
 
 // ----------------------------------------------------------------------------------------------- phase A
@@ -90,7 +98,7 @@ template <int C>
 __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
   constexpr int HW = kSsTW + 4, HH = kSsTH + 4;
   constexpr int ROWB = (HW * C + 3 + 3) / 4 * 4;
-  constexpr size_t maxColor = 255 * C, maxDesc = 16 * C;  // s_nColorMaxDataRange_*, s_nDescMaxDataRange_*
+  constexpr uint32_t maxColor = 255 * C, maxDesc = 16 * C;  // s_nColorMaxDataRange_*, s_nDescMaxDataRange_*
   __shared__ uint32_t tile[HH][ROWB / 4];
   __shared__ uint8_t lut[256];
   __shared__ unsigned nz_block;
@@ -129,43 +137,75 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
     };
     const int8_t dxs[16] = {-1, 1, 1, -1, 1, 0, -1, 0, -2, 2, 2, -2, 0, 0, 2, -2}, dys[16] = {1, -1, 1, -1, 0, -1, 0, 1, -2, 2, -2, 2, 2, -2, 0, 0};
     int cur[C];
-    uint32_t nb[C][4];
+    uint32_t nb[C][8];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       cur[c] = at(ly + 2, lx + 2, c);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) nb[c][q] = 0;
-#pragma unroll
-      for (int b = 0; b < 16; ++b) nb[c][b >> 2] |= (uint32_t)at(ly + 2 + dys[b], lx + 2 + dxs[b], c) << (8 * (b & 3));
+      for (int k = 0; k < 8; ++k)
+        nb[c][k] = ((uint32_t)at(ly + 2 + dys[k], lx + 2 + dxs[k], c) << 16) | (uint32_t)at(ly + 2 + dys[8 + k], lx + 2 + dxs[8 + k], c);
     }
+    // every load of the pixel's state is issued here, before the sample loop, and every store happens after it: one memory
+    // round trip instead of a chain of them (the kernel is latency-bound, not bandwidth-bound)
     float Rv = a.R[i], Vv = a.V[i], Tv = a.T[i];
     const int unst_old = a.unstable[i];
+    const float rawLT_old = a.RawLT[i], rawST_old = a.RawSTOld[i], finLT = a.FinLT[i], finST = a.FinST[i];
+    const float dlast_old = a.DlastOld[i], dminLT_old = a.DminLT[i], dminST_old = a.DminST[i];
+    const int lastfg = a.lastFG[i], blink = a.blinks[i];
+    int lastc[C];
+    unsigned lastd[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) lastc[c] = a.lastColor[i * C + c], lastd[c] = a.lastDesc[i * C + c];
+    const int unst = (Rv > 3.0f || (rawLT_old - finLT) > 0.1f || (rawST_old - finST) > 0.1f) ? 1 : 0;  // :467
+    // the random neighbour of the background branch (:526-551) depends only on `unst`: fetch its two map values now
+    const bool use3 = a.use3x3 && !unst;
+    int xn, yn;
+    {
+      const uint32_t r4 = ss_rand(fr, pi, 4);
+      if (use3) {
+        const int r = (int)(r4 % 8u);
+        xn = x + kSsN3[r][0], yn = y + kSsN3[r][1];
+      } else {
+        const int r = (int)(r4 % 24u);
+        xn = x + kSsN5[r][0], yn = y + kSsN5[r][1];
+      }
+      xn = min(max(xn, 2), a.cols - 3), yn = min(max(yn, 2), a.rows - 3);
+    }
+    const size_t j = sN + (size_t)yn * a.cols + xn;
+    const float nbrLast = a.DlastOld[j], nbrRaw = a.RawSTOld[j];  // previous frame's copy (contract)
     const int stabOff = a.nMinColor / 5;
-    const size_t colorThr = (size_t)((Rv * (float)a.nMinColor) - (float)((!unst_old) * stabOff)) / (C == 1 ? 2 : 1);                  // :459 / :328 (trailing /2)
-    const size_t descThr = ((size_t)1 << ((size_t)floorf(Rv + 0.5f))) + (size_t)a.nDescOff + (size_t)(unst_old * a.nDescOff);        // :460
-    const size_t totColorThr = colorThr * 3, totDescThr = descThr * 3, scColorThr = totColorThr / 2;
+    const uint32_t colorThr = (uint32_t)((Rv * (float)a.nMinColor) - (float)((!unst_old) * stabOff)) / (C == 1 ? 2 : 1);                  // :459 / :328 (trailing /2)
+    const uint32_t descThr = (1u << ((uint32_t)floorf(Rv + 0.5f))) + (uint32_t)a.nDescOff + (uint32_t)(unst_old * a.nDescOff);        // :460
+    const uint32_t totColorThr = colorThr * 3, totDescThr = descThr * 3, scColorThr = totColorThr / 2;
     unsigned intra[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) intra[c] = ss_lbsp(nb[c], cur[c], lut[cur[c]]);  // :465-466 / :331
-    const float rawST_old = a.RawSTOld[i];
-    const int unst = (Rv > 3.0f || (a.RawLT[i] - a.FinLT[i]) > 0.1f || (rawST_old - a.FinST[i]) > 0.1f) ? 1 : 0;  // :467
-    a.unstable[i] = (uint8_t)unst;
-    size_t minDesc = maxDesc, minSum = maxColor;
+    uint32_t minDesc = maxDesc, minSum = maxColor;
     int good = 0, idx = 0;
     const size_t sbase = (size_t)stream * a.nS * N;
-    while (good < a.nReq && idx < a.nS) {  // :469-497 (BGR) / :334-357 (gray)
-      const uint8_t* bc = a.color + (sbase + (size_t)idx * N + p) * C;
-      const uint16_t* bd = a.desc + (sbase + (size_t)idx * N + p) * C;
+    const uint8_t* cp = a.color + (sbase + p) * C;   // sample idx of this pixel: + idx * N * C
+    const uint16_t* dp = a.desc + (sbase + p) * C;
+    const size_t sstride = N * C;
+    int bc[C], nbc[C];
+    unsigned bd[C], nbd[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) bc[c] = nbc[c] = cp[c], bd[c] = nbd[c] = dp[c];
+    while (good < a.nReq && idx < a.nS) {  // :469-497 (BGR) / :334-357 (gray); sample idx+1 is in flight while idx is tested
+      if (idx + 1 < a.nS) {
+        cp += sstride, dp += sstride;
+#pragma unroll
+        for (int c = 0; c < C; ++c) nbc[c] = cp[c], nbd[c] = dp[c];
+      }
       if constexpr (C == 1) {
         const int bcc = bc[0];
-        const size_t cd = (size_t)abs(cur[0] - bcc);
+        const uint32_t cd = (uint32_t)abs(cur[0] - bcc);
         if (cd <= colorThr) {
           const unsigned bdc = bd[0];
-          const size_t intraD = (size_t)__popc(intra[0] ^ bdc);
+          const uint32_t intraD = (uint32_t)__popc(intra[0] ^ bdc);
           const unsigned inter = ss_lbsp(nb[0], bcc, lut[bcc]);
-          const size_t dd = (intraD + (size_t)__popc(inter ^ bdc)) / 2;
+          const uint32_t dd = (intraD + (uint32_t)__popc(inter ^ bdc)) / 2;
           if (dd <= descThr) {
-            size_t sd = (dd / 4) * (255 / 16) + cd;
+            uint32_t sd = (dd / 4) * (255 / 16) + cd;
             sd = sd < 255 ? sd : 255;
             if (sd <= colorThr) {
               minDesc = minDesc > dd ? dd : minDesc;
@@ -175,22 +215,22 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
           }
         }
       } else {
-        size_t totDesc = 0, totSum = 0;
+        uint32_t totDesc = 0, totSum = 0;
         bool ok = true;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           if (ok) {
             const int bcc = bc[c];
-            const size_t cd = (size_t)abs(cur[c] - bcc);
+            const uint32_t cd = (uint32_t)abs(cur[c] - bcc);
             if (cd > scColorThr) {
               ok = false;
             } else {
               const unsigned bdc = bd[c];
-              const size_t intraD = (size_t)__popc(intra[c] ^ bdc);
+              const uint32_t intraD = (uint32_t)__popc(intra[c] ^ bdc);
               const unsigned inter = ss_lbsp(nb[c], bcc, lut[bcc]);
-              const size_t interD = (size_t)__popc(inter ^ bdc);
-              const size_t dd = (intraD + interD) / 2;
-              size_t sd = (dd / 2) * (255 / 16) + cd;
+              const uint32_t interD = (uint32_t)__popc(inter ^ bdc);
+              const uint32_t dd = (intraD + interD) / 2;
+              uint32_t sd = (dd / 2) * (255 / 16) + cd;
               sd = sd < 255 ? sd : 255;
               if (sd > scColorThr)
                 ok = false;
@@ -206,17 +246,20 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
         }
       }
       idx++;
+#pragma unroll
+      for (int c = 0; c < C; ++c) bc[c] = nbc[c], bd[c] = nbd[c];
     }
-    size_t l1 = 0, hd = 0;
+    uint32_t l1 = 0, hd = 0;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      l1 += (size_t)abs((int)a.lastColor[i * C + c] - cur[c]);
-      hd += (size_t)__popc(((unsigned)a.lastDesc[i * C + c] ^ intra[c]) & 0xffffu);
+      l1 += (uint32_t)abs(lastc[c] - cur[c]);
+      hd += (uint32_t)__popc((lastd[c] ^ intra[c]) & 0xffffu);
     }
     const float fLT = a.fLT, fST = a.fST;
     const float normLast = ((float)l1 / maxColor + (float)hd / maxDesc) / 2;  // :498
-    a.DlastNew[i] = a.DlastOld[i] * (1.0f - fST) + normLast * fST;
-    float dminLT = a.DminLT[i], dminST = a.DminST[i], rawLT = a.RawLT[i], rawST = rawST_old;
+    a.DlastNew[i] = dlast_old * (1.0f - fST) + normLast * fST;
+    a.unstable[i] = (uint8_t)unst;
+    float dminLT = dminLT_old, dminST = dminST_old, rawLT = rawLT_old, rawST = rawST_old;
     bool isfg;
     uint16_t reqSelf = 0, reqNbr = 0;
     if (good < a.nReq) {  // foreground :500-515
@@ -235,22 +278,10 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
       rawLT = rawLT * (1.0f - fLT);
       rawST = rawST * (1.0f - fST);
       isfg = false;
-      const size_t lr = (size_t)ceilf(Tv);
+      const uint32_t lr = (uint32_t)ceilf(Tv);  // (the reference computes these in size_t; every value fits 31 bits)
       if ((ss_rand(fr, pi, 2) % lr) == 0) reqSelf = ss_req(ss_rand(fr, pi, 3) % (uint32_t)a.nS, 12);
-      const bool use3 = a.use3x3 && !unst;
-      int xn, yn;
-      if (use3) {
-        const int r = (int)(ss_rand(fr, pi, 4) % 8u);
-        xn = x + kSsN3[r][0], yn = y + kSsN3[r][1];
-      } else {
-        const int r = (int)(ss_rand(fr, pi, 4) % 24u);
-        xn = x + kSsN5[r][0], yn = y + kSsN5[r][1];
-      }
-      xn = min(max(xn, 2), a.cols - 3), yn = min(max(yn, 2), a.rows - 3);
-      const size_t nrand = ss_rand(fr, pi, 5);
-      const size_t j = sN + (size_t)yn * a.cols + xn;
-      const float nbrLast = a.DlastOld[j], nbrRaw = a.RawSTOld[j];  // previous frame's copy (contract)
-      if ((nrand % (use3 ? lr : (lr / 2 + 1))) == 0 || (nbrRaw > 0.995f && nbrLast < 0.010f && (nrand % ((size_t)sc.capLo)) == 0))
+      const uint32_t nrand = ss_rand(fr, pi, 5);
+      if ((nrand % (use3 ? lr : (lr / 2 + 1))) == 0 || (nbrRaw > 0.995f && nbrLast < 0.010f && (nrand % ((uint32_t)sc.capLo)) == 0))
         reqNbr = ss_req(ss_rand(fr, pi, 6) % (uint32_t)a.nS, (yn - y + 2) * 5 + (xn - x + 2));
     }
     a.DminLT[i] = dminLT, a.DminST[i] = dminST, a.RawLT[i] = rawLT, a.RawSTNew[i] = rawST;
@@ -258,7 +289,6 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
     a.req[i * 2] = reqSelf, a.req[i * 2 + 1] = reqNbr;
     // feedback :553-576
     const float dmin_min = dminLT < dminST ? dminLT : dminST, dmin_max = dminLT > dminST ? dminLT : dminST;
-    const int lastfg = a.lastFG[i];
     if (lastfg || (dmin_min < 0.1f && isfg)) {
       if (Tv < sc.capHi) Tv += div_rn(0.5f, dmin_max * Vv);
     } else if (Tv > sc.capLo)
@@ -267,7 +297,7 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
       Tv = sc.capLo;
     else if (Tv > sc.capHi)
       Tv = sc.capHi;
-    if (dmin_max > 0.1f && a.blinks[i])
+    if (dmin_max > 0.1f && blink)
       Vv += 1.0f;
     else if (Vv > 0.1f) {
       Vv -= lastfg ? 0.1f / 4 : unst ? 0.1f / 2 : 0.1f;
