@@ -215,34 +215,41 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
           }
         }
       } else {
-        uint32_t totDesc = 0, totSum = 0;
+        // The reference walks the channels in order and drops the sample at the first failed test (:474-491); a sample is
+        // kept only if every test passes, so the tests may run in any order.  Cheap exact rejections first (colour
+        // distances, then lower bounds from the intra half of the descriptor distance: dd >= intraD/2 and sd grows with
+        // dd); the three inter-LBSP descriptors are computed only for samples that can still pass.  Late iterations are
+        // mostly pixels that match nothing: they now cost a fraction of a full test.
+        uint32_t cd[3], intraD[3], lbDesc = 0, lbSum = 0;
         bool ok = true;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          if (ok) {
-            const int bcc = bc[c];
-            const uint32_t cd = (uint32_t)abs(cur[c] - bcc);
-            if (cd > scColorThr) {
-              ok = false;
-            } else {
-              const unsigned bdc = bd[c];
-              const uint32_t intraD = (uint32_t)__popc(intra[c] ^ bdc);
-              const unsigned inter = ss_lbsp(nb[c], bcc, lut[bcc]);
-              const uint32_t interD = (uint32_t)__popc(inter ^ bdc);
-              const uint32_t dd = (intraD + interD) / 2;
-              uint32_t sd = (dd / 2) * (255 / 16) + cd;
-              sd = sd < 255 ? sd : 255;
-              if (sd > scColorThr)
-                ok = false;
-              else
-                totDesc += dd, totSum += sd;
-            }
-          }
+          cd[c] = (uint32_t)abs(cur[c] - bc[c]);
+          intraD[c] = (uint32_t)__popc(intra[c] ^ bd[c]);
+          const uint32_t lbdd = intraD[c] / 2;
+          uint32_t lbsd = (lbdd / 2) * (255 / 16) + cd[c];
+          lbsd = lbsd < 255 ? lbsd : 255;
+          ok = ok && cd[c] <= scColorThr && lbsd <= scColorThr;
+          lbDesc += lbdd, lbSum += lbsd;
         }
-        if (ok && !(totDesc > totDescThr || totSum > totColorThr)) {
-          minDesc = minDesc > totDesc ? totDesc : minDesc;
-          minSum = minSum > totSum ? totSum : minSum;
-          good++;
+        ok = ok && lbDesc <= totDescThr && lbSum <= totColorThr;
+        if (ok) {
+          uint32_t totDesc = 0, totSum = 0;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const unsigned inter = ss_lbsp(nb[c], bc[c], lut[bc[c]]);
+            const uint32_t interD = (uint32_t)__popc(inter ^ bd[c]);
+            const uint32_t dd = (intraD[c] + interD) / 2;
+            uint32_t sd = (dd / 2) * (255 / 16) + cd[c];
+            sd = sd < 255 ? sd : 255;
+            ok = ok && sd <= scColorThr;
+            totDesc += dd, totSum += sd;
+          }
+          if (ok && !(totDesc > totDescThr || totSum > totColorThr)) {
+            minDesc = minDesc > totDesc ? totDesc : minDesc;
+            minSum = minSum > totSum ? totSum : minSum;
+            good++;
+          }
         }
       }
       idx++;
@@ -335,15 +342,25 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
 // ----------------------------------------------------------------------------------------------- phase B
 template <int C>
 __global__ __launch_bounds__(kBlock) void ss_phase_b_kernel(const SsArgs a) {
-  __shared__ uint32_t rq[kSsTH + 4][kSsTW + 4];  // both requests of a pixel in one dword
+  constexpr int HW = kSsTW + 4, HH = kSsTH + 4;
+  __shared__ uint32_t rq[HH][HW];     // both requests of a source pixel in one dword
+  __shared__ uint8_t lc[HH][HW][C];   // what a requesting source writes: its current colour / intra descriptor (phase A left
+  __shared__ uint16_t ld[HH][HW][C];  // them in lastColor / lastDesc); staged so that the writes below wait on no load
   const int stream = a.first + blockIdx.z;
   const size_t N = (size_t)a.rows * a.cols, sN = (size_t)stream * N;
   const int x0 = blockIdx.x * kSsTW, y0 = blockIdx.y * kSsTH;
-  for (int i = threadIdx.x; i < (kSsTH + 4) * (kSsTW + 4); i += kBlock) {
-    const int ly = i / (kSsTW + 4), lx = i - ly * (kSsTW + 4);
+  for (int i = threadIdx.x; i < HH * HW; i += kBlock) {
+    const int ly = i / HW, lx = i - ly * HW;
     const int y = y0 + ly - 2, x = x0 + lx - 2;
     uint32_t v = 0;
-    if (y >= 2 && y < a.rows - 2 && x >= 2 && x < a.cols - 2) v = *reinterpret_cast<const uint32_t*>(a.req + (sN + (size_t)y * a.cols + x) * 2);
+    if (y >= 2 && y < a.rows - 2 && x >= 2 && x < a.cols - 2) {
+      const size_t src = sN + (size_t)y * a.cols + x;
+      v = *reinterpret_cast<const uint32_t*>(a.req + src * 2);
+      if (v) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) lc[ly][lx][c] = a.lastColor[src * C + c], ld[ly][lx][c] = a.lastDesc[src * C + c];
+      }
+    }
     rq[ly][lx] = v;
   }
   __syncthreads();
@@ -352,23 +369,22 @@ __global__ __launch_bounds__(kBlock) void ss_phase_b_kernel(const SsArgs a) {
   if (!(x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2)) return;
   const size_t p = (size_t)y * a.cols + x;
   const size_t sbase = (size_t)stream * a.nS * N;
+  uint8_t* cp = a.color + (sbase + p) * C;
+  uint16_t* dp = a.desc + (sbase + p) * C;
+  const size_t sstride = N * C;
+#pragma unroll
   for (int dy = -2; dy <= 2; ++dy)
+#pragma unroll
     for (int dx = -2; dx <= 2; ++dx) {  // sources in raster order: a later source overwrites an earlier one, as in the reference's loop
       const uint32_t both = rq[ly + 2 + dy][lx + 2 + dx];
-      if (!both) continue;
+      const uint32_t aimed = SS_REQ_VALID | (uint32_t)(12 - 5 * dy - dx);  // the code of a request whose target is this pixel
 #pragma unroll
       for (int q = 0; q < 2; ++q) {  // self request first, then the neighbour request
-        const unsigned r = (both >> (16 * q)) & 0xffffu;
-        if (!(r & SS_REQ_VALID)) continue;
-        const int code = (int)(r & 0x1f), slot = (int)((r >> 8) & 0x3f);
-        if (dy + code / 5 - 2 != 0 || dx + code % 5 - 2 != 0) continue;  // not aimed at this pixel
-        const size_t src = sN + (size_t)(y + dy) * a.cols + (x + dx);
-        const size_t dst = (sbase + (size_t)slot * N + p) * C;
+        const uint32_t r = (both >> (16 * q)) & 0xffffu;
+        if ((r & (SS_REQ_VALID | 0x1fu)) != aimed) continue;
+        const size_t o = (size_t)((r >> 8) & 0x3fu) * sstride;
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-          a.color[dst + c] = a.lastColor[src * C + c];  // phase A stored the source's current colour / intra descriptor there
-          a.desc[dst + c] = a.lastDesc[src * C + c];
-        }
+        for (int c = 0; c < C; ++c) cp[o + c] = lc[ly + 2 + dy][lx + 2 + dx][c], dp[o + c] = ld[ly + 2 + dy][lx + 2 + dx][c];
       }
     }
 }
