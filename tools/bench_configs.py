@@ -110,6 +110,9 @@ def main():
         run_subsense(2)
         run_subsense(2, kind="smooth")
         return
+    if args.only == "subsense8":
+        run_subsense(8)
+        return
     run(capi.WMV, "WeightedMovingVarianceBGS", 2160, 3840, S, 10)
     run(capi.ABL, "AdaptiveBackgroundLearning", 2160, 3840, S, 10, borrow=False)
     run(capi.WMM, "WeightedMovingMeanBGS (+bg)", 2160, 3840, S, 13, want_bg=True)

@@ -99,6 +99,8 @@ void ss_fill_args(const bgs_engine* e, bgs::SsArgs& a, int first, int cur_pp, un
   a.rows = e->rows, a.cols = e->cols, a.nS = p.subsense_n_samples, a.nReq = p.subsense_n_required, a.nMinColor = p.subsense_min_color_dist_threshold;
   a.nDescOff = p.subsense_desc_dist_threshold_offset, a.nMov = p.subsense_samples_for_moving_avgs, a.lbspOff = p.lbsp_threshold_offset;
   a.use3x3 = d->use3x3, a.lrScaling = d->lrScaling, a.medK = d->medK, a.relT = p.lbsp_rel_threshold;
+  static const int refill = getenv("BGS_SS_REFILL") ? std::max(1, std::min(64, atoi(getenv("BGS_SS_REFILL")))) : bgs::kSsRefill;  // tuning knob
+  a.refill = refill;
   a.frameIndex = frameIndex, a.first = first;
   const int64_t fi = frameIndex ? frameIndex : 1;
   a.fLT = 1.0f / (float)std::min<int64_t>(fi, p.subsense_samples_for_moving_avgs);
@@ -185,7 +187,8 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
   const dim3 tiles((e->cols + bgs::kSsTW - 1) / bgs::kSsTW, (e->rows + bgs::kSsTH - 1) / bgs::kSsTH, count), block(bgs::kBlock);
   {
     Timed tm(e, s, "ss_phase_a_kernel");
-    SS_LAUNCH(ss_phase_a_kernel, tiles, block, s, a);
+    const dim3 tilesA((e->cols + bgs::kSsTW - 1) / bgs::kSsTW, (e->rows + bgs::kSsATH - 1) / bgs::kSsATH, count);
+    SS_LAUNCH(ss_phase_a_kernel, tilesA, block, s, a);
   }
   SS_LAUNCH(ss_phase_b_kernel, tiles, block, s, a);
   hipLaunchKernelGGL(bgs::ss_blink_kernel, dim3(blocks_for(npix)), block, 0, s, a, npix);

@@ -47,7 +47,7 @@ struct SsArgs {
   float *dsLT, *dsST;    // [S][dsh][dsw][3]
   uint8_t* fg;           // [S][N] output mask (may be null)
   uint8_t* bgimg;        // [S][N][3] output background (may be null)
-  int rows, cols, nS, nReq, nMinColor, nDescOff, nMov, lbspOff, use3x3, lrScaling, medK;
+  int rows, cols, nS, nReq, nMinColor, nDescOff, nMov, lbspOff, use3x3, lrScaling, medK, refill;
   float relT, fLT, fST;
   unsigned frameIndex;
   int first;             // first stream of this launch (blockIdx.z is relative to it)
@@ -94,18 +94,33 @@ __device__ __forceinline__ unsigned ss_lbsp(const uint32_t (&nb)[8], int ref, in
 }
 
 // ----------------------------------------------------------------------------------------------- phase A
+// One workgroup owns a 64 x 32 pixel tile (8 pixels per lane) and works in three stages:
+//   1. per pixel (static lane<->pixel map): thresholds from R / unstable, the three intra-LBSP descriptors -> LDS context;
+//   2. the sample-consensus loop (:469-497).  Its trip count is 2 for a quiet pixel and nS = 50 for one that matches
+//      nothing; with one pixel per lane a wave runs as long as its slowest pixel (measured: mean 7.7 trips per pixel, 26 per
+//      64-pixel wave).  So the lanes pull pixels from a queue in LDS instead: a wave refills its idle lanes whenever
+//      a quarter of them (kSsRefill) have finished, and every lane keeps its own sample index;
+//   3. per pixel (static map again): rolling means, update requests, T / v / R feedback, stores.
+// The result of a pixel does not depend on when or where it is processed: every model read is of start-of-frame state.
+constexpr int kSsATH = 32, kSsAPix = kSsTW * kSsATH, kSsRefill = 16;
+constexpr uint32_t kSsNotInterior = 0xffffffffu;
+
 template <int C>
 __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
-  constexpr int HW = kSsTW + 4, HH = kSsTH + 4;
+  constexpr int HW = kSsTW + 4, HH = kSsATH + 4;
   constexpr int ROWB = (HW * C + 3 + 3) / 4 * 4;
   constexpr uint32_t maxColor = 255 * C, maxDesc = 16 * C;  // s_nColorMaxDataRange_*, s_nDescMaxDataRange_*
+  constexpr int PPL = kSsAPix / kBlock;
   __shared__ uint32_t tile[HH][ROWB / 4];
   __shared__ uint8_t lut[256];
-  __shared__ unsigned nz_block;
+  // per pixel: [0] intra0 | intra1 << 16, [1] intra2 | colorThr << 16, [2] descThr, replaced in stage 2 by
+  // good | minDesc << 8 | minSum << 16 (3-dword stride: conflict-free for consecutive pixels)
+  __shared__ uint32_t ctx[kSsAPix][3];
+  __shared__ unsigned nz_block, qhead;
   const int stream = a.first + blockIdx.z;
   const size_t N = (size_t)a.rows * a.cols, sN = (size_t)stream * N;
   const uint8_t* img = a.frame + (size_t)blockIdx.z * N * C;
-  const int x0 = blockIdx.x * kSsTW, y0 = blockIdx.y * kSsTH;
+  const int x0 = blockIdx.x * kSsTW, y0 = blockIdx.y * kSsATH;
   const long imgsz = (long)N * C, rb = (long)(x0 - 2) * C;
   for (int i = threadIdx.x; i < HH * (ROWB / 4); i += kBlock) {
     const int ry = i / (ROWB / 4), rd = i - ry * (ROWB / 4);
@@ -120,24 +135,16 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
     tile[ry][rd] = v;
   }
   lut[threadIdx.x] = a.lut[(size_t)stream * 256 + threadIdx.x];
-  if (threadIdx.x == 0) nz_block = 0;
+  if (threadIdx.x == 0) nz_block = 0, qhead = 0;
   __syncthreads();
-  const int lx = threadIdx.x % kSsTW, ly = threadIdx.x / kSsTW;
-  const int x = x0 + lx, y = y0 + ly;
-  const bool interior = x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2;  // LBSP::validateROI; border pixels are never touched
-  bool nzflag = false;
-  if (interior) {
-    const SsScalars sc = a.sc[stream];
-    const size_t p = (size_t)y * a.cols + x, i = sN + p;
-    const uint32_t fr = a.frameIndex, pi = (uint32_t)p;
-    auto at = [&](int ry, int rx, int c) -> int {
-      const uint8_t* rowp = reinterpret_cast<const uint8_t*>(tile[ry]);
-      const int shift = (int)(((long)(y0 + ry - 2) * a.cols * C + rb) & 3L);
-      return rowp[shift + rx * C + c];
-    };
+  auto at = [&](int ry, int rx, int c) -> int {
+    const uint8_t* rowp = reinterpret_cast<const uint8_t*>(tile[ry]);
+    const int shift = (int)(((long)(y0 + ry - 2) * a.cols * C + rb) & 3L);
+    return rowp[shift + rx * C + c];
+  };
+  // current colour and the 16 LBSP neighbours (packed as ss_lbsp wants them) of tile pixel (ly, lx)
+  auto gather = [&](int ly, int lx, int (&cur)[C], uint32_t (&nb)[C][8]) {
     const int8_t dxs[16] = {-1, 1, 1, -1, 1, 0, -1, 0, -2, 2, 2, -2, 0, 0, 2, -2}, dys[16] = {1, -1, 1, -1, 0, -1, 0, 1, -2, 2, -2, 2, 2, -2, 0, 0};
-    int cur[C];
-    uint32_t nb[C][8];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       cur[c] = at(ly + 2, lx + 2, c);
@@ -145,196 +152,287 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
       for (int k = 0; k < 8; ++k)
         nb[c][k] = ((uint32_t)at(ly + 2 + dys[k], lx + 2 + dxs[k], c) << 16) | (uint32_t)at(ly + 2 + dys[8 + k], lx + 2 + dxs[8 + k], c);
     }
-    // every load of the pixel's state is issued here, before the sample loop, and every store happens after it: one memory
-    // round trip instead of a chain of them (the kernel is latency-bound, not bandwidth-bound)
-    float Rv = a.R[i], Vv = a.V[i], Tv = a.T[i];
-    const int unst_old = a.unstable[i];
-    const float rawLT_old = a.RawLT[i], rawST_old = a.RawSTOld[i], finLT = a.FinLT[i], finST = a.FinST[i];
-    const float dlast_old = a.DlastOld[i], dminLT_old = a.DminLT[i], dminST_old = a.DminST[i];
-    const int lastfg = a.lastFG[i], blink = a.blinks[i];
-    int lastc[C];
-    unsigned lastd[C];
+  };
+  auto interior_of = [&](int x, int y) { return x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2; };  // LBSP::validateROI; border pixels are never touched
+  const size_t sbase = (size_t)stream * a.nS * N;
+  const size_t sstride = N * C;
+
+  // ---- stage 1: thresholds and intra descriptors
+  {
+    float Rs[PPL];
+    int us[PPL];
 #pragma unroll
-    for (int c = 0; c < C; ++c) lastc[c] = a.lastColor[i * C + c], lastd[c] = a.lastDesc[i * C + c];
-    const int unst = (Rv > 3.0f || (rawLT_old - finLT) > 0.1f || (rawST_old - finST) > 0.1f) ? 1 : 0;  // :467
-    // the random neighbour of the background branch (:526-551) depends only on `unst`: fetch its two map values now
-    const bool use3 = a.use3x3 && !unst;
-    int xn, yn;
-    {
-      const uint32_t r4 = ss_rand(fr, pi, 4);
-      if (use3) {
-        const int r = (int)(r4 % 8u);
-        xn = x + kSsN3[r][0], yn = y + kSsN3[r][1];
-      } else {
-        const int r = (int)(r4 % 24u);
-        xn = x + kSsN5[r][0], yn = y + kSsN5[r][1];
-      }
-      xn = min(max(xn, 2), a.cols - 3), yn = min(max(yn, 2), a.rows - 3);
+    for (int r = 0; r < PPL; ++r) {  // all loads first
+      const int q = r * kBlock + threadIdx.x, x = x0 + (q % kSsTW), y = y0 + (q / kSsTW);
+      const bool in = interior_of(x, y);
+      const size_t i = sN + (size_t)y * a.cols + x;
+      Rs[r] = in ? a.R[i] : 1.0f, us[r] = in ? a.unstable[i] : 0;
     }
-    const size_t j = sN + (size_t)yn * a.cols + xn;
-    const float nbrLast = a.DlastOld[j], nbrRaw = a.RawSTOld[j];  // previous frame's copy (contract)
-    const int stabOff = a.nMinColor / 5;
-    const uint32_t colorThr = (uint32_t)((Rv * (float)a.nMinColor) - (float)((!unst_old) * stabOff)) / (C == 1 ? 2 : 1);                  // :459 / :328 (trailing /2)
-    const uint32_t descThr = (1u << ((uint32_t)floorf(Rv + 0.5f))) + (uint32_t)a.nDescOff + (uint32_t)(unst_old * a.nDescOff);        // :460
-    const uint32_t totColorThr = colorThr * 3, totDescThr = descThr * 3, scColorThr = totColorThr / 2;
-    unsigned intra[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) intra[c] = ss_lbsp(nb[c], cur[c], lut[cur[c]]);  // :465-466 / :331
-    uint32_t minDesc = maxDesc, minSum = maxColor;
-    int good = 0, idx = 0;
-    const size_t sbase = (size_t)stream * a.nS * N;
-    const uint8_t* cp = a.color + (sbase + p) * C;   // sample idx of this pixel: + idx * N * C
-    const uint16_t* dp = a.desc + (sbase + p) * C;
-    const size_t sstride = N * C;
-    int bc[C], nbc[C];
-    unsigned bd[C], nbd[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) bc[c] = nbc[c] = cp[c], bd[c] = nbd[c] = dp[c];
-    while (good < a.nReq && idx < a.nS) {  // :469-497 (BGR) / :334-357 (gray); sample idx+1 is in flight while idx is tested
-      if (idx + 1 < a.nS) {
-        cp += sstride, dp += sstride;
-#pragma unroll
-        for (int c = 0; c < C; ++c) nbc[c] = cp[c], nbd[c] = dp[c];
+    for (int r = 0; r < PPL; ++r) {
+      const int q = r * kBlock + threadIdx.x, lx = q % kSsTW, ly = q / kSsTW;
+      if (!interior_of(x0 + lx, y0 + ly)) {
+        ctx[q][2] = kSsNotInterior;
+        continue;
       }
-      if constexpr (C == 1) {
-        const int bcc = bc[0];
-        const uint32_t cd = (uint32_t)abs(cur[0] - bcc);
-        if (cd <= colorThr) {
-          const unsigned bdc = bd[0];
-          const uint32_t intraD = (uint32_t)__popc(intra[0] ^ bdc);
-          const unsigned inter = ss_lbsp(nb[0], bcc, lut[bcc]);
-          const uint32_t dd = (intraD + (uint32_t)__popc(inter ^ bdc)) / 2;
-          if (dd <= descThr) {
-            uint32_t sd = (dd / 4) * (255 / 16) + cd;
-            sd = sd < 255 ? sd : 255;
-            if (sd <= colorThr) {
-              minDesc = minDesc > dd ? dd : minDesc;
-              minSum = minSum > sd ? sd : minSum;
-              good++;
+      const float Rv = Rs[r];
+      const int unst_old = us[r];
+      const int stabOff = a.nMinColor / 5;
+      const uint32_t colorThr = (uint32_t)((Rv * (float)a.nMinColor) - (float)((!unst_old) * stabOff)) / (C == 1 ? 2 : 1);                  // :459 / :328 (trailing /2)
+      const uint32_t descThr = (1u << ((uint32_t)floorf(Rv + 0.5f))) + (uint32_t)a.nDescOff + (uint32_t)(unst_old * a.nDescOff);        // :460
+      int cur[C];
+      uint32_t nb[C][8];
+      gather(ly, lx, cur, nb);
+      unsigned intra[3] = {0, 0, 0};
+#pragma unroll
+      for (int c = 0; c < C; ++c) intra[c] = ss_lbsp(nb[c], cur[c], lut[cur[c]]);  // :465-466 / :331
+      // the thresholds are only ever compared with distances <= 765: clamping them to 16 bits changes no comparison
+      ctx[q][0] = intra[0] | (intra[1] << 16);
+      ctx[q][1] = intra[2] | (min(colorThr, 0xffffu) << 16);
+      ctx[q][2] = min(descThr, 0xffffu);
+    }
+  }
+  __syncthreads();
+
+  // ---- stage 2: sample consensus, lanes fed from the queue
+  {
+    const int lane = threadIdx.x & (kWave - 1);
+    bool active = false, qempty = false;
+    int q = 0, idx = 0, good = 0;
+    uint32_t minDesc = maxDesc, minSum = maxColor, colorThr = 0, descThr = 0;
+    int cur[C], bc[C], nbc[C];
+    unsigned intra[C], bd[C], nbd[C];
+    uint32_t nb[C][8];
+    const uint8_t* cp = a.color;
+    const uint16_t* dp = a.desc;
+#pragma unroll
+    for (int c = 0; c < C; ++c) cur[c] = bc[c] = nbc[c] = 0, intra[c] = bd[c] = nbd[c] = 0;
+    for (;;) {
+      const unsigned long long idle = __ballot(!active);
+      const int nidle = __popcll(idle);
+      if (qempty && nidle == kWave) break;
+      if (!qempty && nidle >= a.refill) {  // wave-uniform
+        const int leader = __ffsll((long long)idle) - 1;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(&qhead, (unsigned)nidle);
+        base = (unsigned)__shfl((int)base, leader);
+        if (base + (unsigned)nidle >= (unsigned)kSsAPix) qempty = true;
+        if (!active) {
+          const unsigned my = base + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+          if (my < (unsigned)kSsAPix && ctx[my][2] != kSsNotInterior) {
+            q = (int)my;
+            const int lx = q % kSsTW, ly = q / kSsTW;
+            const uint32_t c0 = ctx[q][0], c1 = ctx[q][1];
+            descThr = ctx[q][2], colorThr = c1 >> 16;
+            intra[0] = c0 & 0xffffu;
+            if constexpr (C == 3) intra[1] = c0 >> 16, intra[2] = c1 & 0xffffu;
+            gather(ly, lx, cur, nb);
+            const size_t p = (size_t)(y0 + ly) * a.cols + (x0 + lx);
+            cp = a.color + (sbase + p) * C, dp = a.desc + (sbase + p) * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) bc[c] = nbc[c] = cp[c], bd[c] = nbd[c] = dp[c];
+            idx = 0, good = 0, minDesc = maxDesc, minSum = maxColor;
+            active = true;
+          }
+        }
+      }
+      if (active) {
+        if (good < a.nReq && idx < a.nS) {  // :469-497 (BGR) / :334-357 (gray); sample idx+1 is in flight while idx is tested
+          if (idx + 1 < a.nS) {
+            cp += sstride, dp += sstride;
+#pragma unroll
+            for (int c = 0; c < C; ++c) nbc[c] = cp[c], nbd[c] = dp[c];
+          }
+          if constexpr (C == 1) {
+            const int bcc = bc[0];
+            const uint32_t cd = (uint32_t)abs(cur[0] - bcc);
+            if (cd <= colorThr) {
+              const unsigned bdc = bd[0];
+              const uint32_t intraD = (uint32_t)__popc(intra[0] ^ bdc);
+              const unsigned inter = ss_lbsp(nb[0], bcc, lut[bcc]);
+              const uint32_t dd = (intraD + (uint32_t)__popc(inter ^ bdc)) / 2;
+              if (dd <= descThr) {
+                uint32_t sd = (dd / 4) * (255 / 16) + cd;
+                sd = sd < 255 ? sd : 255;
+                if (sd <= colorThr) {
+                  minDesc = minDesc > dd ? dd : minDesc;
+                  minSum = minSum > sd ? sd : minSum;
+                  good++;
+                }
+              }
+            }
+          } else {
+            // The reference walks the channels in order and drops the sample at the first failed test (:474-491); a sample
+            // is kept only if every test passes, so the tests may run in any order.  Cheap exact rejections first (colour
+            // distances, then lower bounds from the intra half of the descriptor distance: dd >= intraD/2 and sd grows
+            // with dd); the three inter-LBSP descriptors are computed only for samples that can still pass.
+            const uint32_t totColorThr = colorThr * 3, totDescThr = descThr * 3, scColorThr = totColorThr / 2;
+            uint32_t cd[3], intraD[3], lbDesc = 0, lbSum = 0;
+            bool ok = true;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              cd[c] = (uint32_t)abs(cur[c] - bc[c]);
+              intraD[c] = (uint32_t)__popc(intra[c] ^ bd[c]);
+              const uint32_t lbdd = intraD[c] / 2;
+              uint32_t lbsd = (lbdd / 2) * (255 / 16) + cd[c];
+              lbsd = lbsd < 255 ? lbsd : 255;
+              ok = ok && cd[c] <= scColorThr && lbsd <= scColorThr;
+              lbDesc += lbdd, lbSum += lbsd;
+            }
+            ok = ok && lbDesc <= totDescThr && lbSum <= totColorThr;
+            if (ok) {
+              uint32_t totDesc = 0, totSum = 0;
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                const unsigned inter = ss_lbsp(nb[c], bc[c], lut[bc[c]]);
+                const uint32_t interD = (uint32_t)__popc(inter ^ bd[c]);
+                const uint32_t dd = (intraD[c] + interD) / 2;
+                uint32_t sd = (dd / 2) * (255 / 16) + cd[c];
+                sd = sd < 255 ? sd : 255;
+                ok = ok && sd <= scColorThr;
+                totDesc += dd, totSum += sd;
+              }
+              if (ok && !(totDesc > totDescThr || totSum > totColorThr)) {
+                minDesc = minDesc > totDesc ? totDesc : minDesc;
+                minSum = minSum > totSum ? totSum : minSum;
+                good++;
+              }
             }
           }
-        }
-      } else {
-        // The reference walks the channels in order and drops the sample at the first failed test (:474-491); a sample is
-        // kept only if every test passes, so the tests may run in any order.  Cheap exact rejections first (colour
-        // distances, then lower bounds from the intra half of the descriptor distance: dd >= intraD/2 and sd grows with
-        // dd); the three inter-LBSP descriptors are computed only for samples that can still pass.  Late iterations are
-        // mostly pixels that match nothing: they now cost a fraction of a full test.
-        uint32_t cd[3], intraD[3], lbDesc = 0, lbSum = 0;
-        bool ok = true;
+          idx++;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          cd[c] = (uint32_t)abs(cur[c] - bc[c]);
-          intraD[c] = (uint32_t)__popc(intra[c] ^ bd[c]);
-          const uint32_t lbdd = intraD[c] / 2;
-          uint32_t lbsd = (lbdd / 2) * (255 / 16) + cd[c];
-          lbsd = lbsd < 255 ? lbsd : 255;
-          ok = ok && cd[c] <= scColorThr && lbsd <= scColorThr;
-          lbDesc += lbdd, lbSum += lbsd;
+          for (int c = 0; c < C; ++c) bc[c] = nbc[c], bd[c] = nbd[c];
         }
-        ok = ok && lbDesc <= totDescThr && lbSum <= totColorThr;
-        if (ok) {
-          uint32_t totDesc = 0, totSum = 0;
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const unsigned inter = ss_lbsp(nb[c], bc[c], lut[bc[c]]);
-            const uint32_t interD = (uint32_t)__popc(inter ^ bd[c]);
-            const uint32_t dd = (intraD[c] + interD) / 2;
-            uint32_t sd = (dd / 2) * (255 / 16) + cd[c];
-            sd = sd < 255 ? sd : 255;
-            ok = ok && sd <= scColorThr;
-            totDesc += dd, totSum += sd;
-          }
-          if (ok && !(totDesc > totDescThr || totSum > totColorThr)) {
-            minDesc = minDesc > totDesc ? totDesc : minDesc;
-            minSum = minSum > totSum ? totSum : minSum;
-            good++;
-          }
+        if (!(good < a.nReq && idx < a.nS)) {
+          ctx[q][2] = (uint32_t)good | (minDesc << 8) | (minSum << 16);
+          active = false;
         }
       }
-      idx++;
-#pragma unroll
-      for (int c = 0; c < C; ++c) bc[c] = nbc[c], bd[c] = nbd[c];
     }
-    uint32_t l1 = 0, hd = 0;
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      l1 += (uint32_t)abs(lastc[c] - cur[c]);
-      hd += (uint32_t)__popc((lastd[c] ^ intra[c]) & 0xffffu);
-    }
-    const float fLT = a.fLT, fST = a.fST;
-    const float normLast = ((float)l1 / maxColor + (float)hd / maxDesc) / 2;  // :498
-    a.DlastNew[i] = dlast_old * (1.0f - fST) + normLast * fST;
-    a.unstable[i] = (uint8_t)unst;
-    float dminLT = dminLT_old, dminST = dminST_old, rawLT = rawLT_old, rawST = rawST_old;
-    bool isfg;
-    uint16_t reqSelf = 0, reqNbr = 0;
-    if (good < a.nReq) {  // foreground :500-515
-      float nm = ((float)minSum / maxColor + (float)minDesc / maxDesc) / 2 + (float)(a.nReq - good) / a.nReq;
-      nm = nm > 1.0f ? 1.0f : nm;
-      dminLT = dminLT * (1.0f - fLT) + nm * fLT;
-      dminST = dminST * (1.0f - fST) + nm * fST;
-      rawLT = rawLT * (1.0f - fLT) + fLT;
-      rawST = rawST * (1.0f - fST) + fST;
-      isfg = true;
-      if (sc.cooldown && (ss_rand(fr, pi, 0) % 2u) == 0) reqSelf = ss_req(ss_rand(fr, pi, 1) % (uint32_t)a.nS, 12);
-    } else {  // background :516-552
-      const float nm = ((float)minSum / maxColor + (float)minDesc / maxDesc) / 2;
-      dminLT = dminLT * (1.0f - fLT) + nm * fLT;
-      dminST = dminST * (1.0f - fST) + nm * fST;
-      rawLT = rawLT * (1.0f - fLT);
-      rawST = rawST * (1.0f - fST);
-      isfg = false;
-      const uint32_t lr = (uint32_t)ceilf(Tv);  // (the reference computes these in size_t; every value fits 31 bits)
-      if ((ss_rand(fr, pi, 2) % lr) == 0) reqSelf = ss_req(ss_rand(fr, pi, 3) % (uint32_t)a.nS, 12);
-      const uint32_t nrand = ss_rand(fr, pi, 5);
-      if ((nrand % (use3 ? lr : (lr / 2 + 1))) == 0 || (nbrRaw > 0.995f && nbrLast < 0.010f && (nrand % ((uint32_t)sc.capLo)) == 0))
-        reqNbr = ss_req(ss_rand(fr, pi, 6) % (uint32_t)a.nS, (yn - y + 2) * 5 + (xn - x + 2));
-    }
-    a.DminLT[i] = dminLT, a.DminST[i] = dminST, a.RawLT[i] = rawLT, a.RawSTNew[i] = rawST;
-    a.raw[i] = isfg ? 255 : 0;
-    a.req[i * 2] = reqSelf, a.req[i * 2 + 1] = reqNbr;
-    // feedback :553-576
-    const float dmin_min = dminLT < dminST ? dminLT : dminST, dmin_max = dminLT > dminST ? dminLT : dminST;
-    if (lastfg || (dmin_min < 0.1f && isfg)) {
-      if (Tv < sc.capHi) Tv += div_rn(0.5f, dmin_max * Vv);
-    } else if (Tv > sc.capLo)
-      Tv -= div_rn(0.25f * Vv, dmin_max);
-    if (Tv < sc.capLo)
-      Tv = sc.capLo;
-    else if (Tv > sc.capHi)
-      Tv = sc.capHi;
-    if (dmin_max > 0.1f && blink)
-      Vv += 1.0f;
-    else if (Vv > 0.1f) {
-      Vv -= lastfg ? 0.1f / 4 : unst ? 0.1f / 2 : 0.1f;
-      if (Vv < 0.1f) Vv = 0.1f;
-    }
-    const float pw = 1.0f + dmin_min * 2;
-    if ((double)Rv < __dmul_rn((double)pw, (double)pw))  // std::pow(float, int) is a double in C++11; the square is exact
-      Rv += 0.01f * (Vv - 0.1f);
-    else {
-      Rv -= div_rn(0.01f, Vv);
-      if (Rv < 1.0f) Rv = 1.0f;
-    }
-    a.R[i] = Rv, a.V[i] = Vv, a.T[i] = Tv;
-    if constexpr (C == 3)
-      nzflag = (__popc(intra[0]) + __popc(intra[1]) + __popc(intra[2])) >= 4;  // :577-578
-    else
-      nzflag = __popc(intra[0]) >= 2;  // :430-431
-#pragma unroll
-    for (int c = 0; c < C; ++c) {  // :579-582
-      a.lastDesc[i * C + c] = (uint16_t)intra[c];
-      a.lastColor[i * C + c] = (uint8_t)cur[c];
-    }
-  } else if (x < a.cols && y < a.rows) {
-    const size_t i = sN + (size_t)y * a.cols + x;
-    a.raw[i] = 0;
-    a.req[i * 2] = 0, a.req[i * 2 + 1] = 0;
-    a.DlastNew[i] = a.DlastOld[i], a.RawSTNew[i] = a.RawSTOld[i];
   }
-  const unsigned long long bal = __ballot(nzflag);
-  if ((threadIdx.x & (kWave - 1)) == 0 && bal) atomicAdd(&nz_block, (unsigned)__popcll(bal));
+  __syncthreads();
+
+  // ---- stage 3: everything after the loop, :498-582
+  const SsScalars sc = a.sc[stream];
+  unsigned nzcount = 0;
+#pragma unroll 2
+  for (int r = 0; r < PPL; ++r) {
+    const int qq = r * kBlock + threadIdx.x, lx = qq % kSsTW, ly = qq / kSsTW;
+    const int x = x0 + lx, y = y0 + ly;
+    if (interior_of(x, y)) {
+      const size_t p = (size_t)y * a.cols + x, i = sN + p;
+      const uint32_t fr = a.frameIndex, pi = (uint32_t)p;
+      float Rv = a.R[i], Vv = a.V[i], Tv = a.T[i];
+      const float rawLT_old = a.RawLT[i], rawST_old = a.RawSTOld[i], finLT = a.FinLT[i], finST = a.FinST[i];
+      const float dlast_old = a.DlastOld[i], dminLT_old = a.DminLT[i], dminST_old = a.DminST[i];
+      const int lastfg = a.lastFG[i], blink = a.blinks[i];
+      int lastc[C], cur[C];
+      unsigned lastd[C], intra[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) lastc[c] = a.lastColor[i * C + c], lastd[c] = a.lastDesc[i * C + c], cur[c] = at(ly + 2, lx + 2, c);
+      const int unst = (Rv > 3.0f || (rawLT_old - finLT) > 0.1f || (rawST_old - finST) > 0.1f) ? 1 : 0;  // :467
+      // the random neighbour of the background branch (:526-551) depends only on `unst`
+      const bool use3 = a.use3x3 && !unst;
+      int xn, yn;
+      {
+        const uint32_t r4 = ss_rand(fr, pi, 4);
+        if (use3) {
+          const int rr = (int)(r4 % 8u);
+          xn = x + kSsN3[rr][0], yn = y + kSsN3[rr][1];
+        } else {
+          const int rr = (int)(r4 % 24u);
+          xn = x + kSsN5[rr][0], yn = y + kSsN5[rr][1];
+        }
+        xn = min(max(xn, 2), a.cols - 3), yn = min(max(yn, 2), a.rows - 3);
+      }
+      const size_t j = sN + (size_t)yn * a.cols + xn;
+      const float nbrLast = a.DlastOld[j], nbrRaw = a.RawSTOld[j];  // previous frame's copy (contract)
+      const uint32_t c0 = ctx[qq][0], c1 = ctx[qq][1], res = ctx[qq][2];
+      intra[0] = c0 & 0xffffu;
+      if constexpr (C == 3) intra[1] = c0 >> 16, intra[2] = c1 & 0xffffu;
+      const int good = (int)(res & 0xffu);
+      const uint32_t minDesc = (res >> 8) & 0xffu, minSum = res >> 16;
+      uint32_t l1 = 0, hd = 0;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        l1 += (uint32_t)abs(lastc[c] - cur[c]);
+        hd += (uint32_t)__popc((lastd[c] ^ intra[c]) & 0xffffu);
+      }
+      const float fLT = a.fLT, fST = a.fST;
+      const float normLast = ((float)l1 / maxColor + (float)hd / maxDesc) / 2;  // :498
+      a.DlastNew[i] = dlast_old * (1.0f - fST) + normLast * fST;
+      a.unstable[i] = (uint8_t)unst;
+      float dminLT = dminLT_old, dminST = dminST_old, rawLT = rawLT_old, rawST = rawST_old;
+      bool isfg;
+      uint16_t reqSelf = 0, reqNbr = 0;
+      if (good < a.nReq) {  // foreground :500-515
+        float nm = ((float)minSum / maxColor + (float)minDesc / maxDesc) / 2 + (float)(a.nReq - good) / a.nReq;
+        nm = nm > 1.0f ? 1.0f : nm;
+        dminLT = dminLT * (1.0f - fLT) + nm * fLT;
+        dminST = dminST * (1.0f - fST) + nm * fST;
+        rawLT = rawLT * (1.0f - fLT) + fLT;
+        rawST = rawST * (1.0f - fST) + fST;
+        isfg = true;
+        if (sc.cooldown && (ss_rand(fr, pi, 0) % 2u) == 0) reqSelf = ss_req(ss_rand(fr, pi, 1) % (uint32_t)a.nS, 12);
+      } else {  // background :516-552
+        const float nm = ((float)minSum / maxColor + (float)minDesc / maxDesc) / 2;
+        dminLT = dminLT * (1.0f - fLT) + nm * fLT;
+        dminST = dminST * (1.0f - fST) + nm * fST;
+        rawLT = rawLT * (1.0f - fLT);
+        rawST = rawST * (1.0f - fST);
+        isfg = false;
+        const uint32_t lr = (uint32_t)ceilf(Tv);  // (the reference computes these in size_t; every value fits 31 bits)
+        if ((ss_rand(fr, pi, 2) % lr) == 0) reqSelf = ss_req(ss_rand(fr, pi, 3) % (uint32_t)a.nS, 12);
+        const uint32_t nrand = ss_rand(fr, pi, 5);
+        if ((nrand % (use3 ? lr : (lr / 2 + 1))) == 0 || (nbrRaw > 0.995f && nbrLast < 0.010f && (nrand % ((uint32_t)sc.capLo)) == 0))
+          reqNbr = ss_req(ss_rand(fr, pi, 6) % (uint32_t)a.nS, (yn - y + 2) * 5 + (xn - x + 2));
+      }
+      a.DminLT[i] = dminLT, a.DminST[i] = dminST, a.RawLT[i] = rawLT, a.RawSTNew[i] = rawST;
+      a.raw[i] = isfg ? 255 : 0;
+      a.req[i * 2] = reqSelf, a.req[i * 2 + 1] = reqNbr;
+      // feedback :553-576
+      const float dmin_min = dminLT < dminST ? dminLT : dminST, dmin_max = dminLT > dminST ? dminLT : dminST;
+      if (lastfg || (dmin_min < 0.1f && isfg)) {
+        if (Tv < sc.capHi) Tv += div_rn(0.5f, dmin_max * Vv);
+      } else if (Tv > sc.capLo)
+        Tv -= div_rn(0.25f * Vv, dmin_max);
+      if (Tv < sc.capLo)
+        Tv = sc.capLo;
+      else if (Tv > sc.capHi)
+        Tv = sc.capHi;
+      if (dmin_max > 0.1f && blink)
+        Vv += 1.0f;
+      else if (Vv > 0.1f) {
+        Vv -= lastfg ? 0.1f / 4 : unst ? 0.1f / 2 : 0.1f;
+        if (Vv < 0.1f) Vv = 0.1f;
+      }
+      const float pw = 1.0f + dmin_min * 2;
+      if ((double)Rv < __dmul_rn((double)pw, (double)pw))  // std::pow(float, int) is a double in C++11; the square is exact
+        Rv += 0.01f * (Vv - 0.1f);
+      else {
+        Rv -= div_rn(0.01f, Vv);
+        if (Rv < 1.0f) Rv = 1.0f;
+      }
+      a.R[i] = Rv, a.V[i] = Vv, a.T[i] = Tv;
+      if constexpr (C == 3)
+        nzcount += (__popc(intra[0]) + __popc(intra[1]) + __popc(intra[2])) >= 4;  // :577-578
+      else
+        nzcount += __popc(intra[0]) >= 2;  // :430-431
+#pragma unroll
+      for (int c = 0; c < C; ++c) {  // :579-582
+        a.lastDesc[i * C + c] = (uint16_t)intra[c];
+        a.lastColor[i * C + c] = (uint8_t)cur[c];
+      }
+    } else if (x < a.cols && y < a.rows) {
+      const size_t i = sN + (size_t)y * a.cols + x;
+      a.raw[i] = 0;
+      a.req[i * 2] = 0, a.req[i * 2 + 1] = 0;
+      a.DlastNew[i] = a.DlastOld[i], a.RawSTNew[i] = a.RawSTOld[i];
+    }
+  }
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) nzcount += __shfl_xor((int)nzcount, o);
+  if ((threadIdx.x & (kWave - 1)) == 0 && nzcount) atomicAdd(&nz_block, nzcount);
   __syncthreads();
   if (threadIdx.x == 0 && nz_block) atomicAdd(&a.sc[stream].nzCount, nz_block);
 }
