@@ -2,7 +2,7 @@
 //
 // Replaces  GMG::process  package_bgs/GMG.cpp:56  ((*fgbg)(img_input, img_foreground) with initializationFrames = 20,
 // decisionThreshold = 0.7); algorithm: OpenCV 2.4 bgfg_gmg.cpp GMG_LoopBody (SURVEY.md App. B.4 — the least certain recall of
-// the whole path; the assumptions G1..G7 are listed in DESIGN.md §5.2).  The median smoothing that follows is morph_kernel.
+// the whole path; the assumptions G1..G7 are listed in DESIGN.md §5.2).  The median smoothing that follows is morph_box_kernel.
 //
 // Layout: SoA planes  colors int32 [F][P], weights f32 [F][P], nfeatures u8 [P]  (F = maxFeatures <= 64); entry f of every
 // pixel lives in plane f, so each step of the per-pixel list walk is one coalesced 256-byte access per wave.  One lane owns
