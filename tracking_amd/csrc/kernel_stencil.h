@@ -26,7 +26,7 @@ struct AsblArgs {
   double aL, bL, aD, bD;   // alphaLearn, 1-alphaLearn, alphaDetection, 1-alphaDetection
 };
 
-constexpr int kAsblTW = 64, kAsblTH = 4;  // one lane per pixel, 256 lanes
+constexpr int kAsblTW = 64, kAsblTH = 16;  // 4 consecutive pixels per lane, 256 lanes
 
 template <int C>
 __device__ __forceinline__ int asbl_gray(const uint8_t* p) {
@@ -36,45 +36,109 @@ __device__ __forceinline__ int asbl_gray(const uint8_t* p) {
     return p[0];
 }
 
+// thresholded |I - B| of one pixel, :50-62; also returns the two float images' values
+__device__ __forceinline__ int asbl_raw(int gray, int bg8, int thr, float& i_f, float& b_f) {
+  const float sf = (float)(1. / 255.);
+  i_f = (float)gray * sf, b_f = (float)bg8 * sf;
+  const float d = fabsf(i_f - b_f);
+  return sat_u8(d * 255.f) > thr ? 1 : 0;
+}
+
+// One workgroup = 64 x 16 pixels.  Stage 1: every lane computes the thresholded difference of its 4 pixels (dword loads
+// when the row pitch allows it) and keeps their float values; the 1-pixel halo ring is computed by the first 164 lanes.
+// Stage 2: 3x3 majority from LDS with byte-wise SWAR sums (cells are 0/1), selective update, dword stores.
 template <int C>
 __global__ __launch_bounds__(kBlock) void asbl_kernel(const AsblArgs a) {
-  __shared__ uint8_t raw[kAsblTH + 2][kAsblTW + 2 + 2];  // thresholded |I-B| of the tile + 1-pixel halo
+  constexpr int PITCH = kAsblTW + 8;  // tile at columns 4..67 (dword aligned), halo at 3 and 68
+  __shared__ uint32_t rawd[kAsblTH + 2][PITCH / 4];
+  uint8_t(*raw)[PITCH] = reinterpret_cast<uint8_t(*)[PITCH]>(rawd);
   const int x0 = blockIdx.x * kAsblTW, y0 = blockIdx.y * kAsblTH;
   const size_t img = (size_t)blockIdx.z * a.rows * a.cols;
   const uint8_t* frame = a.frame + img * C;
   const uint8_t* bg = a.bg_in + img;
-  const float sf = (float)(1. / 255.);
-  // raw mask for the halo'd tile; out-of-image cells replicate the nearest pixel (BORDER_REPLICATE)
-  for (int i = threadIdx.x; i < (kAsblTH + 2) * (kAsblTW + 2); i += kBlock) {
-    const int ly = i / (kAsblTW + 2), lx = i - ly * (kAsblTW + 2);
-    int y = y0 + ly - 1, x = x0 + lx - 1;
-    y = min(max(y, 0), a.rows - 1), x = min(max(x, 0), a.cols - 1);
-    const size_t p = (size_t)y * a.cols + x;
-    const float d = fabsf((float)asbl_gray<C>(frame + p * C) * sf - (float)bg[p] * sf);  // :50-57
-    raw[ly][lx] = (uint8_t)(sat_u8(d * 255.f) > a.thr ? 255 : 0);                          // :59-62
+  const bool vec = (a.cols & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.frame) | reinterpret_cast<uintptr_t>(a.bg_in) | reinterpret_cast<uintptr_t>(a.bg_out)) & 3) == 0;
+  const int lx = (threadIdx.x % (kAsblTW / 4)) * 4, ly = threadIdx.x / (kAsblTW / 4);
+  const int x = x0 + lx, y = y0 + ly;
+  const bool inside = x < a.cols && y < a.rows;  // with vec, the 4 pixels are inside together
+  float i_f[4], b_f[4];
+  {
+    uint8_t fb[4 * C], bb[4];
+    const int yc = min(y, a.rows - 1);  // out-of-image cells replicate the nearest pixel (BORDER_REPLICATE)
+    if (vec && inside) {
+      const size_t p = (size_t)yc * a.cols + x;
+      const uint32_t* fp = reinterpret_cast<const uint32_t*>(frame + p * C);
+#pragma unroll
+      for (int k = 0; k < C; ++k) {
+        const uint32_t w = fp[k];
+        fb[4 * k] = (uint8_t)w, fb[4 * k + 1] = (uint8_t)(w >> 8), fb[4 * k + 2] = (uint8_t)(w >> 16), fb[4 * k + 3] = (uint8_t)(w >> 24);
+      }
+      const uint32_t w = *reinterpret_cast<const uint32_t*>(bg + p);
+      bb[0] = (uint8_t)w, bb[1] = (uint8_t)(w >> 8), bb[2] = (uint8_t)(w >> 16), bb[3] = (uint8_t)(w >> 24);
+    } else {
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const size_t p = (size_t)yc * a.cols + min(x + o, a.cols - 1);
+#pragma unroll
+        for (int c = 0; c < C; ++c) fb[o * C + c] = frame[p * C + c];
+        bb[o] = bg[p];
+      }
+    }
+    uint32_t packed = 0;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) packed |= (uint32_t)asbl_raw(asbl_gray<C>(fb + o * C), bb[o], a.thr, i_f[o], b_f[o]) << (8 * o);
+    rawd[ly + 1][1 + lx / 4] = packed;
+  }
+  if (threadIdx.x < 2 * (kAsblTW + 2) + 2 * kAsblTH) {  // halo ring: rows -1 and TH (66 cells each), columns -1 and TW (16 each)
+    int hy, hx;
+    const int t = threadIdx.x;
+    if (t < 2 * (kAsblTW + 2))
+      hy = t < kAsblTW + 2 ? -1 : kAsblTH, hx = (t % (kAsblTW + 2)) - 1;
+    else
+      hy = (t - 2 * (kAsblTW + 2)) % kAsblTH, hx = (t - 2 * (kAsblTW + 2)) < kAsblTH ? -1 : kAsblTW;
+    const int yy = min(max(y0 + hy, 0), a.rows - 1), xx = min(max(x0 + hx, 0), a.cols - 1);
+    const size_t p = (size_t)yy * a.cols + xx;
+    float fi, fb2;
+    raw[hy + 1][4 + hx] = (uint8_t)asbl_raw(asbl_gray<C>(frame + p * C), bg[p], a.thr, fi, fb2);
   }
   __syncthreads();
-  const int lx = threadIdx.x % kAsblTW, ly = threadIdx.x / kAsblTW;
-  const int x = x0 + lx, y = y0 + ly;
-  if (x >= a.cols || y >= a.rows) return;
-  // cv::medianBlur(k=3) of a {0,255} image = majority of the 9 cells
-  int cnt = 0;
+  if (!inside) return;
+  // cv::medianBlur(k=3) of a {0,255} image = majority of the 9 cells; column sums of the 3 rows, byte-wise
+  uint32_t s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll
-  for (int dy = 0; dy < 3; ++dy)
+  for (int dy = 0; dy < 3; ++dy) s0 += rawd[ly + dy][lx / 4] >> 24, s1 += rawd[ly + dy][lx / 4 + 1], s2 += rawd[ly + dy][lx / 4 + 2] & 0xffu;  // (bytes 0-2 / 69-71 of a row are never written)
+  // columns x-1 .. x+4 are byte 3 of s0, bytes 0..3 of s1, byte 0 of s2
+  const uint32_t left = s0, right = s2;
+  const uint32_t cnt4 = s1 + ((s1 << 8) | left) + ((s1 >> 8) | (right << 24));  // per byte: c[o-1] + c[o] + c[o+1] (<= 9)
+  uint32_t out_b = 0, out_m = 0;
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) cnt += raw[ly + dy][lx + dx] != 0;
-  const int m = cnt >= 5 ? 255 : 0;
-  const size_t p = (size_t)y * a.cols + x;
-  const float i_f = (float)asbl_gray<C>(frame + p * C) * sf;
-  float b_f = (float)bg[p] * sf;
-  if (a.learn)
-    b_f = add_weighted(i_f, a.aL, b_f, a.bL);  // :69  (MatExpr -> addWeighted)
-  else if (m == 0)
-    b_f = (float)__dadd_rn(__dmul_rn(a.aD, (double)i_f), __dmul_rn(a.bD, (double)b_f));  // :83-86 scalar double expression
-  const int b8 = sat_u8(b_f * 255.f);  // :92-94
-  a.bg_out[img + p] = (uint8_t)b8;
-  if (a.bg_img) a.bg_img[img + p] = (uint8_t)b8;
-  if (a.fg) a.fg[img + p] = (uint8_t)m;
+  for (int o = 0; o < 4; ++o) {
+    const int m = ((cnt4 >> (8 * o)) & 0xffu) >= 5 ? 255 : 0;
+    float bf = b_f[o];
+    if (a.learn)
+      bf = add_weighted(i_f[o], a.aL, bf, a.bL);  // :69  (MatExpr -> addWeighted)
+    else if (m == 0)
+      bf = (float)__dadd_rn(__dmul_rn(a.aD, (double)i_f[o]), __dmul_rn(a.bD, (double)bf));  // :83-86 scalar double expression
+    out_b |= (uint32_t)sat_u8(bf * 255.f) << (8 * o);  // :92-94
+    out_m |= (uint32_t)m << (8 * o);
+  }
+  const size_t p = img + (size_t)y * a.cols + x;
+  if (vec) {
+    *reinterpret_cast<uint32_t*>(a.bg_out + p) = out_b;
+    if (a.bg_img && (reinterpret_cast<uintptr_t>(a.bg_img) & 3) == 0)
+      *reinterpret_cast<uint32_t*>(a.bg_img + p) = out_b;
+    else if (a.bg_img)
+      for (int o = 0; o < 4; ++o) a.bg_img[p + o] = (uint8_t)(out_b >> (8 * o));
+    if (a.fg && (reinterpret_cast<uintptr_t>(a.fg) & 3) == 0)
+      *reinterpret_cast<uint32_t*>(a.fg + p) = out_m;
+    else if (a.fg)
+      for (int o = 0; o < 4; ++o) a.fg[p + o] = (uint8_t)(out_m >> (8 * o));
+  } else {
+    for (int o = 0; o < 4 && x + o < a.cols; ++o) {
+      a.bg_out[p + o] = (uint8_t)(out_b >> (8 * o));
+      if (a.bg_img) a.bg_img[p + o] = (uint8_t)(out_b >> (8 * o));
+      if (a.fg) a.fg[p + o] = (uint8_t)(out_m >> (8 * o));
+    }
+  }
 }
 
 // ----------------------------------------------------------------------------------------------------- LBSP
