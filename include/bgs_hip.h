@@ -242,6 +242,24 @@ int bgs_lbsp_describe_device(int hip_device, const void* d_img, int rows, int co
 int bgs_mask_morph_device(int hip_device, const void* d_src, void* d_dst, int rows, int cols, int op, int ksize,
                           int iterations, void* hip_stream);
 
+/* Connected-component seeding of a byte mask on device: what OpenCV-legacy's blob detector derives
+ * from the mask right after IBGS::process (ustc_src/trackingMain.cpp:56-57, :166; cvFindContours + bounding rectangles;
+ * in-tree kin: package_bgs/jmo/BlobExtraction.cpp).  Components are the maximal 8- (or 4-) connected sets of non-zero
+ * pixels.  A component is named by `root`, the raster index (y*cols + x) of its first pixel; boxes are written sorted by
+ * root, so the output is deterministic.  *d_count receives the number of components found (it may exceed max_boxes;
+ * only the first max_boxes are written).  d_labels (optional, [rows*cols] int32): root of each pixel's component, -1 for
+ * background.  d_work: bgs_mask_components_workspace(rows, cols) bytes of device scratch; with d_work the call is
+ * asynchronous on hip_stream, with NULL it allocates, synchronises and frees (slow path). */
+typedef struct bgs_box {
+  int32_t x, y, w, h; /* bounding rectangle */
+  int32_t area;       /* pixels in the component */
+  int32_t root;       /* raster index of the component's first pixel */
+} bgs_box;
+size_t bgs_mask_components_workspace(int rows, int cols);
+int bgs_mask_components_device(int hip_device, const void* d_mask, int rows, int cols, int connectivity,
+                               int32_t* d_labels, bgs_box* d_boxes, int max_boxes, int32_t* d_count, void* d_work,
+                               void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -191,6 +191,55 @@ void orc_lbsp_describe(const uint8_t* img, size_t step, int rows, int cols, int 
 
 /* ---------------------------------------------------------------- engine plumbing */
 
+/* N1: connected components of a byte mask (the definition the GPU kernels are checked against; the reference's consumer,
+ * OpenCV-legacy's CvBlobDetectorCC -> cvFindContours + bounding rects, ustc_src/trackingMain.cpp:56-57, is not in the
+ * tree).  Raster scan; every unlabelled non-zero pixel starts a component named by its own raster index (root) and is
+ * flooded with an explicit stack, so components come out in increasing root order.  labels: root per pixel, -1 for
+ * background (may be NULL).  Returns the number of components; writes the first max_boxes. */
+int orc_components(const uint8_t* mask, int rows, int cols, int connectivity, int32_t* labels, bgs_box* boxes, int max_boxes) {
+  const size_t n = (size_t)rows * cols;
+  int32_t* L = labels ? labels : (int32_t*)malloc(n * sizeof(int32_t));
+  int32_t* stack = (int32_t*)malloc(n * sizeof(int32_t));
+  for (size_t i = 0; i < n; ++i) L[i] = -1;
+  int count = 0;
+  for (size_t p = 0; p < n; ++p) {
+    if (!mask[p] || L[p] >= 0) continue;
+    int minx = cols, miny = rows, maxx = -1, maxy = -1, area = 0;
+    size_t top = 0;
+    stack[top++] = (int32_t)p;
+    L[p] = (int32_t)p;
+    while (top) {
+      const int32_t q = stack[--top];
+      const int y = q / cols, x = q - y * cols;
+      if (x < minx) minx = x;
+      if (x > maxx) maxx = x;
+      if (y < miny) miny = y;
+      if (y > maxy) maxy = y;
+      area++;
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          if (!dy && !dx) continue;
+          if (connectivity == 4 && dy && dx) continue;
+          const int yy = y + dy, xx = x + dx;
+          if (yy < 0 || yy >= rows || xx < 0 || xx >= cols) continue;
+          const size_t r = (size_t)yy * cols + xx;
+          if (mask[r] && L[r] < 0) {
+            L[r] = (int32_t)p;
+            stack[top++] = (int32_t)r;
+          }
+        }
+    }
+    if (count < max_boxes) {
+      bgs_box b = {minx, miny, maxx - minx + 1, maxy - miny + 1, area, (int32_t)p};
+      boxes[count] = b;
+    }
+    count++;
+  }
+  free(stack);
+  if (!labels) free(L);
+  return count;
+}
+
 int orc_default_params(bgs_algo algo, bgs_params* p) {
   if (!p) return BGS_ERR_INVALID;
   uint32_t sz = p->struct_size;

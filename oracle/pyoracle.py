@@ -51,6 +51,8 @@ def lib():
             getattr(l, n).restype = None
         l.orc_floodfill_from_origin.argtypes = [_P, C.c_int, C.c_int, C.c_uint8]
         l.orc_floodfill_from_origin.restype = None
+        l.orc_components.argtypes = [_P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int]
+        l.orc_components.restype = C.c_int
         _lib = l
     return _lib
 
@@ -169,6 +171,18 @@ def floodfill_from_origin(img, newval=255):
     out = np.ascontiguousarray(img).copy()
     lib().orc_floodfill_from_origin(_ptr(out), out.shape[0], out.shape[1], newval)
     return out
+
+
+BOX_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4"), ("area", "<i4"), ("root", "<i4")])
+
+
+def components(mask, connectivity=8, max_boxes=1 << 20):
+    """(labels int32 [rows][cols] = root index or -1, boxes[count] as BOX_DTYPE sorted by root)."""
+    m = np.ascontiguousarray(mask, np.uint8)
+    labels = np.empty(m.shape, np.int32)
+    boxes = np.zeros(max_boxes, BOX_DTYPE)
+    n = lib().orc_components(_ptr(m), m.shape[0], m.shape[1], connectivity, _ptr(labels), _ptr(boxes), max_boxes)
+    return labels, boxes[:min(n, max_boxes)], n
 
 
 # ---- reference-built checkers (oracle/_ref, compiled from /root/reference sources in this container) ----

@@ -680,3 +680,76 @@ def test_gmg_gray_and_ragged(golden_gray):
     run_pair(capi.GMG, np.concatenate([golden_gray, golden_gray]), params=_params(capi.GMG, gmg_init_frames=6))
     frames = synth.random_frames(12, 37, 53, 3, seed=4)
     run_pair(capi.GMG, frames, params=_params(capi.GMG, gmg_init_frames=5))
+
+
+def _cc_masks(shape, rng):
+    rows, cols = shape
+    yield "empty", np.zeros(shape, np.uint8)
+    yield "full", np.full(shape, 255, np.uint8)
+    for density in (0.05, 0.3, 0.45, 0.6):  # 0.45-0.6: around the percolation thresholds of 8- and 4-connectivity
+        yield "random%.2f" % density, np.where(rng.random(shape) < density, 255, 0).astype(np.uint8)
+    m = np.zeros(shape, np.uint8)  # isolated pixels on a lattice: the maximum number of components
+    m[::2, ::2] = 1
+    yield "lattice", m
+    m = np.zeros(shape, np.uint8)  # diagonal staircases: joined only under 8-connectivity
+    for k in range(0, rows + cols, 7):
+        for t in range(min(rows, cols)):
+            y, x = t, k - t
+            if 0 <= x < cols:
+                m[y, x] = 200
+    yield "diagonals", m
+    if rows > 8 and cols > 8:
+        m = np.zeros(shape, np.uint8)  # one serpentine component spanning the image: long union-find chains
+        m[1:-1:4, 1:-1] = 255
+        m[1:-1, 1] = 255
+        m[3:-1:8, 1] = 0
+        m[1:-1, -2] |= np.where((np.arange(rows - 2) // 4) % 2 == 0, 255, 0).astype(np.uint8)
+        yield "serpentine", m
+        m = np.zeros(shape, np.uint8)  # blobs like a foreground mask: filled rectangles and rings
+        for _ in range(12):
+            y, x = rng.integers(0, rows - 4), rng.integers(0, cols - 4)
+            h, w = rng.integers(2, max(3, rows // 3)), rng.integers(2, max(3, cols // 3))
+            m[y:y + h, x:x + w] = 255
+            if h > 6 and w > 6:
+                m[y + 2:y + h - 2, x + 2:x + w - 2] = 0
+        yield "blobs", m
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (37, 53), (1, 1), (1, 300), (300, 1), (130, 257), (240, 320)])
+@pytest.mark.parametrize("connectivity", [8, 4])
+def test_connected_components_vs_oracle(shape, connectivity):
+    """N1: labels (root per pixel), boxes sorted by root, areas, count - identical to the oracle's flood-fill labelling."""
+    torch = _torch()
+    from tracking_amd.engine import mask_components_device
+    rng = np.random.default_rng(shape[0] * 7919 + shape[1] + connectivity)
+    for tag, m in _cc_masks(shape, rng):
+        want_l, want_b, want_n = pyoracle.components(m, connectivity)
+        labels, boxes, n = mask_components_device(torch.from_numpy(m).cuda(), connectivity, max_boxes=shape[0] * shape[1] + 1)
+        assert n == want_n, (tag, n, want_n)
+        assert np.array_equal(labels.cpu().numpy(), want_l), tag
+        got = boxes.cpu().numpy()
+        want = np.stack([want_b[f] for f in ("x", "y", "w", "h", "area", "root")], axis=1) if want_n else np.zeros((0, 6), np.int32)
+        assert np.array_equal(got, want), tag
+
+
+def test_connected_components_truncation_and_full_size():
+    """max_boxes smaller than the component count: the count is still the total, the first boxes are still exact;
+    1080p mask from the SuBSENSE-like blob generator; no label image requested."""
+    torch = _torch()
+    from tracking_amd.engine import mask_components_device
+    rng = np.random.default_rng(5)
+    m = np.where(rng.random((96, 160)) < 0.2, 255, 0).astype(np.uint8)
+    want_l, want_b, want_n = pyoracle.components(m, 8)
+    assert want_n > 40
+    labels, boxes, n = mask_components_device(torch.from_numpy(m).cuda(), 8, max_boxes=40, want_labels=False)
+    assert labels is None and n == want_n and boxes.shape[0] == 40
+    assert np.array_equal(boxes.cpu().numpy()[:, 5], want_b["root"][:40]) and np.array_equal(boxes.cpu().numpy()[:, 4], want_b["area"][:40])
+    big = np.zeros((1080, 1920), np.uint8)
+    for _ in range(60):
+        y, x = rng.integers(0, 1000), rng.integers(0, 1800)
+        big[y:y + rng.integers(5, 80), x:x + rng.integers(5, 120)] = 255
+    big[rng.random(big.shape) < 0.001] = 255
+    want_l, want_b, want_n = pyoracle.components(big, 8)
+    labels, boxes, n = mask_components_device(torch.from_numpy(big).cuda(), 8, max_boxes=8192)
+    assert n == want_n and np.array_equal(labels.cpu().numpy(), want_l)
+    assert np.array_equal(boxes.cpu().numpy(), np.stack([want_b[f] for f in ("x", "y", "w", "h", "area", "root")], axis=1))

@@ -299,3 +299,41 @@ def test_gmg_oracle_phases(golden_frames):
     w = o.get_state("weights", (64, n), np.float32)
     assert nf.min() >= 1 and nf.max() <= 64
     assert np.allclose(w.sum(0), 1.0, atol=0.05)  # histograms stay (nearly) normalised
+
+
+def test_unit_absdiff_is_integer_absdiff():
+    """The reference converts frames to float/255, takes |I - B| and converts back (AdaptiveBackgroundLearning.cpp:50,64;
+    AdaptiveSelectiveBackgroundLearning.cpp:50-57).  For all 65 536 byte pairs that round trip equals |i - b|: the kernels use
+    the integer form (abl_kernel, asbl_kernel); this is the exhaustive check that licenses it."""
+    sf = np.float32(1.0 / 255.0)
+    i = np.arange(256, dtype=np.float32)[:, None] * sf
+    b = np.arange(256, dtype=np.float32)[None, :] * sf
+    v = (np.abs(i - b).astype(np.float32) * np.float32(255.0)).astype(np.float32)
+    got = np.clip(np.rint(v), 0, 255).astype(np.int64)  # cv::saturate_cast<uchar>(float): cvRound, ties to even
+    want = np.abs(np.arange(256)[:, None] - np.arange(256)[None, :])
+    assert np.array_equal(got, want)
+    assert float(np.min(np.abs(v - np.floor(v) - 0.5))) > 0.4  # nowhere near a rounding tie
+
+
+@pytest.mark.parametrize("connectivity", [8, 4])
+def test_components_oracle_vs_scipy(connectivity):
+    """The oracle's connected components against an independent implementation (scipy.ndimage.label + find_objects):
+    same partition, same bounding boxes and areas, roots = first pixel in raster order, boxes sorted by root."""
+    from scipy import ndimage
+    rng = np.random.default_rng(connectivity)
+    structure = np.ones((3, 3), int) if connectivity == 8 else None
+    for shape, density in (((40, 60), 0.3), ((40, 60), 0.55), ((1, 50), 0.5), ((33, 1), 0.5), ((64, 64), 0.0), ((64, 64), 1.0)):
+        m = np.where(rng.random(shape) < density, 255, 0).astype(np.uint8)
+        labels, boxes, n = pyoracle.components(m, connectivity)
+        ref, nref = ndimage.label(m, structure=structure)
+        assert n == nref == len(boxes)
+        assert np.array_equal(labels >= 0, m != 0)
+        # same partition: scipy label -> our root must be a bijection, and the root is the component's smallest raster index
+        for k, sl in enumerate(ndimage.find_objects(ref), start=1):
+            sel = ref == k
+            roots = np.unique(labels[sel])
+            assert len(roots) == 1 and roots[0] == np.flatnonzero(sel.ravel())[0]
+            b = boxes[boxes["root"] == roots[0]][0]
+            assert (b["y"], b["x"], b["h"], b["w"]) == (sl[0].start, sl[1].start, sl[0].stop - sl[0].start, sl[1].stop - sl[1].start)
+            assert b["area"] == int(sel.sum())
+        assert np.all(np.diff(boxes["root"]) > 0)

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "kernel_gmg.h"
+#include "kernel_cc.h"
 #include "kernel_mog1.h"
 #include "kernel_mog2.h"
 #include "kernel_pointwise.h"
@@ -1027,6 +1028,53 @@ int bgs_mask_morph_device(int hip_device, const void* d_src, void* d_dst, int ro
     (void)hipFree(tmp);
   }
   if (er != hipSuccess) return fail(BGS_ERR_HIP, "morph kernel launch failed: %s", hipGetErrorString(er));
+  return BGS_OK;
+}
+
+size_t bgs_mask_components_workspace(int rows, int cols) {
+  if (rows <= 0 || cols <= 0) return 0;
+  const size_t n = (size_t)rows * cols, nb = (n + bgs::kCcPerBlock - 1) / bgs::kCcPerBlock;
+  return (2 * n + nb + 16) * sizeof(int32_t);  // labels (when the caller passes none) + ids + per-block root counts
+}
+
+int bgs_mask_components_device(int hip_device, const void* d_mask, int rows, int cols, int connectivity, int32_t* d_labels,
+                               bgs_box* d_boxes, int max_boxes, int32_t* d_count, void* d_work, void* hip_stream) {
+  static_assert(sizeof(bgs_box) == sizeof(bgs::CcBox), "bgs_box layout");
+  if (!d_mask || !d_boxes || !d_count || rows <= 0 || cols <= 0 || max_boxes < 0 || (connectivity != 4 && connectivity != 8))
+    return fail(BGS_ERR_INVALID, "bgs_mask_components_device: bad argument");
+  const size_t n = (size_t)rows * cols;
+  if (n >= (size_t)0x7fffffff) return fail(BGS_ERR_UNSUPPORTED, "bgs_mask_components_device: image too large for 32-bit labels");
+  HIP_TRY(hipSetDevice(hip_device));
+  hipStream_t s = (hipStream_t)hip_stream;
+  void* own = nullptr;
+  if (!d_work) {
+    HIP_TRY(hipMalloc(&own, bgs_mask_components_workspace(rows, cols)));
+    d_work = own;
+  }
+  const int nb = (int)((n + bgs::kCcPerBlock - 1) / bgs::kCcPerBlock);
+  int* id = (int*)d_work;
+  int* L = d_labels ? (int*)d_labels : id + n;
+  int* blockCount = id + 2 * n;
+  const int conn8 = connectivity == 8;
+  const dim3 grid(blocks_for(n)), block(bgs::kBlock);
+  hipLaunchKernelGGL(bgs::cc_init_kernel, grid, block, 0, s, (const uint8_t*)d_mask, L, rows, cols, conn8);
+  hipLaunchKernelGGL(bgs::cc_compress_kernel, grid, block, 0, s, L, n);
+  hipLaunchKernelGGL(bgs::cc_merge_kernel, grid, block, 0, s, L, rows, cols, conn8);
+  hipLaunchKernelGGL(bgs::cc_compress_kernel, grid, block, 0, s, L, n);
+  hipLaunchKernelGGL(bgs::cc_count_kernel, dim3(nb), block, 0, s, (const int*)L, n, blockCount);
+  hipLaunchKernelGGL(bgs::cc_scan_kernel, dim3(1), block, 0, s, blockCount, nb, (int*)d_count);
+  hipLaunchKernelGGL(bgs::cc_scatter_kernel, dim3(nb), block, 0, s, (const int*)L, n, (const int*)blockCount, id, (bgs::CcBox*)d_boxes, max_boxes);
+  if (max_boxes > 0) {
+    hipLaunchKernelGGL(bgs::cc_boxes_kernel, grid, block, 0, s, (const int*)L, (const int*)id, rows, cols, (bgs::CcBox*)d_boxes, max_boxes);
+    hipLaunchKernelGGL(bgs::cc_finish_kernel, dim3(blocks_for((size_t)max_boxes)), block, 0, s, (bgs::CcBox*)d_boxes, (const int*)d_count, max_boxes);
+  }
+  hipError_t er = hipGetLastError();
+  if (own) {
+    const hipError_t e2 = hipStreamSynchronize(s);
+    if (er == hipSuccess) er = e2;
+    (void)hipFree(own);
+  }
+  if (er != hipSuccess) return fail(BGS_ERR_HIP, "connected components failed: %s", hipGetErrorString(er));
   return BGS_OK;
 }
 

@@ -1,0 +1,210 @@
+// kernel_cc.h — N1: connected-component seeding of a foreground mask on the device, so that only blob rectangles
+// (not full masks) cross PCIe to the blob tracker.
+//
+// In the reference the mask goes straight from IBGS::process into OpenCV-legacy's blob detector
+// (ustc_src/trackingMain.cpp:56-57 cvCreateBlobDetectorCC/Simple, :166 DetectNewBlob), which finds the 8-connected
+// foreground regions through cvFindContours and keeps their bounding rectangles; package_bgs/jmo/BlobExtraction.cpp is
+// the in-tree run-length labeller of the same kind.  OpenCV legacy is not in the tree, so the contract here is the
+// definition itself: components = maximal 8- (or 4-) connected sets of non-zero pixels; a component is named by the
+// raster index of its first pixel ("root"); boxes come out sorted by root.
+//
+// Algorithm: label equivalence with union-find (the minimum index wins, so the root IS the first pixel in raster order):
+//   cc_init      L[p] = smallest-index foreground neighbour among NW, N, NE, W (else p);  -1 for background
+//   cc_compress  L[p] = root(L[p])
+//   cc_merge     union(p, n) for every foreground neighbour pair  (atomicMin on the larger root)
+//   cc_compress  again: every pixel now holds its component's root
+//   cc_count / cc_scan / cc_scatter   roots -> dense ids in raster order (wave ballot + popcount prefix, two-level scan)
+//   cc_boxes     per pixel atomicMin/Max/Add into its component's box (one atomic per wave where the wave is uniform)
+//   cc_finish    (minx, miny, maxx, maxy) -> (x, y, w, h)
+#pragma once
+#include "bgs_device.h"
+
+namespace bgs {
+
+struct CcBox {
+  int x, y, w, h, area, root;  // during accumulation: x,y = min corner, w,h = max corner
+};
+
+constexpr int kCcPerBlock = kBlock * 4;  // pixels per workgroup in the counting kernels
+
+__device__ __forceinline__ int cc_find(const int* L, int p) {
+  int r = L[p];
+  while (true) {
+    const int q = L[r];
+    if (q == r) return r;
+    r = q;
+  }
+}
+
+__device__ __forceinline__ void cc_union(int* L, int a, int b) {
+  while (true) {
+    a = cc_find(L, a), b = cc_find(L, b);
+    if (a == b) return;
+    if (a > b) {
+      const int t = a;
+      a = b, b = t;
+    }
+    const int old = atomicMin(&L[b], a);  // b was a root when we looked: make it point at the smaller root
+    if (old == b) return;
+    b = old;  // somebody re-rooted b in between: retry from there
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void cc_init_kernel(const uint8_t* mask, int* L, int rows, int cols, int conn8) {
+  const size_t N = (size_t)rows * cols;
+  const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= N) return;
+  if (!mask[p]) {
+    L[p] = -1;
+    return;
+  }
+  const int y = (int)(p / cols), x = (int)(p - (size_t)y * cols);
+  int l = (int)p;
+  if (x > 0 && mask[p - 1]) l = (int)p - 1;
+  if (y > 0) {
+    if (conn8 && x + 1 < cols && mask[p - cols + 1]) l = (int)p - cols + 1;
+    if (mask[p - cols]) l = (int)p - cols;
+    if (conn8 && x > 0 && mask[p - cols - 1]) l = (int)p - cols - 1;
+  }
+  L[p] = l;
+}
+
+__global__ __launch_bounds__(kBlock) void cc_compress_kernel(int* L, size_t N) {
+  const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= N) return;
+  const int l = L[p];
+  if (l < 0 || l == (int)p) return;
+  L[p] = cc_find(L, l);  // concurrent writers only ever store an ancestor: any value read on the way is valid
+}
+
+__global__ __launch_bounds__(kBlock) void cc_merge_kernel(int* L, int rows, int cols, int conn8) {
+  const size_t N = (size_t)rows * cols;
+  const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= N || L[p] < 0) return;
+  const int y = (int)(p / cols), x = (int)(p - (size_t)y * cols);
+  // W and N (and the two upper diagonals) cover every adjacent pair once
+  if (x > 0 && L[p - 1] >= 0) cc_union(L, (int)p, (int)p - 1);
+  if (y > 0) {
+    if (L[p - cols] >= 0) cc_union(L, (int)p, (int)p - cols);
+    if (conn8) {
+      // a diagonal neighbour is already joined through N or W/E unless that orthogonal pixel is background
+      if (x > 0 && L[p - cols - 1] >= 0 && L[p - cols] < 0 && L[p - 1] < 0) cc_union(L, (int)p, (int)p - cols - 1);
+      if (x + 1 < cols && L[p - cols + 1] >= 0 && L[p - cols] < 0) cc_union(L, (int)p, (int)p - cols + 1);
+    }
+  }
+}
+
+// number of roots in each chunk of kCcPerBlock pixels
+__global__ __launch_bounds__(kBlock) void cc_count_kernel(const int* L, size_t N, int* blockCount) {
+  __shared__ int wsum[kBlock / kWave];
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const size_t p = (size_t)blockIdx.x * kCcPerBlock + k * kBlock + threadIdx.x;
+    const bool root = p < N && L[p] == (int)p;
+    c += __popcll(__ballot(root));  // same value in every lane of the wave
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0) wsum[threadIdx.x / kWave] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) blockCount[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// exclusive scan of blockCount[nb] in place by one workgroup; total -> *count
+__global__ __launch_bounds__(kBlock) void cc_scan_kernel(int* blockCount, int nb, int* count) {
+  __shared__ int part[kBlock];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += kBlock) {
+    const int i = base + threadIdx.x;
+    const int v = i < nb ? blockCount[i] : 0;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < kBlock; o <<= 1) {  // Hillis-Steele inclusive scan
+      const int t = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+      __syncthreads();
+      part[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nb) blockCount[i] = carry + part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == kBlock - 1) carry += part[kBlock - 1];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *count = carry;
+}
+
+// dense id of every root, in raster order; the boxes start empty
+__global__ __launch_bounds__(kBlock) void cc_scatter_kernel(const int* L, size_t N, const int* blockOffset, int* id, CcBox* boxes, int max_boxes) {
+  __shared__ int wbase[4][kBlock / kWave];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  bool root[4];
+  unsigned long long bal[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const size_t p = (size_t)blockIdx.x * kCcPerBlock + k * kBlock + threadIdx.x;
+    root[k] = p < N && L[p] == (int)p;
+    bal[k] = __ballot(root[k]);
+    if (lane == 0) wbase[k][wave] = __popcll(bal[k]);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // 16 wave counts -> exclusive offsets in pixel order (k major, wave minor)
+    int run = blockOffset[blockIdx.x];
+    for (int k = 0; k < 4; ++k)
+      for (int w = 0; w < kBlock / kWave; ++w) {
+        const int c = wbase[k][w];
+        wbase[k][w] = run;
+        run += c;
+      }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (!root[k]) continue;
+    const size_t p = (size_t)blockIdx.x * kCcPerBlock + k * kBlock + threadIdx.x;
+    const int my = wbase[k][wave] + __popcll(bal[k] & ((1ull << lane) - 1ull));
+    id[p] = my;
+    if (my < max_boxes) boxes[my] = CcBox{0x7fffffff, 0x7fffffff, -1, -1, 0, (int)p};
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void cc_boxes_kernel(const int* L, const int* id, int rows, int cols, CcBox* boxes, int max_boxes) {
+  const size_t N = (size_t)rows * cols;
+  const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const int l = p < N ? L[p] : -1;
+  const int my = l >= 0 ? id[l] : -1;
+  const bool take = my >= 0 && my < max_boxes;
+  int y = 0, x = 0;
+  if (p < N) y = (int)(p / cols), x = (int)(p - (size_t)y * cols);
+  // a big blob fills whole waves: reduce inside the wave and issue one set of atomics instead of 64
+  const int first = __shfl(my, __ffsll((long long)__ballot(true)) - 1);
+  if (__all(my == first)) {
+    if (!take) return;
+    int mnx = x, mny = y, mxx = x, mxy = y, cnt = 1;
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+      mnx = min(mnx, __shfl_xor(mnx, o)), mny = min(mny, __shfl_xor(mny, o));
+      mxx = max(mxx, __shfl_xor(mxx, o)), mxy = max(mxy, __shfl_xor(mxy, o));
+      cnt += __shfl_xor(cnt, o);
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+      CcBox* b = boxes + my;
+      atomicMin(&b->x, mnx), atomicMin(&b->y, mny), atomicMax(&b->w, mxx), atomicMax(&b->h, mxy), atomicAdd(&b->area, cnt);
+    }
+    return;
+  }
+  if (take) {
+    CcBox* b = boxes + my;
+    atomicMin(&b->x, x), atomicMin(&b->y, y), atomicMax(&b->w, x), atomicMax(&b->h, y), atomicAdd(&b->area, 1);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void cc_finish_kernel(CcBox* boxes, const int* count, int max_boxes) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= min(*count, max_boxes)) return;
+  CcBox b = boxes[i];
+  b.w = b.w - b.x + 1, b.h = b.h - b.y + 1;
+  boxes[i] = b;
+}
+
+}  // namespace bgs

@@ -40,8 +40,8 @@ __device__ __forceinline__ int asbl_gray(const uint8_t* p) {
 __device__ __forceinline__ int asbl_raw(int gray, int bg8, int thr, float& i_f, float& b_f) {
   const float sf = (float)(1. / 255.);
   i_f = (float)gray * sf, b_f = (float)bg8 * sf;
-  const float d = fabsf(i_f - b_f);
-  return sat_u8(d * 255.f) > thr ? 1 : 0;
+  // saturate(|i/255 - b/255| * 255) == |i - b| for every byte pair (CPU test test_unit_absdiff_is_integer_absdiff)
+  return abs(gray - bg8) > thr ? 1 : 0;
 }
 
 // One workgroup = 64 x 16 pixels.  Stage 1: every lane computes the thresholded difference of its 4 pixels (dword loads

@@ -143,3 +143,24 @@ def mask_morph_device(src, op, ksize=3, iterations=1, device=0, hip_stream=None)
         hip_stream = torch.cuda.current_stream().cuda_stream
     capi.check(capi.lib().bgs_mask_morph_device(device, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), rows, cols, op, ksize, iterations, C.c_void_p(hip_stream)))
     return dst
+
+
+BOX_FIELDS = ("x", "y", "w", "h", "area", "root")
+
+
+def mask_components_device(mask, connectivity=8, max_boxes=4096, want_labels=True, device=0, hip_stream=None):
+    """Connected components of a torch CUDA uint8 mask [rows][cols] (bgs_mask_components_device).
+    Returns (labels int32 [rows][cols] or None, boxes int32 [min(count, max_boxes)][6] = BOX_FIELDS, count)."""
+    import torch
+    rows, cols = mask.shape
+    if hip_stream is None:
+        hip_stream = torch.cuda.current_stream().cuda_stream
+    labels = torch.empty((rows, cols), dtype=torch.int32, device=mask.device) if want_labels else None
+    boxes = torch.zeros((max(max_boxes, 1), 6), dtype=torch.int32, device=mask.device)
+    count = torch.zeros(1, dtype=torch.int32, device=mask.device)
+    work = torch.empty(capi.lib().bgs_mask_components_workspace(rows, cols), dtype=torch.uint8, device=mask.device)
+    capi.check(capi.lib().bgs_mask_components_device(device, C.c_void_p(mask.data_ptr()), rows, cols, connectivity,
+                                                     C.c_void_p(labels.data_ptr() if want_labels else 0), C.c_void_p(boxes.data_ptr()), max_boxes,
+                                                     C.c_void_p(count.data_ptr()), C.c_void_p(work.data_ptr()), C.c_void_p(hip_stream)))
+    n = int(count.item())
+    return labels, boxes[:min(n, max_boxes)], n
