@@ -100,6 +100,31 @@ def run_subsense(S, steps=30, kind="surv"):
     e.close()
 
 
+def run_cc():
+    """N1: connected components of a 1080p foreground-like mask (blobs + salt noise) and of a worst case (random 45 %)."""
+    import numpy as np
+    from tracking_amd.engine import mask_components_device
+    rng = np.random.default_rng(1)
+    blobs = np.zeros((1080, 1920), np.uint8)
+    for _ in range(60):
+        y, x = rng.integers(0, 1000), rng.integers(0, 1800)
+        blobs[y:y + rng.integers(5, 80), x:x + rng.integers(5, 120)] = 255
+    blobs[rng.random(blobs.shape) < 0.001] = 255
+    for name, m in (("blobs+noise", blobs), ("random 45%", np.where(rng.random((1080, 1920)) < 0.45, 255, 0).astype(np.uint8)), ("full", np.full((1080, 1920), 255, np.uint8))):
+        d = torch.from_numpy(m).cuda()
+        for _ in range(3):
+            labels, boxes, n = mask_components_device(d, 8, max_boxes=65536)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            labels, boxes, n = mask_components_device(d, 8, max_boxes=65536)
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 20
+        print("connected components 1920x1080 %-12s: %d components, %.3f ms per mask (incl. count read-back) -> %.1f Mpix/s" % (name, n, ms, 1080 * 1920 / ms / 1e3))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=8)
@@ -109,6 +134,9 @@ def main():
     if args.only == "subsense":
         run_subsense(2)
         run_subsense(2, kind="smooth")
+        return
+    if args.only == "cc":
+        run_cc()
         return
     if args.only == "subsense8":
         run_subsense(8)

@@ -1065,7 +1065,7 @@ int bgs_mask_components_device(int hip_device, const void* d_mask, int rows, int
   hipLaunchKernelGGL(bgs::cc_scan_kernel, dim3(1), block, 0, s, blockCount, nb, (int*)d_count);
   hipLaunchKernelGGL(bgs::cc_scatter_kernel, dim3(nb), block, 0, s, (const int*)L, n, (const int*)blockCount, id, (bgs::CcBox*)d_boxes, max_boxes);
   if (max_boxes > 0) {
-    hipLaunchKernelGGL(bgs::cc_boxes_kernel, grid, block, 0, s, (const int*)L, (const int*)id, rows, cols, (bgs::CcBox*)d_boxes, max_boxes);
+    hipLaunchKernelGGL(bgs::cc_boxes_kernel, dim3(blocks_for((n + bgs::kCcBoxPer - 1) / bgs::kCcBoxPer)), block, 0, s, (const int*)L, (const int*)id, rows, cols, (bgs::CcBox*)d_boxes, max_boxes);
     hipLaunchKernelGGL(bgs::cc_finish_kernel, dim3(blocks_for((size_t)max_boxes)), block, 0, s, (bgs::CcBox*)d_boxes, (const int*)d_count, max_boxes);
   }
   hipError_t er = hipGetLastError();

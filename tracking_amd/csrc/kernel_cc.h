@@ -14,7 +14,7 @@
 //   cc_merge     union(p, n) for every foreground neighbour pair  (atomicMin on the larger root)
 //   cc_compress  again: every pixel now holds its component's root
 //   cc_count / cc_scan / cc_scatter   roots -> dense ids in raster order (wave ballot + popcount prefix, two-level scan)
-//   cc_boxes     per pixel atomicMin/Max/Add into its component's box (one atomic per wave where the wave is uniform)
+//   cc_boxes     atomicMin/Max/Add into the component's box, merged per lane run and per wave first
 //   cc_finish    (minx, miny, maxx, maxy) -> (x, y, w, h)
 #pragma once
 #include "bgs_device.h"
@@ -168,34 +168,48 @@ __global__ __launch_bounds__(kBlock) void cc_scatter_kernel(const int* L, size_t
   }
 }
 
+// Boxes: a wave walks 1024 consecutive pixels (16 per lane, coalesced).  A lane keeps one open accumulator and flushes
+// it with atomics only when its component changes; at the end the wave merges the open accumulators of lanes that hold
+// the same component (one butterfly per distinct component) so that a big blob costs one set of atomics per wave
+// instead of one per pixel (1080p: full mask 2.0 -> 0.3 ms, percolating random mask 50 -> 2.5 ms, blob mask 0.84 -> 0.12 ms).
+constexpr int kCcBoxPer = 16;
+
+__device__ __forceinline__ void cc_box_atomics(CcBox* b, int mnx, int mny, int mxx, int mxy, int cnt) {
+  atomicMin(&b->x, mnx), atomicMin(&b->y, mny), atomicMax(&b->w, mxx), atomicMax(&b->h, mxy), atomicAdd(&b->area, cnt);
+}
+
 __global__ __launch_bounds__(kBlock) void cc_boxes_kernel(const int* L, const int* id, int rows, int cols, CcBox* boxes, int max_boxes) {
   const size_t N = (size_t)rows * cols;
-  const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  const int l = p < N ? L[p] : -1;
-  const int my = l >= 0 ? id[l] : -1;
-  const bool take = my >= 0 && my < max_boxes;
-  int y = 0, x = 0;
-  if (p < N) y = (int)(p / cols), x = (int)(p - (size_t)y * cols);
-  // a big blob fills whole waves: reduce inside the wave and issue one set of atomics instead of 64
-  const int first = __shfl(my, __ffsll((long long)__ballot(true)) - 1);
-  if (__all(my == first)) {
-    if (!take) return;
-    int mnx = x, mny = y, mxx = x, mxy = y, cnt = 1;
+  const int lane = threadIdx.x & (kWave - 1);
+  const size_t wave0 = ((size_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave) * (kWave * kCcBoxPer);
+  int cid = -1, cl = -1, mnx = 0x7fffffff, mny = 0x7fffffff, mxx = -1, mxy = -1, cnt = 0;
+  for (int k = 0; k < kCcBoxPer; ++k) {
+    const size_t p = wave0 + (size_t)k * kWave + lane;
+    const int l = p < N ? L[p] : -1;
+    if (l < 0) continue;
+    if (l != cl) {  // a different component than the one this lane has open
+      if (cid >= 0 && cid < max_boxes) cc_box_atomics(boxes + cid, mnx, mny, mxx, mxy, cnt);
+      cl = l, cid = id[l];
+      mnx = mny = 0x7fffffff, mxx = mxy = -1, cnt = 0;
+    }
+    const int y = (int)(p / cols), x = (int)(p - (size_t)y * cols);
+    mnx = min(mnx, x), mny = min(mny, y), mxx = max(mxx, x), mxy = max(mxy, y), cnt++;
+  }
+  if (cid >= max_boxes) cid = -1;
+  unsigned long long pending = __ballot(cid >= 0);
+  while (pending) {  // wave-uniform
+    const int leader = __ffsll((long long)pending) - 1;
+    const int lid = __shfl(cid, leader);
+    const bool mine = cid == lid;
+    int a = mine ? mnx : 0x7fffffff, b = mine ? mny : 0x7fffffff, c = mine ? mxx : -1, d = mine ? mxy : -1, e = mine ? cnt : 0;
 #pragma unroll
     for (int o = kWave / 2; o > 0; o >>= 1) {
-      mnx = min(mnx, __shfl_xor(mnx, o)), mny = min(mny, __shfl_xor(mny, o));
-      mxx = max(mxx, __shfl_xor(mxx, o)), mxy = max(mxy, __shfl_xor(mxy, o));
-      cnt += __shfl_xor(cnt, o);
+      a = min(a, __shfl_xor(a, o)), b = min(b, __shfl_xor(b, o));
+      c = max(c, __shfl_xor(c, o)), d = max(d, __shfl_xor(d, o));
+      e += __shfl_xor(e, o);
     }
-    if ((threadIdx.x & (kWave - 1)) == 0) {
-      CcBox* b = boxes + my;
-      atomicMin(&b->x, mnx), atomicMin(&b->y, mny), atomicMax(&b->w, mxx), atomicMax(&b->h, mxy), atomicAdd(&b->area, cnt);
-    }
-    return;
-  }
-  if (take) {
-    CcBox* b = boxes + my;
-    atomicMin(&b->x, x), atomicMin(&b->y, y), atomicMax(&b->w, x), atomicMax(&b->h, y), atomicAdd(&b->area, 1);
+    if (lane == leader) cc_box_atomics(boxes + lid, a, b, c, d, e);
+    pending &= ~__ballot(mine);
   }
 }
 
