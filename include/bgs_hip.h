@@ -44,6 +44,12 @@ typedef enum bgs_algo {
   BGS_SUBSENSE = 9,          /* SuBSENSEBGS::process               package_bgs/pl/SuBSENSE.cpp:21-45 */
   BGS_LBSP_DESC = 10,        /* LBSP::computeRGBDescriptor         package_bgs/pl/LBSP.h:50-95 */
   BGS_SIGMA_DELTA = 11,      /* SigmaDeltaBGS::process             package_bgs/bl/SigmaDeltaBGS.cpp */
+  /* the in-tree dp/ models (3-channel frames only; output = the high-threshold mask, no background image) */
+  BGS_DP_ZIVKOVIC_AGMM = 12, /* DPZivkovicAGMMBGS::process         package_bgs/dp/DPZivkovicAGMMBGS.cpp:29-80 */
+  BGS_DP_GRIMSON_GMM = 13,   /* DPGrimsonGMMBGS::process           package_bgs/dp/DPGrimsonGMMBGS.cpp:29-82 */
+  BGS_DP_WREN_GA = 14,       /* DPWrenGABGS::process               package_bgs/dp/DPWrenGABGS.cpp:29-81 */
+  BGS_DP_MEAN = 15,          /* DPMeanBGS::process                 package_bgs/dp/DPMeanBGS.cpp:29-82 */
+  BGS_DP_ADAPTIVE_MEDIAN = 16, /* DPAdaptiveMedianBGS::process     package_bgs/dp/DPAdaptiveMedianBGS.cpp:29-81 */
   BGS_ALGO_COUNT
 } bgs_algo;
 
@@ -130,12 +136,17 @@ typedef struct bgs_params {
   int32_t gmg_quantization_levels; /* 16 */
   int32_t gmg_smoothing_radius;    /* 7 (cv::medianBlur kernel size; 0 = off) */
   int32_t gmg_update_background_model; /* 1 */
-  int32_t gmg_pad_;
+  int32_t dp_sampling_rate;        /* dp/ AdaptiveMedian: 7  DPAdaptiveMedianBGS.cpp:19 */
   double gmg_learning_rate;        /* 0.025 */
   double gmg_background_prior;     /* 0.8 */
   double gmg_decision_threshold;   /* 0.7  GMG.cpp:19, :45 (OpenCV default 0.8) */
 
-  uint32_t reserved[3];
+  /* package_bgs/dp/ wrappers (DP*BGS.cpp:19 constructors): threshold = LowThreshold (HighThreshold = 2x, the mask that is
+   * returned), alpha, gaussians = MaxModes (1..8).  learningFrames of WrenGA / Mean / AdaptiveMedian = learning_frames above
+   * (default 30 for those three; it has no effect because the wrappers clear the update mask every frame). */
+  float dp_threshold;   /* Zivkovic 25, Grimson 9, WrenGA 12.25, Mean 2700, AdaptiveMedian 40 */
+  float dp_alpha;       /* Zivkovic 0.001, Grimson 0.01, WrenGA 0.005, Mean 1e-6 */
+  int32_t dp_gaussians; /* 3 */
 } bgs_params;
 
 int bgs_abi_version(void);
@@ -227,6 +238,10 @@ void bgs_destroy(bgs_engine* e);
 const char* bgs_last_error(void);
 
 /* ---- stand-alone device primitives (rows §8a10, §8f N1) ------------------------------ */
+
+/* State planes of the dp/ models (bgs_get_state): "modes" f32 [K*F][n] with F = 5 (sigma, mu0, mu1, mu2, weight) for
+ * Zivkovic and 6 (variance, mu0, mu1, mu2, weight, significants) for Grimson, plane index k*F + f; "nmodes" u8 [n];
+ * WrenGA "gauss" f32 [4][n] (mu0..2, var); Mean "mean" f32 [3][n]; AdaptiveMedian "median" u8 [n*3]. */
 
 /* LBSP 16-bit double-cross descriptors of a whole 8UC3 / 8UC1 image (LBSP.h:50-95,
  * LBSP_16bits_dbcross_{3ch3t,1ch}.i).  d_desc: [rows][cols][channels] uint16; the

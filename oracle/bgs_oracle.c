@@ -28,6 +28,7 @@
  */
 #include "bgs_oracle.h"
 #include "subsense_oracle.h"
+#include "dp_oracle.h"
 
 #include <float.h>
 #include <math.h>
@@ -53,6 +54,7 @@ struct orc_engine {
   /* SigmaDelta: Mt = bgimg, Vt */
   uint8_t* vt;
   ss_state* ss; /* SuBSENSE (subsense_oracle.c) */
+  dp_state* dp; /* package_bgs/dp models (dp_oracle.c) */
   /* GMG: per pixel up to maxFeatures {colour, weight} + count */
   int32_t* gmg_colors;
   float* gmg_weights;
@@ -288,6 +290,17 @@ int orc_default_params(bgs_algo algo, bgs_params* p) {
   p->sd_amp_factor = 1;
   p->sd_min_var = 15;
   p->sd_max_var = 255;
+  /* package_bgs/dp wrappers, DP*BGS.cpp:19 */
+  p->dp_gaussians = 3;
+  p->dp_sampling_rate = 7;
+  switch (algo) {
+    case BGS_DP_ZIVKOVIC_AGMM: p->dp_threshold = 25.0f, p->dp_alpha = 0.001f; break;
+    case BGS_DP_GRIMSON_GMM: p->dp_threshold = 9.0f, p->dp_alpha = 0.01f; break;
+    case BGS_DP_WREN_GA: p->dp_threshold = 12.25f, p->dp_alpha = 0.005f, p->learning_frames = 30; break;
+    case BGS_DP_MEAN: p->dp_threshold = 2700.0f, p->dp_alpha = 1e-6f, p->learning_frames = 30; break;
+    case BGS_DP_ADAPTIVE_MEDIAN: p->dp_threshold = 40.0f, p->learning_frames = 30; break;
+    default: break;
+  }
   return BGS_OK;
 }
 
@@ -329,6 +342,7 @@ void orc_destroy(orc_engine* e) {
   free(e->mix);
   free(e->vt);
   ss_destroy(e->ss);
+  dp_destroy(e->dp);
   free(e->gmg_colors);
   free(e->gmg_weights);
   free(e->gmg_nfeat);
@@ -1041,6 +1055,20 @@ int orc_process(orc_engine* e, const uint8_t* in, int rows, int cols, int channe
       if (channels != 3) return BGS_ERR_UNSUPPORTED;
       flags = sd_process(e, fg, fg_step);
       break;
+    case BGS_DP_ZIVKOVIC_AGMM:
+    case BGS_DP_GRIMSON_GMM:
+    case BGS_DP_WREN_GA:
+    case BGS_DP_MEAN:
+    case BGS_DP_ADAPTIVE_MEDIAN: /* dp_oracle.c; RgbImage accessors assume 3 channels */
+      if (channels != 3) return BGS_ERR_UNSUPPORTED;
+      if (!e->dp) {
+        rc = dp_create(e->algo, &e->p, e->cur, rows, cols, &e->dp);
+        if (rc) return rc;
+      }
+      rc = dp_process(e->dp, e->cur, e->nframes, e->tmp8b);
+      write_mask(e, e->tmp8b, fg, fg_step);
+      flags = BGS_FG_VALID;
+      break;
     default: return BGS_ERR_UNSUPPORTED;
   }
   if (rc) return rc;
@@ -1101,6 +1129,7 @@ int64_t orc_get_state(orc_engine* e, const char* plane, void* dst, size_t cap) {
     }
   }
   if (e->algo == BGS_SUBSENSE && e->ss) return ss_get_state(e->ss, plane, dst, cap);
+  if (e->dp) return dp_get_state(e->dp, plane, dst, cap);
   if (e->algo == BGS_GMG && e->gmg_colors) { /* canonical: colors int32 [F][n], weights f32 [F][n], nfeatures int32 [n] */
     const int F = e->p.gmg_max_features;
     if (!strcmp(plane, "nfeatures")) {

@@ -26,6 +26,11 @@ ALGOS = {
     "MixtureOfGaussianV2BGS": capi.MOG2,
     "SigmaDeltaBGS": capi.SIGMA_DELTA,
     "GMG": capi.GMG,
+    "DPZivkovicAGMMBGS": capi.DP_ZIVKOVIC_AGMM,
+    "DPGrimsonGMMBGS": capi.DP_GRIMSON_GMM,
+    "DPWrenGABGS": capi.DP_WREN_GA,
+    "DPMeanBGS": capi.DP_MEAN,
+    "DPAdaptiveMedianBGS": capi.DP_ADAPTIVE_MEDIAN,
 }
 STATE_TOL = 1e-4
 
@@ -62,7 +67,24 @@ def check_mog1_state(eng, orc, n, C=3, stream=0):
         assert err <= STATE_TOL, "%s: max |delta| %g > %g" % (plane, err, STATE_TOL)
 
 
+def check_dp_state(name, eng, orc, n, K=3, stream=0):
+    """package_bgs/dp models: float planes within 1e-4 (observed 0), mode counts / median bytes exact."""
+    planes = {"DPZivkovicAGMMBGS": ("modes", K * 5), "DPGrimsonGMMBGS": ("modes", K * 6), "DPWrenGABGS": ("gauss", 4), "DPMeanBGS": ("mean", 3)}
+    if name in planes:
+        plane, q = planes[name]
+        a, b = eng.get_state(plane, (q, n), np.float32, stream=stream), orc.get_state(plane, (q, n), np.float32)
+        both_nan = np.isnan(a) & np.isnan(b)
+        err = float(np.max(np.abs(np.where(both_nan, 0, a - b))))
+        assert err <= STATE_TOL, "%s %s: max |delta| %g" % (name, plane, err)
+    if name in ("DPZivkovicAGMMBGS", "DPGrimsonGMMBGS"):
+        assert np.array_equal(eng.get_state("nmodes", (n,), np.uint8, stream=stream), orc.get_state("nmodes", (n,), np.uint8))
+    if name == "DPAdaptiveMedianBGS":
+        assert np.array_equal(eng.get_state("median", (n * 3,), np.uint8, stream=stream), orc.get_state("median", (n * 3,), np.uint8))
+
+
 def check_state(name, eng, orc, n, stream=0):
+    if name.startswith("DP"):
+        check_dp_state(name, eng, orc, n, stream=stream)
     if name == "MixtureOfGaussianV2BGS":
         check_mog2_state(eng, orc, n, stream)
     if name == "MixtureOfGaussianV1BGS":
@@ -153,7 +175,9 @@ def test_warmup_outputs_untouched():
     """FD frame 1, WMM/WMV frames 1-2 return with outputs untouched; FD/WMV never write a background."""
     frames = synth.random_frames(4, 16, 32, 3, seed=5)
     for algo, warm, has_bg in ((capi.FRAME_DIFF, 1, False), (capi.WMM, 2, True), (capi.WMV, 2, False), (capi.STATIC_FRAME_DIFF, 0, True), (capi.ABL, 0, True),
-                               (capi.ASBL, 0, True), (capi.MOG1, 0, False), (capi.MOG2, 0, True), (capi.SIGMA_DELTA, 1, False), (capi.GMG, 0, False)):
+                               (capi.ASBL, 0, True), (capi.MOG1, 0, False), (capi.MOG2, 0, True), (capi.SIGMA_DELTA, 1, False), (capi.GMG, 0, False),
+                               (capi.DP_ZIVKOVIC_AGMM, 0, False), (capi.DP_GRIMSON_GMM, 0, False), (capi.DP_WREN_GA, 0, False), (capi.DP_MEAN, 0, False),
+                               (capi.DP_ADAPTIVE_MEDIAN, 0, False)):
         eng = Engine(algo)
         for t, f in enumerate(frames):
             fg, bg = eng.process(f)
@@ -753,3 +777,46 @@ def test_connected_components_truncation_and_full_size():
     labels, boxes, n = mask_components_device(torch.from_numpy(big).cuda(), 8, max_boxes=8192)
     assert n == want_n and np.array_equal(labels.cpu().numpy(), want_l)
     assert np.array_equal(boxes.cpu().numpy(), np.stack([want_b[f] for f in ("x", "y", "w", "h", "area", "root")], axis=1))
+
+
+DP_NAMES = ["DPZivkovicAGMMBGS", "DPGrimsonGMMBGS", "DPWrenGABGS", "DPMeanBGS", "DPAdaptiveMedianBGS"]
+
+
+@pytest.mark.parametrize("name", DP_NAMES)
+def test_dp_models_long_clip_with_scene_changes(name, golden_frames):
+    """package_bgs/dp (N4): 72 frames = the golden clip, a brightness-shifted copy and its reverse, so that modes are created,
+    matched, re-sorted, pruned and replaced (GMMs), the median walks, and the single gaussian saturates its variance clamp."""
+    shifted = np.clip(golden_frames.astype(np.int32) + 60, 0, 255).astype(np.uint8)
+    frames = np.concatenate([golden_frames, shifted, golden_frames[::-1]])
+    eng, orc, _ = run_pair(ALGOS[name], frames)
+    check_dp_state(name, eng, orc, frames.shape[1] * frames.shape[2])
+
+
+@pytest.mark.parametrize("kw", [dict(dp_gaussians=1), dict(dp_gaussians=2), dict(dp_gaussians=5), dict(dp_alpha=0.2), dict(dp_alpha=0.6, dp_gaussians=4),
+                                dict(dp_threshold=2.0), dict(dp_threshold=400.0, dp_alpha=0.05)])
+@pytest.mark.parametrize("name", ["DPZivkovicAGMMBGS", "DPGrimsonGMMBGS"])
+def test_dp_gmm_parameter_variants(name, kw):
+    """MaxModes 1..5 (template instances), large alpha (weights fall under the prune limit: the mode count shrinks inside
+    the update loop, ZivkovicAGMM.cpp:240-245), tight and loose thresholds."""
+    frames = synth.random_frames(30, 24, 40, 3, seed=len(name) + int(kw.get("dp_gaussians", 0)))
+    frames[10:20] = frames[:10]  # repeated content: existing modes get matched, not only created
+    p = _params(ALGOS[name], **kw)
+    eng, orc, _ = run_pair(ALGOS[name], frames, params=p)
+    check_dp_state(name, eng, orc, 24 * 40, K=p.dp_gaussians)
+
+
+@pytest.mark.parametrize("name,kw", [("DPWrenGABGS", dict(dp_alpha=0.3)), ("DPWrenGABGS", dict(dp_threshold=1.0)), ("DPMeanBGS", dict(dp_alpha=0.9)),
+                                     ("DPMeanBGS", dict(dp_threshold=100.0, dp_alpha=0.5)), ("DPAdaptiveMedianBGS", dict(dp_sampling_rate=1)),
+                                     ("DPAdaptiveMedianBGS", dict(dp_sampling_rate=2, dp_threshold=3.0)), ("DPAdaptiveMedianBGS", dict(dp_sampling_rate=3, dp_threshold=0.5))])
+def test_dp_simple_models_parameter_variants(name, kw, golden_frames):
+    eng, orc, _ = run_pair(ALGOS[name], golden_frames, params=_params(ALGOS[name], **kw))
+    check_dp_state(name, eng, orc, golden_frames.shape[1] * golden_frames.shape[2])
+
+
+def test_dp_models_reject_single_channel(golden_gray):
+    for name in DP_NAMES:
+        with pytest.raises(capi.BgsError) as ei:
+            Engine(ALGOS[name]).process(golden_gray[0])
+        assert ei.value.code == capi.ERR_UNSUPPORTED
+        with pytest.raises(RuntimeError):
+            pyoracle.Oracle(ALGOS[name]).process(golden_gray[0])

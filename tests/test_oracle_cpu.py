@@ -86,7 +86,9 @@ def test_framediff_matches_independent_formula(golden_frames):
 
 
 @pytest.mark.parametrize("name,algo", [("fd", capi.FRAME_DIFF), ("sfd", capi.STATIC_FRAME_DIFF), ("wmm", capi.WMM), ("wmv", capi.WMV),
-                                       ("abl", capi.ABL), ("asbl", capi.ASBL), ("mog2", capi.MOG2), ("mog1", capi.MOG1), ("sd", capi.SIGMA_DELTA), ("gmg", capi.GMG), ("subsense", capi.SUBSENSE)])
+                                       ("abl", capi.ABL), ("asbl", capi.ASBL), ("mog2", capi.MOG2), ("mog1", capi.MOG1), ("sd", capi.SIGMA_DELTA), ("gmg", capi.GMG), ("subsense", capi.SUBSENSE),
+                                       ("dpziv", capi.DP_ZIVKOVIC_AGMM), ("dpgrim", capi.DP_GRIMSON_GMM), ("dpwren", capi.DP_WREN_GA), ("dpmean", capi.DP_MEAN),
+                                       ("dpmedian", capi.DP_ADAPTIVE_MEDIAN)])
 def test_oracle_regression_vectors(name, algo, golden_frames, oracle_regress):
     o = pyoracle.Oracle(algo)
     want = oracle_regress[name + "_fg"]
@@ -337,3 +339,47 @@ def test_components_oracle_vs_scipy(connectivity):
             assert (b["y"], b["x"], b["h"], b["w"]) == (sl[0].start, sl[1].start, sl[0].stop - sl[0].start, sl[1].stop - sl[1].start)
             assert b["area"] == int(sel.sum())
         assert np.all(np.diff(boxes["root"]) > 0)
+
+
+def test_dp_oracle_invariants(golden_frames):
+    """package_bgs/dp restatement (dp_oracle.c): properties the sources guarantee, checked on the golden clip.
+    Zivkovic: weights of the used modes sum to 1 and are sorted descending (ZivkovicAGMM.cpp:219-234, 259-263), variances stay in
+    [4, 180] (:192); first frame: every pixel creates its first mode, and an empty model has no background gaussian -> all
+    foreground.  Grimson: modes sorted by weight/sqrt(variance).  WrenGA: variance clamp.  AdaptiveMedian: the median moves
+    by at most one grey level and only on frames with frame % samplingRate == 1 (AdaptiveMedianBGS.cpp:60)."""
+    n = golden_frames.shape[1] * golden_frames.shape[2]
+    for algo, F in ((capi.DP_ZIVKOVIC_AGMM, 5), (capi.DP_GRIMSON_GMM, 6)):
+        o = pyoracle.Oracle(algo)
+        fg, bg = o.process(golden_frames[0])
+        assert bg is None and (fg == 255).all()
+        assert (o.get_state("nmodes", (n,), np.uint8) == 1).all()
+        for f in golden_frames[1:]:
+            o.process(f)
+        m = o.get_state("modes", (3, F, n), np.float32)
+        nm = o.get_state("nmodes", (n,), np.uint8)
+        assert nm.min() >= 1 and nm.max() <= 3
+        used = np.arange(3)[:, None] < nm[None, :]
+        w = np.where(used, m[:, 4], 0)
+        assert np.allclose(w.sum(0), 1, atol=1e-5)
+        var = m[:, 0][used]
+        assert var.min() >= 4 and var.max() <= 180
+        key = m[:, 4] if F == 5 else m[:, 5]
+        for k in range(2):
+            both = used[k] & used[k + 1]
+            assert (key[k][both] >= key[k + 1][both]).all()
+    o = pyoracle.Oracle(capi.DP_WREN_GA)
+    fg, _ = o.process(golden_frames[0])
+    assert (fg == 0).all()  # the model IS the first frame
+    for f in golden_frames[1:]:
+        o.process(f)
+    g = o.get_state("gauss", (4, n), np.float32)
+    assert g[3].min() >= 4 and g[3].max() <= 180
+    o = pyoracle.Oracle(capi.DP_ADAPTIVE_MEDIAN)
+    prev = None
+    for t, f in enumerate(golden_frames):
+        o.process(f)
+        med = o.get_state("median", (n * 3,), np.uint8).astype(int)
+        if prev is not None:
+            step = np.abs(med - prev).max()
+            assert step <= 1 and (step == 0 or t % 7 == 1)
+        prev = med

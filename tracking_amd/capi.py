@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libbgs_hip.so")
 
 # bgs_algo (include/bgs_hip.h)
 FRAME_DIFF, STATIC_FRAME_DIFF, WMM, WMV, ABL, ASBL, MOG2, MOG1, GMG, SUBSENSE, LBSP_DESC, SIGMA_DELTA = range(12)
+DP_ZIVKOVIC_AGMM, DP_GRIMSON_GMM, DP_WREN_GA, DP_MEAN, DP_ADAPTIVE_MEDIAN = range(12, 17)
 FG_VALID, BG_VALID = 1, 2
 OPT_BORROW_FRAMES, OPT_MOG2_PIXELS_PER_LANE, OPT_MOG2_TILED, OPT_XCD_SWIZZLE, OPT_PLACEMENT_PROBE, OPT_MOG2_SPARSE = 1, 2, 3, 4, 5, 6
 
@@ -62,11 +63,13 @@ class BgsParams(C.Structure):
         ("gmg_quantization_levels", C.c_int32),
         ("gmg_smoothing_radius", C.c_int32),
         ("gmg_update_background_model", C.c_int32),
-        ("gmg_pad_", C.c_int32),
+        ("dp_sampling_rate", C.c_int32),
         ("gmg_learning_rate", C.c_double),
         ("gmg_background_prior", C.c_double),
         ("gmg_decision_threshold", C.c_double),
-        ("reserved", C.c_uint32 * 3),
+        ("dp_threshold", C.c_float),
+        ("dp_alpha", C.c_float),
+        ("dp_gaussians", C.c_int32),
     ]
 
 

@@ -21,6 +21,7 @@
 
 #include "kernel_gmg.h"
 #include "kernel_cc.h"
+#include "kernel_dp.h"
 #include "kernel_mog1.h"
 #include "kernel_mog2.h"
 #include "kernel_pointwise.h"
@@ -76,6 +77,7 @@ struct bgs_engine {
   uint8_t* bgstate2 = nullptr;  // ASBL: second buffer of the ping-pong pair (the 3x3 median reads neighbours' OLD background)
   std::vector<uint8_t> flip;    // ASBL: which buffer holds the current background, per stream
   float* mog1_state = nullptr;  // MOG1 model (kernel_mog1.h, tiled)
+  float* dp_state = nullptr;    // package_bgs/dp models (kernel_dp.h): [S][planes][n]
   SsDevice* ss = nullptr;       // SuBSENSE model (engine_subsense.h)
   int32_t* gmg_colors = nullptr;  // GMG histograms (kernel_gmg.h)
   float* gmg_weights = nullptr;
@@ -114,10 +116,10 @@ void ss_free(bgs_engine* e);  // engine_subsense.h
 void free_all(bgs_engine* e) {
   for (auto& r : e->ring)
     if (r) (void)hipFree(r), r = nullptr;
-  void* dev[] = {e->gmg_colors, e->gmg_weights, e->gmg_nfeat, e->bgstate, e->bgstate2, e->mog1_state, e->mog2_state, e->mog2_nmodes, e->d_in, e->d_fg, e->d_bg};
+  void* dev[] = {e->dp_state, e->gmg_colors, e->gmg_weights, e->gmg_nfeat, e->bgstate, e->bgstate2, e->mog1_state, e->mog2_state, e->mog2_nmodes, e->d_in, e->d_fg, e->d_bg};
   for (void* d : dev)
     if (d) (void)hipFree(d);
-  e->gmg_colors = nullptr, e->gmg_weights = nullptr, e->gmg_nfeat = nullptr, e->bgstate = e->bgstate2 = nullptr, e->mog1_state = nullptr, e->mog2_state = nullptr, e->mog2_nmodes = nullptr, e->d_in = e->d_fg = e->d_bg = nullptr;
+  e->dp_state = nullptr, e->gmg_colors = nullptr, e->gmg_weights = nullptr, e->gmg_nfeat = nullptr, e->bgstate = e->bgstate2 = nullptr, e->mog1_state = nullptr, e->mog2_state = nullptr, e->mog2_nmodes = nullptr, e->d_in = e->d_fg = e->d_bg = nullptr;
   void* host[] = {e->h_in, e->h_fg, e->h_bg};
   for (void* h : host)
     if (h) (void)hipHostFree(h);
@@ -135,6 +137,9 @@ int check_params(bgs_algo algo, const bgs_params& p) {
   if (algo == BGS_GMG && p.gmg_smoothing_radius != 0 && (p.gmg_smoothing_radius < 3 || p.gmg_smoothing_radius > 15 || p.gmg_smoothing_radius % 2 == 0))
     return fail(BGS_ERR_UNSUPPORTED, "GMG smoothingRadius (cv::medianBlur kernel) must be 0 or odd 3..15, got %d", p.gmg_smoothing_radius);
   if (algo == BGS_MOG2 && p.mog2_nmixtures != bgs::kMog2K) return fail(BGS_ERR_UNSUPPORTED, "MOG2 kernel is built for K=%d mixtures, got %d", bgs::kMog2K, p.mog2_nmixtures);
+  if ((algo == BGS_DP_ZIVKOVIC_AGMM || algo == BGS_DP_GRIMSON_GMM) && (p.dp_gaussians < 1 || p.dp_gaussians > 5))
+    return fail(BGS_ERR_UNSUPPORTED, "dp GMM kernels are built for 1..5 gaussians, got %d", p.dp_gaussians);
+  if (algo == BGS_DP_ADAPTIVE_MEDIAN && p.dp_sampling_rate == 0) return fail(BGS_ERR_UNSUPPORTED, "AdaptiveMedian samplingRate 0 (frame_num %% 0)");
   return BGS_OK;
 }
 
@@ -299,6 +304,7 @@ int mog2_allocate(bgs_engine* e) {
 }
 
 #include "engine_subsense.h"
+#include "engine_dp.h"
 
 int allocate(bgs_engine* e, int rows, int cols, int ch) {
   if (rows <= 0 || cols <= 0) return fail(BGS_ERR_INVALID, "bad geometry %dx%d", rows, cols);
@@ -323,6 +329,11 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
     case BGS_MOG1:
     case BGS_MOG2:
     case BGS_SUBSENSE: break;
+    case BGS_DP_ZIVKOVIC_AGMM:
+    case BGS_DP_GRIMSON_GMM: e->state_ch = 1; break;  // bgstate = modes per pixel
+    case BGS_DP_WREN_GA:
+    case BGS_DP_MEAN: break;
+    case BGS_DP_ADAPTIVE_MEDIAN: e->state_ch = 3; break;  // bgstate = the median image
     default: return fail(BGS_ERR_UNSUPPORTED, "algorithm %d is not implemented in this build", (int)e->algo);
   }
   for (int i = 0; i < e->nring; ++i) HIP_TRY(hipMalloc((void**)&e->ring[i], fb));
@@ -347,6 +358,10 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
   }
   if (e->algo == BGS_SUBSENSE) {
     int rc = ss_allocate(e);
+    if (rc) return rc;
+  }
+  if (is_dp(e->algo)) {
+    int rc = dp_allocate(e);
     if (rc) return rc;
   }
   if (!e->stream) HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
@@ -531,6 +546,15 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
       flags = BGS_FG_VALID;
       break;
     }
+    case BGS_DP_ZIVKOVIC_AGMM:
+    case BGS_DP_GRIMSON_GMM:
+    case BGS_DP_WREN_GA:
+    case BGS_DP_MEAN:
+    case BGS_DP_ADAPTIVE_MEDIAN: {
+      int rc = dp_process(e, first, count, t, d_frames, d_fg, d_bits, s, &flags);
+      if (rc) return rc;
+      break;
+    }
     case BGS_ASBL: {
       const int cur = e->flip[first];
       for (int i = first; i < first + count; ++i)
@@ -684,6 +708,17 @@ int bgs_default_params(bgs_algo algo, bgs_params* p) {
   p->sd_amp_factor = 1;
   p->sd_min_var = 15;
   p->sd_max_var = 255;
+  // package_bgs/dp wrappers, DP*BGS.cpp:19
+  p->dp_gaussians = 3;
+  p->dp_sampling_rate = 7;
+  switch (algo) {
+    case BGS_DP_ZIVKOVIC_AGMM: p->dp_threshold = 25.0f, p->dp_alpha = 0.001f; break;
+    case BGS_DP_GRIMSON_GMM: p->dp_threshold = 9.0f, p->dp_alpha = 0.01f; break;
+    case BGS_DP_WREN_GA: p->dp_threshold = 12.25f, p->dp_alpha = 0.005f, p->learning_frames = 30; break;
+    case BGS_DP_MEAN: p->dp_threshold = 2700.0f, p->dp_alpha = 1e-6f, p->learning_frames = 30; break;
+    case BGS_DP_ADAPTIVE_MEDIAN: p->dp_threshold = 40.0f, p->learning_frames = 30; break;
+    default: break;
+  }
   return BGS_OK;
 }
 
@@ -868,6 +903,14 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
     }
   }
   if (e->algo == BGS_SUBSENSE && e->ss) return ss_get_state(e, stream, plane, dst, cap);
+  if (is_dp(e->algo)) {  // planes are stored canonically: [stream][plane][n]
+    const int planes = dp_planes_of(e);
+    const char* fname = (e->algo == BGS_DP_WREN_GA) ? "gauss" : (e->algo == BGS_DP_MEAN) ? "mean" : "modes";
+    if (planes && !strcmp(plane, fname)) return copy_bytes((const uint8_t*)(e->dp_state + (size_t)stream * planes * n), (size_t)planes * n * 4);
+    if (e->state_ch == 1 && !strcmp(plane, "nmodes")) return copy_bytes(e->bgstate + off, n);
+    if (e->state_ch == 3 && !strcmp(plane, "median")) return copy_bytes(e->bgstate + off * 3, n * 3);
+    return fail(BGS_ERR_STATE, "unknown state plane '%s' for algorithm %d", plane, (int)e->algo);
+  }
   if (e->algo == BGS_GMG && e->gmg_colors) {  // canonical: colors int32 [F][n], weights f32 [F][n] (entries past the count exported as 0), nfeatures int32 [n]
     const size_t F = (size_t)e->p.gmg_max_features;
     std::vector<uint8_t> nf(n);

@@ -1,0 +1,83 @@
+// engine_dp.h — host side of the package_bgs/dp/ models (kernel_dp.h); included inside bgs_hip.hip's anonymous namespace.
+// State per stream: `dp_planes` float planes of n pixels (GMM modes / WrenGA gaussian / Mean), plus e->bgstate
+// (mode count per pixel, or the AdaptiveMedian byte image).
+
+bool is_dp(bgs_algo a) { return a >= BGS_DP_ZIVKOVIC_AGMM && a <= BGS_DP_ADAPTIVE_MEDIAN; }
+
+int dp_planes_of(const bgs_engine* e) {
+  switch (e->algo) {
+    case BGS_DP_ZIVKOVIC_AGMM: return e->p.dp_gaussians * 5;
+    case BGS_DP_GRIMSON_GMM: return e->p.dp_gaussians * 6;
+    case BGS_DP_WREN_GA: return 4;
+    case BGS_DP_MEAN: return 3;
+    default: return 0;
+  }
+}
+
+int dp_allocate(bgs_engine* e) {
+  if (e->ch != 3) return fail(BGS_ERR_UNSUPPORTED, "the dp/ models read RgbImage pixels: 3-channel frames only (dp/Image.h:257-265)");
+  const size_t P = e->n * e->S;
+  const int planes = dp_planes_of(e);
+  if (planes) {
+    HIP_TRY(hipMalloc((void**)&e->dp_state, P * planes * sizeof(float)));
+    HIP_TRY(hipMemset(e->dp_state, 0, P * planes * sizeof(float)));  // InitModel of the GMMs: everything 0
+  }
+  if (e->bgstate) HIP_TRY(hipMemset(e->bgstate, 0, P * e->state_ch));
+  return BGS_OK;
+}
+
+template <bool GRIMSON>
+void dp_launch_gmm(int K, unsigned blocks, hipStream_t s, const bgs::DpArgs& a) {
+  switch (K) {
+    case 1: hipLaunchKernelGGL((bgs::dp_gmm_kernel<1, GRIMSON>), dim3(blocks), dim3(bgs::kBlock), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((bgs::dp_gmm_kernel<2, GRIMSON>), dim3(blocks), dim3(bgs::kBlock), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((bgs::dp_gmm_kernel<3, GRIMSON>), dim3(blocks), dim3(bgs::kBlock), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((bgs::dp_gmm_kernel<4, GRIMSON>), dim3(blocks), dim3(bgs::kBlock), 0, s, a); break;
+    default: hipLaunchKernelGGL((bgs::dp_gmm_kernel<5, GRIMSON>), dim3(blocks), dim3(bgs::kBlock), 0, s, a); break;
+  }
+}
+
+// one frame (number t, 0-based = the wrappers' frameNumber) for streams [first, first+count)
+int dp_process(bgs_engine* e, int first, int count, int64_t t, const uint8_t* d_frames, uint8_t* d_fg, uint64_t* d_bits, hipStream_t s, uint32_t* flags) {
+  const bgs_params& p = e->p;
+  bgs::DpArgs a{};
+  a.frame = d_frames, a.state = e->dp_state, a.bstate = e->bgstate, a.fg = d_fg, a.fg_bits = d_bits;
+  a.n = e->n, a.npix = e->n * count, a.first = first;
+  a.low = p.dp_threshold, a.high = 2 * a.low, a.alpha = p.dp_alpha;  // HighThreshold = 2*LowThreshold, e.g. DPZivkovicAGMMBGS.cpp:58
+  a.update = 0;
+  const unsigned blocks = blocks_for(a.npix);
+  if (t == 0 && (e->algo == BGS_DP_WREN_GA || e->algo == BGS_DP_MEAN))  // InitModel from the first frame
+    hipLaunchKernelGGL(bgs::dp_init_kernel, dim3(blocks), dim3(bgs::kBlock), 0, s, a, e->algo == BGS_DP_WREN_GA ? 4 : 3, 36.0f);
+  if (t == 0 && e->algo == BGS_DP_ADAPTIVE_MEDIAN)
+    HIP_TRY(hipMemcpyAsync(e->bgstate + (size_t)first * e->n * 3, d_frames, a.npix * 3, hipMemcpyDeviceToDevice, s));
+  switch (e->algo) {
+    case BGS_DP_ZIVKOVIC_AGMM: {
+      Timed tm(e, s, "dp_gmm_kernel");
+      dp_launch_gmm<false>(p.dp_gaussians, blocks, s, a);
+      break;
+    }
+    case BGS_DP_GRIMSON_GMM: {
+      Timed tm(e, s, "dp_gmm_kernel");
+      dp_launch_gmm<true>(p.dp_gaussians, blocks, s, a);
+      break;
+    }
+    case BGS_DP_WREN_GA: {
+      Timed tm(e, s, "dp_wren_kernel");
+      hipLaunchKernelGGL(bgs::dp_wren_kernel, dim3(blocks), dim3(bgs::kBlock), 0, s, a);
+      break;
+    }
+    case BGS_DP_MEAN: {
+      Timed tm(e, s, "dp_mean_kernel");
+      hipLaunchKernelGGL(bgs::dp_mean_kernel, dim3(blocks), dim3(bgs::kBlock), 0, s, a);
+      break;
+    }
+    default: {
+      a.update = (t % p.dp_sampling_rate) == 1;  // AdaptiveMedianBGS.cpp:60
+      Timed tm(e, s, "dp_median_kernel");
+      hipLaunchKernelGGL(bgs::dp_median_kernel, dim3(blocks), dim3(bgs::kBlock), 0, s, a);
+      break;
+    }
+  }
+  *flags = BGS_FG_VALID;  // img_bgmodel is never written by the dp wrappers
+  return BGS_OK;
+}

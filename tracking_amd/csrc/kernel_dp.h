@@ -1,0 +1,310 @@
+// kernel_dp.h — SURVEY.md N4: the in-tree package_bgs/dp/ background models, one fused kernel each.
+//
+//   dp_gmm_kernel<K, false>  ZivkovicAGMM::SubtractPixel  package_bgs/dp/ZivkovicAGMM.cpp:103-364  (DPZivkovicAGMMBGS.cpp:29-80)
+//   dp_gmm_kernel<K, true>   GrimsonGMM::SubtractPixel    package_bgs/dp/GrimsonGMM.cpp:119-295    (DPGrimsonGMMBGS.cpp:29-82)
+//   dp_wren_kernel           WrenGA::SubtractPixel + Update  package_bgs/dp/WrenGA.cpp:79-134       (DPWrenGABGS.cpp:29-81)
+//   dp_mean_kernel           MeanBGS::SubtractPixel + Update package_bgs/dp/MeanBGS.cpp:52-98       (DPMeanBGS.cpp:29-82)
+//   dp_median_kernel         AdaptiveMedianBGS::SubtractPixel + Update  dp/AdaptiveMedianBGS.cpp:58-108 (DPAdaptiveMedianBGS.cpp:29-81)
+//
+// The wrappers return the HIGH-threshold mask (2 x threshold), clear the update mask before Update (so the update
+// always fires) and never write a background image.  Pixel bytes are taken in memory order (pixel(0) = first byte).
+// State: planar SoA per stream, plane q of stream s at state + (s*planes + q)*n: one lane per pixel, every access a
+// coalesced dword row.  The sources' control flow is kept statement by statement (mode count that shrinks inside the
+// loop, adjacent-swap sorts, stale entries past the count left untouched) with all indices static after unrolling.
+#pragma once
+#include "bgs_device.h"
+
+namespace bgs {
+
+struct DpArgs {
+  const uint8_t* frame;  // [count][n][3]
+  float* state;          // [S][planes][n]   (GMMs, WrenGA, Mean)
+  uint8_t* bstate;       // nmodes [S][n]  |  median [S][n][3]
+  uint8_t* fg;           // [count][n] or null
+  uint64_t* fg_bits;     // [count][n/64] or null
+  size_t n;              // pixels per stream
+  size_t npix;           // pixels of this launch (count * n)
+  int first;             // first stream of this launch
+  float low, high, alpha;
+  int update;            // AdaptiveMedian: frame_num % samplingRate == 1
+};
+
+__device__ __forceinline__ void dp_store_mask(const DpArgs& a, size_t gp, bool active, int m) {
+  if (active && a.fg) a.fg[gp] = (uint8_t)m;
+  if (a.fg_bits) {  // npix % 64 == 0 is checked on the host: a wave is either all active or all idle
+    const unsigned long long w = __ballot(active && m != 0);
+    if ((threadIdx.x & (kWave - 1)) == 0 && active) a.fg_bits[gp >> 6] = w;
+  }
+}
+
+template <int K, bool GRIMSON>
+__global__ __launch_bounds__(kBlock) void dp_gmm_kernel(const DpArgs a) {
+  constexpr int F = GRIMSON ? 6 : 5;
+  // field order inside a mode = the source's struct: Zivkovic {sigma, muR, muG, muB, weight}, Grimson {variance, muR, muG, muB, weight, significants}
+  constexpr int VAR = 0, MU = 1, WEIGHT = 4, SIG = 5;
+  const size_t gp = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool active = gp < a.npix;
+  int mask = 0;
+  if (active) {
+    const size_t s = gp / a.n, i = gp - s * a.n;
+    float* st = a.state + ((size_t)(a.first + s) * K * F) * a.n + i;
+    uint8_t* pn = a.bstate + (size_t)(a.first + s) * a.n + i;
+    float g[K][F];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int f = 0; f < F; ++f) g[k][f] = st[(size_t)(k * F + f) * a.n];
+    int nModes = *pn;
+    const float px[3] = {(float)a.frame[gp * 3], (float)a.frame[gp * 3 + 1], (float)a.frame[gp * 3 + 2]};
+    const float m_bg_threshold = 0.75f, m_variance = 36.0f, m_complexity_prior = 0.05f;
+    const float Alpha = a.alpha;
+    bool bFitsPDF = false, bBackgroundHigh = false;
+    const float fOneMinAlpha = 1 - Alpha;
+    const float prune = -Alpha * m_complexity_prior;  // Zivkovic only
+    float totalWeight = 0.0f;
+    int backgroundGaussians = 0;
+    {
+      double sum = 0.0;
+      bool stop = false;
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if (k < nModes && !stop) {
+          if (sum < (double)m_bg_threshold) {
+            backgroundGaussians++;
+            sum = __dadd_rn(sum, (double)g[k][WEIGHT]);
+          } else
+            stop = true;
+        }
+    }
+    auto swap_modes = [&](float(&x)[F], float(&y)[F]) {
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        const float t = x[f];
+        x[f] = y[f], y[f] = t;
+      }
+    };
+#pragma unroll
+    for (int im = 0; im < K; ++im) {
+      if (im < nModes) {  // nModes shrinks inside the loop, as in the source
+        float weight = g[im][WEIGHT];
+        if (!bFitsPDF) {
+          const float var = g[im][VAR], muR = g[im][MU], muG = g[im][MU + 1], muB = g[im][MU + 2];
+          const float dR = muR - px[0], dG = muG - px[1], dB = muB - px[2];
+          const float dist = (dR * dR + dG * dG + dB * dB);
+          if (dist < a.high * var && im < backgroundGaussians) bBackgroundHigh = true;
+          if (dist < a.low * var) {
+            bFitsPDF = true;
+            const float k = div_rn(Alpha, weight);
+            if constexpr (GRIMSON) {
+              weight = fOneMinAlpha * weight + Alpha;
+            } else {
+              weight = fOneMinAlpha * weight + prune;
+              weight += Alpha;
+            }
+            g[im][WEIGHT] = weight;
+            g[im][MU] = muR - k * (dR);
+            g[im][MU + 1] = muG - k * (dG);
+            g[im][MU + 2] = muB - k * (dB);
+            const float sigmanew = var + k * (dist - var);
+            g[im][VAR] = sigmanew < 4 ? 4 : sigmanew > 5 * m_variance ? 5 * m_variance : sigmanew;
+            if constexpr (GRIMSON) {
+              g[im][SIG] = div_rn(g[im][WEIGHT], sqrt_rn(g[im][VAR]));
+            } else {
+              bool stop = false;  // ZivkovicAGMM.cpp:219-234: move the grown mode up while it outweighs its predecessor
+#pragma unroll
+              for (int il = im; il > 0; --il)
+                if (!stop) {
+                  if (g[il][WEIGHT] > g[il - 1][WEIGHT])
+                    swap_modes(g[il], g[il - 1]);
+                  else
+                    stop = true;
+                }
+            }
+          } else {
+            if constexpr (GRIMSON) {
+              weight = fOneMinAlpha * weight;
+              if (weight < 0.0f) weight = 0.0f, nModes--;
+              g[im][WEIGHT] = weight;
+              g[im][SIG] = div_rn(weight, sqrt_rn(g[im][VAR]));
+            } else {
+              weight = fOneMinAlpha * weight + prune;
+              if (weight < -prune) weight = 0.0f, nModes--;
+              g[im][WEIGHT] = weight;
+            }
+          }
+        } else {
+          if constexpr (GRIMSON) {
+            weight = fOneMinAlpha * weight;
+            if (weight < 0.0f) weight = 0.0f, nModes--;
+            g[im][WEIGHT] = weight;
+            g[im][SIG] = div_rn(weight, sqrt_rn(g[im][VAR]));
+          } else {
+            weight = fOneMinAlpha * weight + prune;
+            if (weight < -prune) weight = 0.0f, nModes--;
+            g[im][WEIGHT] = weight;
+          }
+        }
+        totalWeight += weight;
+      }
+    }
+    // stable insertion by adjacent swaps, largest `significants` first (qsort + compareGMM, GrimsonGMM.cpp:45-56)
+    auto grimson_sort = [&](int count) {
+#pragma unroll
+      for (int i2 = 1; i2 < K; ++i2)
+        if (i2 < count) {
+          bool stop = false;
+#pragma unroll
+          for (int j = i2; j > 0; --j)
+            if (!stop) {
+              if (g[j - 1][F - 1] < g[j][F - 1])
+                swap_modes(g[j - 1], g[j]);
+              else
+                stop = true;
+            }
+        }
+    };
+    if constexpr (GRIMSON) {
+      const double invTotalWeight = 1.0 / (double)totalWeight;
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if (k < nModes) {
+          g[k][WEIGHT] *= (float)invTotalWeight;
+          g[k][SIG] = div_rn(g[k][WEIGHT], sqrt_rn(g[k][VAR]));
+        }
+      grimson_sort(nModes);
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if (k < nModes) g[k][WEIGHT] = div_rn(g[k][WEIGHT], totalWeight);
+    }
+    if (!bFitsPDF) {
+      if (nModes < K) nModes++;  // else: replace the weakest (the last one)
+      const int last = nModes - 1;
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if (k == last) {
+          if constexpr (GRIMSON) {
+            g[k][MU] = px[0], g[k][MU + 1] = px[1], g[k][MU + 2] = px[2];
+            g[k][VAR] = m_variance;
+            g[k][SIG] = 0;
+          }
+          g[k][WEIGHT] = nModes == 1 ? 1.0f : Alpha;
+        }
+      float sum = 0.0f;
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if (k < nModes) sum += g[k][WEIGHT];
+      if constexpr (GRIMSON) {
+        const double invSum = 1.0 / (double)sum;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          if (k < nModes) {
+            g[k][WEIGHT] *= (float)invSum;
+            g[k][SIG] = div_rn(g[k][WEIGHT], sqrt_rn(g[k][VAR]));
+          }
+      } else {
+        const float invSum = div_rn(1.0f, sum);
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          if (k < nModes) g[k][WEIGHT] *= invSum;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          if (k == last) g[k][MU] = px[0], g[k][MU + 1] = px[1], g[k][MU + 2] = px[2], g[k][VAR] = m_variance;
+        bool stop = false;  // ZivkovicAGMM.cpp:331-345
+#pragma unroll
+        for (int il = K - 1; il > 0; --il)
+          if (il <= last && !stop) {
+            if (g[il][WEIGHT] > g[il - 1][WEIGHT])
+              swap_modes(g[il], g[il - 1]);
+            else
+              stop = true;
+          }
+      }
+    }
+    if constexpr (GRIMSON) grimson_sort(nModes);  // the second qsort runs whether or not a mode was added (:281)
+    *pn = (uint8_t)nModes;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int f = 0; f < F; ++f) st[(size_t)(k * F + f) * a.n] = g[k][f];
+    mask = bBackgroundHigh ? 0 : 255;
+  }
+  dp_store_mask(a, gp, active, mask);
+}
+
+__global__ __launch_bounds__(kBlock) void dp_wren_kernel(const DpArgs a) {
+  const size_t gp = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool active = gp < a.npix;
+  int mask = 0;
+  if (active) {
+    const size_t s = gp / a.n, i = gp - s * a.n;
+    float* st = a.state + ((size_t)(a.first + s) * 4) * a.n + i;
+    float mu[3] = {st[0], st[a.n], st[2 * a.n]}, var = st[3 * a.n];
+    const float px[3] = {(float)a.frame[gp * 3], (float)a.frame[gp * 3 + 1], (float)a.frame[gp * 3 + 2]};
+    float dist = 0;  // SubtractPixel, WrenGA.cpp:113-134
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float delta = mu[ch] - px[ch];
+      dist += delta * delta;
+    }
+    mask = dist > a.high * var ? 255 : 0;
+    const float dR = mu[0] - px[0], dG = mu[1] - px[1], dB = mu[2] - px[2];  // Update, :79-111
+    const float d2 = (dR * dR + dG * dG + dB * dB);
+    mu[0] -= a.alpha * (dR), mu[1] -= a.alpha * (dG), mu[2] -= a.alpha * (dB);
+    const float sigmanew = var + a.alpha * (d2 - var);
+    var = sigmanew < 4 ? 4 : sigmanew > 5 * 36.0f ? 5 * 36.0f : sigmanew;
+    st[0] = mu[0], st[a.n] = mu[1], st[2 * a.n] = mu[2], st[3 * a.n] = var;
+  }
+  dp_store_mask(a, gp, active, mask);
+}
+
+__global__ __launch_bounds__(kBlock) void dp_mean_kernel(const DpArgs a) {
+  const size_t gp = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool active = gp < a.npix;
+  int mask = 0;
+  if (active) {
+    const size_t s = gp / a.n, i = gp - s * a.n;
+    float* st = a.state + ((size_t)(a.first + s) * 3) * a.n + i;
+    float dist = 0;  // SubtractPixel, MeanBGS.cpp:77-98
+    float mean[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      mean[ch] = st[(size_t)ch * a.n];
+      const float px = (float)a.frame[gp * 3 + ch];
+      dist += (px - mean[ch]) * (px - mean[ch]);
+      st[(size_t)ch * a.n] = a.alpha * mean[ch] + (1.0f - a.alpha) * px;  // Update, :52-75
+    }
+    mask = dist > a.high ? 255 : 0;
+  }
+  dp_store_mask(a, gp, active, mask);
+}
+
+__global__ __launch_bounds__(kBlock) void dp_median_kernel(const DpArgs a) {
+  const size_t gp = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool active = gp < a.npix;
+  int mask = 0;
+  if (active) {
+    uint8_t* med = a.bstate + ((size_t)a.first * a.n + gp) * 3;
+    bool bgd = true;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const int px = a.frame[gp * 3 + ch], m = med[ch];
+      bgd = bgd && (float)abs(px - m) <= a.high;  // AdaptiveMedianBGS.cpp:92-108
+      if (a.update) med[ch] = (uint8_t)(px > m ? m + 1 : px < m ? m - 1 : m);  // :58-84
+    }
+    mask = bgd ? 0 : 255;
+  }
+  dp_store_mask(a, gp, active, mask);
+}
+
+// WrenGA / Mean: model = the first frame (InitModel); one lane per pixel
+__global__ __launch_bounds__(kBlock) void dp_init_kernel(const DpArgs a, int planes, float var0) {
+  const size_t gp = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (gp >= a.npix) return;
+  const size_t s = gp / a.n, i = gp - s * a.n;
+  float* st = a.state + ((size_t)(a.first + s) * planes) * a.n + i;
+  for (int ch = 0; ch < 3; ++ch) st[(size_t)ch * a.n] = (float)a.frame[gp * 3 + ch];
+  if (planes == 4) st[3 * a.n] = var0;
+}
+
+}  // namespace bgs
