@@ -11,6 +11,15 @@ FrameProcessor::FrameProcessor()
       enableWeightedMovingMeanBGS(false), weightedMovingVariance(nullptr), enableWeightedMovingVarianceBGS(false), mixtureOfGaussianV1BGS(nullptr),
       enableMixtureOfGaussianV1BGS(false), mixtureOfGaussianV2BGS(nullptr), enableMixtureOfGaussianV2BGS(false), adaptiveBackgroundLearning(nullptr),
       enableAdaptiveBackgroundLearning(false), adaptiveSelectiveBackgroundLearning(nullptr), enableAdaptiveSelectiveBackgroundLearning(false) {
+  gmg = nullptr, enableGMG = false;
+  adaptiveMedian = nullptr, enableDPAdaptiveMedianBGS = false;
+  grimsonGMM = nullptr, enableDPGrimsonGMMBGS = false;
+  zivkovicAGMM = nullptr, enableDPZivkovicAGMMBGS = false;
+  temporalMean = nullptr, enableDPMeanBGS = false;
+  wrenGA = nullptr, enableDPWrenGABGS = false;
+  sdbgs = nullptr, enableSigmaDeltaBGS = false;
+  ssbgs = nullptr, enableSuBSENSEBGS = false;
+
   std::cout << "FrameProcessor()" << std::endl;
   loadConfig();  // FrameProcessor.cpp:26-27
   saveConfig();
@@ -26,6 +35,14 @@ void FrameProcessor::init() {  // FrameProcessor.cpp:35-155
   if (enableMixtureOfGaussianV1BGS) mixtureOfGaussianV1BGS = new MixtureOfGaussianV1BGS;
   if (enableMixtureOfGaussianV2BGS) mixtureOfGaussianV2BGS = new MixtureOfGaussianV2BGS;
   if (enableAdaptiveBackgroundLearning) adaptiveBackgroundLearning = new AdaptiveBackgroundLearning;
+  if (enableGMG) gmg = new GMG;
+  if (enableDPAdaptiveMedianBGS) adaptiveMedian = new DPAdaptiveMedianBGS;
+  if (enableDPGrimsonGMMBGS) grimsonGMM = new DPGrimsonGMMBGS;
+  if (enableDPZivkovicAGMMBGS) zivkovicAGMM = new DPZivkovicAGMMBGS;
+  if (enableDPMeanBGS) temporalMean = new DPMeanBGS;
+  if (enableDPWrenGABGS) wrenGA = new DPWrenGABGS;
+  if (enableSigmaDeltaBGS) sdbgs = new SigmaDeltaBGS;
+  if (enableSuBSENSEBGS) ssbgs = new SuBSENSEBGS;
   if (enableAdaptiveSelectiveBackgroundLearning) adaptiveSelectiveBackgroundLearning = new AdaptiveSelectiveBackgroundLearning;
 }
 
@@ -47,6 +64,14 @@ void FrameProcessor::process(const Image& img_input) {  // :169-340
   if (enableMixtureOfGaussianV1BGS) process("MixtureOfGaussianV1BGS", mixtureOfGaussianV1BGS, img_prep, img_mog1);
   if (enableMixtureOfGaussianV2BGS) process("MixtureOfGaussianV2BGS", mixtureOfGaussianV2BGS, img_prep, img_mog2);
   if (enableAdaptiveBackgroundLearning) process("AdaptiveBackgroundLearning", adaptiveBackgroundLearning, img_prep, img_bkgl_fgmask);
+  if (enableGMG) process("GMG", gmg, img_prep, img_gmg);
+  if (enableDPAdaptiveMedianBGS) process("DPAdaptiveMedianBGS", adaptiveMedian, img_prep, img_adpmed);
+  if (enableDPGrimsonGMMBGS) process("DPGrimsonGMMBGS", grimsonGMM, img_prep, img_grigmm);
+  if (enableDPZivkovicAGMMBGS) process("DPZivkovicAGMMBGS", zivkovicAGMM, img_prep, img_zivgmm);
+  if (enableDPMeanBGS) process("DPMeanBGS", temporalMean, img_prep, img_tmpmean);
+  if (enableDPWrenGABGS) process("DPWrenGABGS", wrenGA, img_prep, img_wrenga);
+  if (enableSigmaDeltaBGS) process("SigmaDeltaBGS", sdbgs, img_prep, img_sdbgs);
+  if (enableSuBSENSEBGS) process("SuBSENSEBGS", ssbgs, img_prep, img_ssbgs);
   if (enableAdaptiveSelectiveBackgroundLearning)
     process("AdaptiveSelectiveBackgroundLearning", adaptiveSelectiveBackgroundLearning, img_prep, img_asbl);
   firstTime = false;
@@ -54,6 +79,14 @@ void FrameProcessor::process(const Image& img_input) {  // :169-340
 
 void FrameProcessor::finish() {  // :342-482 (reverse order of init)
   delete adaptiveSelectiveBackgroundLearning, adaptiveSelectiveBackgroundLearning = nullptr;
+  delete ssbgs, ssbgs = nullptr;
+  delete sdbgs, sdbgs = nullptr;
+  delete wrenGA, wrenGA = nullptr;
+  delete temporalMean, temporalMean = nullptr;
+  delete zivkovicAGMM, zivkovicAGMM = nullptr;
+  delete grimsonGMM, grimsonGMM = nullptr;
+  delete adaptiveMedian, adaptiveMedian = nullptr;
+  delete gmg, gmg = nullptr;
   delete adaptiveBackgroundLearning, adaptiveBackgroundLearning = nullptr;
   delete mixtureOfGaussianV2BGS, mixtureOfGaussianV2BGS = nullptr;
   delete mixtureOfGaussianV1BGS, mixtureOfGaussianV1BGS = nullptr;
@@ -85,6 +118,14 @@ void FrameProcessor::saveConfig() {  // :496-552 (keys of the classes this build
   fs.writeInt("enableMixtureOfGaussianV1BGS", enableMixtureOfGaussianV1BGS);
   fs.writeInt("enableMixtureOfGaussianV2BGS", enableMixtureOfGaussianV2BGS);
   fs.writeInt("enableAdaptiveBackgroundLearning", enableAdaptiveBackgroundLearning);
+  fs.writeInt("enableGMG", enableGMG);
+  fs.writeInt("enableDPAdaptiveMedianBGS", enableDPAdaptiveMedianBGS);
+  fs.writeInt("enableDPGrimsonGMMBGS", enableDPGrimsonGMMBGS);
+  fs.writeInt("enableDPZivkovicAGMMBGS", enableDPZivkovicAGMMBGS);
+  fs.writeInt("enableDPMeanBGS", enableDPMeanBGS);
+  fs.writeInt("enableDPWrenGABGS", enableDPWrenGABGS);
+  fs.writeInt("enableSigmaDeltaBGS", enableSigmaDeltaBGS);
+  fs.writeInt("enableSuBSENSEBGS", enableSuBSENSEBGS);
   fs.writeInt("enableAdaptiveSelectiveBackgroundLearning", enableAdaptiveSelectiveBackgroundLearning);
   fs.save("./config/FrameProcessor.xml");
 }
@@ -101,6 +142,14 @@ void FrameProcessor::loadConfig() {  // :554-610 (defaults: PreProcessor and Fra
   enableMixtureOfGaussianV1BGS = fs.readInt("enableMixtureOfGaussianV1BGS", false);
   enableMixtureOfGaussianV2BGS = fs.readInt("enableMixtureOfGaussianV2BGS", false);
   enableAdaptiveBackgroundLearning = fs.readInt("enableAdaptiveBackgroundLearning", false);
+  enableGMG = fs.readInt("enableGMG", false);
+  enableDPAdaptiveMedianBGS = fs.readInt("enableDPAdaptiveMedianBGS", false);
+  enableDPGrimsonGMMBGS = fs.readInt("enableDPGrimsonGMMBGS", false);
+  enableDPZivkovicAGMMBGS = fs.readInt("enableDPZivkovicAGMMBGS", false);
+  enableDPMeanBGS = fs.readInt("enableDPMeanBGS", false);
+  enableDPWrenGABGS = fs.readInt("enableDPWrenGABGS", false);
+  enableSigmaDeltaBGS = fs.readInt("enableSigmaDeltaBGS", false);
+  enableSuBSENSEBGS = fs.readInt("enableSuBSENSEBGS", false);
   enableAdaptiveSelectiveBackgroundLearning = fs.readInt("enableAdaptiveSelectiveBackgroundLearning", false);
 }
 

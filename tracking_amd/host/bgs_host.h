@@ -513,6 +513,60 @@ class SuBSENSEBGS : public HipBGSBase {
   }
 };
 
+// package_bgs/dp/DP*BGS.{h,cpp}: the wrapper reads its XML every frame but hands the values to the model only once, inside
+// `if(firstTime)` (e.g. DPZivkovicAGMMBGS.cpp:48-65) - later edits of the file change what saveConfig would write, not the
+// running model.  Mirrored: the values go into params_ only while firstTime is true.
+#define BGS_HIP_DP_CLASS(Class, ALGO, WRITE_BODY, READ_BODY)                  \
+  class Class : public HipBGSBase {                                           \
+   public:                                                                     \
+    Class() : HipBGSBase(ALGO, #Class), showOutput(true) {                    \
+      threshold = params_.dp_threshold, alpha = params_.dp_alpha, gaussians = params_.dp_gaussians; \
+      learningFrames = params_.learning_frames, samplingRate = params_.dp_sampling_rate; \
+    }                                                                          \
+    BGS_HIP_BANNER_DTOR(Class)                                                \
+   private:                                                                    \
+    double threshold, alpha;                                                   \
+    int gaussians, learningFrames, samplingRate;                               \
+    bool showOutput;                                                           \
+    void saveConfig() override {                                               \
+      XmlConfig fs;                                                            \
+      fs.beginWrite();                                                         \
+      WRITE_BODY fs.writeInt("showOutput", showOutput);                       \
+      fs.save(configPath());                                                   \
+    }                                                                          \
+    void loadConfig() override {                                               \
+      XmlConfig fs;                                                            \
+      fs.load(configPath());                                                   \
+      READ_BODY showOutput = fs.readInt("showOutput", true);                  \
+      if (firstTime) {                                                         \
+        params_.dp_threshold = (float)threshold, params_.dp_alpha = (float)alpha, params_.dp_gaussians = gaussians; \
+        params_.learning_frames = learningFrames, params_.dp_sampling_rate = samplingRate; \
+      }                                                                        \
+    }                                                                          \
+  };
+
+// DPZivkovicAGMMBGS.cpp:82-104
+BGS_HIP_DP_CLASS(DPZivkovicAGMMBGS, BGS_DP_ZIVKOVIC_AGMM,
+                 fs.writeReal("threshold", threshold); fs.writeReal("alpha", alpha); fs.writeInt("gaussians", gaussians);,
+                 threshold = fs.readReal("threshold", 25.0f); alpha = fs.readReal("alpha", 0.001f); gaussians = fs.readInt("gaussians", 3);)
+// DPGrimsonGMMBGS.cpp:84-105
+BGS_HIP_DP_CLASS(DPGrimsonGMMBGS, BGS_DP_GRIMSON_GMM,
+                 fs.writeReal("threshold", threshold); fs.writeReal("alpha", alpha); fs.writeInt("gaussians", gaussians);,
+                 threshold = fs.readReal("threshold", 9.0); alpha = fs.readReal("alpha", 0.01); gaussians = fs.readInt("gaussians", 3);)
+// DPWrenGABGS.cpp:83-104
+BGS_HIP_DP_CLASS(DPWrenGABGS, BGS_DP_WREN_GA,
+                 fs.writeReal("threshold", threshold); fs.writeReal("alpha", alpha); fs.writeInt("learningFrames", learningFrames);,
+                 threshold = fs.readReal("threshold", 12.25f); alpha = fs.readReal("alpha", 0.005f); learningFrames = fs.readInt("learningFrames", 30);)
+// DPMeanBGS.cpp:84-105 (threshold is an int there)
+BGS_HIP_DP_CLASS(DPMeanBGS, BGS_DP_MEAN,
+                 fs.writeInt("threshold", (int)threshold); fs.writeReal("alpha", alpha); fs.writeInt("learningFrames", learningFrames);,
+                 threshold = fs.readInt("threshold", 2700); alpha = fs.readReal("alpha", 1e-6f); learningFrames = fs.readInt("learningFrames", 30);)
+// DPAdaptiveMedianBGS.cpp:83-104
+BGS_HIP_DP_CLASS(DPAdaptiveMedianBGS, BGS_DP_ADAPTIVE_MEDIAN,
+                 fs.writeInt("threshold", (int)threshold); fs.writeInt("samplingRate", samplingRate); fs.writeInt("learningFrames", learningFrames);,
+                 threshold = fs.readInt("threshold", 40); samplingRate = fs.readInt("samplingRate", 7); learningFrames = fs.readInt("learningFrames", 30);)
+#undef BGS_HIP_DP_CLASS
+
 #undef BGS_HIP_BANNER_DTOR
 
 }  // namespace bgs_hip
