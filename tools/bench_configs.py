@@ -100,6 +100,15 @@ def run_subsense(S, steps=30, kind="surv"):
     e.close()
 
 
+def run_dp():
+    """N4: the package_bgs/dp models at 1080p x 16 streams (state r/w + frame + mask bytes per pixel)."""
+    run(capi.DP_ZIVKOVIC_AGMM, "DPZivkovicAGMMBGS (K=3)", 1080, 1920, 16, 126, borrow=False)
+    run(capi.DP_GRIMSON_GMM, "DPGrimsonGMMBGS (K=3)", 1080, 1920, 16, 150, borrow=False)
+    run(capi.DP_WREN_GA, "DPWrenGABGS", 1080, 1920, 16, 36, borrow=False)
+    run(capi.DP_MEAN, "DPMeanBGS", 1080, 1920, 16, 28, borrow=False)
+    run(capi.DP_ADAPTIVE_MEDIAN, "DPAdaptiveMedianBGS", 1080, 1920, 16, 10, borrow=False)
+
+
 def run_cc():
     """N1: connected components of a 1080p foreground-like mask (blobs + salt noise) and of a worst case (random 45 %)."""
     import numpy as np
@@ -134,6 +143,9 @@ def main():
     if args.only == "subsense":
         run_subsense(2)
         run_subsense(2, kind="smooth")
+        return
+    if args.only == "dp":
+        run_dp()
         return
     if args.only == "cc":
         run_cc()
