@@ -50,6 +50,7 @@ typedef enum bgs_algo {
   BGS_DP_WREN_GA = 14,       /* DPWrenGABGS::process               package_bgs/dp/DPWrenGABGS.cpp:29-81 */
   BGS_DP_MEAN = 15,          /* DPMeanBGS::process                 package_bgs/dp/DPMeanBGS.cpp:29-82 */
   BGS_DP_ADAPTIVE_MEDIAN = 16, /* DPAdaptiveMedianBGS::process     package_bgs/dp/DPAdaptiveMedianBGS.cpp:29-81 */
+  BGS_LOBSTER = 17,          /* LOBSTERBGS::process                package_bgs/pl/LOBSTER.cpp:20-45 */
   BGS_ALGO_COUNT
 } bgs_algo;
 
@@ -115,7 +116,9 @@ typedef struct bgs_params {
   double mog1_var_threshold;   /* 2.5*2.5 */
   double mog1_noise_sigma;     /* 15 (30*0.5) */
 
-  /* LBSP descriptor / SuBSENSE (package_bgs/pl/SuBSENSE.cpp:8-14) */
+  /* LBSP descriptor / SuBSENSE (package_bgs/pl/SuBSENSE.cpp:8-14).  LOBSTER (package_bgs/pl/LOBSTER.cpp:5-12) uses the same
+   * fields: lbsp_rel_threshold (0.365), lbsp_threshold_offset (0), subsense_min_color_dist_threshold = nColorDistThreshold (30),
+   * subsense_n_samples = nBGSamples (35), subsense_n_required (2), subsense_desc_dist_threshold_offset = nDescDistThreshold (4). */
   float lbsp_rel_threshold;    /* 0.333 */
   int32_t lbsp_threshold_offset;/* 0 (base-ctor default) */
   int32_t subsense_min_color_dist_threshold; /* 30 */

@@ -299,6 +299,10 @@ int orc_default_params(bgs_algo algo, bgs_params* p) {
     case BGS_DP_WREN_GA: p->dp_threshold = 12.25f, p->dp_alpha = 0.005f, p->learning_frames = 30; break;
     case BGS_DP_MEAN: p->dp_threshold = 2700.0f, p->dp_alpha = 1e-6f, p->learning_frames = 30; break;
     case BGS_DP_ADAPTIVE_MEDIAN: p->dp_threshold = 40.0f, p->learning_frames = 30; break;
+    case BGS_LOBSTER: /* BackgroundSubtractorLOBSTER.h:6-16 */
+      p->lbsp_rel_threshold = 0.365f, p->subsense_desc_dist_threshold_offset = 4, p->subsense_min_color_dist_threshold = 30;
+      p->subsense_n_samples = 35, p->subsense_n_required = 2;
+      break;
     default: break;
   }
   return BGS_OK;
@@ -1055,6 +1059,21 @@ int orc_process(orc_engine* e, const uint8_t* in, int rows, int cols, int channe
       if (channels != 3) return BGS_ERR_UNSUPPORTED;
       flags = sd_process(e, fg, fg_step);
       break;
+    case BGS_LOBSTER: { /* LOBSTERBGS::process, package_bgs/pl/LOBSTER.cpp:20-45 */
+      if (!e->ss) {
+        rc = lob_create(&e->p, e->cur, rows, cols, channels, &e->ss);
+        if (rc) return rc;
+      }
+      uint8_t* bgc = bg ? (uint8_t*)malloc(e->n * channels) : NULL;
+      rc = lob_process(e->ss, e->cur, e->tmp8b, bgc);
+      write_mask(e, e->tmp8b, fg, fg_step);
+      if (bgc) {
+        write_img(e, bgc, channels, bg, bg_step);
+        free(bgc);
+      }
+      flags = BGS_FG_VALID | BGS_BG_VALID;
+      break;
+    }
     case BGS_DP_ZIVKOVIC_AGMM:
     case BGS_DP_GRIMSON_GMM:
     case BGS_DP_WREN_GA:
@@ -1128,7 +1147,7 @@ int64_t orc_get_state(orc_engine* e, const char* plane, void* dst, size_t cap) {
       return (int64_t)(n * K * C * 4);
     }
   }
-  if (e->algo == BGS_SUBSENSE && e->ss) return ss_get_state(e->ss, plane, dst, cap);
+  if ((e->algo == BGS_SUBSENSE || e->algo == BGS_LOBSTER) && e->ss) return ss_get_state(e->ss, plane, dst, cap);
   if (e->dp) return dp_get_state(e->dp, plane, dst, cap);
   if (e->algo == BGS_GMG && e->gmg_colors) { /* canonical: colors int32 [F][n], weights f32 [F][n], nfeatures int32 [n] */
     const int F = e->p.gmg_max_features;

@@ -112,6 +112,10 @@ struct ss_state {
   /* scratch */
   uint8_t *raw, *t1, *t2, *t3;
   uint16_t* req; /* [n][2]: self request, neighbour request */
+  /* LOBSTER variant (lob_* below) */
+  int lobster, nColorThr, nDescThr;
+  uint8_t* curColor;  /* scratch: the frame's colour / intra descriptor of pixels that posted an update request */
+  uint16_t* curDesc;
 };
 
 #define REQ_VALID 0x8000u
@@ -127,7 +131,7 @@ void ss_destroy(ss_state* s) {
   if (!s) return;
   void* ptrs[] = {s->color, s->desc, s->R, s->V, s->T, s->Dlast[0], s->Dlast[1], s->DminLT, s->DminST, s->RawLT, s->RawST[0], s->RawST[1], s->FinLT,
                   s->FinST, s->unstable, s->blinks, s->lastFG, s->lastRaw, s->lastRawBlink, s->lastDilInv, s->lastColor, s->lastDesc, s->dsLT, s->dsST,
-                  s->raw, s->t1, s->t2, s->t3, s->req};
+                  s->raw, s->t1, s->t2, s->t3, s->req, s->curColor, s->curDesc};
   for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) free(ptrs[i]);
   free(s);
 }
@@ -397,9 +401,11 @@ static void ss_phase_b(ss_state* s) {
             const int code = (int)(r & 0x1f), slot = (int)((r >> 8) & 0x3f);
             const int ty = ys + code / 5 - 2, tx = xs + code % 5 - 2;
             if (ty != y || tx != x) continue;
+            const uint8_t* srcC = s->lobster ? s->curColor : s->lastColor; /* = current frame colour of the source */
+            const uint16_t* srcD = s->lobster ? s->curDesc : s->lastDesc;  /* = its current intra descriptor */
             for (int c = 0; c < s->C; ++c) {
-              s->color[((size_t)slot * n + j) * s->C + c] = s->lastColor[i * s->C + c]; /* = current frame colour of the source */
-              s->desc[((size_t)slot * n + j) * s->C + c] = s->lastDesc[i * s->C + c];   /* = its current intra descriptor */
+              s->color[((size_t)slot * n + j) * s->C + c] = srcC[i * s->C + c];
+              s->desc[((size_t)slot * n + j) * s->C + c] = srcD[i * s->C + c];
             }
           }
         }
@@ -535,7 +541,7 @@ int64_t ss_get_state(ss_state* s, const char* plane, void* dst, size_t cap) {
              {"color", s->color, (size_t)s->nS * n * s->C}, {"desc", s->desc, (size_t)s->nS * n * 2 * s->C}, {"lut", s->lut, 256}};
   for (size_t k = 0; k < sizeof(tab) / sizeof(tab[0]); ++k)
     if (!strcmp(plane, tab[k].name)) {
-      if (cap < tab[k].bytes) return BGS_ERR_STATE;
+      if (!tab[k].p || cap < tab[k].bytes) return BGS_ERR_STATE;
       memcpy(dst, tab[k].p, tab[k].bytes);
       return (int64_t)tab[k].bytes;
     }
@@ -547,4 +553,130 @@ int64_t ss_get_state(ss_state* s, const char* plane, void* dst, size_t cap) {
     return 7 * sizeof(double);
   }
   return BGS_ERR_STATE;
+}
+
+
+/* ================================================================================================== LOBSTER
+ * LOBSTERBGS::process (package_bgs/pl/LOBSTER.cpp:20-45) over BackgroundSubtractorLOBSTER (package_bgs/pl/
+ * BackgroundSubtractorLOBSTER.cpp): initialize :29-121, refreshModel :123-170, operator() :172-284, getBackgroundImage
+ * :286-303.  Same family as SuBSENSE (LBSP descriptors + colour samples, consensus with early exit, stochastic self /
+ * 3x3-neighbour replacement) without the feedback loops, so the same two-phase / counter-RNG contract applies (header
+ * of this file): draw slots per pixel and frame are 0 "rand()%nLearningRate" (self), 1 sample slot (self), 2
+ * "rand()%nLearningRate" (neighbour), 3 neighbour position, 4 sample slot (neighbour); refreshModel uses ss_refresh.
+ * LOBSTERBGS calls operator() with the default learning rate BGSLOBSTER_DEFAULT_LEARNING_RATE = 16. */
+#define LOB_LEARNING_RATE 16u
+
+int lob_create(const bgs_params* p, const uint8_t* img, int rows, int cols, int C, ss_state** out) {
+  if (rows < 5 || cols < 5) return BGS_ERR_UNSUPPORTED; /* LBSP::validateROI leaves nothing: CV_Assert(nROIPxCount>0) :52 */
+  if (C != 1 && C != 3) return BGS_ERR_UNSUPPORTED;
+  if (p->subsense_n_required > p->subsense_n_samples) return BGS_ERR_UNSUPPORTED; /* CV_Assert :19 */
+  ss_state* s = (ss_state*)calloc(1, sizeof(*s));
+  s->lobster = 1;
+  s->rows = rows, s->cols = cols, s->C = C, s->n = (size_t)rows * cols;
+  s->nS = p->subsense_n_samples, s->nReq = p->subsense_n_required;
+  s->nColorThr = p->subsense_min_color_dist_threshold, s->nDescThr = p->subsense_desc_dist_threshold_offset;
+  s->relT = p->lbsp_rel_threshold, s->lbspOff = p->lbsp_threshold_offset;
+  s->medK = 9; /* DEFAULT_MEDIAN_BLUR_KERNEL_SIZE, BackgroundSubtractorLBSP.cpp:17 */
+  const size_t n = s->n;
+  s->lastFG = (uint8_t*)calloc(n, 1);
+  s->lastColor = (uint8_t*)calloc(n, C), s->lastDesc = (uint16_t*)calloc(n * C, 2);
+  s->curColor = (uint8_t*)calloc(n, C), s->curDesc = (uint16_t*)calloc(n * C, 2);
+  s->color = (uint8_t*)calloc((size_t)s->nS * n, C), s->desc = (uint16_t*)calloc((size_t)s->nS * n * C, 2);
+  s->raw = (uint8_t*)calloc(n, 1);
+  s->req = (uint16_t*)calloc(n * 2, 2);
+  for (int t = 0; t < 256; ++t) { /* :85-86 (1ch: the sum / 2) and :103-104 */
+    float v = (float)(size_t)t * s->relT + (float)(size_t)s->lbspOff;
+    if (C == 1) v = v / 2;
+    s->lut[t] = sat_u8_f(v);
+  }
+  for (int y = 2; y < rows - 2; ++y)
+    for (int x = 2; x < cols - 2; ++x) { /* :87-98 / :105-119 */
+      const size_t i = (size_t)y * cols + x;
+      for (int c = 0; c < C; ++c) {
+        const int v = img[i * C + c];
+        s->lastColor[i * C + c] = (uint8_t)v;
+        s->lastDesc[i * C + c] = (uint16_t)lbsp1(img, cols, C, x, y, c, v, s->lut[v]);
+      }
+    }
+  ss_refresh(s, 1.0f, 0); /* :120 refreshModel(1.0f): frameIndex 0, all of lastFG is 0 */
+  *out = s;
+  return BGS_OK;
+}
+
+int lob_process(ss_state* s, const uint8_t* img, uint8_t* fg, uint8_t* bg) {
+  const size_t n = s->n;
+  const int rows = s->rows, cols = s->cols, C = s->C, nS = s->nS;
+  ++s->frameIndex;
+  const uint32_t fr = (uint32_t)s->frameIndex;
+  memset(s->raw, 0, n); /* oCurrFGMask = 0 :180 */
+  memset(s->req, 0, n * 4);
+  /* phase A: classification against the model as it stood at the start of the frame + update requests */
+  const size_t descThr3 = (size_t)s->nDescThr * 3, colorThr3 = (size_t)s->nColorThr * 3; /* :225-228 */
+  const size_t scDesc = descThr3 / 2, scColor = colorThr3 / 2;
+  for (int y = 2; y < rows - 2; ++y)
+    for (int x = 2; x < cols - 2; ++x) {
+      const size_t i = (size_t)y * cols + x;
+      const uint8_t* cur = img + i * C;
+      size_t good = 0, idx = 0;
+      while (good < (size_t)s->nReq && idx < (size_t)nS) {
+        const uint8_t* bc = s->color + (idx * n + i) * C;
+        const uint16_t* bd = s->desc + (idx * n + i) * C;
+        if (C == 1) { /* :192-205 */
+          const size_t cd = (size_t)abs((int)cur[0] - (int)bc[0]);
+          if (cd <= (size_t)s->nColorThr / 2) {
+            const unsigned in = lbsp1(img, cols, 1, x, y, 0, bc[0], s->lut[bc[0]]);
+            if ((size_t)popc16(in ^ bd[0]) <= (size_t)s->nDescThr) good++;
+          }
+        } else { /* :241-258 */
+          size_t totC = 0, totD = 0;
+          int ok = 1;
+          for (int c = 0; c < 3 && ok; ++c) {
+            const size_t cd = (size_t)abs((int)cur[c] - (int)bc[c]);
+            if (cd > scColor) {
+              ok = 0;
+              break;
+            }
+            const unsigned in = lbsp1(img, cols, 3, x, y, c, bc[c], s->lut[bc[c]]);
+            const size_t dd = (size_t)popc16(in ^ bd[c]);
+            if (dd > scDesc) {
+              ok = 0;
+              break;
+            }
+            totC += cd, totD += dd;
+          }
+          if (ok && totD <= descThr3 && totC <= colorThr3) good++;
+        }
+        idx++;
+      }
+      if (good < (size_t)s->nReq) {
+        s->raw[i] = 255; /* :207 / :260 */
+      } else {
+        const uint32_t pi = (uint32_t)i;
+        uint16_t reqSelf = 0, reqNbr = 0;
+        if ((ss_rand(fr, pi, 0) % LOB_LEARNING_RATE) == 0) reqSelf = REQ(ss_rand(fr, pi, 1) % (uint32_t)nS, 12); /* :209-214 / :262-269 */
+        if ((ss_rand(fr, pi, 2) % LOB_LEARNING_RATE) == 0) { /* :215-222 / :270-279, getRandNeighborPosition_3x3 RandUtils.h:59-71 */
+          const int r = (int)(ss_rand(fr, pi, 3) % 8u);
+          const int xn = clampi(x + SS_N3[r][0], 2, cols - 3), yn = clampi(y + SS_N3[r][1], 2, rows - 3);
+          reqNbr = REQ(ss_rand(fr, pi, 4) % (uint32_t)nS, (yn - y + 2) * 5 + (xn - x + 2));
+        }
+        s->req[i * 2] = reqSelf, s->req[i * 2 + 1] = reqNbr;
+        if (reqSelf || reqNbr)
+          for (int c = 0; c < C; ++c) { /* what the update writes: the current colour and its intra descriptor */
+            s->curColor[i * C + c] = cur[c];
+            s->curDesc[i * C + c] = (uint16_t)lbsp1(img, cols, C, x, y, c, cur[c], s->lut[cur[c]]);
+          }
+      }
+    }
+  ss_phase_b(s);
+  orc_median_blur_u8(s->raw, s->lastFG, rows, cols, s->medK); /* :281 */
+  memcpy(fg, s->lastFG, n);                                    /* :282 */
+  if (bg) { /* getBackgroundImage :286-303 */
+    for (size_t i = 0; i < n; ++i)
+      for (int c = 0; c < C; ++c) {
+        float acc = 0;
+        for (int k = 0; k < nS; ++k) acc += ((float)s->color[((size_t)k * n + i) * C + c]) / nS;
+        bg[i * C + c] = sat_u8_f(acc);
+      }
+  }
+  return BGS_OK;
 }

@@ -13,6 +13,9 @@ int ss_create(const bgs_params* p, const uint8_t* first_frame, int rows, int col
 int ss_process(ss_state* s, const uint8_t* img, uint8_t* fg, uint8_t* bg);
 int64_t ss_get_state(ss_state* s, const char* plane, void* dst, size_t cap);
 void ss_destroy(ss_state* s);
+/* LOBSTERBGS (same state type, fewer planes) */
+int lob_create(const bgs_params* p, const uint8_t* first_frame, int rows, int cols, int channels, ss_state** out);
+int lob_process(ss_state* s, const uint8_t* img, uint8_t* fg, uint8_t* bg);
 #ifdef __cplusplus
 }
 #endif

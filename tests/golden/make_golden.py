@@ -65,7 +65,7 @@ def main():
     out = {}
     for name, algo in [("fd", capi.FRAME_DIFF), ("sfd", capi.STATIC_FRAME_DIFF), ("wmm", capi.WMM), ("wmv", capi.WMV),
                        ("abl", capi.ABL), ("asbl", capi.ASBL), ("mog2", capi.MOG2), ("mog1", capi.MOG1), ("sd", capi.SIGMA_DELTA), ("gmg", capi.GMG), ("subsense", capi.SUBSENSE),
-                       ("dpziv", capi.DP_ZIVKOVIC_AGMM), ("dpgrim", capi.DP_GRIMSON_GMM), ("dpwren", capi.DP_WREN_GA), ("dpmean", capi.DP_MEAN), ("dpmedian", capi.DP_ADAPTIVE_MEDIAN)]:
+                       ("dpziv", capi.DP_ZIVKOVIC_AGMM), ("dpgrim", capi.DP_GRIMSON_GMM), ("dpwren", capi.DP_WREN_GA), ("dpmean", capi.DP_MEAN), ("dpmedian", capi.DP_ADAPTIVE_MEDIAN), ("lobster", capi.LOBSTER)]:
         o = po.Oracle(algo)
         fgs, bgs = [], []
         for f in frames:

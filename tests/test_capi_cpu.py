@@ -50,7 +50,7 @@ def test_abi_version_and_defaults():
 
 def test_defaults_agree_with_oracle():
     from oracle import pyoracle
-    for algo in range(17):
+    for algo in range(18):
         a = capi.default_params(algo)
         b = capi.BgsParams()
         b.struct_size = C.sizeof(capi.BgsParams)

@@ -820,3 +820,61 @@ def test_dp_models_reject_single_channel(golden_gray):
         assert ei.value.code == capi.ERR_UNSUPPORTED
         with pytest.raises(RuntimeError):
             pyoracle.Oracle(ALGOS[name]).process(golden_gray[0])
+
+
+def check_lobster_state(eng, orc, rows, cols, nS=35, stream=0, C=3):
+    n = rows * cols
+    assert np.array_equal(eng.get_state("lastfg", (n,), np.uint8, stream=stream), orc.get_state("lastfg", (n,), np.uint8))
+    assert np.array_equal(eng.get_state("lastcolor", (n * C,), np.uint8, stream=stream), orc.get_state("lastcolor", (n * C,), np.uint8))
+    assert np.array_equal(eng.get_state("lastdesc", (n * C,), np.uint16, stream=stream), orc.get_state("lastdesc", (n * C,), np.uint16))
+    assert np.array_equal(eng.get_state("color", (nS, n, C), np.uint8, stream=stream), orc.get_state("color", (nS, n, C), np.uint8)), "colour samples"
+    assert np.array_equal(eng.get_state("desc", (nS, n, C), np.uint16, stream=stream), orc.get_state("desc", (nS, n, C), np.uint16)), "descriptor samples"
+    assert np.array_equal(eng.get_state("lut", (256,), np.uint8, stream=stream), orc.get_state("lut", (256,), np.uint8))
+
+
+def test_lobster_golden_frames_and_scene_change(golden_frames):
+    """LOBSTERBGS (N4): masks, backgrounds and the whole sample model (35 colour + descriptor samples) equal the oracle under the
+    two-phase / counter-RNG contract it shares with SuBSENSE; the second half of the clip is brightness-shifted."""
+    shifted = np.clip(golden_frames.astype(np.int32) + 50, 0, 255).astype(np.uint8)
+    frames = np.concatenate([golden_frames, shifted[:12]])
+    eng, orc, outs = run_pair(capi.LOBSTER, frames)
+    check_lobster_state(eng, orc, frames.shape[1], frames.shape[2])
+    assert outs[0][0].max() == 0 and outs[len(golden_frames)][0].mean() > 50  # first frame: all background; after the cut: mostly foreground
+
+
+@pytest.mark.parametrize("shape", [(37, 53), (5, 5), (6, 70), (130, 67)])
+def test_lobster_ragged_sizes(shape):
+    frames = synth.random_frames(8, shape[0], shape[1], 3, seed=shape[0] + shape[1])
+    frames[4:] = frames[:4]  # repeated content so that part of the image is background and posts update requests
+    eng, orc, _ = run_pair(capi.LOBSTER, frames)
+    check_lobster_state(eng, orc, shape[0], shape[1])
+
+
+@pytest.mark.parametrize("kw", [dict(subsense_n_samples=8, subsense_n_required=1), dict(subsense_n_samples=20, subsense_n_required=4), dict(subsense_min_color_dist_threshold=12),
+                                dict(subsense_desc_dist_threshold_offset=1), dict(lbsp_rel_threshold=0.2, lbsp_threshold_offset=6)])
+def test_lobster_param_variants(kw, golden_frames):
+    p = _params(capi.LOBSTER, **kw)
+    eng, orc, _ = run_pair(capi.LOBSTER, golden_frames[:14], params=p)
+    check_lobster_state(eng, orc, golden_frames.shape[1], golden_frames.shape[2], nS=p.subsense_n_samples)
+
+
+def test_lobster_grayscale_and_streams(golden_gray):
+    """1-channel path (BackgroundSubtractorLOBSTER.cpp:183-223: thresholds / 2, LUT / 2) and 3 interleaved streams through the device batch."""
+    eng, orc, _ = run_pair(capi.LOBSTER, golden_gray)
+    check_lobster_state(eng, orc, golden_gray.shape[1], golden_gray.shape[2], C=1)
+    torch = _torch()
+    S, T, H, W = 3, 7, 40, 72
+    clips = np.stack([synth.s_smooth(T, H, W, seed=50 + s, device="cpu").numpy() for s in range(S)])
+    eng = Engine(capi.LOBSTER, n_streams=S)
+    eng.set_geometry(H, W, 3)
+    orcs = [pyoracle.Oracle(capi.LOBSTER) for _ in range(S)]
+    for t in range(T):
+        d_frames = torch.from_numpy(np.ascontiguousarray(clips[:, t])).cuda()
+        d_fg = torch.empty((S, H, W), dtype=torch.uint8, device="cuda")
+        d_bg = torch.empty((S, H, W, 3), dtype=torch.uint8, device="cuda")
+        eng.process_batch_device(d_frames, d_fg, d_bg, None)
+        for s in range(S):
+            ofg, obg = orcs[s].process(clips[s, t])
+            assert np.array_equal(d_fg[s].cpu().numpy(), ofg) and np.array_equal(d_bg[s].cpu().numpy(), obg), (t, s)
+    for s in range(S):
+        check_lobster_state(eng, orcs[s], H, W, stream=s)

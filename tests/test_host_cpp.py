@@ -14,7 +14,7 @@ DEMO = os.path.join(ROOT, "tracking_amd", "lib", "bgs_demo")
 
 CLASSES = ["FrameDifferenceBGS", "StaticFrameDifferenceBGS", "WeightedMovingMeanBGS", "WeightedMovingVarianceBGS",
            "MixtureOfGaussianV1BGS", "MixtureOfGaussianV2BGS", "AdaptiveBackgroundLearning", "AdaptiveSelectiveBackgroundLearning",
-           "GMG", "DPAdaptiveMedianBGS", "DPGrimsonGMMBGS", "DPZivkovicAGMMBGS", "DPMeanBGS", "DPWrenGABGS", "SigmaDeltaBGS", "SuBSENSEBGS"]
+           "GMG", "DPAdaptiveMedianBGS", "DPGrimsonGMMBGS", "DPZivkovicAGMMBGS", "DPMeanBGS", "DPWrenGABGS", "SigmaDeltaBGS", "SuBSENSEBGS", "LOBSTERBGS"]
 
 
 @pytest.fixture(scope="module")
@@ -71,7 +71,7 @@ def test_demo_masks_equal_oracle_for_every_class(demo, tmp_path, golden_frames):
     from oracle import pyoracle
     from tracking_amd import capi
     algo = dict(zip(CLASSES, [capi.FRAME_DIFF, capi.STATIC_FRAME_DIFF, capi.WMM, capi.WMV, capi.MOG1, capi.MOG2, capi.ABL, capi.ASBL,
-                              capi.GMG, capi.DP_ADAPTIVE_MEDIAN, capi.DP_GRIMSON_GMM, capi.DP_ZIVKOVIC_AGMM, capi.DP_MEAN, capi.DP_WREN_GA, capi.SIGMA_DELTA, capi.SUBSENSE]))
+                              capi.GMG, capi.DP_ADAPTIVE_MEDIAN, capi.DP_GRIMSON_GMM, capi.DP_ZIVKOVIC_AGMM, capi.DP_MEAN, capi.DP_WREN_GA, capi.SIGMA_DELTA, capi.SUBSENSE, capi.LOBSTER]))
     write_fp_config(str(tmp_path / "config"), CLASSES, tictoc="MixtureOfGaussianV2BGS")
     # a non-default per-class config must be honoured too (the reference re-reads it every frame)
     (tmp_path / "config" / "DPGrimsonGMMBGS.xml").write_text(

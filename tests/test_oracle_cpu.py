@@ -88,7 +88,7 @@ def test_framediff_matches_independent_formula(golden_frames):
 @pytest.mark.parametrize("name,algo", [("fd", capi.FRAME_DIFF), ("sfd", capi.STATIC_FRAME_DIFF), ("wmm", capi.WMM), ("wmv", capi.WMV),
                                        ("abl", capi.ABL), ("asbl", capi.ASBL), ("mog2", capi.MOG2), ("mog1", capi.MOG1), ("sd", capi.SIGMA_DELTA), ("gmg", capi.GMG), ("subsense", capi.SUBSENSE),
                                        ("dpziv", capi.DP_ZIVKOVIC_AGMM), ("dpgrim", capi.DP_GRIMSON_GMM), ("dpwren", capi.DP_WREN_GA), ("dpmean", capi.DP_MEAN),
-                                       ("dpmedian", capi.DP_ADAPTIVE_MEDIAN)])
+                                       ("dpmedian", capi.DP_ADAPTIVE_MEDIAN), ("lobster", capi.LOBSTER)])
 def test_oracle_regression_vectors(name, algo, golden_frames, oracle_regress):
     o = pyoracle.Oracle(algo)
     want = oracle_regress[name + "_fg"]

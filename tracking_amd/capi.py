@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libbgs_hip.so")
 # bgs_algo (include/bgs_hip.h)
 FRAME_DIFF, STATIC_FRAME_DIFF, WMM, WMV, ABL, ASBL, MOG2, MOG1, GMG, SUBSENSE, LBSP_DESC, SIGMA_DELTA = range(12)
 DP_ZIVKOVIC_AGMM, DP_GRIMSON_GMM, DP_WREN_GA, DP_MEAN, DP_ADAPTIVE_MEDIAN = range(12, 17)
+LOBSTER = 17
 FG_VALID, BG_VALID = 1, 2
 OPT_BORROW_FRAMES, OPT_MOG2_PIXELS_PER_LANE, OPT_MOG2_TILED, OPT_XCD_SWIZZLE, OPT_PLACEMENT_PROBE, OPT_MOG2_SPARSE = 1, 2, 3, 4, 5, 6
 

@@ -328,7 +328,8 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
     case BGS_GMG: e->state_ch = 1; break;  // bgstate = the unsmoothed mask
     case BGS_MOG1:
     case BGS_MOG2:
-    case BGS_SUBSENSE: break;
+    case BGS_SUBSENSE:
+    case BGS_LOBSTER: break;
     case BGS_DP_ZIVKOVIC_AGMM:
     case BGS_DP_GRIMSON_GMM: e->state_ch = 1; break;  // bgstate = modes per pixel
     case BGS_DP_WREN_GA:
@@ -362,6 +363,10 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
   }
   if (is_dp(e->algo)) {
     int rc = dp_allocate(e);
+    if (rc) return rc;
+  }
+  if (e->algo == BGS_LOBSTER) {
+    int rc = lob_allocate(e);
     if (rc) return rc;
   }
   if (!e->stream) HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
@@ -521,6 +526,13 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
     case BGS_SUBSENSE: {
       if (d_bits) return fail(BGS_ERR_UNSUPPORTED, "SuBSENSE writes the byte mask only");
       int rc = ss_process(e, first, count, d_frames, d_fg, d_bg, s, t);
+      if (rc) return rc;
+      flags = BGS_FG_VALID | BGS_BG_VALID;
+      break;
+    }
+    case BGS_LOBSTER: {
+      if (d_bits) return fail(BGS_ERR_UNSUPPORTED, "LOBSTER writes the byte mask only");
+      int rc = lob_process(e, first, count, d_frames, d_fg, d_bg, s, t);
       if (rc) return rc;
       flags = BGS_FG_VALID | BGS_BG_VALID;
       break;
@@ -717,6 +729,10 @@ int bgs_default_params(bgs_algo algo, bgs_params* p) {
     case BGS_DP_WREN_GA: p->dp_threshold = 12.25f, p->dp_alpha = 0.005f, p->learning_frames = 30; break;
     case BGS_DP_MEAN: p->dp_threshold = 2700.0f, p->dp_alpha = 1e-6f, p->learning_frames = 30; break;
     case BGS_DP_ADAPTIVE_MEDIAN: p->dp_threshold = 40.0f, p->learning_frames = 30; break;
+    case BGS_LOBSTER:  // BackgroundSubtractorLOBSTER.h:6-16
+      p->lbsp_rel_threshold = 0.365f, p->subsense_desc_dist_threshold_offset = 4, p->subsense_min_color_dist_threshold = 30;
+      p->subsense_n_samples = 35, p->subsense_n_required = 2;
+      break;
     default: break;
   }
   return BGS_OK;
@@ -902,7 +918,7 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
       return (int64_t)need;
     }
   }
-  if (e->algo == BGS_SUBSENSE && e->ss) return ss_get_state(e, stream, plane, dst, cap);
+  if ((e->algo == BGS_SUBSENSE || e->algo == BGS_LOBSTER) && e->ss) return ss_get_state(e, stream, plane, dst, cap);
   if (is_dp(e->algo)) {  // planes are stored canonically: [stream][plane][n]
     const int planes = dp_planes_of(e);
     const char* fname = (e->algo == BGS_DP_WREN_GA) ? "gauss" : (e->algo == BGS_DP_MEAN) ? "mean" : "modes";

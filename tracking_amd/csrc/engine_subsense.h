@@ -18,8 +18,8 @@ enum { SS_UNSTABLE, SS_BLINKS, SS_LASTFG, SS_LASTRAW, SS_LASTRAWBLINK, SS_LASTDI
   } while (0)
 
 struct SsDevice {
-  uint8_t *color = nullptr, *lut = nullptr, *lastColor = nullptr;
-  uint16_t *desc = nullptr, *lastDesc = nullptr, *req = nullptr;
+  uint8_t *color = nullptr, *lut = nullptr, *lastColor = nullptr, *curColor = nullptr;  // cur*: LOBSTER scratch (kernel_subsense.h)
+  uint16_t *desc = nullptr, *lastDesc = nullptr, *req = nullptr, *curDesc = nullptr;
   float* f32[SS_NF32] = {nullptr};
   uint8_t* u8[SS_NU8] = {nullptr};
   float *dsLT = nullptr, *dsST = nullptr;
@@ -31,7 +31,7 @@ struct SsDevice {
   int use3x3 = 1, lrScaling = 0, medK = 9;
   float capLo0 = 4.f, capHi0 = 512.f;
   void release() {
-    void* p[] = {color, lut, lastColor, desc, lastDesc, req, dsLT, dsST, sc, changed, mbits, rbits};
+    void* p[] = {color, lut, lastColor, curColor, desc, lastDesc, curDesc, req, dsLT, dsST, sc, changed, mbits, rbits};
     for (void* q : p)
       if (q) (void)hipFree(q);
     for (auto& q : f32)
@@ -39,7 +39,7 @@ struct SsDevice {
     for (auto& q : u8)
       if (q) (void)hipFree(q), q = nullptr;
     if (h_changed) (void)hipHostFree(h_changed);
-    color = lut = lastColor = nullptr, desc = lastDesc = req = nullptr, dsLT = dsST = nullptr, sc = nullptr, changed = h_changed = nullptr, mbits = rbits = nullptr;
+    color = lut = lastColor = curColor = nullptr, desc = lastDesc = req = curDesc = nullptr, dsLT = dsST = nullptr, sc = nullptr, changed = h_changed = nullptr, mbits = rbits = nullptr;
   }
 };
 
@@ -231,6 +231,11 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
 
 int64_t ss_get_state(bgs_engine* e, int stream, const char* plane, void* dst, size_t cap) {
   SsDevice* d = e->ss;
+  if (e->algo == BGS_LOBSTER) {  // the LOBSTER model has no feedback maps
+    bool ok = false;
+    for (const char* nm : {"lastfg", "lastcolor", "lastdesc", "color", "desc", "lut"}) ok = ok || !strcmp(plane, nm);
+    if (!ok) return fail(BGS_ERR_STATE, "unknown state plane '%s' for LOBSTER", plane);
+  }
   const size_t N = e->n, off = N * stream, nS = (size_t)e->p.subsense_n_samples, C = (size_t)e->ch;
   const int cur = d->pp[stream];
   struct Ent {
@@ -272,6 +277,91 @@ int64_t ss_get_state(bgs_engine* e, int stream, const char* plane, void* dst, si
     return 7 * sizeof(double);
   }
   return fail(BGS_ERR_STATE, "unknown state plane '%s' for SuBSENSE", plane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- LOBSTER
+// LOBSTERBGS::process (package_bgs/pl/LOBSTER.cpp:20-45): same sample planes as SuBSENSE, no feedback maps.
+int lob_allocate(bgs_engine* e) {
+  if (e->rows < 5 || e->cols < 5) return fail(BGS_ERR_UNSUPPORTED, "LOBSTER needs at least 5x5 pixels (LBSP::validateROI)");
+  const bgs_params& p = e->p;
+  if (p.subsense_n_samples < 1 || p.subsense_n_samples > 63 || p.subsense_n_required > p.subsense_n_samples)
+    return fail(BGS_ERR_UNSUPPORTED, "LOBSTER: nBGSamples must be 1..63 and nRequiredBGSamples <= nBGSamples");
+  SsDevice* d = new SsDevice();
+  e->ss = d;
+  const size_t N = e->n, P = N * e->S, nS = (size_t)p.subsense_n_samples, C = (size_t)e->ch;
+  HIP_TRY(hipMalloc((void**)&d->color, P * nS * C));
+  HIP_TRY(hipMalloc((void**)&d->desc, P * nS * C * 2));
+  HIP_TRY(hipMalloc((void**)&d->lastColor, P * C));
+  HIP_TRY(hipMalloc((void**)&d->lastDesc, P * C * 2));
+  HIP_TRY(hipMalloc((void**)&d->curColor, P * C));
+  HIP_TRY(hipMalloc((void**)&d->curDesc, P * C * 2));
+  HIP_TRY(hipMalloc((void**)&d->req, P * 2 * 2));
+  HIP_TRY(hipMalloc((void**)&d->lut, (size_t)e->S * 256));
+  HIP_TRY(hipMalloc((void**)&d->u8[SS_LASTFG], P));
+  HIP_TRY(hipMalloc((void**)&d->u8[SS_RAW], P));
+  d->medK = 9;  // DEFAULT_MEDIAN_BLUR_KERNEL_SIZE, BackgroundSubtractorLBSP.cpp:17
+  d->pp.assign(e->S, 0);
+  return BGS_OK;
+}
+
+void lob_fill_args(const bgs_engine* e, bgs::SsArgs& a, int first, unsigned frameIndex) {
+  const SsDevice* d = e->ss;
+  const bgs_params& p = e->p;
+  a.color = d->color, a.desc = d->desc, a.lastColor = d->lastColor, a.lastDesc = d->lastDesc, a.req = d->req, a.lut = d->lut;
+  a.lastFG = d->u8[SS_LASTFG], a.raw = d->u8[SS_RAW];
+  a.rows = e->rows, a.cols = e->cols, a.nS = p.subsense_n_samples, a.nReq = p.subsense_n_required;
+  a.nMinColor = p.subsense_min_color_dist_threshold, a.nDescOff = p.subsense_desc_dist_threshold_offset;
+  a.frameIndex = frameIndex, a.first = first;
+}
+
+int lob_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uint8_t* d_fg, uint8_t* d_bg, hipStream_t s, int64_t t) {
+  SsDevice* d = e->ss;
+  const size_t N = e->n, off = N * first, npix = N * count, nS = (size_t)e->p.subsense_n_samples, C = (size_t)e->ch;
+  if (!aligned(d_frames, 4)) return fail(BGS_ERR_INVALID, "LOBSTER: frames must be 4-byte aligned");
+  const dim3 block(bgs::kBlock);
+  if (t == 0) {  // LOBSTER.cpp:27-34: construct + initialize on the first frame, then fall through to operator()
+    uint8_t lut[256];
+    for (int v = 0; v < 256; ++v) {  // BackgroundSubtractorLOBSTER.cpp:85-86 (gray: the sum / 2), :103-104
+      float f = (float)(size_t)v * e->p.lbsp_rel_threshold + (float)(size_t)e->p.lbsp_threshold_offset;
+      if (e->ch == 1) f = f / 2;
+      const long r = std::lrint((double)f);
+      lut[v] = (uint8_t)std::min<long>(std::max<long>(r, 0), 255);
+    }
+    for (int i = first; i < first + count; ++i) HIP_TRY(hipMemcpyAsync(d->lut + (size_t)i * 256, lut, 256, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));  // lut lives on this stack frame
+    HIP_TRY(hipMemsetAsync(d->u8[SS_LASTFG] + off, 0, npix, s));
+    HIP_TRY(hipMemsetAsync(d->color + off * nS * C, 0, npix * nS * C, s));
+    HIP_TRY(hipMemsetAsync(d->desc + off * nS * C, 0, npix * nS * C * 2, s));
+    bgs::LbspArgs la{};
+    la.img = d_frames, la.desc = d->lastDesc + off * C, la.rows = e->rows, la.cols = e->cols;
+    std::memcpy(la.lut, lut, 256);
+    const dim3 lgrid((e->cols + bgs::kLbspTW - 1) / bgs::kLbspTW, (e->rows + bgs::kLbspTH - 1) / bgs::kLbspTH, count);
+    if (e->ch == 3)
+      hipLaunchKernelGGL((bgs::lbsp_kernel<3>), lgrid, block, 0, s, la);
+    else
+      hipLaunchKernelGGL((bgs::lbsp_kernel<1>), lgrid, block, 0, s, la);
+    bgs::SsArgs a0{};
+    lob_fill_args(e, a0, first, 0);
+    a0.frame = d_frames;
+    SS_LAUNCH(ss_init_lastcolor_kernel, dim3(blocks_for(N), 1, count), block, s, a0);
+    SS_LAUNCH(ss_refresh_kernel, dim3(blocks_for(N), 1, count), block, s, a0, 0);  // refreshModel(1.0f), :120
+  }
+  bgs::SsArgs a{};
+  lob_fill_args(e, a, first, (unsigned)(t + 1));
+  a.frame = d_frames, a.fg = d_fg, a.bgimg = d_bg;
+  a.lastColor = d->curColor, a.lastDesc = d->curDesc;  // phase A writes / phase B reads what a requesting pixel copies into the model
+  const dim3 tiles((e->cols + bgs::kSsTW - 1) / bgs::kSsTW, (e->rows + bgs::kSsTH - 1) / bgs::kSsTH, count);
+  {
+    Timed tm(e, s, "lob_phase_a_kernel");
+    SS_LAUNCH(lob_phase_a_kernel, tiles, block, s, a);
+  }
+  SS_LAUNCH(ss_phase_b_kernel, tiles, block, s, a);
+  uint8_t* lastFG = d->u8[SS_LASTFG] + off;
+  ss_morph(d->u8[SS_RAW] + off, lastFG, e->rows, e->cols, count, 3, d->medK, s);  // cv::medianBlur(oCurrFGMask, m_oLastFGMask, 9) :281
+  if (d_fg) HIP_TRY(hipMemcpyAsync(d_fg, lastFG, npix, hipMemcpyDeviceToDevice, s));  // :282
+  if (d_bg) SS_LAUNCH(ss_background_kernel, dim3(blocks_for(N * e->ch), 1, count), block, s, a);  // getBackgroundImage :286-303
+  HIP_TRY(hipGetLastError());
+  return BGS_OK;
 }
 
 void ss_free(bgs_engine* e) {

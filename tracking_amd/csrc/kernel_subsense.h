@@ -437,6 +437,121 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
   if (threadIdx.x == 0 && nz_block) atomicAdd(&a.sc[stream].nzCount, nz_block);
 }
 
+// ----------------------------------------------------------------------------------------------- LOBSTER, phase A
+// BackgroundSubtractorLOBSTER::operator() (package_bgs/pl/BackgroundSubtractorLOBSTER.cpp:172-284): the sample-consensus
+// test of SuBSENSE with fixed thresholds and no feedback maps; update requests go through the same phase B.
+// a.nMinColor = nColorDistThreshold, a.nDescOff = nDescDistThreshold; a.lastColor / a.lastDesc point at SCRATCH planes here
+// (what a requesting pixel will write: its current colour and intra descriptor) - LOBSTER's own last-frame images are
+// only read by refreshModel.  Learning rate = BGSLOBSTER_DEFAULT_LEARNING_RATE (LOBSTER.cpp:36 passes none).
+template <int C>
+__global__ __launch_bounds__(kBlock) void lob_phase_a_kernel(const SsArgs a) {
+  constexpr int HW = kSsTW + 4, HH = kSsTH + 4;
+  constexpr int ROWB = (HW * C + 3 + 3) / 4 * 4;
+  constexpr uint32_t kLearningRate = 16;
+  __shared__ uint32_t tile[HH][ROWB / 4];
+  __shared__ uint8_t lut[256];
+  const int stream = a.first + blockIdx.z;
+  const size_t N = (size_t)a.rows * a.cols, sN = (size_t)stream * N;
+  const uint8_t* img = a.frame + (size_t)blockIdx.z * N * C;
+  const int x0 = blockIdx.x * kSsTW, y0 = blockIdx.y * kSsTH;
+  const long imgsz = (long)N * C, rb = (long)(x0 - 2) * C;
+  for (int i = threadIdx.x; i < HH * (ROWB / 4); i += kBlock) {
+    const int ry = i / (ROWB / 4), rd = i - ry * (ROWB / 4);
+    const int y = min(max(y0 + ry - 2, 0), a.rows - 1);
+    const long off = (((long)y * a.cols * C + rb) & ~3L) + 4L * rd;
+    uint32_t v = 0;
+    if (off >= 0 && off + 4 <= imgsz)
+      v = *reinterpret_cast<const uint32_t*>(img + off);
+    else if (off < imgsz && off + 4 > 0)
+      for (int b = 0; b < 4; ++b)
+        if (off + b >= 0 && off + b < imgsz) v |= (uint32_t)img[off + b] << (8 * b);
+    tile[ry][rd] = v;
+  }
+  lut[threadIdx.x] = a.lut[(size_t)stream * 256 + threadIdx.x];
+  __syncthreads();
+  const int lx = threadIdx.x % kSsTW, ly = threadIdx.x / kSsTW;
+  const int x = x0 + lx, y = y0 + ly;
+  if (x >= a.cols || y >= a.rows) return;
+  const size_t p = (size_t)y * a.cols + x, i = sN + p;
+  if (!(x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2)) {  // outside LBSP::validateROI: never foreground, never updated
+    a.raw[i] = 0;
+    a.req[i * 2] = 0, a.req[i * 2 + 1] = 0;
+    return;
+  }
+  auto at = [&](int ry, int rx, int c) -> int {
+    const uint8_t* rowp = reinterpret_cast<const uint8_t*>(tile[ry]);
+    const int shift = (int)(((long)(y0 + ry - 2) * a.cols * C + rb) & 3L);
+    return rowp[shift + rx * C + c];
+  };
+  const int8_t dxs[16] = {-1, 1, 1, -1, 1, 0, -1, 0, -2, 2, 2, -2, 0, 0, 2, -2}, dys[16] = {1, -1, 1, -1, 0, -1, 0, 1, -2, 2, -2, 2, 2, -2, 0, 0};
+  int cur[C];
+  uint32_t nb[C][8];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    cur[c] = at(ly + 2, lx + 2, c);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      nb[c][k] = ((uint32_t)at(ly + 2 + dys[k], lx + 2 + dxs[k], c) << 16) | (uint32_t)at(ly + 2 + dys[8 + k], lx + 2 + dxs[8 + k], c);
+  }
+  const uint32_t colorThr = (uint32_t)a.nMinColor, descThr = (uint32_t)a.nDescOff;
+  const uint32_t descThr3 = descThr * 3, colorThr3 = colorThr * 3, scDesc = descThr3 / 2, scColor = colorThr3 / 2;  // :225-228
+  const size_t sbase = (size_t)stream * a.nS * N, sstride = N * C;
+  const uint8_t* cp = a.color + (sbase + p) * C;
+  const uint16_t* dp = a.desc + (sbase + p) * C;
+  int good = 0, idx = 0;
+  while (good < a.nReq && idx < a.nS) {  // :192-205 (gray) / :241-258 (BGR)
+    if constexpr (C == 1) {
+      const int bcc = cp[0];
+      const uint32_t cd = (uint32_t)abs(cur[0] - bcc);
+      if (cd <= colorThr / 2) {
+        const unsigned inter = ss_lbsp(nb[0], bcc, lut[bcc]);
+        if ((uint32_t)__popc(inter ^ (unsigned)dp[0]) <= descThr) good++;
+      }
+    } else {
+      uint32_t totC = 0, totD = 0;
+      bool ok = true;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        if (ok) {
+          const int bcc = cp[c];
+          const uint32_t cd = (uint32_t)abs(cur[c] - bcc);
+          if (cd > scColor) {
+            ok = false;
+          } else {
+            const unsigned inter = ss_lbsp(nb[c], bcc, lut[bcc]);
+            const uint32_t dd = (uint32_t)__popc(inter ^ (unsigned)dp[c]);
+            if (dd > scDesc)
+              ok = false;
+            else
+              totC += cd, totD += dd;
+          }
+        }
+      if (ok && totD <= descThr3 && totC <= colorThr3) good++;
+    }
+    idx++;
+    cp += sstride, dp += sstride;
+  }
+  uint16_t reqSelf = 0, reqNbr = 0;
+  if (good >= a.nReq) {
+    const uint32_t fr = a.frameIndex, pi = (uint32_t)p;
+    if ((ss_rand(fr, pi, 0) % kLearningRate) == 0) reqSelf = ss_req(ss_rand(fr, pi, 1) % (uint32_t)a.nS, 12);  // :209-214 / :262-269
+    if ((ss_rand(fr, pi, 2) % kLearningRate) == 0) {                                                             // :215-222 / :270-279
+      const int r = (int)(ss_rand(fr, pi, 3) % 8u);
+      const int xn = min(max(x + kSsN3[r][0], 2), a.cols - 3), yn = min(max(y + kSsN3[r][1], 2), a.rows - 3);
+      reqNbr = ss_req(ss_rand(fr, pi, 4) % (uint32_t)a.nS, (yn - y + 2) * 5 + (xn - x + 2));
+    }
+    if (reqSelf | reqNbr) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        a.lastColor[i * C + c] = (uint8_t)cur[c];
+        a.lastDesc[i * C + c] = (uint16_t)ss_lbsp(nb[c], cur[c], lut[cur[c]]);
+      }
+    }
+  }
+  a.raw[i] = good < a.nReq ? 255 : 0;  // :207 / :260
+  a.req[i * 2] = reqSelf, a.req[i * 2 + 1] = reqNbr;
+}
+
 // ----------------------------------------------------------------------------------------------- phase B
 template <int C>
 __global__ __launch_bounds__(kBlock) void ss_phase_b_kernel(const SsArgs a) {

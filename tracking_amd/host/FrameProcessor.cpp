@@ -19,6 +19,7 @@ FrameProcessor::FrameProcessor()
   wrenGA = nullptr, enableDPWrenGABGS = false;
   sdbgs = nullptr, enableSigmaDeltaBGS = false;
   ssbgs = nullptr, enableSuBSENSEBGS = false;
+  lobgs = nullptr, enableLOBSTERBGS = false;
 
   std::cout << "FrameProcessor()" << std::endl;
   loadConfig();  // FrameProcessor.cpp:26-27
@@ -43,6 +44,7 @@ void FrameProcessor::init() {  // FrameProcessor.cpp:35-155
   if (enableDPWrenGABGS) wrenGA = new DPWrenGABGS;
   if (enableSigmaDeltaBGS) sdbgs = new SigmaDeltaBGS;
   if (enableSuBSENSEBGS) ssbgs = new SuBSENSEBGS;
+  if (enableLOBSTERBGS) lobgs = new LOBSTERBGS;
   if (enableAdaptiveSelectiveBackgroundLearning) adaptiveSelectiveBackgroundLearning = new AdaptiveSelectiveBackgroundLearning;
 }
 
@@ -72,6 +74,7 @@ void FrameProcessor::process(const Image& img_input) {  // :169-340
   if (enableDPWrenGABGS) process("DPWrenGABGS", wrenGA, img_prep, img_wrenga);
   if (enableSigmaDeltaBGS) process("SigmaDeltaBGS", sdbgs, img_prep, img_sdbgs);
   if (enableSuBSENSEBGS) process("SuBSENSEBGS", ssbgs, img_prep, img_ssbgs);
+  if (enableLOBSTERBGS) process("LOBSTERBGS", lobgs, img_prep, img_lobgs);
   if (enableAdaptiveSelectiveBackgroundLearning)
     process("AdaptiveSelectiveBackgroundLearning", adaptiveSelectiveBackgroundLearning, img_prep, img_asbl);
   firstTime = false;
@@ -79,6 +82,7 @@ void FrameProcessor::process(const Image& img_input) {  // :169-340
 
 void FrameProcessor::finish() {  // :342-482 (reverse order of init)
   delete adaptiveSelectiveBackgroundLearning, adaptiveSelectiveBackgroundLearning = nullptr;
+  delete lobgs, lobgs = nullptr;
   delete ssbgs, ssbgs = nullptr;
   delete sdbgs, sdbgs = nullptr;
   delete wrenGA, wrenGA = nullptr;
@@ -126,6 +130,7 @@ void FrameProcessor::saveConfig() {  // :496-552 (keys of the classes this build
   fs.writeInt("enableDPWrenGABGS", enableDPWrenGABGS);
   fs.writeInt("enableSigmaDeltaBGS", enableSigmaDeltaBGS);
   fs.writeInt("enableSuBSENSEBGS", enableSuBSENSEBGS);
+  fs.writeInt("enableLOBSTERBGS", enableLOBSTERBGS);
   fs.writeInt("enableAdaptiveSelectiveBackgroundLearning", enableAdaptiveSelectiveBackgroundLearning);
   fs.save("./config/FrameProcessor.xml");
 }
@@ -150,6 +155,7 @@ void FrameProcessor::loadConfig() {  // :554-610 (defaults: PreProcessor and Fra
   enableDPWrenGABGS = fs.readInt("enableDPWrenGABGS", false);
   enableSigmaDeltaBGS = fs.readInt("enableSigmaDeltaBGS", false);
   enableSuBSENSEBGS = fs.readInt("enableSuBSENSEBGS", false);
+  enableLOBSTERBGS = fs.readInt("enableLOBSTERBGS", false);
   enableAdaptiveSelectiveBackgroundLearning = fs.readInt("enableAdaptiveSelectiveBackgroundLearning", false);
 }
 

@@ -35,7 +35,7 @@ class FrameProcessor : public IFrameProcessor {
 
   // the masks the reference keeps as img_framediff, img_staticfdiff, ... (FrameProcessor.h:99-170)
   Image img_prep, img_framediff, img_staticfdiff, img_wmovmean, img_movvar, img_mog1, img_mog2, img_bkgl_fgmask, img_asbl;
-  Image img_gmg, img_adpmed, img_grigmm, img_zivgmm, img_tmpmean, img_wrenga, img_sdbgs, img_ssbgs;  // FrameProcessor.h:120-236
+  Image img_gmg, img_adpmed, img_grigmm, img_zivgmm, img_tmpmean, img_wrenga, img_sdbgs, img_ssbgs, img_lobgs;  // FrameProcessor.h:120-236
   double lastDuration() const { return duration; }
 
  private:
@@ -77,6 +77,8 @@ class FrameProcessor : public IFrameProcessor {
   bool enableSigmaDeltaBGS;
   SuBSENSEBGS* ssbgs;
   bool enableSuBSENSEBGS;
+  LOBSTERBGS* lobgs;
+  bool enableLOBSTERBGS;
   AdaptiveSelectiveBackgroundLearning* adaptiveSelectiveBackgroundLearning;  // not in the reference's FrameProcessor (Demo.cpp / USTC_BGS type 7 only)
   bool enableAdaptiveSelectiveBackgroundLearning;
 

@@ -35,9 +35,9 @@ int main(int argc, char** argv) {
     fp->init();
     const char* names[] = {"FrameDifferenceBGS", "StaticFrameDifferenceBGS", "WeightedMovingMeanBGS", "WeightedMovingVarianceBGS",
                            "MixtureOfGaussianV1BGS", "MixtureOfGaussianV2BGS", "AdaptiveBackgroundLearning", "AdaptiveSelectiveBackgroundLearning",
-                           "GMG", "DPAdaptiveMedianBGS", "DPGrimsonGMMBGS", "DPZivkovicAGMMBGS", "DPMeanBGS", "DPWrenGABGS", "SigmaDeltaBGS", "SuBSENSEBGS"};
+                           "GMG", "DPAdaptiveMedianBGS", "DPGrimsonGMMBGS", "DPZivkovicAGMMBGS", "DPMeanBGS", "DPWrenGABGS", "SigmaDeltaBGS", "SuBSENSEBGS", "LOBSTERBGS"};
     Image* masks[] = {&fp->img_framediff, &fp->img_staticfdiff, &fp->img_wmovmean, &fp->img_movvar, &fp->img_mog1, &fp->img_mog2, &fp->img_bkgl_fgmask, &fp->img_asbl,
-                     &fp->img_gmg, &fp->img_adpmed, &fp->img_grigmm, &fp->img_zivgmm, &fp->img_tmpmean, &fp->img_wrenga, &fp->img_sdbgs, &fp->img_ssbgs};
+                     &fp->img_gmg, &fp->img_adpmed, &fp->img_grigmm, &fp->img_zivgmm, &fp->img_tmpmean, &fp->img_wrenga, &fp->img_sdbgs, &fp->img_ssbgs, &fp->img_lobgs};
     std::vector<std::ofstream> outs;
     for (const char* nm : names) outs.emplace_back((prefix + "." + nm + ".raw").c_str(), std::ios::binary);
     Image frame(rows, cols, 3);

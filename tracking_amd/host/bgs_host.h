@@ -513,6 +513,38 @@ class SuBSENSEBGS : public HipBGSBase {
   }
 };
 
+// package_bgs/pl/LOBSTER.{h,cpp}: like SuBSENSEBGS, the parameters are handed to the model once, when it is built on the first frame
+class LOBSTERBGS : public HipBGSBase {
+ public:
+  LOBSTERBGS() : HipBGSBase(BGS_LOBSTER, "LOBSTERBGS"), showOutput(true) {}
+  ~LOBSTERBGS() override {}
+ private:
+  bool showOutput;
+  void saveConfig() override {  // LOBSTER.cpp:47-58
+    XmlConfig fs;
+    fs.beginWrite();
+    fs.writeReal("fRelLBSPThreshold", params_.lbsp_rel_threshold);
+    fs.writeInt("nLBSPThresholdOffset", params_.lbsp_threshold_offset);
+    fs.writeInt("nDescDistThreshold", params_.subsense_desc_dist_threshold_offset);
+    fs.writeInt("nColorDistThreshold", params_.subsense_min_color_dist_threshold);
+    fs.writeInt("nBGSamples", params_.subsense_n_samples);
+    fs.writeInt("nRequiredBGSamples", params_.subsense_n_required);
+    fs.writeInt("showOutput", showOutput);
+    fs.save(configPath());
+  }
+  void loadConfig() override {  // :60-73
+    XmlConfig fs;
+    fs.load(configPath());
+    params_.lbsp_rel_threshold = (float)fs.readReal("fRelLBSPThreshold", 0.365f);
+    params_.lbsp_threshold_offset = fs.readInt("nLBSPThresholdOffset", 0);
+    params_.subsense_desc_dist_threshold_offset = fs.readInt("nDescDistThreshold", 4);
+    params_.subsense_min_color_dist_threshold = fs.readInt("nColorDistThreshold", 30);
+    params_.subsense_n_samples = fs.readInt("nBGSamples", 35);
+    params_.subsense_n_required = fs.readInt("nRequiredBGSamples", 2);
+    showOutput = fs.readInt("showOutput", true);
+  }
+};
+
 // package_bgs/dp/DP*BGS.{h,cpp}: the wrapper reads its XML every frame but hands the values to the model only once, inside
 // `if(firstTime)` (e.g. DPZivkovicAGMMBGS.cpp:48-65) - later edits of the file change what saveConfig would write, not the
 // running model.  Mirrored: the values go into params_ only while firstTime is true.
