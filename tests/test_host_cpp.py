@@ -97,3 +97,38 @@ def test_demo_masks_equal_oracle_for_every_class(demo, tmp_path, golden_frames):
                 assert (got[t] == 7).all(), (c, t)  # output left untouched (still empty) -> demo writes the 0x07 marker
             else:
                 assert np.array_equal(got[t], fg), (c, t)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("utype,algo_name", [(36, "SUBSENSE"), (5, "MOG2"), (11, "DP_ZIVKOVIC_AGMM"), (37, "LOBSTER"), (0, "FRAME_DIFF")])
+def test_ustc_bgs_type_table(demo, tmp_path, golden_frames, utype, algo_name):
+    """USTC_BGS(type).Process / GetMask (ustc_src/ustc_bgs.cpp): type 36 is what trackingMain.cpp builds.  GetMask() hands out the
+    last mask; for FrameDifference the first frame leaves img_mask empty (written as the 0x07 marker)."""
+    from oracle import pyoracle
+    from tracking_amd import capi
+    os.makedirs(tmp_path / "config")
+    frames = golden_frames[:8]
+    raw = os.path.join(str(tmp_path), "frames.raw")
+    frames.tofile(raw)
+    n, rows, cols = frames.shape[:3]
+    r = subprocess.run([demo, raw, str(rows), str(cols), str(n), os.path.join(str(tmp_path), "out"), str(utype)], cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.fromfile(str(tmp_path / "out.ustc.raw"), np.uint8).reshape(n, rows, cols)
+    o = pyoracle.Oracle(getattr(capi, algo_name))
+    last = None
+    for t in range(n):
+        fg, _ = o.process(frames[t])
+        last = fg if fg is not None else last
+        if last is None:
+            assert (got[t] == 7).all()
+        else:
+            assert np.array_equal(got[t], last), t
+
+
+@pytest.mark.gpu
+def test_ustc_bgs_rejects_types_outside_the_path(demo, tmp_path, golden_frames):
+    os.makedirs(tmp_path / "config")
+    raw = os.path.join(str(tmp_path), "frames.raw")
+    golden_frames[:2].tofile(raw)
+    r = subprocess.run([demo, raw, "80", "96", "2", os.path.join(str(tmp_path), "out"), "23"], cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode == 1 and "outside the package_bgs hot path" in r.stdout

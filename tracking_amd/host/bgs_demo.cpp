@@ -1,14 +1,17 @@
 // bgs_demo.cpp — the build's own small harness in the pattern of the reference's Demo2.cpp:142-168 (frames/N.png loop) and
 // Main.cpp:63-72 (hard failures surface as one std::exception).  OpenCV is absent, so frames come from a raw file:
-//     bgs_demo <frames.raw> <rows> <cols> <n_frames> <out_prefix>
+//     bgs_demo <frames.raw> <rows> <cols> <n_frames> <out_prefix> [ustc_type]
 // frames.raw = n_frames x rows x cols x 3 bytes (BGR).  For every class enabled in ./config/FrameProcessor.xml the mask of
 // each frame is appended to <out_prefix>.<ClassName>.raw (frames whose output the class leaves untouched are written as 0x07).
+// With a 6th argument the frames go through USTC_BGS(type) instead (ustc_src/ustc_bgs.cpp) and GetMask() of every frame is
+// written to <out_prefix>.ustc.raw.
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <vector>
 
 #include "FrameProcessor.h"
+#include "ustc_bgs.h"
 
 using namespace bgs_hip;
 
@@ -31,6 +34,20 @@ int main(int argc, char** argv) {
   try {
     std::ifstream in(argv[1], std::ios::binary);
     if (!in) throw Exception(BGS_ERR_INVALID, std::string("cannot open ") + argv[1]);
+    if (argc >= 7) {  // the tracker's FG detector: Process(frame) then GetMask(), trackingMain.cpp:152-166
+      USTC_BGS fg(std::atoi(argv[6]));
+      std::ofstream out((prefix + ".ustc.raw").c_str(), std::ios::binary);
+      Image frame(rows, cols, 3);
+      for (int t = 0; t < n; ++t) {
+        in.read((char*)frame.data, (size_t)rows * cols * 3);
+        if (!in) throw Exception(BGS_ERR_INVALID, "short read on frame file");
+        fg.Process(frame);
+        const Image* m = fg.GetMask();
+        dump(out, m ? *m : Image(), rows, cols);
+      }
+      fg.Release();
+      return 0;
+    }
     FrameProcessor* fp = new FrameProcessor;
     fp->init();
     const char* names[] = {"FrameDifferenceBGS", "StaticFrameDifferenceBGS", "WeightedMovingMeanBGS", "WeightedMovingVarianceBGS",
