@@ -149,7 +149,8 @@ struct Timed {
   hipEvent_t a = nullptr, b = nullptr;
   Timed(bgs_engine* e_, hipStream_t s_, const char* name, bool enable = true) : e(e_), s(s_) {
     if (enable) e->kernel_name = name;
-    if (enable && e->timing && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, s);
+    // bounded: timing is a measurement aid, a caller that leaves it on must not grow the list forever
+    if (enable && e->timing && e->events.size() < 16384 && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, s);
   }
   ~Timed() {
     if (a && b) {
