@@ -923,7 +923,7 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
   if (is_dp(e->algo)) {  // planes are stored canonically: [stream][plane][n]
     const int planes = dp_planes_of(e);
     const char* fname = (e->algo == BGS_DP_WREN_GA) ? "gauss" : (e->algo == BGS_DP_MEAN) ? "mean" : "modes";
-    if (planes && !strcmp(plane, fname)) return copy_bytes((const uint8_t*)(e->dp_state + (size_t)stream * planes * n), (size_t)planes * n * 4);
+    if (planes && !strcmp(plane, fname)) return dp_export_planes(e, stream, planes, dst, cap);
     if (e->state_ch == 1 && !strcmp(plane, "nmodes")) return copy_bytes(e->bgstate + off, n);
     if (e->state_ch == 3 && !strcmp(plane, "median")) return copy_bytes(e->bgstate + off * 3, n * 3);
     return fail(BGS_ERR_STATE, "unknown state plane '%s' for algorithm %d", plane, (int)e->algo);

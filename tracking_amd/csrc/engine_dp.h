@@ -1,6 +1,6 @@
 // engine_dp.h — host side of the package_bgs/dp/ models (kernel_dp.h); included inside bgs_hip.hip's anonymous namespace.
-// State per stream: `dp_planes` float planes of n pixels (GMM modes / WrenGA gaussian / Mean), plus e->bgstate
-// (mode count per pixel, or the AdaptiveMedian byte image).
+// State: `dp_planes` float planes, tiled over the global pixel index (kernel_dp.h), plus e->bgstate (mode count per pixel,
+// or the AdaptiveMedian byte image).
 
 bool is_dp(bgs_algo a) { return a >= BGS_DP_ZIVKOVIC_AGMM && a <= BGS_DP_ADAPTIVE_MEDIAN; }
 
@@ -19,8 +19,9 @@ int dp_allocate(bgs_engine* e) {
   const size_t P = e->n * e->S;
   const int planes = dp_planes_of(e);
   if (planes) {
-    HIP_TRY(hipMalloc((void**)&e->dp_state, P * planes * sizeof(float)));
-    HIP_TRY(hipMemset(e->dp_state, 0, P * planes * sizeof(float)));  // InitModel of the GMMs: everything 0
+    const size_t tiles = (P + bgs::kDpTile - 1) / bgs::kDpTile;
+    HIP_TRY(hipMalloc((void**)&e->dp_state, tiles * planes * bgs::kDpTile * sizeof(float)));
+    HIP_TRY(hipMemset(e->dp_state, 0, tiles * planes * bgs::kDpTile * sizeof(float)));  // InitModel of the GMMs: everything 0
   }
   if (e->bgstate) HIP_TRY(hipMemset(e->bgstate, 0, P * e->state_ch));
   return BGS_OK;
@@ -44,7 +45,7 @@ int dp_process(bgs_engine* e, int first, int count, int64_t t, const uint8_t* d_
   a.frame = d_frames, a.state = e->dp_state, a.bstate = e->bgstate, a.fg = d_fg, a.fg_bits = d_bits;
   a.n = e->n, a.npix = e->n * count, a.first = first;
   a.low = p.dp_threshold, a.high = 2 * a.low, a.alpha = p.dp_alpha;  // HighThreshold = 2*LowThreshold, e.g. DPZivkovicAGMMBGS.cpp:58
-  a.update = 0;
+  a.update = 0, a.xcd_swizzle = e->xcd_swizzle;
   const unsigned blocks = blocks_for(a.npix);
   if (t == 0 && (e->algo == BGS_DP_WREN_GA || e->algo == BGS_DP_MEAN))  // InitModel from the first frame
     hipLaunchKernelGGL(bgs::dp_init_kernel, dim3(blocks), dim3(bgs::kBlock), 0, s, a, e->algo == BGS_DP_WREN_GA ? 4 : 3, 36.0f);
@@ -80,4 +81,19 @@ int dp_process(bgs_engine* e, int first, int count, int64_t t, const uint8_t* d_
   }
   *flags = BGS_FG_VALID;  // img_bgmodel is never written by the dp wrappers
   return BGS_OK;
+}
+
+// canonical export [plane][n] of one stream from the tiled device layout
+int64_t dp_export_planes(bgs_engine* e, int stream, int planes, void* dst, size_t cap) {
+  const size_t n = e->n, g0 = (size_t)stream * n, T = bgs::kDpTile;
+  if (cap < (size_t)planes * n * 4) return fail(BGS_ERR_STATE, "buffer too small for %d planes", planes);
+  const size_t t0 = g0 / T, t1 = (g0 + n - 1) / T + 1, TF = (size_t)planes * T;
+  std::vector<float> tiles((t1 - t0) * TF);
+  if (hipMemcpy(tiles.data(), e->dp_state + t0 * TF, tiles.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+  for (int q = 0; q < planes; ++q)
+    for (size_t i = 0; i < n; ++i) {
+      const size_t g = g0 + i;
+      ((float*)dst)[(size_t)q * n + i] = tiles[(g / T - t0) * TF + (size_t)q * T + g % T];
+    }
+  return (int64_t)planes * n * 4;
 }
