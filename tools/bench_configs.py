@@ -106,7 +106,7 @@ def run_dp():
     run(capi.DP_GRIMSON_GMM, "DPGrimsonGMMBGS (K=3)", 1080, 1920, 16, 150, borrow=False)
     run(capi.DP_WREN_GA, "DPWrenGABGS", 1080, 1920, 16, 36, borrow=False)
     run(capi.DP_MEAN, "DPMeanBGS", 1080, 1920, 16, 28, borrow=False)
-    run(capi.DP_ADAPTIVE_MEDIAN, "DPAdaptiveMedianBGS", 1080, 1920, 16, 10, borrow=False)
+    run(capi.DP_ADAPTIVE_MEDIAN, "DPAdaptiveMedianBGS", 1080, 1920, 16, 7, borrow=False)  # 3 frame + 3 median + 1 mask (+3/7 write-back); state is MALL-resident
 
 
 def run_cc():

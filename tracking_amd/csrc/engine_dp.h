@@ -75,7 +75,11 @@ int dp_process(bgs_engine* e, int first, int count, int64_t t, const uint8_t* d_
     default: {
       a.update = (t % p.dp_sampling_rate) == 1;  // AdaptiveMedianBGS.cpp:60
       Timed tm(e, s, "dp_median_kernel");
-      hipLaunchKernelGGL(bgs::dp_median_kernel, dim3(blocks), dim3(bgs::kBlock), 0, s, a);
+      const uint8_t* med0 = e->bgstate + (size_t)first * e->n * 3;
+      if (a.npix % 4 == 0 && aligned(d_frames, 4) && aligned(med0, 4) && (!d_fg || aligned(d_fg, 4)))
+        hipLaunchKernelGGL((bgs::dp_median_kernel<4>), dim3(blocks_for(a.npix / 4)), dim3(bgs::kBlock), 0, s, a);
+      else
+        hipLaunchKernelGGL((bgs::dp_median_kernel<1>), dim3(blocks), dim3(bgs::kBlock), 0, s, a);
       break;
     }
   }

@@ -287,22 +287,66 @@ __global__ __launch_bounds__(kBlock) void dp_mean_kernel(const DpArgs a) {
   dp_store_mask(a, gp, active, mask);
 }
 
+// G = 4: a lane owns 4 consecutive pixels (3 dwords of frame, 3 dwords of median, 1 dword of mask); G = 1 for sizes /
+// pointers that are not 4-aligned
+template <int G>
 __global__ __launch_bounds__(kBlock) void dp_median_kernel(const DpArgs a) {
-  const size_t gp = xcd_block(a.xcd_swizzle) * kBlock + threadIdx.x;
+  const size_t gp = (xcd_block(a.xcd_swizzle) * kBlock + threadIdx.x) * G;
   const bool active = gp < a.npix;
-  int mask = 0;
+  uint32_t mask4 = 0;
   if (active) {
     uint8_t* med = a.bstate + ((size_t)a.first * a.n + gp) * 3;
-    bool bgd = true;
+    uint8_t fb[G * 3], mb[G * 3];
+    if constexpr (G == 4) {
+      const uint32_t* fw = reinterpret_cast<const uint32_t*>(a.frame + gp * 3);
+      const uint32_t* mw = reinterpret_cast<const uint32_t*>(med);
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      const int px = a.frame[gp * 3 + ch], m = med[ch];
-      bgd = bgd && (float)abs(px - m) <= a.high;  // AdaptiveMedianBGS.cpp:92-108
-      if (a.update) med[ch] = (uint8_t)(px > m ? m + 1 : px < m ? m - 1 : m);  // :58-84
+      for (int k = 0; k < 3; ++k) {
+        const uint32_t f = fw[k], m = mw[k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[4 * k + j] = (uint8_t)(f >> (8 * j)), mb[4 * k + j] = (uint8_t)(m >> (8 * j));
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) fb[j] = a.frame[gp * 3 + j], mb[j] = med[j];
     }
-    mask = bgd ? 0 : 255;
+#pragma unroll
+    for (int o = 0; o < G; ++o) {
+      bool bgd = true;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const int px = fb[o * 3 + ch], m = mb[o * 3 + ch];
+        bgd = bgd && (float)abs(px - m) <= a.high;  // AdaptiveMedianBGS.cpp:92-108
+        mb[o * 3 + ch] = (uint8_t)(px > m ? m + 1 : px < m ? m - 1 : m);  // :58-84 (stored only on update frames)
+      }
+      mask4 |= (bgd ? 0u : 255u) << (8 * o);
+    }
+    if (a.update) {
+      if constexpr (G == 4) {
+        uint32_t* mw = reinterpret_cast<uint32_t*>(med);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) mw[k] = (uint32_t)mb[4 * k] | ((uint32_t)mb[4 * k + 1] << 8) | ((uint32_t)mb[4 * k + 2] << 16) | ((uint32_t)mb[4 * k + 3] << 24);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) med[j] = mb[j];
+      }
+    }
+    if (a.fg) {
+      if constexpr (G == 4)
+        *reinterpret_cast<uint32_t*>(a.fg + gp) = mask4;
+      else
+        a.fg[gp] = (uint8_t)mask4;
+    }
   }
-  dp_store_mask(a, gp, active, mask);
+  if (a.fg_bits) {
+    if constexpr (G == 4) {
+      const uint32_t nib = (mask4 & 1u) | ((mask4 >> 7) & 2u) | ((mask4 >> 14) & 4u) | ((mask4 >> 21) & 8u);
+      store_packed_mask<4>(a.fg_bits, gp, nib, active);
+    } else {
+      const unsigned long long w = __ballot(active && mask4 != 0);
+      if ((threadIdx.x & (kWave - 1)) == 0 && active) a.fg_bits[gp >> 6] = w;
+    }
+  }
 }
 
 // WrenGA / Mean: model = the first frame (InitModel); one lane per pixel
