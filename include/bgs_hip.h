@@ -277,6 +277,14 @@ size_t bgs_mask_components_workspace(int rows, int cols);
 int bgs_mask_components_device(int hip_device, const void* d_mask, int rows, int cols, int connectivity,
                                int32_t* d_labels, bgs_box* d_boxes, int max_boxes, int32_t* d_count, void* d_work,
                                void* hip_stream);
+/* The same for `images` masks stored back to back ([images][rows][cols], e.g. the d_fg of bgs_process_batch_device): one
+ * set of launches for all of them.  Boxes are sorted by (image, root); d_offsets [images+1] receives the prefix sums of the
+ * per-image component counts, so image k owns d_boxes[d_offsets[k] .. d_offsets[k+1]) (entries past max_boxes are not
+ * written); roots and labels are relative to their own image. */
+size_t bgs_mask_components_batch_workspace(int images, int rows, int cols);
+int bgs_mask_components_batch_device(int hip_device, const void* d_masks, int images, int rows, int cols, int connectivity,
+                                     int32_t* d_labels, bgs_box* d_boxes, int max_boxes, int32_t* d_offsets, void* d_work,
+                                     void* hip_stream);
 
 #ifdef __cplusplus
 }

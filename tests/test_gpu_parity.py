@@ -878,3 +878,26 @@ def test_lobster_grayscale_and_streams(golden_gray):
             assert np.array_equal(d_fg[s].cpu().numpy(), ofg) and np.array_equal(d_bg[s].cpu().numpy(), obg), (t, s)
     for s in range(S):
         check_lobster_state(eng, orcs[s], H, W, stream=s)
+
+
+@pytest.mark.parametrize("connectivity", [8, 4])
+def test_connected_components_batch(connectivity):
+    """Stack of masks in one call: no component may leak across an image boundary (first/last rows are made busy on purpose),
+    boxes come out grouped per image in root order, offsets are the prefix sums of the per-image counts; one image is empty."""
+    torch = _torch()
+    from tracking_amd.engine import mask_components_batch_device
+    rng = np.random.default_rng(connectivity)
+    S, H, W = 5, 37, 70
+    masks = np.where(rng.random((S, H, W)) < 0.35, 255, 0).astype(np.uint8)
+    masks[:, 0, :] = 255
+    masks[:, -1, ::2] = 255
+    masks[3] = 0
+    labels, boxes, off = mask_components_batch_device(torch.from_numpy(masks).cuda(), connectivity, max_boxes=S * H * W, want_labels=True)
+    got_b, got_l, off = boxes.cpu().numpy(), labels.cpu().numpy(), off.numpy()
+    assert off[0] == 0 and len(off) == S + 1
+    for s in range(S):
+        want_l, want_b, want_n = pyoracle.components(masks[s], connectivity)
+        assert off[s + 1] - off[s] == want_n, s
+        assert np.array_equal(got_l[s], want_l), s
+        want = np.stack([want_b[f] for f in ("x", "y", "w", "h", "area", "root")], axis=1) if want_n else np.zeros((0, 6), np.int32)
+        assert np.array_equal(got_b[off[s]:off[s + 1]], want), s

@@ -1091,43 +1091,50 @@ int bgs_mask_morph_device(int hip_device, const void* d_src, void* d_dst, int ro
   return BGS_OK;
 }
 
-size_t bgs_mask_components_workspace(int rows, int cols) {
-  if (rows <= 0 || cols <= 0) return 0;
-  const size_t n = (size_t)rows * cols, nb = (n + bgs::kCcPerBlock - 1) / bgs::kCcPerBlock;
+size_t bgs_mask_components_workspace(int rows, int cols) { return bgs_mask_components_batch_workspace(1, rows, cols); }
+
+size_t bgs_mask_components_batch_workspace(int images, int rows, int cols) {
+  if (images <= 0 || rows <= 0 || cols <= 0) return 0;
+  const size_t n = (size_t)images * rows * cols, nb = (n + bgs::kCcPerBlock - 1) / bgs::kCcPerBlock;
   return (2 * n + nb + 16) * sizeof(int32_t);  // labels (when the caller passes none) + ids + per-block root counts
 }
 
-int bgs_mask_components_device(int hip_device, const void* d_mask, int rows, int cols, int connectivity, int32_t* d_labels,
-                               bgs_box* d_boxes, int max_boxes, int32_t* d_count, void* d_work, void* hip_stream) {
+// images stacked back to back are labelled as one tall image whose links never cross an image boundary
+static int cc_run(int hip_device, const void* d_mask, int images, int rows, int cols, int connectivity, int32_t* d_labels, bgs_box* d_boxes, int max_boxes,
+                  int32_t* d_count, int32_t* d_offsets, void* d_work, void* hip_stream) {
   static_assert(sizeof(bgs_box) == sizeof(bgs::CcBox), "bgs_box layout");
-  if (!d_mask || !d_boxes || !d_count || rows <= 0 || cols <= 0 || max_boxes < 0 || (connectivity != 4 && connectivity != 8))
-    return fail(BGS_ERR_INVALID, "bgs_mask_components_device: bad argument");
-  const size_t n = (size_t)rows * cols;
-  if (n >= (size_t)0x7fffffff) return fail(BGS_ERR_UNSUPPORTED, "bgs_mask_components_device: image too large for 32-bit labels");
+  if (!d_mask || !d_boxes || (!d_count && !d_offsets) || images <= 0 || rows <= 0 || cols <= 0 || max_boxes < 0 || (connectivity != 4 && connectivity != 8))
+    return fail(BGS_ERR_INVALID, "bgs_mask_components: bad argument");
+  const size_t imgN = (size_t)rows * cols, n = imgN * images;
+  if (n >= (size_t)0x7fffffff) return fail(BGS_ERR_UNSUPPORTED, "bgs_mask_components: too many pixels for 32-bit labels");
   HIP_TRY(hipSetDevice(hip_device));
   hipStream_t s = (hipStream_t)hip_stream;
   void* own = nullptr;
   if (!d_work) {
-    HIP_TRY(hipMalloc(&own, bgs_mask_components_workspace(rows, cols)));
+    HIP_TRY(hipMalloc(&own, bgs_mask_components_batch_workspace(images, rows, cols)));
     d_work = own;
   }
   const int nb = (int)((n + bgs::kCcPerBlock - 1) / bgs::kCcPerBlock);
   int* id = (int*)d_work;
   int* L = d_labels ? (int*)d_labels : id + n;
   int* blockCount = id + 2 * n;
-  const int conn8 = connectivity == 8;
+  int* total = d_count ? (int*)d_count : blockCount + nb;  // scratch slot when only offsets are wanted
+  const int conn8 = connectivity == 8, allRows = rows * images;
   const dim3 grid(blocks_for(n)), block(bgs::kBlock);
-  hipLaunchKernelGGL(bgs::cc_init_kernel, grid, block, 0, s, (const uint8_t*)d_mask, L, rows, cols, conn8);
+  if (d_offsets) HIP_TRY(hipMemsetAsync(d_offsets, 0, ((size_t)images + 1) * sizeof(int32_t), s));
+  hipLaunchKernelGGL(bgs::cc_init_kernel, grid, block, 0, s, (const uint8_t*)d_mask, L, allRows, cols, rows, conn8);
   hipLaunchKernelGGL(bgs::cc_compress_kernel, grid, block, 0, s, L, n);
-  hipLaunchKernelGGL(bgs::cc_merge_kernel, grid, block, 0, s, L, rows, cols, conn8);
+  hipLaunchKernelGGL(bgs::cc_merge_kernel, grid, block, 0, s, L, allRows, cols, rows, conn8);
   hipLaunchKernelGGL(bgs::cc_compress_kernel, grid, block, 0, s, L, n);
   hipLaunchKernelGGL(bgs::cc_count_kernel, dim3(nb), block, 0, s, (const int*)L, n, blockCount);
-  hipLaunchKernelGGL(bgs::cc_scan_kernel, dim3(1), block, 0, s, blockCount, nb, (int*)d_count);
-  hipLaunchKernelGGL(bgs::cc_scatter_kernel, dim3(nb), block, 0, s, (const int*)L, n, (const int*)blockCount, id, (bgs::CcBox*)d_boxes, max_boxes);
+  hipLaunchKernelGGL(bgs::cc_scan_kernel, dim3(1), block, 0, s, blockCount, nb, total);
+  hipLaunchKernelGGL(bgs::cc_scatter_kernel, dim3(nb), block, 0, s, (const int*)L, n, (const int*)blockCount, id, (bgs::CcBox*)d_boxes, max_boxes, (int*)d_offsets, imgN);
   if (max_boxes > 0) {
-    hipLaunchKernelGGL(bgs::cc_boxes_kernel, dim3(blocks_for((n + bgs::kCcBoxPer - 1) / bgs::kCcBoxPer)), block, 0, s, (const int*)L, (const int*)id, rows, cols, (bgs::CcBox*)d_boxes, max_boxes);
-    hipLaunchKernelGGL(bgs::cc_finish_kernel, dim3(blocks_for((size_t)max_boxes)), block, 0, s, (bgs::CcBox*)d_boxes, (const int*)d_count, max_boxes);
+    hipLaunchKernelGGL(bgs::cc_boxes_kernel, dim3(blocks_for((n + bgs::kCcBoxPer - 1) / bgs::kCcBoxPer)), block, 0, s, (const int*)L, (const int*)id, allRows, cols, rows, (bgs::CcBox*)d_boxes, max_boxes);
+    hipLaunchKernelGGL(bgs::cc_finish_kernel, dim3(blocks_for((size_t)max_boxes)), block, 0, s, (bgs::CcBox*)d_boxes, (const int*)total, max_boxes, (int)imgN);
   }
+  if (d_offsets) hipLaunchKernelGGL(bgs::cc_offsets_kernel, dim3(1), dim3(1), 0, s, (int*)d_offsets, images);
+  if (d_labels && images > 1) hipLaunchKernelGGL(bgs::cc_localize_kernel, grid, block, 0, s, L, n, imgN);
   hipError_t er = hipGetLastError();
   if (own) {
     const hipError_t e2 = hipStreamSynchronize(s);
@@ -1136,6 +1143,18 @@ int bgs_mask_components_device(int hip_device, const void* d_mask, int rows, int
   }
   if (er != hipSuccess) return fail(BGS_ERR_HIP, "connected components failed: %s", hipGetErrorString(er));
   return BGS_OK;
+}
+
+int bgs_mask_components_device(int hip_device, const void* d_mask, int rows, int cols, int connectivity, int32_t* d_labels, bgs_box* d_boxes, int max_boxes,
+                               int32_t* d_count, void* d_work, void* hip_stream) {
+  if (!d_count) return fail(BGS_ERR_INVALID, "bgs_mask_components_device: d_count is NULL");
+  return cc_run(hip_device, d_mask, 1, rows, cols, connectivity, d_labels, d_boxes, max_boxes, d_count, nullptr, d_work, hip_stream);
+}
+
+int bgs_mask_components_batch_device(int hip_device, const void* d_masks, int images, int rows, int cols, int connectivity, int32_t* d_labels, bgs_box* d_boxes,
+                                     int max_boxes, int32_t* d_offsets, void* d_work, void* hip_stream) {
+  if (!d_offsets) return fail(BGS_ERR_INVALID, "bgs_mask_components_batch_device: d_offsets is NULL");
+  return cc_run(hip_device, d_masks, images, rows, cols, connectivity, d_labels, d_boxes, max_boxes, nullptr, d_offsets, d_work, hip_stream);
 }
 
 }  // extern "C"

@@ -50,7 +50,8 @@ __device__ __forceinline__ void cc_union(int* L, int a, int b) {
   }
 }
 
-__global__ __launch_bounds__(kBlock) void cc_init_kernel(const uint8_t* mask, int* L, int rows, int cols, int conn8) {
+// `rows` = rows of the whole stack of images, `img_rows` = rows of one image: no link crosses an image boundary
+__global__ __launch_bounds__(kBlock) void cc_init_kernel(const uint8_t* mask, int* L, int rows, int cols, int img_rows, int conn8) {
   const size_t N = (size_t)rows * cols;
   const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= N) return;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(kBlock) void cc_init_kernel(const uint8_t* mask, in
   const int y = (int)(p / cols), x = (int)(p - (size_t)y * cols);
   int l = (int)p;
   if (x > 0 && mask[p - 1]) l = (int)p - 1;
-  if (y > 0) {
+  if (y % img_rows > 0) {
     if (conn8 && x + 1 < cols && mask[p - cols + 1]) l = (int)p - cols + 1;
     if (mask[p - cols]) l = (int)p - cols;
     if (conn8 && x > 0 && mask[p - cols - 1]) l = (int)p - cols - 1;
@@ -77,14 +78,14 @@ __global__ __launch_bounds__(kBlock) void cc_compress_kernel(int* L, size_t N) {
   L[p] = cc_find(L, l);  // concurrent writers only ever store an ancestor: any value read on the way is valid
 }
 
-__global__ __launch_bounds__(kBlock) void cc_merge_kernel(int* L, int rows, int cols, int conn8) {
+__global__ __launch_bounds__(kBlock) void cc_merge_kernel(int* L, int rows, int cols, int img_rows, int conn8) {
   const size_t N = (size_t)rows * cols;
   const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= N || L[p] < 0) return;
   const int y = (int)(p / cols), x = (int)(p - (size_t)y * cols);
   // W and N (and the two upper diagonals) cover every adjacent pair once
   if (x > 0 && L[p - 1] >= 0) cc_union(L, (int)p, (int)p - 1);
-  if (y > 0) {
+  if (y % img_rows > 0) {
     if (L[p - cols] >= 0) cc_union(L, (int)p, (int)p - cols);
     if (conn8) {
       // a diagonal neighbour is already joined through N or W/E unless that orthogonal pixel is background
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void cc_scan_kernel(int* blockCount, int nb
 }
 
 // dense id of every root, in raster order; the boxes start empty
-__global__ __launch_bounds__(kBlock) void cc_scatter_kernel(const int* L, size_t N, const int* blockOffset, int* id, CcBox* boxes, int max_boxes) {
+__global__ __launch_bounds__(kBlock) void cc_scatter_kernel(const int* L, size_t N, const int* blockOffset, int* id, CcBox* boxes, int max_boxes, int* perImage, size_t imgN) {
   __shared__ int wbase[4][kBlock / kWave];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   bool root[4];
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(kBlock) void cc_scatter_kernel(const int* L, size_t
     const int my = wbase[k][wave] + __popcll(bal[k] & ((1ull << lane) - 1ull));
     id[p] = my;
     if (my < max_boxes) boxes[my] = CcBox{0x7fffffff, 0x7fffffff, -1, -1, 0, (int)p};
+    if (perImage) atomicAdd(&perImage[p / imgN + 1], 1);  // components of image k are counted in slot k+1 (prefix-summed later)
   }
 }
 
@@ -178,7 +180,7 @@ __device__ __forceinline__ void cc_box_atomics(CcBox* b, int mnx, int mny, int m
   atomicMin(&b->x, mnx), atomicMin(&b->y, mny), atomicMax(&b->w, mxx), atomicMax(&b->h, mxy), atomicAdd(&b->area, cnt);
 }
 
-__global__ __launch_bounds__(kBlock) void cc_boxes_kernel(const int* L, const int* id, int rows, int cols, CcBox* boxes, int max_boxes) {
+__global__ __launch_bounds__(kBlock) void cc_boxes_kernel(const int* L, const int* id, int rows, int cols, int img_rows, CcBox* boxes, int max_boxes) {
   const size_t N = (size_t)rows * cols;
   const int lane = threadIdx.x & (kWave - 1);
   const size_t wave0 = ((size_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave) * (kWave * kCcBoxPer);
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void cc_boxes_kernel(const int* L, const in
       cl = l, cid = id[l];
       mnx = mny = 0x7fffffff, mxx = mxy = -1, cnt = 0;
     }
-    const int y = (int)(p / cols), x = (int)(p - (size_t)y * cols);
+    const int yy = (int)(p / cols), x = (int)(p - (size_t)yy * cols), y = yy % img_rows;
     mnx = min(mnx, x), mny = min(mny, y), mxx = max(mxx, x), mxy = max(mxy, y), cnt++;
   }
   if (cid >= max_boxes) cid = -1;
@@ -213,12 +215,29 @@ __global__ __launch_bounds__(kBlock) void cc_boxes_kernel(const int* L, const in
   }
 }
 
-__global__ __launch_bounds__(kBlock) void cc_finish_kernel(CcBox* boxes, const int* count, int max_boxes) {
+__global__ __launch_bounds__(kBlock) void cc_finish_kernel(CcBox* boxes, const int* count, int max_boxes, int imgN) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= min(*count, max_boxes)) return;
   CcBox b = boxes[i];
   b.w = b.w - b.x + 1, b.h = b.h - b.y + 1;
+  b.root %= imgN;  // raster index inside its own image
   boxes[i] = b;
+}
+
+// batch: per-image counts (slots 1..images) -> offsets[0..images]; labels -> roots relative to their image
+__global__ void cc_offsets_kernel(int* offsets, int images) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int run = 0;
+    offsets[0] = 0;
+    for (int k = 1; k <= images; ++k) run += offsets[k], offsets[k] = run;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void cc_localize_kernel(int* L, size_t N, size_t imgN) {
+  const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= N) return;
+  const int l = L[p];
+  if (l >= 0) L[p] = (int)((size_t)l - (p / imgN) * imgN);
 }
 
 }  // namespace bgs

@@ -164,3 +164,22 @@ def mask_components_device(mask, connectivity=8, max_boxes=4096, want_labels=Tru
                                                      C.c_void_p(count.data_ptr()), C.c_void_p(work.data_ptr()), C.c_void_p(hip_stream)))
     n = int(count.item())
     return labels, boxes[:min(n, max_boxes)], n
+
+
+def mask_components_batch_device(masks, connectivity=8, max_boxes=65536, want_labels=False, device=0, hip_stream=None):
+    """Connected components of a stack of masks, torch CUDA uint8 [images][rows][cols], in one set of launches
+    (bgs_mask_components_batch_device).  Returns (labels or None, boxes int32 [min(total, max_boxes)][6], offsets int32 [images+1]):
+    image k owns boxes[offsets[k]:offsets[k+1]]."""
+    import torch
+    images, rows, cols = masks.shape
+    if hip_stream is None:
+        hip_stream = torch.cuda.current_stream().cuda_stream
+    labels = torch.empty((images, rows, cols), dtype=torch.int32, device=masks.device) if want_labels else None
+    boxes = torch.zeros((max(max_boxes, 1), 6), dtype=torch.int32, device=masks.device)
+    offsets = torch.zeros(images + 1, dtype=torch.int32, device=masks.device)
+    work = torch.empty(capi.lib().bgs_mask_components_batch_workspace(images, rows, cols), dtype=torch.uint8, device=masks.device)
+    capi.check(capi.lib().bgs_mask_components_batch_device(device, C.c_void_p(masks.data_ptr()), images, rows, cols, connectivity,
+                                                           C.c_void_p(labels.data_ptr() if want_labels else 0), C.c_void_p(boxes.data_ptr()), max_boxes,
+                                                           C.c_void_p(offsets.data_ptr()), C.c_void_p(work.data_ptr()), C.c_void_p(hip_stream)))
+    off = offsets.cpu()
+    return labels, boxes[:min(int(off[-1]), max_boxes)], off
