@@ -24,6 +24,81 @@ struct GmgArgs {
   double lr, prior, thr;
 };
 
+// Short lists (the usual case: a static pixel sees a handful of quantised colours) are handled in registers: when no lane
+// of the wave has more than kGmgFast - 1 features, the first kGmgFast entries are fetched with independent loads, the list
+// operations below run on registers with static indices, and the entries are written back once.  Same arithmetic in the
+// same order as the general path (gmg_pixel_lists), which stays for long lists.
+constexpr int kGmgFast = 8;
+
+__device__ __forceinline__ void gmg_fast(const GmgArgs& a, bool active, size_t sp, size_t p0, int nf, int color) {
+  int c[kGmgFast];
+  float w[kGmgFast];
+#pragma unroll
+  for (int i = 0; i < kGmgFast; ++i) {
+    c[i] = 0, w[i] = 0.f;
+    if (active && i < nf) c[i] = a.colors[(size_t)i * a.plane + sp], w[i] = a.weights[(size_t)i * a.plane + sp];
+  }
+  int idx = -1;
+  float wfound = 0.f;
+#pragma unroll
+  for (int i = 0; i < kGmgFast; ++i)
+    if (i < nf && idx < 0 && c[i] == color) idx = i, wfound = w[i];
+  bool isfg = false;
+  if (a.typical) {
+    const double wd = (double)wfound;
+    const double num = __dmul_rn(wd, a.prior);
+    const double den = __dadd_rn(num, __dmul_rn(__dsub_rn(1.0, wd), __dsub_rn(1.0, a.prior)));
+    isfg = __dsub_rn(1.0, __ddiv_rn(num, den)) > a.thr;
+  }
+  if (a.update && active) {
+    const double decay = a.typical ? __dsub_rn(1.0, a.lr) : 1.0;
+    const float ins = a.typical ? (float)a.lr : 1.0f;
+    const bool found = idx >= 0, full = !found && nf == a.F;
+    const float front_w = found ? ins + (a.typical ? (float)__dmul_rn((double)wfound, decay) : wfound) : ins;
+    const int shift_end = found ? idx : (full ? nf - 1 : -1);
+    int prev_c = 0;
+    float prev_w = 0.f;
+#pragma unroll
+    for (int i = 0; i < kGmgFast; ++i)
+      if (i < nf && (a.typical || i <= shift_end)) {
+        const int ci = c[i];
+        float wi = w[i];
+        if (a.typical) wi = (float)__dmul_rn((double)wi, decay);
+        if (i <= shift_end) {
+          c[i] = i == 0 ? color : prev_c;
+          w[i] = i == 0 ? front_w : prev_w;
+          prev_c = ci, prev_w = wi;
+        } else {
+          w[i] = wi;
+        }
+      }
+    bool appended = false;
+    if (!found && !full) {
+#pragma unroll
+      for (int i = 0; i < kGmgFast; ++i)
+        if (i == nf) c[i] = color, w[i] = ins;
+      ++nf;
+      appended = true;
+    }
+    if (a.typical ? appended : (a.normalize_now != 0)) {
+      float total = 0.0f;
+#pragma unroll
+      for (int i = 0; i < kGmgFast; ++i)
+        if (i < nf) total += w[i];
+      if (total != 0.0f) {
+#pragma unroll
+        for (int i = 0; i < kGmgFast; ++i)
+          if (i < nf) w[i] = div_rn(w[i], total);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kGmgFast; ++i)
+      if (i < nf) a.colors[(size_t)i * a.plane + sp] = c[i], a.weights[(size_t)i * a.plane + sp] = w[i];
+    a.nfeat[sp] = (uint8_t)nf;
+  }
+  if (active) a.raw[p0] = isfg ? 255 : 0;
+}
+
 __global__ __launch_bounds__(kBlock) void gmg_kernel(const GmgArgs a) {
   const size_t p0 = (size_t)blockIdx.x * kBlock + threadIdx.x;
   const bool active = p0 < a.npix;
@@ -35,6 +110,10 @@ __global__ __launch_bounds__(kBlock) void gmg_kernel(const GmgArgs a) {
     for (int c = 0; c < a.C; ++c)  // G1: (int)((v - 0.0) * levels / (255.0 - 0.0)) << 8c, in double
       feat |= (unsigned)(int)__ddiv_rn(__dmul_rn((double)a.frame[p0 * a.C + c], (double)a.levels), 255.0) << (8 * c);
     color = (int)feat;
+  }
+  if (a.F >= kGmgFast && !__any(nf >= kGmgFast)) {  // wave-uniform
+    gmg_fast(a, active, sp, p0, nf, color);
+    return;
   }
   // pass 1: findFeature
   int idx = -1;
