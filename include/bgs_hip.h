@@ -253,6 +253,9 @@ const char* bgs_last_error(void);
  * (BackgroundSubtractorSuBSENSE.cpp:209-210, 227-228), host pointer. */
 int bgs_lbsp_describe_device(int hip_device, const void* d_img, int rows, int cols, int channels,
                              const uint8_t* t_lut, void* d_desc, void* hip_stream);
+/* the same for `images` frames stored back to back ([images][rows][cols][channels]) in one launch */
+int bgs_lbsp_describe_batch_device(int hip_device, const void* d_img, int images, int rows, int cols, int channels,
+                                   const uint8_t* t_lut, void* d_desc, void* hip_stream);
 
 /* 3x3 morphology / median / hole-fill post-processing of a byte mask on device
  * (BackgroundSubtractorSuBSENSE.cpp:624-640). op: 0 erode3x3, 1 dilate3x3, 2 median(ksize),

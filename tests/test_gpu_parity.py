@@ -901,3 +901,16 @@ def test_connected_components_batch(connectivity):
         assert np.array_equal(got_l[s], want_l), s
         want = np.stack([want_b[f] for f in ("x", "y", "w", "h", "area", "root")], axis=1) if want_n else np.zeros((0, 6), np.int32)
         assert np.array_equal(got_b[off[s]:off[s + 1]], want), s
+
+
+def test_lbsp_batch_equals_single_images():
+    """bgs_lbsp_describe_batch_device: a stack of frames in one launch gives the descriptors of each frame alone (and the oracle's)."""
+    torch = _torch()
+    from tracking_amd.engine import lbsp_describe_batch_device, lbsp_describe_device
+    lut = pyoracle.lbsp_lut(0.333, 0, 3)
+    imgs = synth.random_frames(3, 46, 68, 3, seed=77)
+    d = torch.from_numpy(imgs).cuda()
+    got = lbsp_describe_batch_device(d, lut).cpu().numpy().view(np.uint16)
+    for k in range(3):
+        assert np.array_equal(got[k], lbsp_describe_device(d[k], lut).cpu().numpy().view(np.uint16))
+        assert np.array_equal(got[k], pyoracle.lbsp_describe(imgs[k], lut))

@@ -100,6 +100,40 @@ def run_subsense(S, steps=30, kind="surv"):
     e.close()
 
 
+def run_lbsp():
+    # LBSP descriptors, 1080p
+    img = synth.s_surv(1, 1080, 1920, seed=9, device="cuda")[0]
+    from oracle import pyoracle
+    lut = pyoracle.lbsp_lut(0.333, 0, 3)
+    out = torch.empty((1080, 1920, 3), dtype=torch.int16, device="cuda")
+    for _ in range(5):
+        lbsp_describe_device(img, lut, out=out)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(50):
+        lbsp_describe_device(img, lut, out=out)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 50
+    px = 1080 * 1920
+    print("%-34s 1920x1080 x1: %.4f ms -> %8.1f Mpix/s  %7.1f GB/s algorithmic (9 B/px)" % ("LBSP descriptors (lbsp_kernel)", ms, px / ms / 1e3, 9 * px / ms / 1e6))
+    from tracking_amd.engine import lbsp_describe_batch_device
+    imgs = synth.s_surv(16, 1080, 1920, seed=9, device="cuda")
+    for _ in range(3):
+        lbsp_describe_batch_device(imgs, lut)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(20):
+        lbsp_describe_batch_device(imgs, lut)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 20
+    px = 16 * 1080 * 1920
+    print("%-34s 1920x1080 x16 (one launch): %.4f ms -> %8.1f Mpix/s  %7.1f GB/s algorithmic (9 B/px, incl. the output allocation)" % ("LBSP descriptors (lbsp_kernel)", ms, px / ms / 1e3, 9 * px / ms / 1e6))
+
+
+
 def run_pipeline(S=8, steps=30):
     """Frames in HBM -> SuBSENSE masks -> blob rectangles, all on the device; only the boxes and offsets cross PCIe."""
     from tracking_amd.engine import mask_components_batch_device
@@ -173,6 +207,9 @@ def main():
         run_subsense(2)
         run_subsense(2, kind="smooth")
         return
+    if args.only == "lbsp":
+        run_lbsp()
+        return
     if args.only == "pipeline":
         run_pipeline()
         return
@@ -198,24 +235,7 @@ def main():
     run(capi.GMG, "GMG (data-dependent traffic)", 1080, 1920, 8, 16, borrow=False, cpu_frames=8, cpu_warm=5, params=pg)
     run_subsense(2)
     run_subsense(2, kind="smooth")
-    # LBSP descriptors, 1080p
-    img = synth.s_surv(1, 1080, 1920, seed=9, device="cuda")[0]
-    from oracle import pyoracle
-    lut = pyoracle.lbsp_lut(0.333, 0, 3)
-    out = torch.empty((1080, 1920, 3), dtype=torch.int16, device="cuda")
-    for _ in range(5):
-        lbsp_describe_device(img, lut, out=out)
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(50):
-        lbsp_describe_device(img, lut, out=out)
-    b.record()
-    torch.cuda.synchronize()
-    ms = a.elapsed_time(b) / 50
-    px = 1080 * 1920
-    print("%-34s 1920x1080 x1: %.4f ms -> %8.1f Mpix/s  %7.1f GB/s algorithmic (9 B/px)" % ("LBSP descriptors (lbsp_kernel)", ms, px / ms / 1e3, 9 * px / ms / 1e6))
-
+    run_lbsp()
 
 if __name__ == "__main__":
     main()

@@ -99,6 +99,7 @@ SYMBOLS = [
     ("bgs_destroy", None, [_P]),
     ("bgs_last_error", C.c_char_p, []),
     ("bgs_lbsp_describe_device", C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    ("bgs_lbsp_describe_batch_device", C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     ("bgs_mask_morph_device", C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     ("bgs_mask_components_workspace", C.c_size_t, [C.c_int, C.c_int]),
     ("bgs_mask_components_device", C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P]),

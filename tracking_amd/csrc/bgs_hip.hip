@@ -1021,14 +1021,20 @@ void bgs_destroy(bgs_engine* e) {
 }
 
 int bgs_lbsp_describe_device(int hip_device, const void* d_img, int rows, int cols, int channels, const uint8_t* t_lut, void* d_desc, void* hip_stream) {
-  if (!d_img || !d_desc || !t_lut || rows <= 0 || cols <= 0) return fail(BGS_ERR_INVALID, "bad argument");
+  return bgs_lbsp_describe_batch_device(hip_device, d_img, 1, rows, cols, channels, t_lut, d_desc, hip_stream);
+}
+
+int bgs_lbsp_describe_batch_device(int hip_device, const void* d_img, int images, int rows, int cols, int channels, const uint8_t* t_lut, void* d_desc,
+                                   void* hip_stream) {
+  if (!d_img || !d_desc || !t_lut || rows <= 0 || cols <= 0 || images <= 0 || images > 65535) return fail(BGS_ERR_INVALID, "bad argument");
+  if (images > 1 && ((size_t)rows * cols * channels) % 4) return fail(BGS_ERR_INVALID, "batched images must each be a multiple of 4 bytes (4-byte aligned rows of dwords)");
   if (channels != 1 && channels != 3) return fail(BGS_ERR_UNSUPPORTED, "channels must be 1 or 3");
   if (!aligned(d_img, 4)) return fail(BGS_ERR_INVALID, "image must be 4-byte aligned");
   HIP_TRY(hipSetDevice(hip_device));
   bgs::LbspArgs a{};
   a.img = (const uint8_t*)d_img, a.desc = (uint16_t*)d_desc, a.rows = rows, a.cols = cols;
   std::memcpy(a.lut, t_lut, 256);
-  const dim3 grid((cols + bgs::kLbspTW - 1) / bgs::kLbspTW, (rows + bgs::kLbspTH - 1) / bgs::kLbspTH, 1);
+  const dim3 grid((cols + bgs::kLbspTW - 1) / bgs::kLbspTW, (rows + bgs::kLbspTH - 1) / bgs::kLbspTH, images);
   if (channels == 3)
     hipLaunchKernelGGL((bgs::lbsp_kernel<3>), grid, dim3(bgs::kBlock), 0, (hipStream_t)hip_stream, a);
   else

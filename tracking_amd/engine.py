@@ -131,6 +131,19 @@ def lbsp_describe_device(img, lut, out=None, device=0, hip_stream=None):
     return out
 
 
+def lbsp_describe_batch_device(imgs, lut, device=0, hip_stream=None):
+    """imgs: torch CUDA uint8 [images][rows][cols][C]; one launch for the whole stack.  Returns int16-typed uint16 descriptors."""
+    import torch
+    images, rows, cols, ch = imgs.shape
+    out = torch.empty((images, rows, cols, ch), dtype=torch.int16, device=imgs.device)
+    if hip_stream is None:
+        hip_stream = torch.cuda.current_stream().cuda_stream
+    lut = np.ascontiguousarray(lut, dtype=np.uint8)
+    capi.check(capi.lib().bgs_lbsp_describe_batch_device(device, C.c_void_p(imgs.data_ptr()), images, rows, cols, ch, lut.ctypes.data_as(C.c_void_p),
+                                                         C.c_void_p(out.data_ptr()), C.c_void_p(hip_stream)))
+    return out
+
+
 MORPH_ERODE, MORPH_DILATE, MORPH_MEDIAN, MORPH_MEDIAN_BINARY, MORPH_FLOODFILL_ORIGIN = 0, 1, 2, 3, 4
 
 
