@@ -914,3 +914,21 @@ def test_lbsp_batch_equals_single_images():
     for k in range(3):
         assert np.array_equal(got[k], lbsp_describe_device(d[k], lut).cpu().numpy().view(np.uint16))
         assert np.array_equal(got[k], pyoracle.lbsp_describe(imgs[k], lut))
+
+
+def test_model_sizing_parameters_are_frozen_after_the_first_frame(golden_frames):
+    """The reference hands these values to its model once (SuBSENSE.cpp:27-36, DP*BGS.cpp `if(firstTime)`): a later bgs_set_params
+    with a different sample / gaussian count must neither resize nor overrun the model - it is ignored, as in the reference."""
+    for algo, field, big in ((capi.LOBSTER, "subsense_n_samples", 60), (capi.SUBSENSE, "subsense_n_samples", 63), (capi.DP_ZIVKOVIC_AGMM, "dp_gaussians", 5),
+                             (capi.DP_GRIMSON_GMM, "dp_gaussians", 5)):
+        p = _params(algo, **{field: 2})
+        if field == "subsense_n_samples":
+            p.subsense_n_required = 1
+        eng, orc = Engine(algo, params=p), pyoracle.Oracle(algo, params=p)
+        for t, f in enumerate(golden_frames[:6]):
+            if t == 2:
+                q = _params(algo, **{field: big})
+                eng.set_params(q)  # ignored for the running model
+            fg, bg = eng.process(f)
+            ofg, obg = orc.process(f)
+            assert np.array_equal(fg, ofg), (algo, t)

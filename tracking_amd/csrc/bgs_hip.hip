@@ -137,6 +137,7 @@ int check_params(bgs_algo algo, const bgs_params& p) {
   if (algo == BGS_GMG && p.gmg_smoothing_radius != 0 && (p.gmg_smoothing_radius < 3 || p.gmg_smoothing_radius > 15 || p.gmg_smoothing_radius % 2 == 0))
     return fail(BGS_ERR_UNSUPPORTED, "GMG smoothingRadius (cv::medianBlur kernel) must be 0 or odd 3..15, got %d", p.gmg_smoothing_radius);
   if (algo == BGS_MOG2 && p.mog2_nmixtures != bgs::kMog2K) return fail(BGS_ERR_UNSUPPORTED, "MOG2 kernel is built for K=%d mixtures, got %d", bgs::kMog2K, p.mog2_nmixtures);
+  if (algo == BGS_MOG1 && p.mog1_nmixtures != bgs::kMog1K) return fail(BGS_ERR_UNSUPPORTED, "MOG1 kernel is built for K=%d mixtures, got %d", bgs::kMog1K, p.mog1_nmixtures);
   if ((algo == BGS_DP_ZIVKOVIC_AGMM || algo == BGS_DP_GRIMSON_GMM) && (p.dp_gaussians < 1 || p.dp_gaussians > 5))
     return fail(BGS_ERR_UNSUPPORTED, "dp GMM kernels are built for 1..5 gaussians, got %d", p.dp_gaussians);
   if (algo == BGS_DP_ADAPTIVE_MEDIAN && p.dp_sampling_rate == 0) return fail(BGS_ERR_UNSUPPORTED, "AdaptiveMedian samplingRate 0 (frame_num %% 0)");
@@ -785,7 +786,25 @@ int bgs_set_params(bgs_engine* e, const bgs_params* params) {
   if (params->struct_size != sizeof(bgs_params)) return fail(BGS_ERR_INVALID, "bgs_params.struct_size mismatch");
   int rc = check_params(e->algo, *params);
   if (rc) return rc;
+  const bgs_params old = e->p;
   e->p = *params;
+  if (e->n) {
+    // Parameters the reference hands to its model object once, when it is built on the first frame, stay as they were:
+    // later values are ignored there too (SuBSENSE.cpp:27-36, LOBSTER.cpp:27-34, DP*BGS.cpp `if(firstTime)`), and here they
+    // also size the device buffers.
+    bgs_params& p = e->p;
+    if (e->algo == BGS_SUBSENSE || e->algo == BGS_LOBSTER) {
+      p.lbsp_rel_threshold = old.lbsp_rel_threshold, p.lbsp_threshold_offset = old.lbsp_threshold_offset;
+      p.subsense_min_color_dist_threshold = old.subsense_min_color_dist_threshold, p.subsense_n_samples = old.subsense_n_samples;
+      p.subsense_n_required = old.subsense_n_required, p.subsense_samples_for_moving_avgs = old.subsense_samples_for_moving_avgs;
+      p.subsense_desc_dist_threshold_offset = old.subsense_desc_dist_threshold_offset;
+    }
+    if (is_dp(e->algo)) {
+      p.dp_threshold = old.dp_threshold, p.dp_alpha = old.dp_alpha, p.dp_gaussians = old.dp_gaussians;
+      p.dp_sampling_rate = old.dp_sampling_rate, p.learning_frames = old.learning_frames;
+    }
+    if (e->algo == BGS_GMG) p.gmg_max_features = old.gmg_max_features;  // sizes the histogram planes
+  }
   return BGS_OK;
 }
 
