@@ -383,3 +383,25 @@ def test_dp_oracle_invariants(golden_frames):
             step = np.abs(med - prev).max()
             assert step <= 1 and (step == 0 or t % 7 == 1)
         prev = med
+
+
+def test_morphology_oracle_vs_scipy():
+    """The oracle's cv::-style primitives against independent implementations: median (BORDER_REPLICATE) = scipy median_filter
+    mode='nearest'; erode/dilate with cells outside the image ignored = grey_erosion/dilation with cval 255/0; n iterations of
+    3x3 = one (2n+1)^2 box; floodFill from the origin = the 4-connected region of equal value containing (0,0)."""
+    from scipy import ndimage
+    rng = np.random.default_rng(3)
+    for shape in ((40, 57), (9, 9), (1, 30), (25, 2)):
+        g = rng.integers(0, 256, shape, dtype=np.uint8)
+        b = np.where(rng.random(shape) < 0.45, 255, 0).astype(np.uint8)
+        for k in (3, 5, 9):
+            assert np.array_equal(pyoracle.median_blur(g, k), ndimage.median_filter(g, size=k, mode="nearest")), (shape, k)
+            assert np.array_equal(pyoracle.median_blur(b, k), ndimage.median_filter(b, size=k, mode="nearest")), (shape, k)
+        for it in (1, 2, 3):
+            sz = 2 * it + 1
+            assert np.array_equal(pyoracle.erode3x3(g, it), ndimage.grey_erosion(g, size=(sz, sz), mode="constant", cval=255)), (shape, it)
+            assert np.array_equal(pyoracle.dilate3x3(g, it), ndimage.grey_dilation(g, size=(sz, sz), mode="constant", cval=0)), (shape, it)
+        lab, _ = ndimage.label(b == b[0, 0])  # 4-connected by default
+        want = b.copy()
+        want[lab == lab[0, 0]] = 255
+        assert np.array_equal(pyoracle.floodfill_from_origin(b, 255), want), shape
