@@ -305,6 +305,58 @@ int mog2_allocate(bgs_engine* e) {
   return rc;
 }
 
+// The placement probe of mog2_allocate for any other big, long-lived model: `run(candidate)` must enqueue ONE dense pass of the
+// kernel that will stream the buffer (on e->stream) and return a bgs status.  Picks the fastest of up to probe_max candidates.
+template <class Run>
+int probe_allocate(bgs_engine* e, void** out, size_t bytes, Run run) {
+  const int tries = std::min(e->probe_max, 16);
+  if (tries <= 1 || bytes < ((size_t)768 << 20)) {
+    HIP_TRY(hipMalloc(out, bytes));
+    return BGS_OK;
+  }
+  hipEvent_t ev0, ev1;
+  HIP_TRY(hipEventCreate(&ev0));
+  HIP_TRY(hipEventCreate(&ev1));
+  void* cand[16] = {nullptr};
+  int n = 0, best = 0, rc = BGS_OK;
+  float tmin = 1e30f;
+  for (; n < tries; ++n) {
+    if (hipMalloc(&cand[n], bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      break;  // out of memory: settle for what we have
+    }
+    (void)hipMemsetAsync(cand[n], 0, bytes, e->stream);
+    for (int i = 0; i < 2 && !rc; ++i) rc = run(cand[n]);
+    (void)hipEventRecord(ev0, e->stream);
+    for (int i = 0; i < 4 && !rc; ++i) rc = run(cand[n]);
+    (void)hipEventRecord(ev1, e->stream);
+    if (rc || hipEventSynchronize(ev1) != hipSuccess) {
+      rc = rc ? rc : fail(BGS_ERR_HIP, "placement probe failed: %s", hipGetErrorString(hipGetLastError()));
+      ++n;
+      break;
+    }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    e->probe_ms[n] = ms / 4;
+    if (ms < tmin) tmin = ms, best = n;
+  }
+  e->probe_n = n, e->probe_pick = best;
+  for (int i = 0; i < n; ++i)
+    if (i != best || rc) (void)hipFree(cand[i]);
+  (void)hipEventDestroy(ev0), (void)hipEventDestroy(ev1);
+  if (rc) return rc;
+  if (!n) return fail(BGS_ERR_NOMEM, "out of device memory for the model (%zu bytes)", bytes);
+  HIP_TRY(hipMemsetAsync(cand[best], 0, bytes, e->stream));  // hand the model over in its initial (all-zero) state
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  *out = cand[best];
+  if (getenv("BGS_DEBUG_PROBE")) {
+    fprintf(stderr, "[bgs] placement probe (%zu MB):", bytes >> 20);
+    for (int i = 0; i < n; ++i) fprintf(stderr, " %.3f%s", e->probe_ms[i], i == best ? "*" : "");
+    fprintf(stderr, " ms per dense launch\n");
+  }
+  return BGS_OK;
+}
+
 #include "engine_subsense.h"
 #include "engine_dp.h"
 
@@ -352,7 +404,29 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
   if (e->algo == BGS_MOG1) {
     const size_t planes = ch == 3 ? bgs::mog1_planes<3>() : bgs::mog1_planes<1>();
     const size_t tiles = (P + bgs::kMog1Tile - 1) / bgs::kMog1Tile;
-    HIP_TRY(hipMalloc((void**)&e->mog1_state, tiles * planes * bgs::kMog1Tile * sizeof(float)));
+    if (!e->stream) HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    const size_t bytes = tiles * planes * bgs::kMog1Tile * sizeof(float);
+    uint8_t* d_zero = nullptr;  // a black frame for the probe launches
+    const bool probing = e->probe_max > 1 && bytes >= ((size_t)768 << 20);
+    if (probing) {
+      HIP_TRY(hipMalloc((void**)&d_zero, P * ch));
+      HIP_TRY(hipMemsetAsync(d_zero, 0, P * ch, e->stream));
+    }
+    int rc = probe_allocate(e, (void**)&e->mog1_state, bytes, [&](void* cand) -> int {
+      bgs::Mog1Args m{};
+      m.state = (float*)cand, m.state_off = 0, m.npix = P, m.frame = d_zero, m.fg = nullptr, m.fg_bits = nullptr;
+      m.alpha = 0.05f, m.T = 0.7f, m.vT = 6.25f, m.w0 = 0.05f, m.sk0 = 0.001f, m.var0 = 900.f, m.minVar = 225.f;
+      m.thr = 15, m.enable_thr = 1, m.packed = 0, m.xcd_swizzle = e->xcd_swizzle;
+      const bool px2 = P % 2 == 0;
+      const dim3 grid(blocks_for(px2 ? P / 2 : P)), block(bgs::kBlock);
+      if (ch == 3 && px2) hipLaunchKernelGGL((bgs::mog1_update_kernel<3, 2>), grid, block, 0, e->stream, m);
+      if (ch == 3 && !px2) hipLaunchKernelGGL((bgs::mog1_update_kernel<3, 1>), grid, block, 0, e->stream, m);
+      if (ch == 1 && px2) hipLaunchKernelGGL((bgs::mog1_update_kernel<1, 2>), grid, block, 0, e->stream, m);
+      if (ch == 1 && !px2) hipLaunchKernelGGL((bgs::mog1_update_kernel<1, 1>), grid, block, 0, e->stream, m);
+      return hipGetLastError() == hipSuccess ? BGS_OK : fail(BGS_ERR_HIP, "probe launch failed");
+    });
+    if (d_zero) (void)hipFree(d_zero);
+    if (rc) return rc;
   }
   if (!e->stream) HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   if (e->algo == BGS_MOG2) {

@@ -14,19 +14,6 @@ int dp_planes_of(const bgs_engine* e) {
   }
 }
 
-int dp_allocate(bgs_engine* e) {
-  if (e->ch != 3) return fail(BGS_ERR_UNSUPPORTED, "the dp/ models read RgbImage pixels: 3-channel frames only (dp/Image.h:257-265)");
-  const size_t P = e->n * e->S;
-  const int planes = dp_planes_of(e);
-  if (planes) {
-    const size_t tiles = (P + bgs::kDpTile - 1) / bgs::kDpTile;
-    HIP_TRY(hipMalloc((void**)&e->dp_state, tiles * planes * bgs::kDpTile * sizeof(float)));
-    HIP_TRY(hipMemset(e->dp_state, 0, tiles * planes * bgs::kDpTile * sizeof(float)));  // InitModel of the GMMs: everything 0
-  }
-  if (e->bgstate) HIP_TRY(hipMemset(e->bgstate, 0, P * e->state_ch));
-  return BGS_OK;
-}
-
 template <bool GRIMSON>
 void dp_launch_gmm(int K, unsigned blocks, hipStream_t s, const bgs::DpArgs& a) {
   switch (K) {
@@ -36,6 +23,41 @@ void dp_launch_gmm(int K, unsigned blocks, hipStream_t s, const bgs::DpArgs& a) 
     case 4: hipLaunchKernelGGL((bgs::dp_gmm_kernel<4, GRIMSON>), dim3(blocks), dim3(bgs::kBlock), 0, s, a); break;
     default: hipLaunchKernelGGL((bgs::dp_gmm_kernel<5, GRIMSON>), dim3(blocks), dim3(bgs::kBlock), 0, s, a); break;
   }
+}
+
+int dp_allocate(bgs_engine* e) {
+  if (e->ch != 3) return fail(BGS_ERR_UNSUPPORTED, "the dp/ models read RgbImage pixels: 3-channel frames only (dp/Image.h:257-265)");
+  const size_t P = e->n * e->S;
+  const int planes = dp_planes_of(e);
+  if (planes) {
+    const size_t tiles = (P + bgs::kDpTile - 1) / bgs::kDpTile, bytes = tiles * planes * bgs::kDpTile * sizeof(float);
+    if (!e->stream) HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    uint8_t* d_zero = nullptr;  // a black frame for the probe launches (probe_allocate, bgs_hip.hip)
+    const bool probing = e->probe_max > 1 && bytes >= ((size_t)768 << 20);
+    if (probing) {
+      HIP_TRY(hipMalloc((void**)&d_zero, P * 3));
+      HIP_TRY(hipMemsetAsync(d_zero, 0, P * 3, e->stream));
+      if (e->bgstate) HIP_TRY(hipMemsetAsync(e->bgstate, 0, P * e->state_ch, e->stream));
+    }
+    int rc = probe_allocate(e, (void**)&e->dp_state, bytes, [&](void* cand) -> int {
+      bgs::DpArgs a{};
+      a.frame = d_zero, a.state = (float*)cand, a.bstate = e->bgstate, a.fg = nullptr, a.fg_bits = nullptr;
+      a.n = e->n, a.npix = P, a.first = 0, a.low = 25.f, a.high = 50.f, a.alpha = 0.01f, a.update = 0, a.xcd_swizzle = e->xcd_swizzle;
+      const unsigned blocks = blocks_for(P);
+      switch (e->algo) {
+        case BGS_DP_ZIVKOVIC_AGMM: dp_launch_gmm<false>(e->p.dp_gaussians, blocks, e->stream, a); break;
+        case BGS_DP_GRIMSON_GMM: dp_launch_gmm<true>(e->p.dp_gaussians, blocks, e->stream, a); break;
+        case BGS_DP_WREN_GA: hipLaunchKernelGGL(bgs::dp_wren_kernel, dim3(blocks), dim3(bgs::kBlock), 0, e->stream, a); break;
+        default: hipLaunchKernelGGL(bgs::dp_mean_kernel, dim3(blocks), dim3(bgs::kBlock), 0, e->stream, a); break;
+      }
+      return hipGetLastError() == hipSuccess ? BGS_OK : fail(BGS_ERR_HIP, "probe launch failed");
+    });
+    if (d_zero) (void)hipFree(d_zero);
+    if (rc) return rc;
+    if (!probing) HIP_TRY(hipMemset(e->dp_state, 0, bytes));  // InitModel of the GMMs: everything 0 (the probe hands its pick over zeroed)
+  }
+  if (e->bgstate) HIP_TRY(hipMemset(e->bgstate, 0, P * e->state_ch));
+  return BGS_OK;
 }
 
 // one frame (number t, 0-based = the wrappers' frameNumber) for streams [first, first+count)
