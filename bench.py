@@ -112,7 +112,7 @@ def surv_leg(local, S, fg, steps=200, sparse=1):
     out = {"mpixels_per_s": round(mpix, 1), "streams_1080p30": round(mpix / (ROWS * COLS / 1e6) / 30.0, 1), "kernel_ms": round(ms, 4),
            "mean_live_modes_stream0": round(float(nm.mean()), 3), "foreground_ratio": round(float((fg != 0).float().mean()), 4),
            "sparse_mode": sparse,
-           "note": "S_surv input, %d streams; BGS_OPT_MOG2_SPARSE=%d (1 = unchanged planes not written back, 2 = also planes of absent modes not read, 3 = automatic choice [default])" % (S, sparse)}
+           "note": "S_surv input, %d streams; BGS_OPT_MOG2_SPARSE=%d (1 = unchanged planes not written back, 2/4 = also planes of absent modes not read, per wave / per lane, 3 = automatic choice between 1 and 4 [default])" % (S, sparse)}
     eng.close()
     del pool
     return out

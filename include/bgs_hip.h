@@ -183,8 +183,9 @@ int bgs_set_params(bgs_engine* e, const bgs_params* params);
 #define BGS_OPT_XCD_SWIZZLE 4
 #define BGS_OPT_PLACEMENT_PROBE 5
 #define BGS_OPT_MOG2_SPARSE 6   /* exact traffic reduction: 0 dense; 1 planes nothing changed in are not written back;
-                                   2 also skip loading the planes of modes no pixel of a wave has (best on quiet scenes, ~8 % slower
-                                   when every mode is live); 3 (default) switch between 1 and 2 from a sparsity sample of the scene */
+                                   2 also skip loading the planes of modes no pixel of a wave has; 4 the same per lane (4 pixels)
+                                   instead of per wave, loads and stores of partial rows; 3 (default) switch between 1 and 4 from a
+                                   sparsity sample of the scene */
 int bgs_set_option(bgs_engine* e, int option, int64_t value);
 
 /* Fix rows x cols x channels up front and allocate the model (device path). */

@@ -88,7 +88,7 @@ struct bgs_engine {
   bool mog2_tiled = true;
   int mog2_px = 0;                 // pixels per lane, 0 = widest the alignment allows
   int xcd_swizzle = 1;             // XCD-aware block order (kernel_mog2.h)
-  int mog2_sparse = 3;             // data-dependent plane skipping (kernel_mog2.h): 0 dense, 1 stores, 2 stores+loads, 3 = choose 1 or 2 from the scene
+  int mog2_sparse = 3;             // data-dependent plane skipping (kernel_mog2.h): 0 dense, 1 stores, 2 stores+loads per wave, 4 per lane, 3 = choose 1 or 4 from the scene
   int mog2_sparse_now = 1;         // what auto mode currently runs
   unsigned* d_stat = nullptr;      // device: {sampled waves, sparse waves}
   unsigned* h_stat = nullptr;      // pinned copy
@@ -193,7 +193,7 @@ int launch_mog2(bgs_engine* e, bgs::Mog2Args& a, hipStream_t s, bool timed = tru
       const unsigned total = e->h_stat[0], sparse_waves = e->h_stat[1];
       if (total >= 64) {
         const float frac = (float)sparse_waves / (float)total;
-        if (frac > 0.30f) e->mog2_sparse_now = 2;
+        if (frac > 0.30f) e->mog2_sparse_now = 4;
         if (frac < 0.15f) e->mog2_sparse_now = 1;
       }
     }
@@ -908,7 +908,7 @@ int bgs_set_option(bgs_engine* e, int option, int64_t value) {
       e->mog2_tiled = value != 0;
       return BGS_OK;
     case 4: e->xcd_swizzle = value != 0; return BGS_OK;
-    case 6: e->mog2_sparse = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 3); return BGS_OK;
+    case 6: e->mog2_sparse = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 4); return BGS_OK;
     case 5:
       if (e->n) return fail(BGS_ERR_INVALID, "the placement probe runs when the geometry is set");
       e->probe_max = (int)value;

@@ -35,7 +35,8 @@ struct Mog2Args {
   int thr, enable_thr, shadow_val;
   int shadow, want_bg, packed;  // wave-uniform feature switches
   unsigned* stat;               // null, or 2 counters: sampled waves, sampled waves whose largest nmodes is below K-1 (auto mode)
-  int sparse;                   // 0 dense; 1 skip the stores of planes nothing changed in; 2 also skip the loads of modes no pixel of the wave has
+  int sparse;                   // 0 dense; 1 skip the stores of planes nothing changed in; 2 also skip the loads of modes no pixel of the wave has;
+                                // 4 the same per lane (4 pixels) instead of per wave: partial rows, traffic follows the live modes
   int xcd_swizzle;              // workgroups that share an XCD walk one contiguous eighth of the launch
 };
 
@@ -265,10 +266,16 @@ __global__ __launch_bounds__(kBlock) void mog2_update_kernel(const Mog2Args a) {
     };
     int nload = kMog2K;
     load_mode(0);
+    // sparse == 4: the same two rules per LANE (its PX pixels) instead of per wave.  A lane loads modes 0..min(its largest
+    // nmodes, K-1) - index nmodes included, so that a mode created there by one pixel does not clobber the stale entry of the
+    // lane's other pixels - and stores a plane only if one of its own pixels changed it (which implies it was loaded).
+    const bool lanewise = a.sparse >= 4;
+    int lane_need = kMog2K;
     if (a.sparse >= 2) {
       int lane_max = 0;
 #pragma unroll
       for (int j = 0; j < PX; ++j) lane_max = max(lane_max, (int)((nmw >> (8 * j)) & 0xffu));
+      if (lanewise) lane_need = lane_max;
       int M = 0;
 #pragma unroll
       for (int n = 1; n <= kMog2K; ++n)
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void mog2_update_kernel(const Mog2Args a) {
     }
 #pragma unroll
     for (int k = 1; k < kMog2K; ++k) {
-      if (k < nload) {
+      if (k < nload && k <= lane_need) {
         load_mode(k);
       } else {
 #pragma unroll
@@ -331,14 +338,15 @@ __global__ __launch_bounds__(kBlock) void mog2_update_kernel(const Mog2Args a) {
     const bool all = !a.sparse;
 #pragma unroll
     for (int k = 0; k < kMog2K; ++k) {
-      if (all || __any((dirty_w >> k) & 1u)) store_f<PX>(a.state + mog2_plane_off<TILED>(a, k, sp), st[k]);
-      if (all || __any((dirty_m >> k) & 1u)) {
+      const bool dw = (dirty_w >> k) & 1u, dm = (dirty_m >> k) & 1u;
+      if (all || (lanewise ? dw : (bool)__any(dw))) store_f<PX>(a.state + mog2_plane_off<TILED>(a, k, sp), st[k]);
+      if (all || (lanewise ? dm : (bool)__any(dm))) {
         store_f<PX>(a.state + mog2_plane_off<TILED>(a, 5 + k, sp), st[5 + k]);
 #pragma unroll
         for (int c = 0; c < 3; ++c) store_f<PX>(a.state + mog2_plane_off<TILED>(a, 10 + 3 * k + c, sp), st[10 + 3 * k + c]);
       }
     }
-    const bool nm_dirty = all || __any(nm_out != nmw);
+    const bool nm_dirty = all || (lanewise ? nm_out != nmw : (bool)__any(nm_out != nmw));
     if constexpr (PX == 4) {
       if (nm_dirty) *reinterpret_cast<uint32_t*>(nmp) = nm_out;
       if (a.fg) *reinterpret_cast<uint32_t*>(a.fg + p0) = mask_word;
