@@ -932,3 +932,30 @@ def test_model_sizing_parameters_are_frozen_after_the_first_frame(golden_frames)
             fg, bg = eng.process(f)
             ofg, obg = orc.process(f)
             assert np.array_equal(fg, ofg), (algo, t)
+
+
+@pytest.mark.parametrize("level", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("shape", [(64, 256), (37, 53)])
+def test_mog2_sparse_levels_are_exact(level, shape):
+    """BGS_OPT_MOG2_SPARSE only changes which planes move: masks, backgrounds and the whole model (including the stale entries
+    past each pixel's mode count) must equal the oracle at every level.  The clip mixes quiet pixels (1 mode), a moving box
+    (modes created / replaced) and a noisy band (all 5 modes live), so lanes and waves with different mode counts sit side by side."""
+    torch = _torch()
+    rng = np.random.default_rng(level * 10 + shape[0])
+    H, W = shape
+    T = 16
+    base = rng.integers(0, 256, (H, W, 3))
+    frames = np.repeat(base[None], T, 0).astype(np.int32)
+    frames[:, :, : W // 5] = rng.integers(0, 256, (T, H, W // 5, 3))  # noisy band
+    for t in range(T):
+        x = (t * 5) % max(1, W - 12)
+        frames[t, H // 3: H // 3 + 8, x: x + 12] = 255 - frames[t, H // 3: H // 3 + 8, x: x + 12]  # moving box
+    frames = frames.astype(np.uint8)
+    eng = Engine(capi.MOG2)
+    eng.set_option(capi.OPT_MOG2_SPARSE, level)
+    orc = pyoracle.Oracle(capi.MOG2)
+    for t, f in enumerate(frames):
+        fg, bg = eng.process(f)
+        ofg, obg = orc.process(f)
+        assert np.array_equal(fg, ofg) and np.array_equal(bg, obg), (level, t)
+    check_mog2_state(eng, orc, H * W)
