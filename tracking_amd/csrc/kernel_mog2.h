@@ -266,16 +266,17 @@ __global__ __launch_bounds__(kBlock) void mog2_update_kernel(const Mog2Args a) {
     };
     int nload = kMog2K;
     load_mode(0);
-    // sparse == 4: the same two rules per LANE (its PX pixels) instead of per wave.  A lane loads modes 0..min(its largest
-    // nmodes, K-1) - index nmodes included, so that a mode created there by one pixel does not clobber the stale entry of the
-    // lane's other pixels - and stores a plane only if one of its own pixels changed it (which implies it was loaded).
+    // sparse == 4: the same two rules per LANE (its PX pixels) instead of per wave.  With L = the largest nmodes among the
+    // lane's pixels, the lane loads modes 0..L-1 only and stores a plane only if one of its own pixels changed it.  The one
+    // unloaded slot a pixel can still write is index L (a pixel with nmodes == L creating a mode): the lane's other pixels
+    // keep stale, unread entries there, so that slot is written per pixel (scalar stores), never as a vector.
     const bool lanewise = a.sparse >= 4;
     int lane_need = kMog2K;
     if (a.sparse >= 2) {
       int lane_max = 0;
 #pragma unroll
       for (int j = 0; j < PX; ++j) lane_max = max(lane_max, (int)((nmw >> (8 * j)) & 0xffu));
-      if (lanewise) lane_need = lane_max;
+      if (lanewise) lane_need = lane_max - 1;
       int M = 0;
 #pragma unroll
       for (int n = 1; n <= kMog2K; ++n)
@@ -339,6 +340,19 @@ __global__ __launch_bounds__(kBlock) void mog2_update_kernel(const Mog2Args a) {
 #pragma unroll
     for (int k = 0; k < kMog2K; ++k) {
       const bool dw = (dirty_w >> k) & 1u, dm = (dirty_m >> k) & 1u;
+      if (lanewise && k > lane_need) {  // slot not loaded by this lane: only a pixel that now owns a mode here may write, and only its own element
+        if (dw || dm) {
+#pragma unroll
+          for (int j = 0; j < PX; ++j)
+            if ((int)((nm_out >> (8 * j)) & 0xffu) > k) {
+              a.state[mog2_plane_off<TILED>(a, k, sp) + j] = st[k][j];
+              a.state[mog2_plane_off<TILED>(a, 5 + k, sp) + j] = st[5 + k][j];
+#pragma unroll
+              for (int c = 0; c < 3; ++c) a.state[mog2_plane_off<TILED>(a, 10 + 3 * k + c, sp) + j] = st[10 + 3 * k + c][j];
+            }
+        }
+        continue;
+      }
       if (all || (lanewise ? dw : (bool)__any(dw))) store_f<PX>(a.state + mog2_plane_off<TILED>(a, k, sp), st[k]);
       if (all || (lanewise ? dm : (bool)__any(dm))) {
         store_f<PX>(a.state + mog2_plane_off<TILED>(a, 5 + k, sp), st[5 + k]);
