@@ -41,12 +41,12 @@ def cpu_rate(algo, frames_np, warm=3, params=None):
     return n * frames_np.shape[1] * frames_np.shape[2] / dt / 1e6, threads
 
 
-def run(algo, name, rows, cols, S, bpp, steps=60, borrow=True, want_bg=False, cpu_frames=6, cpu_warm=3, params=None):
+def run(algo, name, rows, cols, S, bpp, steps=60, borrow=True, want_bg=False, cpu_frames=6, cpu_warm=3, params=None, kind="surv"):
     dev = torch.device("cuda", 0)
     T = 8
     pool = torch.empty((T, S, rows, cols, 3), dtype=torch.uint8, device=dev)
     for s in range(S):
-        pool[:, s] = synth.s_surv(T, rows, cols, seed=4321 + s, device=dev)
+        pool[:, s] = (synth.s_surv if kind == "surv" else synth.s_sat)(T, rows, cols, seed=4321 + s, device=dev)
     e = Engine(algo, n_streams=S, params=params)
     e.set_geometry(rows, cols, 3)
     if borrow:
@@ -165,8 +165,10 @@ def run_pipeline(S=8, steps=30):
 
 def run_dp():
     """N4: the package_bgs/dp models at 1080p x 16 streams (state r/w + frame + mask bytes per pixel)."""
-    run(capi.DP_ZIVKOVIC_AGMM, "DPZivkovicAGMMBGS (K=3)", 1080, 1920, 16, 126, borrow=False)
-    run(capi.DP_GRIMSON_GMM, "DPGrimsonGMMBGS (K=3)", 1080, 1920, 16, 150, borrow=False)
+    run(capi.DP_ZIVKOVIC_AGMM, "DPZivkovicAGMMBGS (K=3, S_sat)", 1080, 1920, 16, 126, borrow=False, kind="sat", cpu_frames=0)
+    run(capi.DP_GRIMSON_GMM, "DPGrimsonGMMBGS (K=3, S_sat)", 1080, 1920, 16, 150, borrow=False, kind="sat", cpu_frames=0)
+    run(capi.DP_ZIVKOVIC_AGMM, "DPZivkovicAGMMBGS (K=3, S_surv)", 1080, 1920, 16, 126, borrow=False)
+    run(capi.DP_GRIMSON_GMM, "DPGrimsonGMMBGS (K=3, S_surv)", 1080, 1920, 16, 150, borrow=False)
     run(capi.DP_WREN_GA, "DPWrenGABGS", 1080, 1920, 16, 36, borrow=False)
     run(capi.DP_MEAN, "DPMeanBGS", 1080, 1920, 16, 28, borrow=False)
     run(capi.DP_ADAPTIVE_MEDIAN, "DPAdaptiveMedianBGS", 1080, 1920, 16, 7, borrow=False)  # 3 frame + 3 median + 1 mask (+3/7 write-back); state is MALL-resident

@@ -59,12 +59,20 @@ __global__ __launch_bounds__(kBlock) void dp_gmm_kernel(const DpArgs a) {
   if (active) {
     float* st = dp_plane0(a, gp, K * F);
     uint8_t* pn = a.bstate + (size_t)a.first * a.n + gp;
+    // Data-dependent traffic (exact): the sources never read a mode at an index >= the pixel's count (they only create one
+    // there, writing every field), so only the used modes are loaded; at the end a field is stored if its bits changed, or
+    // unconditionally when the slot was not loaded and is now in use.  One lane = one pixel: no neighbour shares the slot.
+    int nModes = *pn;
+    const int nLoaded = nModes;
     float g[K][F];
+    uint32_t g0[K][F];
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
-      for (int f = 0; f < F; ++f) g[k][f] = st[(k * F + f) * kDpTile];
-    int nModes = *pn;
+      for (int f = 0; f < F; ++f) {
+        g[k][f] = k < nLoaded ? st[(k * F + f) * kDpTile] : 0.f;
+        g0[k][f] = __float_as_uint(g[k][f]);
+      }
     const float px[3] = {(float)a.frame[gp * 3], (float)a.frame[gp * 3 + 1], (float)a.frame[gp * 3 + 2]};
     const float m_bg_threshold = 0.75f, m_variance = 36.0f, m_complexity_prior = 0.05f;
     const float Alpha = a.alpha;
@@ -232,11 +240,12 @@ __global__ __launch_bounds__(kBlock) void dp_gmm_kernel(const DpArgs a) {
       }
     }
     if constexpr (GRIMSON) grimson_sort(nModes);  // the second qsort runs whether or not a mode was added (:281)
-    *pn = (uint8_t)nModes;
+    if (nModes != nLoaded) *pn = (uint8_t)nModes;
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
-      for (int f = 0; f < F; ++f) st[(k * F + f) * kDpTile] = g[k][f];
+      for (int f = 0; f < F; ++f)
+        if (k < nLoaded ? __float_as_uint(g[k][f]) != g0[k][f] : k < nModes) st[(k * F + f) * kDpTile] = g[k][f];
     mask = bBackgroundHigh ? 0 : 255;
   }
   dp_store_mask(a, gp, active, mask);
