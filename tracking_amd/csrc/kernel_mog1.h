@@ -189,6 +189,7 @@ __global__ __launch_bounds__(kBlock) void mog1_update_kernel(const Mog1Args a) {
 #pragma unroll
     for (int i = 0; i < PX * C; ++i) px[i] = a.frame[p0 * C + i];
     uint32_t mword = 0;
+    uint64_t dirty = 0;  // NP <= 40 planes
 #pragma unroll
     for (int j = 0; j < PX; ++j) {
       Mog1Px<C> s;
@@ -204,15 +205,22 @@ __global__ __launch_bounds__(kBlock) void mog1_update_kernel(const Mog1Args a) {
       const int m = thr_bin(mog1_pixel<C>(s, pix, a), a.thr, a.enable_thr);
       mword |= (uint32_t)m << (8 * j);
       bits |= (uint32_t)(m != 0) << j;
+      // write-back is data-dependent (exact): a plane is stored only if one of this lane's pixels changed its bits.  On a
+      // quiet scene one mode matches and only the weights / sort keys of the others move; their means and variances stay.
+      auto put = [&](int q, float v) {
+        dirty |= (uint64_t)(__float_as_uint(st[q][j]) != __float_as_uint(v)) << q;
+        st[q][j] = v;
+      };
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        st[k * R][j] = s.sk[k], st[k * R + 1][j] = s.w[k];
+        put(k * R, s.sk[k]), put(k * R + 1, s.w[k]);
 #pragma unroll
-        for (int c = 0; c < C; ++c) st[k * R + 2 + c][j] = s.mu[k][c], st[k * R + 2 + C + c][j] = s.var[k][c];
+        for (int c = 0; c < C; ++c) put(k * R + 2 + c, s.mu[k][c]), put(k * R + 2 + C + c, s.var[k][c]);
       }
     }
 #pragma unroll
-    for (int q = 0; q < NP; ++q) store_f<PX>(a.state + mog1_plane_off<C>(q, sp), st[q]);
+    for (int q = 0; q < NP; ++q)
+      if ((dirty >> q) & 1ull) store_f<PX>(a.state + mog1_plane_off<C>(q, sp), st[q]);
     if (a.fg) {
 #pragma unroll
       for (int j = 0; j < PX; ++j) a.fg[p0 + j] = (uint8_t)(mword >> (8 * j));
