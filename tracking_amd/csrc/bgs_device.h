@@ -129,4 +129,23 @@ __device__ __forceinline__ void store_packed_mask(uint64_t* words, size_t first_
   if (lane % LANES == 0 && lane_in_range) words[first_pixel_of_lane >> 6] = v;
 }
 
+// LBSP descriptor of `ref` (threshold t) against the 16 neighbours of one channel, two neighbours per dword as 16-bit
+// lanes: dword k = neighbour k (LBSP bit 15-k) in the high half, neighbour 8+k (bit 7-k) in the low half.
+// |v - ref| > t  <=>  v outside [lo, hi] = [max(ref-t,0), min(ref+t,255)]  <=>  (v - lo) mod 2^16 > hi - lo, so one packed
+// wrap-around subtract, one packed saturating subtract and a packed min give the two flags of a dword (v_pk_* on CDNA).
+__device__ __forceinline__ unsigned ss_lbsp(const uint32_t (&nb)[8], int ref, int t) {
+  const unsigned lo = (unsigned)max(ref - t, 0), w = (unsigned)min(ref + t, 255) - lo;
+  const unsigned lo2 = lo * 0x10001u, w2 = w * 0x10001u, one = 0x10001u;
+  unsigned acc = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    unsigned u, d, f;  // (the compiler turns the portable form of this into compare + select per half: twice the instructions)
+    asm("v_pk_sub_u16 %0, %1, %2" : "=v"(u) : "v"(nb[k]), "v"(lo2));
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(u), "v"(w2));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(f) : "v"(d), "v"(one));
+    acc = (acc << 1) | f;
+  }
+  return (acc & 0xffu) | ((acc >> 8) & 0xff00u);
+}
+
 }  // namespace bgs

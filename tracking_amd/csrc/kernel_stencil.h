@@ -160,6 +160,8 @@ __global__ __launch_bounds__(kBlock) void lbsp_kernel(const LbspArgs a) {
   constexpr int HW = kLbspTW + 4, HH = kLbspTH + 4;   // tile + 2-pixel halo
   constexpr int ROWB = (HW * C + 3 + 3) / 4 * 4;       // LDS row pitch in bytes (room for the alignment shift)
   __shared__ uint32_t tile[HH][ROWB / 4];
+  __shared__ uint8_t lut[256];
+  lut[threadIdx.x] = a.lut[threadIdx.x];
   const int x0 = blockIdx.x * kLbspTW, y0 = blockIdx.y * kLbspTH;
   const size_t imgsz = (size_t)a.rows * a.cols * C;
   const uint8_t* img = a.img + (size_t)blockIdx.z * imgsz;
@@ -204,14 +206,11 @@ __global__ __launch_bounds__(kBlock) void lbsp_kernel(const LbspArgs a) {
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const int ref = at(ly + 2, lx + 2, c);
-      const int t = a.lut[ref];
-      unsigned res = 0;
+      uint32_t nb[8];  // two neighbours per dword, as ss_lbsp wants them (bit 15-k in the high half, bit 7-k in the low half)
 #pragma unroll
-      for (int b = 0; b < 16; ++b) {
-        const int v = at(ly + 2 + kLbspDy[b], lx + 2 + kLbspDx[b], c);
-        res |= (unsigned)(abs(v - ref) > t) << (15 - b);
-      }
-      out[c] = (uint16_t)res;
+      for (int b = 0; b < 8; ++b)
+        nb[b] = ((uint32_t)at(ly + 2 + kLbspDy[b], lx + 2 + kLbspDx[b], c) << 16) | (uint32_t)at(ly + 2 + kLbspDy[8 + b], lx + 2 + kLbspDx[8 + b], c);
+      out[c] = (uint16_t)ss_lbsp(nb, ref, lut[ref]);
     }
   }
 }

@@ -74,25 +74,6 @@ __device__ __constant__ const int8_t kSsN5[24][2] = {{-2, 2},  {-1, 2},  {0, 2},
 #define SS_REQ_VALID 0x8000u
 __device__ __forceinline__ uint16_t ss_req(unsigned slot, int code) { return (uint16_t)(SS_REQ_VALID | (slot << 8) | (unsigned)code); }
 
-// LBSP descriptor of `ref` (threshold t) against the 16 neighbours of one channel, two neighbours per dword as 16-bit
-// lanes: dword k = neighbour k (LBSP bit 15-k) in the high half, neighbour 8+k (bit 7-k) in the low half.
-// |v - ref| > t  <=>  v outside [lo, hi] = [max(ref-t,0), min(ref+t,255)]  <=>  (v - lo) mod 2^16 > hi - lo, so one packed
-// wrap-around subtract, one packed saturating subtract and a packed min give the two flags of a dword (v_pk_* on CDNA).
-__device__ __forceinline__ unsigned ss_lbsp(const uint32_t (&nb)[8], int ref, int t) {
-  const unsigned lo = (unsigned)max(ref - t, 0), w = (unsigned)min(ref + t, 255) - lo;
-  const unsigned lo2 = lo * 0x10001u, w2 = w * 0x10001u, one = 0x10001u;
-  unsigned acc = 0;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    unsigned u, d, f;  // (the compiler turns the portable form of this into compare + select per half: twice the instructions)
-    asm("v_pk_sub_u16 %0, %1, %2" : "=v"(u) : "v"(nb[k]), "v"(lo2));
-    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(u), "v"(w2));
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(f) : "v"(d), "v"(one));
-    acc = (acc << 1) | f;
-  }
-  return (acc & 0xffu) | ((acc >> 8) & 0xff00u);
-}
-
 // ----------------------------------------------------------------------------------------------- phase A
 // One workgroup owns a 64 x 32 pixel tile (8 pixels per lane) and works in three stages:
 //   1. per pixel (static lane<->pixel map): thresholds from R / unstable, the three intra-LBSP descriptors -> LDS context;
