@@ -1222,7 +1222,6 @@ static int cc_run(int hip_device, const void* d_mask, int images, int rows, int 
   const dim3 grid(blocks_for(n)), block(bgs::kBlock);
   if (d_offsets) HIP_TRY(hipMemsetAsync(d_offsets, 0, ((size_t)images + 1) * sizeof(int32_t), s));
   hipLaunchKernelGGL(bgs::cc_init_kernel, grid, block, 0, s, (const uint8_t*)d_mask, L, allRows, cols, rows, conn8);
-  hipLaunchKernelGGL(bgs::cc_compress_kernel, grid, block, 0, s, L, n);
   hipLaunchKernelGGL(bgs::cc_merge_kernel, grid, block, 0, s, L, allRows, cols, rows, conn8);
   hipLaunchKernelGGL(bgs::cc_compress_kernel, grid, block, 0, s, L, n);
   hipLaunchKernelGGL(bgs::cc_count_kernel, dim3(nb), block, 0, s, (const int*)L, n, blockCount);

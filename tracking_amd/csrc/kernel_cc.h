@@ -9,10 +9,9 @@
 // raster index of its first pixel ("root"); boxes come out sorted by root.
 //
 // Algorithm: label equivalence with union-find (the minimum index wins, so the root IS the first pixel in raster order):
-//   cc_init      L[p] = smallest-index foreground neighbour among NW, N, NE, W (else p);  -1 for background
-//   cc_compress  L[p] = root(L[p])
-//   cc_merge     union(p, n) for every foreground neighbour pair  (atomicMin on the larger root)
-//   cc_compress  again: every pixel now holds its component's root
+//   cc_init      L[p] = head of p's horizontal run inside its wave's 64-pixel span (ballot + clz);  -1 for background
+//   cc_merge     union(p, n) for the links not covered by a run: span boundaries, N, and the upper diagonals (atomicMin on the larger root)
+//   cc_compress  every pixel now holds its component's root
 //   cc_count / cc_scan / cc_scatter   roots -> dense ids in raster order (wave ballot + popcount prefix, two-level scan)
 //   cc_boxes     atomicMin/Max/Add into the component's box, merged per lane run and per wave first
 //   cc_finish    (minx, miny, maxx, maxy) -> (x, y, w, h)
@@ -50,24 +49,29 @@ __device__ __forceinline__ void cc_union(int* L, int a, int b) {
   }
 }
 
-// `rows` = rows of the whole stack of images, `img_rows` = rows of one image: no link crosses an image boundary
+// `rows` = rows of the whole stack of images, `img_rows` = rows of one image: no link crosses an image boundary.
+// Initial labels = horizontal runs: a wave covers 64 consecutive pixels; from the ballot of the foreground flags every lane
+// finds the start of its run inside the wave (highest position <= lane where the "continues from the left" bit is clear), so
+// every pixel starts one hop from its run head and the union-find trees stay shallow (linking N/NW first, as a plain
+// neighbour rule does, builds chains as long as the image is tall).
 __global__ __launch_bounds__(kBlock) void cc_init_kernel(const uint8_t* mask, int* L, int rows, int cols, int img_rows, int conn8) {
   const size_t N = (size_t)rows * cols;
   const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (p >= N) return;
-  if (!mask[p]) {
+  const bool in = p < N;
+  const bool fg = in && mask[p] != 0;
+  const int lane = threadIdx.x & (kWave - 1);
+  const unsigned long long m = __ballot(fg);
+  const unsigned long long rowstart = __ballot(in && (p % (size_t)cols) == 0);
+  const unsigned long long cont = m & (m << 1) & ~rowstart;  // bit i: pixels i-1 and i are both foreground and in the same row
+  if (!in) return;
+  if (!fg) {
     L[p] = -1;
     return;
   }
-  const int y = (int)(p / cols), x = (int)(p - (size_t)y * cols);
-  int l = (int)p;
-  if (x > 0 && mask[p - 1]) l = (int)p - 1;
-  if (y % img_rows > 0) {
-    if (conn8 && x + 1 < cols && mask[p - cols + 1]) l = (int)p - cols + 1;
-    if (mask[p - cols]) l = (int)p - cols;
-    if (conn8 && x > 0 && mask[p - cols - 1]) l = (int)p - cols - 1;
-  }
-  L[p] = l;
+  const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+  const int start = 63 - __clzll((long long)(~cont & upto));  // bit 0 of cont is always clear, so this is never empty
+  L[p] = (int)(p - (size_t)(lane - start));
+  (void)img_rows, (void)conn8;
 }
 
 __global__ __launch_bounds__(kBlock) void cc_compress_kernel(int* L, size_t N) {
@@ -83,10 +87,14 @@ __global__ __launch_bounds__(kBlock) void cc_merge_kernel(int* L, int rows, int 
   const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= N || L[p] < 0) return;
   const int y = (int)(p / cols), x = (int)(p - (size_t)y * cols);
-  // W and N (and the two upper diagonals) cover every adjacent pair once
-  if (x > 0 && L[p - 1] >= 0) cc_union(L, (int)p, (int)p - 1);
+  // horizontal: inside a wave's 64-pixel span (same p -> lane map as cc_init_kernel) a run already shares one label; only the
+  // span's first pixel can continue a run of the previous span.  (No test on L[p] here: other lanes are re-rooting it.)
+  if (x > 0 && (p & (kWave - 1)) == 0 && L[p - 1] >= 0) cc_union(L, (int)p, (int)p - 1);
   if (y % img_rows > 0) {
-    if (L[p - cols] >= 0) cc_union(L, (int)p, (int)p - cols);
+    // vertical: where this pixel and its W neighbour (same span, hence same label) both sit under foreground, W has already
+    // made the link - only the first pixel of every overlap between a run and the run above unites them
+    const bool wdone = x > 0 && (p & (kWave - 1)) != 0 && L[p - 1] >= 0 && L[p - cols - 1] >= 0;
+    if (L[p - cols] >= 0 && !wdone) cc_union(L, (int)p, (int)p - cols);
     if (conn8) {
       // a diagonal neighbour is already joined through N or W/E unless that orthogonal pixel is background
       if (x > 0 && L[p - cols - 1] >= 0 && L[p - cols] < 0 && L[p - 1] < 0) cc_union(L, (int)p, (int)p - cols - 1);
