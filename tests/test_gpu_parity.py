@@ -959,3 +959,35 @@ def test_mog2_sparse_levels_are_exact(level, shape):
         ofg, obg = orc.process(f)
         assert np.array_equal(fg, ofg) and np.array_equal(bg, obg), (level, t)
     check_mog2_state(eng, orc, H * W)
+
+
+def test_bench_geometry_32_streams_1080p_sampled_parity():
+    """The bench.py workload itself (BASELINE configs[4] share of one GPU): 32 x 1920x1080 streams in one launch - a 6.7 GB model,
+    i.e. byte offsets far past 2^32 - checked against the oracle on 2 048 random pixels of every stream (MOG2 is pointwise), plus
+    the packed mask against the byte mask over all 66 M pixels."""
+    torch = _torch()
+    S, H, W, T = 32, 1080, 1920, 6
+    eng = Engine(capi.MOG2, n_streams=S)
+    eng.set_geometry(H, W, 3)
+    rng = np.random.default_rng(2024)
+    idx = np.sort(rng.choice(H * W, 2048, replace=False))
+    idx[-1] = H * W - 1  # the very last pixel of every stream
+    d_idx = torch.from_numpy(idx).cuda()
+    orcs = [pyoracle.Oracle(capi.MOG2) for _ in range(S)]
+    d_fg = torch.empty((S, H, W), dtype=torch.uint8, device="cuda")
+    d_bits = torch.zeros((S, H * W // 64), dtype=torch.int64, device="cuda")
+    for t in range(T):
+        frames = torch.stack([synth.s_sat(1, H, W, seed=100 + s, device="cuda", t0=t)[0] for s in range(S)])
+        eng.process_batch_device(frames, d_fg, None, d_bits)
+        torch.cuda.synchronize()
+        samp = frames.reshape(S, H * W, 3)[:, d_idx].cpu().numpy()
+        got = d_fg.reshape(S, H * W)[:, d_idx].cpu().numpy()
+        for s in range(S):
+            ofg, _ = orcs[s].process(samp[s].reshape(32, 64, 3), want_bg=False)
+            assert np.array_equal(got[s].reshape(32, 64), ofg), (t, s)
+    bits = d_bits.cpu().numpy().view(np.uint8)
+    unpacked = np.unpackbits(bits.reshape(S, -1), axis=1, bitorder="little")
+    assert np.array_equal(unpacked != 0, d_fg.reshape(S, -1).cpu().numpy() != 0)
+    for s in (0, S - 1):
+        w = eng.get_state("w", (5, H * W), np.float32, stream=s)
+        assert np.array_equal(w[:, idx], orcs[s].get_state("w", (5, 2048), np.float32)), s
