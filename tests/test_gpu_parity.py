@@ -991,3 +991,29 @@ def test_bench_geometry_32_streams_1080p_sampled_parity():
     for s in (0, S - 1):
         w = eng.get_state("w", (5, H * W), np.float32, stream=s)
         assert np.array_equal(w[:, idx], orcs[s].get_state("w", (5, 2048), np.float32)), s
+
+
+@pytest.mark.parametrize("algo,S,T", [(capi.SUBSENSE, 8, 3), (capi.MOG1, 16, 4), (capi.DP_GRIMSON_GMM, 32, 3)])
+def test_large_batches_match_single_stream_engines(algo, S, T):
+    """Models past 4 GB (SuBSENSE: 8 x 1080p x 50 samples = 7.5 GB; MOG1: 16 x 1080p = 5.3 GB; Grimson: 32 x 1080p = 4.8 GB): the
+    last stream of the batch must equal a single-stream engine fed the same frames (which the other tests hold against the
+    oracle) - the 64-bit offset check for the layouts the oracle is too slow to replay at this size."""
+    torch = _torch()
+    H, W = 1080, 1920
+    clips = [synth.s_surv(T, H, W, seed=900 + s, device="cuda") for s in (0, S - 1)]
+    filler = synth.s_surv(1, H, W, seed=77, device="cuda")[0]
+    big = Engine(algo, n_streams=S)
+    big.set_geometry(H, W, 3)
+    singles = [Engine(algo), Engine(algo)]
+    for e in singles:
+        e.set_geometry(H, W, 3)
+    fg = torch.empty((S, H, W), dtype=torch.uint8, device="cuda")
+    fg1 = torch.empty((1, H, W), dtype=torch.uint8, device="cuda")
+    frames = filler.unsqueeze(0).repeat(S, 1, 1, 1)
+    for t in range(T):
+        frames[0], frames[S - 1] = clips[0][t], clips[1][t]
+        big.process_batch_device(frames, fg, None, None)
+        for k, s in enumerate((0, S - 1)):
+            singles[k].process_batch_device(clips[k][t:t + 1], fg1, None, None)
+            torch.cuda.synchronize()
+            assert torch.equal(fg[s], fg1[0]), (t, s)
