@@ -17,7 +17,9 @@
 //
 // Layout per stream: colour samples u8 [nS][N][3], descriptor samples u16 [nS][N][3] (one contiguous plane per sample index,
 // so the early-exit sample loop reads one coalesced row of each plane per iteration), ten f32 maps [N] (+2 second copies),
-// byte maps [N].  The current frame's 5x5 neighbourhood is staged through LDS once per workgroup (64x4 pixel tile + halo 2).
+// byte maps [N].  The current frame's 5x5 neighbourhood is staged through LDS once per workgroup (phase A: 64x32 pixel tile +
+// halo 2, with an LDS work queue over its pixels; phase B and LOBSTER's phase A: 64x4).
+//   lob_phase_a_kernel   LOBSTER's operator()                     BackgroundSubtractorLOBSTER.cpp:172-284 (shares phase B, refresh, background)
 #pragma once
 #include "bgs_device.h"
 
