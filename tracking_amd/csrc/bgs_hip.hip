@@ -87,7 +87,7 @@ struct bgs_engine {
   uint8_t* mog2_nmodes = nullptr;  // planar layout only
   bool mog2_tiled = true;
   int mog2_px = 0;                 // pixels per lane, 0 = widest the alignment allows
-  int xcd_swizzle = 1;             // XCD-aware block order (kernel_mog2.h)
+  int xcd_swizzle = 1;             // XCD-aware block order (kernel_mog2.h): 0 off, 1 model kernels (MOG2, MOG1, dp), 2 also the byte-stream kernels
   int mog2_sparse = 3;             // data-dependent plane skipping (kernel_mog2.h): 0 dense, 1 stores, 2 stores+loads per wave, 4 per lane, 3 = choose 1 or 4 from the scene
   int mog2_sparse_now = 1;         // what auto mode currently runs
   unsigned* d_stat = nullptr;      // device: {sampled waves, sparse waves}
@@ -482,10 +482,12 @@ int ensure_staging(bgs_engine* e) {
   } while (0)
 
 // widest pixel group every pointer and the pixel count allow
-int pick_group(const bgs::FrameArgs& a, int C) {
+// (`cap`: measured optimum of the kernel: wmm / wmv run ~10 % faster with 4 pixels per lane than with 16, abl the other way round)
+int pick_group(const bgs::FrameArgs& a, int C, int cap = 16) {
   const void* ptrs[] = {a.cur, a.p1, a.p2, a.state_out, a.fg, a.bg};
   int G = 16;
   if (a.npix % 16) G = (a.npix % 4) ? 1 : 4;
+  if (G > cap) G = cap;
   for (const void* p : ptrs) {
     if (!p) continue;
     if (G == 16 && !aligned(p, 16)) G = 4;
@@ -518,7 +520,10 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
 
   bgs::FrameArgs a{};
   a.cur = d_frames, a.fg = d_fg, a.bg = d_bg, a.fg_bits = d_bits, a.npix = npix;
-  a.thr = p.threshold, a.enable_thr = p.enable_threshold, a.enable_weight = p.enable_weight, a.xcd_swizzle = e->xcd_swizzle;
+  a.thr = p.threshold, a.enable_thr = p.enable_threshold, a.enable_weight = p.enable_weight;
+  // The XCD-aware block order pays where a workgroup's working set is a multi-plane tile (MOG2, MOG1, dp); the byte-stream
+  // kernels run 2-5 % faster in plain block order (tools/ab_pointwise.py), so they only use it at level 2 (for A/B runs).
+  a.xcd_swizzle = e->xcd_swizzle >= 2;
 
   const bool whole = (first == 0 && count == e->S);
   if (e->borrow && !whole && e->nring) return fail(BGS_ERR_INVALID, "borrowed frame history needs whole-batch calls");
@@ -540,7 +545,7 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
       }
       if (t >= warm) {
         a.cur = cur, a.p1 = h1, a.p2 = h2;
-        const int G = pick_group(a, C);
+        const int G = pick_group(a, C, e->algo == BGS_FRAME_DIFF ? 16 : 4);
         if (e->algo == BGS_FRAME_DIFF)
           LAUNCH_FRAME_KERNEL(framediff_kernel, "framediff_kernel");
         else if (e->algo == BGS_WMM)
@@ -622,7 +627,7 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
       }
       bgs::SigmaDeltaArgs q{};
       q.cur = d_frames, q.mt = mt, q.vt = vt, q.fg = d_fg, q.fg_bits = d_bits, q.npix = npix;
-      q.N = (uint32_t)p.sd_amp_factor, q.vmin = (uint8_t)p.sd_min_var, q.vmax = (uint8_t)p.sd_max_var, q.xcd_swizzle = e->xcd_swizzle;
+      q.N = (uint32_t)p.sd_amp_factor, q.vmin = (uint8_t)p.sd_min_var, q.vmax = (uint8_t)p.sd_max_var, q.xcd_swizzle = e->xcd_swizzle >= 2;
       int G = 16;
       if (npix % 16 || !aligned(d_frames, 16) || !aligned(mt, 16) || !aligned(vt, 16) || (d_fg && !aligned(d_fg, 16))) G = (npix % 4 || !aligned(d_frames, 4) || !aligned(mt, 4) || (d_fg && !aligned(d_fg, 4))) ? 1 : 4;
       {
@@ -907,7 +912,7 @@ int bgs_set_option(bgs_engine* e, int option, int64_t value) {
       if (e->n) return fail(BGS_ERR_INVALID, "the model layout must be chosen before the geometry is set");
       e->mog2_tiled = value != 0;
       return BGS_OK;
-    case 4: e->xcd_swizzle = value != 0; return BGS_OK;
+    case 4: e->xcd_swizzle = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return BGS_OK;
     case 6: e->mog2_sparse = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 4); return BGS_OK;
     case 5:
       if (e->n) return fail(BGS_ERR_INVALID, "the placement probe runs when the geometry is set");
