@@ -74,14 +74,14 @@ def run(algo, name, rows, cols, S, bpp, steps=60, borrow=True, want_bg=False, cp
     e.close()
 
 
-def run_subsense(S, steps=30, kind="surv"):
+def run_subsense(S, steps=30, kind="surv", algo=None, label="SuBSENSEBGS"):
     """BASELINE configs[3]: SuBSENSE at 1920x1080 (per-frame wall time: ~20 launches incl. the flood-fill host loop)."""
     dev = torch.device("cuda", 0)
     rows, cols, T = 1080, 1920, 8
     pool = torch.empty((T, S, rows, cols, 3), dtype=torch.uint8, device=dev)
     for s in range(S):
         pool[:, s] = (synth.s_surv if kind == "surv" else synth.s_smooth)(T, rows, cols, seed=4321 + s, device=dev)
-    e = Engine(capi.SUBSENSE, n_streams=S)
+    e = Engine(capi.SUBSENSE if algo is None else algo, n_streams=S)
     e.set_geometry(rows, cols, 3)
     fg = torch.empty((S, rows, cols), dtype=torch.uint8, device=dev)
     for t in range(6):
@@ -96,7 +96,7 @@ def run_subsense(S, steps=30, kind="surv"):
     ms, n, kname = e.kernel_timing()
     px = S * rows * cols
     print("%-34s %dx%d x%d streams: %.3f ms/frame-step wall -> %8.1f Mpix/s (%.1f 1080p frames/s); %s %.3f ms; fg ratio %.3f"
-          % ("SuBSENSEBGS (%s input)" % kind, cols, rows, S, wall * 1e3, px / wall / 1e6, S / wall, kname, ms, float((fg != 0).float().mean())))
+          % ("%s (%s input)" % (label, kind), cols, rows, S, wall * 1e3, px / wall / 1e6, S / wall, kname, ms, float((fg != 0).float().mean())))
     e.close()
 
 
@@ -220,6 +220,10 @@ def main():
         return
     if args.only == "cc":
         run_cc()
+        return
+    if args.only == "lobster":
+        run_subsense(8, algo=capi.LOBSTER, label="LOBSTERBGS")
+        run_subsense(8, kind="smooth", algo=capi.LOBSTER, label="LOBSTERBGS")
         return
     if args.only == "subsense8":
         run_subsense(8)
