@@ -482,13 +482,22 @@ __global__ __launch_bounds__(kBlock) void lob_phase_a_kernel(const SsArgs a) {
   const uint8_t* cp = a.color + (sbase + p) * C;
   const uint16_t* dp = a.desc + (sbase + p) * C;
   int good = 0, idx = 0;
-  while (good < a.nReq && idx < a.nS) {  // :192-205 (gray) / :241-258 (BGR)
+  int bc[C], nbc[C];
+  unsigned bd[C], nbd[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) bc[c] = nbc[c] = cp[c], bd[c] = nbd[c] = dp[c];
+  while (good < a.nReq && idx < a.nS) {  // :192-205 (gray) / :241-258 (BGR); sample idx+1 is in flight while idx is tested (the loop is latency-bound)
+    if (idx + 1 < a.nS) {
+      cp += sstride, dp += sstride;
+#pragma unroll
+      for (int c = 0; c < C; ++c) nbc[c] = cp[c], nbd[c] = dp[c];
+    }
     if constexpr (C == 1) {
-      const int bcc = cp[0];
+      const int bcc = bc[0];
       const uint32_t cd = (uint32_t)abs(cur[0] - bcc);
       if (cd <= colorThr / 2) {
         const unsigned inter = ss_lbsp(nb[0], bcc, lut[bcc]);
-        if ((uint32_t)__popc(inter ^ (unsigned)dp[0]) <= descThr) good++;
+        if ((uint32_t)__popc(inter ^ bd[0]) <= descThr) good++;
       }
     } else {
       uint32_t totC = 0, totD = 0;
@@ -496,13 +505,13 @@ __global__ __launch_bounds__(kBlock) void lob_phase_a_kernel(const SsArgs a) {
 #pragma unroll
       for (int c = 0; c < 3; ++c)
         if (ok) {
-          const int bcc = cp[c];
+          const int bcc = bc[c];
           const uint32_t cd = (uint32_t)abs(cur[c] - bcc);
           if (cd > scColor) {
             ok = false;
           } else {
             const unsigned inter = ss_lbsp(nb[c], bcc, lut[bcc]);
-            const uint32_t dd = (uint32_t)__popc(inter ^ (unsigned)dp[c]);
+            const uint32_t dd = (uint32_t)__popc(inter ^ bd[c]);
             if (dd > scDesc)
               ok = false;
             else
@@ -512,7 +521,8 @@ __global__ __launch_bounds__(kBlock) void lob_phase_a_kernel(const SsArgs a) {
       if (ok && totD <= descThr3 && totC <= colorThr3) good++;
     }
     idx++;
-    cp += sstride, dp += sstride;
+#pragma unroll
+    for (int c = 0; c < C; ++c) bc[c] = nbc[c], bd[c] = nbd[c];
   }
   uint16_t reqSelf = 0, reqNbr = 0;
   if (good >= a.nReq) {
