@@ -182,9 +182,34 @@ __global__ __launch_bounds__(kBlock) void mog1_update_kernel(const Mog1Args a) {
   uint32_t bits = 0;
   if (active) {
     const size_t sp = a.state_off + p0;
+    // Data-dependent traffic (exact).  The reference never reads the mean / variance of a mode whose weight is below
+    // FLT_EPSILON (its scan stops there, bgfg_gaussmix.cpp) - it only ever creates a mode in such a slot, writing every
+    // field.  So the weight and sort-key planes of all K modes are loaded first, and the 2C mean / variance planes of mode k
+    // only if one of this lane's pixels has a live mode k.  A slot the lane did not load is written per pixel (scalar
+    // stores) by the pixel that created a mode there, so with PX = 2 the lane's other pixel keeps its stale, unread entries.
     float st[NP][PX];
+    unsigned need = 0;
 #pragma unroll
-    for (int q = 0; q < NP; ++q) load_f<PX>(a.state + mog1_plane_off<C>(q, sp), st[q]);
+    for (int k = 0; k < K; ++k) {
+      load_f<PX>(a.state + mog1_plane_off<C>(k * R, sp), st[k * R]);
+      load_f<PX>(a.state + mog1_plane_off<C>(k * R + 1, sp), st[k * R + 1]);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      bool live = false;
+#pragma unroll
+      for (int j = 0; j < PX; ++j) live = live || st[k * R + 1][j] >= FLT_EPSILON;
+      need |= (unsigned)live << k;
+#pragma unroll
+      for (int f = 2; f < R; ++f) {
+        if (live) {
+          load_f<PX>(a.state + mog1_plane_off<C>(k * R + f, sp), st[k * R + f]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < PX; ++j) st[k * R + f][j] = 0.f;
+        }
+      }
+    }
     uint8_t px[PX * C];
 #pragma unroll
     for (int i = 0; i < PX * C; ++i) px[i] = a.frame[p0 * C + i];
@@ -219,8 +244,21 @@ __global__ __launch_bounds__(kBlock) void mog1_update_kernel(const Mog1Args a) {
       }
     }
 #pragma unroll
-    for (int q = 0; q < NP; ++q)
-      if ((dirty >> q) & 1ull) store_f<PX>(a.state + mog1_plane_off<C>(q, sp), st[q]);
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+      for (int f = 0; f < R; ++f) {
+        const int q = k * R + f;
+        if (f < 2 || ((need >> k) & 1u)) {
+          if ((dirty >> q) & 1ull) store_f<PX>(a.state + mog1_plane_off<C>(q, sp), st[q]);
+        } else {
+          // mean / variance of a slot this lane did not load: the pixel that now owns a mode there writes its own element,
+          // whatever the value (a created field may equal the zero the register was filled with)
+#pragma unroll
+          for (int j = 0; j < PX; ++j)
+            if (st[k * R + 1][j] >= FLT_EPSILON) a.state[mog1_plane_off<C>(q, sp) + j] = st[q][j];
+        }
+      }
+    }
     if (a.fg) {
 #pragma unroll
       for (int j = 0; j < PX; ++j) a.fg[p0 + j] = (uint8_t)(mword >> (8 * j));
