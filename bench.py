@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-bg", action="store_true", help="also produce the background image every frame (+3 B/px)")
     ap.add_argument("--main-only", action="store_true", help="only the timed S_sat leg (used under rocprofv3 so the last K launches are the timed ones)")
-    ap.add_argument("--px", type=int, default=0, help="MOG2 pixels per lane (tuning; 0 = auto = 4)")
+    ap.add_argument("--px", type=int, default=0, help="MOG2 pixels per lane (tuning; 0 = default = 1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

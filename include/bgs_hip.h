@@ -173,7 +173,7 @@ int bgs_set_params(bgs_engine* e, const bgs_params* params);
  *                          1 = use the caller's previous d_frames buffers as history instead of copying each frame
  *                          into the engine's ring; the buffers handed to the previous one (FD) or two (WMM/WMV)
  *                          whole-batch calls must then stay valid and unchanged.  Default 0 (private copy).
- *   BGS_OPT_MOG2_PIXELS_PER_LANE  1, 2 or 4 (tuning knob; 0 = widest the alignment allows).
+ *   BGS_OPT_MOG2_PIXELS_PER_LANE  1, 2 or 4 (tuning knob; 0 = default = 1).
  *   BGS_OPT_MOG2_TILED     1 (default) = tiled AoSoA model, 0 = planar SoA (A/B measurements); before the geometry is set.
  *   BGS_OPT_XCD_SWIZZLE    XCD-aware workgroup order: 1 (default) = for the kernels that stream a multi-plane model
  *                          (MOG2, MOG1, dp/), 2 = also for the byte-stream kernels (slower there: A/B only), 0 = off.

@@ -169,12 +169,11 @@ int launch_mog2(bgs_engine* e, bgs::Mog2Args& a, hipStream_t s, bool timed = tru
   a.xcd_swizzle = e->xcd_swizzle;
   a.sparse = e->mog2_sparse == 3 ? e->mog2_sparse_now : e->mog2_sparse;
   a.stat = (timed && e->mog2_sparse == 3) ? e->d_stat : nullptr;
-  int PX = 4;
-  if (a.npix % 4 || a.state_off % 4 || !aligned(a.frame, 4) || (a.fg && !aligned(a.fg, 4)) || (a.bgimg && !aligned(a.bgimg, 4))) PX = 1;
-  if (e->mog2_px == 1 || e->mog2_px == 2) {
-    if (!(e->mog2_px == 2 && (a.npix % 2 || a.state_off % 2 || !aligned(a.frame, 2)))) PX = std::min(PX, e->mog2_px);
-  }
-  if (PX == 2 && a.fg && !aligned(a.fg, 2)) PX = 1;
+  // One pixel per lane by default: measured equal or better than 2 / 4 everywhere once the write-backs follow what changed
+  // (S_sat 30.8 vs 30.6 Gpixel/s, S_surv 81 vs 75), with half the registers.  BGS_OPT_MOG2_PIXELS_PER_LANE = 2 / 4 for A/B runs.
+  int PX = 1;
+  if (e->mog2_px == 4 && !(a.npix % 4 || a.state_off % 4 || !aligned(a.frame, 4) || (a.fg && !aligned(a.fg, 4)) || (a.bgimg && !aligned(a.bgimg, 4)))) PX = 4;
+  if (e->mog2_px == 2 && !(a.npix % 2 || a.state_off % 2 || !aligned(a.frame, 2) || (a.fg && !aligned(a.fg, 2)))) PX = 2;
   if (a.packed && a.npix % 64) return fail(BGS_ERR_UNSUPPORTED, "packed mask needs pixels %% 64 == 0");
   Timed t(e, s, "mog2_update_kernel", timed);
   const dim3 grid(blocks_for(a.npix / PX)), block(bgs::kBlock);
@@ -259,49 +258,65 @@ int mog2_allocate(bgs_engine* e) {
   float* cand[16] = {nullptr};
   const int saved_sparse = e->mog2_sparse;
   e->mog2_sparse = 0;  // probe with the dense traffic pattern: that is what a busy scene produces
-  int n = 0, best = 0;
-  float tmin = 1e30f, tmax = 0.f;
-  int rc = BGS_OK;
-  for (; n < tries; ++n) {
-    if (hipMalloc((void**)&cand[n], bytes) != hipSuccess) {
-      (void)hipGetLastError();
-      break;  // out of memory: settle for what we have
+  // A dense launch moves 206 B/pixel; on a good placement this part sustains ~6.15 TB/s.  Now and then all
+  // candidates of a round come out slow (seen: eight at 2.45 ms where 2.2 ms is normal), so a round whose best is more than
+  // 6 % off that mark is followed by another one - up to three - keeping the best buffer found so far.
+  const double expect_ms = 206.0 * (double)P / 6.15e12 * 1e3;
+  int n = 0, best = 0, rc = BGS_OK;
+  float* keep = nullptr;
+  float keep_ms = 1e30f;
+  for (int round = 0; round < 3 && !rc; ++round) {
+    n = 0, best = -1;
+    for (; n < tries; ++n) {
+      if (hipMalloc((void**)&cand[n], bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        cand[n] = nullptr;
+        break;  // out of memory: settle for what we have
+      }
+      e->mog2_state = cand[n];
+      bgs::Mog2Args m{};
+      mog2_fill_args(e, m, 0.05);
+      m.frame = d_frame, m.state_off = 0, m.npix = P;
+      mog2_clear(e, m, e->stream);
+      for (int i = 0; i < 2 && !rc; ++i) rc = launch_mog2(e, m, e->stream, false);
+      (void)hipEventRecord(ev0, e->stream);
+      for (int i = 0; i < 4 && !rc; ++i) rc = launch_mog2(e, m, e->stream, false);
+      (void)hipEventRecord(ev1, e->stream);
+      if (rc || hipEventSynchronize(ev1) != hipSuccess) {
+        rc = rc ? rc : fail(BGS_ERR_HIP, "placement probe failed: %s", hipGetErrorString(hipGetLastError()));
+        ++n;
+        break;
+      }
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, ev0, ev1);
+      e->probe_ms[n] = ms / 4;
+      if (ms / 4 < keep_ms) keep_ms = ms / 4, best = n;
+      // no early exit inside a round: there are more than two speed classes (2.83 / 2.55 / 2.30 ms have been seen side by
+      // side), so every candidate is measured and the fastest kept
     }
-    e->mog2_state = cand[n];
-    bgs::Mog2Args m{};
-    mog2_fill_args(e, m, 0.05);
-    m.frame = d_frame, m.state_off = 0, m.npix = P;
-    mog2_clear(e, m, e->stream);
-    for (int i = 0; i < 2 && !rc; ++i) rc = launch_mog2(e, m, e->stream, false);
-    (void)hipEventRecord(ev0, e->stream);
-    for (int i = 0; i < 4 && !rc; ++i) rc = launch_mog2(e, m, e->stream, false);
-    (void)hipEventRecord(ev1, e->stream);
-    if (rc || hipEventSynchronize(ev1) != hipSuccess) {
-      rc = rc ? rc : fail(BGS_ERR_HIP, "placement probe failed: %s", hipGetErrorString(hipGetLastError()));
-      ++n;
-      break;
+    for (int i = 0; i < n; ++i) {
+      if (i == best && !rc) {
+        if (keep) (void)hipFree(keep);
+        keep = cand[i];
+      } else if (cand[i]) {
+        (void)hipFree(cand[i]);
+      }
+      cand[i] = nullptr;
     }
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, ev0, ev1);
-    e->probe_ms[n] = ms / 4;
-    if (ms < tmin) tmin = ms, best = n;
-    tmax = std::max(tmax, ms);
-    // no early exit: there are more than two speed classes (2.83 / 2.55 / 2.30 ms have been seen side by side), so every
-    // candidate is measured and the fastest kept
+    if (getenv("BGS_DEBUG_PROBE")) {
+      fprintf(stderr, "[bgs] placement probe round %d: %d candidates, ms/launch:", round, n);
+      for (int i = 0; i < n; ++i) fprintf(stderr, " %.3f%s", e->probe_ms[i], i == best ? "*" : "");
+      fprintf(stderr, "  (kept %.3f, expected %.3f)\n", keep_ms, expect_ms);
+    }
+    if (!keep || keep_ms <= 1.06 * expect_ms || bytes < ((size_t)2 << 30)) break;
   }
   e->mog2_sparse = saved_sparse;
   e->probe_n = n, e->probe_pick = best;
-  for (int i = 0; i < n; ++i)
-    if (i != best || rc) (void)hipFree(cand[i]);
-  e->mog2_state = rc ? nullptr : cand[best];
+  e->mog2_state = rc ? nullptr : keep;
+  if (rc && keep) (void)hipFree(keep);
   (void)hipFree(d_frame);
   (void)hipEventDestroy(ev0), (void)hipEventDestroy(ev1);
   if (!rc && !e->mog2_state) return fail(BGS_ERR_NOMEM, "out of device memory for the MOG2 model (%zu bytes)", bytes);
-  if (getenv("BGS_DEBUG_PROBE")) {
-    fprintf(stderr, "[bgs] placement probe: %d candidates, ms/launch:", n);
-    for (int i = 0; i < n; ++i) fprintf(stderr, " %.3f%s", e->probe_ms[i], i == best ? "*" : "");
-    fprintf(stderr, "\n");
-  }
   return rc;
 }
 
