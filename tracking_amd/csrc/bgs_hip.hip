@@ -177,6 +177,9 @@ int launch_mog2(bgs_engine* e, bgs::Mog2Args& a, hipStream_t s, bool timed = tru
   if (a.packed && a.npix % 64) return fail(BGS_ERR_UNSUPPORTED, "packed mask needs pixels %% 64 == 0");
   Timed t(e, s, "mog2_update_kernel", timed);
   const dim3 grid(blocks_for(a.npix / PX)), block(bgs::kBlock);
+  unsigned every = 1;  // sample about 256 workgroups per launch whatever the grid: enough to decide, few enough atomics not to show
+  while (grid.x / every > 256) every <<= 1;
+  a.stat_mask = every - 1;
   const bool tiled = e->mog2_tiled;
 #define MOG2_CASE(PXV, TL) \
   if (PX == PXV && tiled == TL) hipLaunchKernelGGL((bgs::mog2_update_kernel<PXV, TL>), grid, block, 0, s, a);

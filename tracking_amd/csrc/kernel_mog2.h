@@ -35,6 +35,7 @@ struct Mog2Args {
   int thr, enable_thr, shadow_val;
   int shadow, want_bg, packed;  // wave-uniform feature switches
   unsigned* stat;               // null, or 2 counters: sampled waves, sampled waves whose largest nmodes is below K-1 (auto mode)
+  unsigned stat_mask;           // workgroups with (blockIdx.x & stat_mask) == 0 are sampled (~256 per launch)
   int sparse;                   // 0 dense; 1 skip the stores of planes nothing changed in; 2 also skip the loads of modes no pixel of the wave has;
                                 // 4 the same per lane (4 pixels) instead of per wave: partial rows, traffic follows the live modes
   int xcd_swizzle;              // workgroups that share an XCD walk one contiguous eighth of the launch
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(kBlock) void mog2_update_kernel(const Mog2Args a) {
         if (__any(lane_max >= n)) M = n;
       nload = min(M + 1, kMog2K);
     }
-    if (a.stat && (blockIdx.x & 63) == 0) {  // scene-sparsity sample for the engine's automatic choice between sparse 1 and 2
+    if (a.stat && (blockIdx.x & a.stat_mask) == 0) {  // scene-sparsity sample for the engine's automatic choice between sparse 1 and 4
       int lane_max = 0;
 #pragma unroll
       for (int j = 0; j < PX; ++j) lane_max = max(lane_max, (int)((nmw >> (8 * j)) & 0xffu));
