@@ -219,385 +219,7 @@ class HipBGSBase : public IBGS {
 #define BGS_HIP_BANNER_DTOR(Class) \
   ~Class() override { std::cout << "~" #Class "()" << std::endl; }
 
-// package_bgs/FrameDifferenceBGS.{h,cpp}
-class FrameDifferenceBGS : public HipBGSBase {
- public:
-  FrameDifferenceBGS() : HipBGSBase(BGS_FRAME_DIFF, "FrameDifferenceBGS"), showOutput(true) {}
-  BGS_HIP_BANNER_DTOR(FrameDifferenceBGS)
- private:
-  bool showOutput;
-  void saveConfig() override {  // FrameDifferenceBGS.cpp:65-74
-    XmlConfig fs;
-    fs.beginWrite();
-    fs.writeInt("enableThreshold", params_.enable_threshold);
-    fs.writeInt("threshold", params_.threshold);
-    fs.writeInt("showOutput", showOutput);
-    fs.save(configPath());
-  }
-  void loadConfig() override {  // :76-85
-    XmlConfig fs;
-    fs.load(configPath());
-    params_.enable_threshold = fs.readInt("enableThreshold", true);
-    params_.threshold = fs.readInt("threshold", 15);
-    showOutput = fs.readInt("showOutput", true);
-  }
-};
-
-// package_bgs/StaticFrameDifferenceBGS.{h,cpp}
-class StaticFrameDifferenceBGS : public HipBGSBase {
- public:
-  StaticFrameDifferenceBGS() : HipBGSBase(BGS_STATIC_FRAME_DIFF, "StaticFrameDifferenceBGS"), showOutput(true) {}
-  BGS_HIP_BANNER_DTOR(StaticFrameDifferenceBGS)
- private:
-  bool showOutput;
-  void saveConfig() override {
-    XmlConfig fs;
-    fs.beginWrite();
-    fs.writeInt("enableThreshold", params_.enable_threshold);
-    fs.writeInt("threshold", params_.threshold);
-    fs.writeInt("showOutput", showOutput);
-    fs.save(configPath());
-  }
-  void loadConfig() override {
-    XmlConfig fs;
-    fs.load(configPath());
-    params_.enable_threshold = fs.readInt("enableThreshold", true);
-    params_.threshold = fs.readInt("threshold", 15);
-    showOutput = fs.readInt("showOutput", true);
-  }
-};
-
-// package_bgs/WeightedMovingMeanBGS.{h,cpp}
-class WeightedMovingMeanBGS : public HipBGSBase {
- public:
-  WeightedMovingMeanBGS() : HipBGSBase(BGS_WMM, "WeightedMovingMeanBGS"), showOutput(true), showBackground(false) {}
-  BGS_HIP_BANNER_DTOR(WeightedMovingMeanBGS)
- private:
-  bool showOutput, showBackground;
-  void saveConfig() override {  // WeightedMovingMeanBGS.cpp:98-109
-    XmlConfig fs;
-    fs.beginWrite();
-    fs.writeInt("enableWeight", params_.enable_weight);
-    fs.writeInt("enableThreshold", params_.enable_threshold);
-    fs.writeInt("threshold", params_.threshold);
-    fs.writeInt("showOutput", showOutput);
-    fs.writeInt("showBackground", showBackground);
-    fs.save(configPath());
-  }
-  void loadConfig() override {  // :111-122
-    XmlConfig fs;
-    fs.load(configPath());
-    params_.enable_weight = fs.readInt("enableWeight", true);
-    params_.enable_threshold = fs.readInt("enableThreshold", true);
-    params_.threshold = fs.readInt("threshold", 15);
-    showOutput = fs.readInt("showOutput", true);
-    showBackground = fs.readInt("showBackground", false);
-  }
-};
-
-// package_bgs/WeightedMovingVarianceBGS.{h,cpp}
-class WeightedMovingVarianceBGS : public HipBGSBase {
- public:
-  WeightedMovingVarianceBGS() : HipBGSBase(BGS_WMV, "WeightedMovingVarianceBGS"), showOutput(true) {}
-  BGS_HIP_BANNER_DTOR(WeightedMovingVarianceBGS)
- private:
-  bool showOutput;
-  void saveConfig() override {  // WeightedMovingVarianceBGS.cpp:139-149
-    XmlConfig fs;
-    fs.beginWrite();
-    fs.writeInt("enableWeight", params_.enable_weight);
-    fs.writeInt("enableThreshold", params_.enable_threshold);
-    fs.writeInt("threshold", params_.threshold);
-    fs.writeInt("showOutput", showOutput);
-    fs.save(configPath());
-  }
-  void loadConfig() override {  // :151-161
-    XmlConfig fs;
-    fs.load(configPath());
-    params_.enable_weight = fs.readInt("enableWeight", true);
-    params_.enable_threshold = fs.readInt("enableThreshold", true);
-    params_.threshold = fs.readInt("threshold", 15);
-    showOutput = fs.readInt("showOutput", true);
-  }
-};
-
-// package_bgs/AdaptiveBackgroundLearning.{h,cpp}
-class AdaptiveBackgroundLearning : public HipBGSBase {
- public:
-  AdaptiveBackgroundLearning() : HipBGSBase(BGS_ABL, "AdaptiveBackgroundLearning"), showForeground(true), showBackground(true) {}
-  BGS_HIP_BANNER_DTOR(AdaptiveBackgroundLearning)
- private:
-  bool showForeground, showBackground;
-  void saveConfig() override {  // AdaptiveBackgroundLearning.cpp:85-97
-    XmlConfig fs;
-    fs.beginWrite();
-    fs.writeReal("alpha", params_.alpha);
-    fs.writeInt("limit", params_.limit);
-    fs.writeInt("enableThreshold", params_.enable_threshold);
-    fs.writeInt("threshold", params_.threshold);
-    fs.writeInt("showForeground", showForeground);
-    fs.writeInt("showBackground", showBackground);
-    fs.save(configPath());
-  }
-  void loadConfig() override {  // :99-111
-    XmlConfig fs;
-    fs.load(configPath());
-    params_.alpha = fs.readReal("alpha", 0.05);
-    params_.limit = fs.readInt("limit", -1);
-    params_.enable_threshold = fs.readInt("enableThreshold", true);
-    params_.threshold = fs.readInt("threshold", 15);
-    showForeground = fs.readInt("showForeground", true);
-    showBackground = fs.readInt("showBackground", true);
-  }
-};
-
-// package_bgs/AdaptiveSelectiveBackgroundLearning.{h,cpp}
-class AdaptiveSelectiveBackgroundLearning : public HipBGSBase {
- public:
-  AdaptiveSelectiveBackgroundLearning() : HipBGSBase(BGS_ASBL, "AdaptiveSelectiveBackgroundLearning"), showOutput(true) {}
-  BGS_HIP_BANNER_DTOR(AdaptiveSelectiveBackgroundLearning)
- private:
-  bool showOutput;
-  void saveConfig() override {  // AdaptiveSelectiveBackgroundLearning.cpp:107-118
-    XmlConfig fs;
-    fs.beginWrite();
-    fs.writeInt("learningFrames", params_.learning_frames);
-    fs.writeReal("alphaLearn", params_.alpha_learn);
-    fs.writeReal("alphaDetection", params_.alpha_detection);
-    fs.writeInt("threshold", params_.threshold);
-    fs.writeInt("showOutput", showOutput);
-    fs.save(configPath());
-  }
-  void loadConfig() override {  // :120-131 (defaults 90 / 25 differ from the ctor's -1 / 15)
-    XmlConfig fs;
-    fs.load(configPath());
-    params_.learning_frames = fs.readInt("learningFrames", 90);
-    params_.alpha_learn = fs.readReal("alphaLearn", 0.05);
-    params_.alpha_detection = fs.readReal("alphaDetection", 0.05);
-    params_.threshold = fs.readInt("threshold", 25);
-    showOutput = fs.readInt("showOutput", true);
-  }
-};
-
-// package_bgs/MixtureOfGaussianV2BGS.{h,cpp}
-class MixtureOfGaussianV2BGS : public HipBGSBase {
- public:
-  MixtureOfGaussianV2BGS() : HipBGSBase(BGS_MOG2, "MixtureOfGaussianV2BGS"), showOutput(true) {}
-  BGS_HIP_BANNER_DTOR(MixtureOfGaussianV2BGS)
- private:
-  bool showOutput;
-  void saveConfig() override {  // MixtureOfGaussianV2BGS.cpp:76-86
-    XmlConfig fs;
-    fs.beginWrite();
-    fs.writeReal("alpha", params_.alpha);
-    fs.writeInt("enableThreshold", params_.enable_threshold);
-    fs.writeInt("threshold", params_.threshold);
-    fs.writeInt("showOutput", showOutput);
-    fs.save(configPath());
-  }
-  void loadConfig() override {  // :88-98
-    XmlConfig fs;
-    fs.load(configPath());
-    params_.alpha = fs.readReal("alpha", 0.05);
-    params_.enable_threshold = fs.readInt("enableThreshold", true);
-    params_.threshold = fs.readInt("threshold", 15);
-    showOutput = fs.readInt("showOutput", true);
-  }
-};
-
-// package_bgs/MixtureOfGaussianV1BGS.{h,cpp}
-class MixtureOfGaussianV1BGS : public HipBGSBase {
- public:
-  MixtureOfGaussianV1BGS() : HipBGSBase(BGS_MOG1, "MixtureOfGaussianV1BGS", /*clears_bg=*/true), showOutput(true) {}
-  BGS_HIP_BANNER_DTOR(MixtureOfGaussianV1BGS)
- private:
-  bool showOutput;
-  void saveConfig() override {  // MixtureOfGaussianV1BGS.cpp:73-83
-    XmlConfig fs;
-    fs.beginWrite();
-    fs.writeReal("alpha", params_.alpha);
-    fs.writeInt("enableThreshold", params_.enable_threshold);
-    fs.writeInt("threshold", params_.threshold);
-    fs.writeInt("showOutput", showOutput);
-    fs.save(configPath());
-  }
-  void loadConfig() override {  // :85-95
-    XmlConfig fs;
-    fs.load(configPath());
-    params_.alpha = fs.readReal("alpha", 0.05);
-    params_.enable_threshold = fs.readInt("enableThreshold", true);
-    params_.threshold = fs.readInt("threshold", 15);
-    showOutput = fs.readInt("showOutput", true);
-  }
-};
-
-// package_bgs/GMG.{h,cpp}
-class GMG : public HipBGSBase {
- public:
-  GMG() : HipBGSBase(BGS_GMG, "GMG", /*clears_bg=*/true), showOutput(true) {}
-  BGS_HIP_BANNER_DTOR(GMG)
- private:
-  bool showOutput;
-  void saveConfig() override {  // GMG.cpp:79-88
-    XmlConfig fs;
-    fs.beginWrite();
-    fs.writeInt("initializationFrames", params_.gmg_init_frames);
-    fs.writeReal("decisionThreshold", params_.gmg_decision_threshold);
-    fs.writeInt("showOutput", showOutput);
-    fs.save(configPath());
-  }
-  void loadConfig() override {  // :90-99
-    XmlConfig fs;
-    fs.load(configPath());
-    params_.gmg_init_frames = fs.readInt("initializationFrames", 20);
-    params_.gmg_decision_threshold = fs.readReal("decisionThreshold", 0.7);
-    showOutput = fs.readInt("showOutput", true);
-  }
-};
-
-// package_bgs/bl/SigmaDeltaBGS.{h,cpp}
-class SigmaDeltaBGS : public HipBGSBase {
- public:
-  SigmaDeltaBGS() : HipBGSBase(BGS_SIGMA_DELTA, "SigmaDeltaBGS"), showOutput(true) {}
-  BGS_HIP_BANNER_DTOR(SigmaDeltaBGS)
- private:
-  bool showOutput;
-  void saveConfig() override {  // SigmaDeltaBGS.cpp:57-66
-    XmlConfig fs;
-    fs.beginWrite();
-    fs.writeInt("ampFactor", params_.sd_amp_factor);
-    fs.writeInt("minVar", params_.sd_min_var);
-    fs.writeInt("maxVar", params_.sd_max_var);
-    fs.writeInt("showOutput", showOutput);
-    fs.save(configPath());
-  }
-  void loadConfig() override {  // :68-79
-    XmlConfig fs;
-    fs.load(configPath());
-    params_.sd_amp_factor = fs.readInt("ampFactor", 1);
-    params_.sd_min_var = fs.readInt("minVar", 15);
-    params_.sd_max_var = fs.readInt("maxVar", 255);
-    showOutput = fs.readInt("showOutput", true);
-  }
-};
-
-// package_bgs/pl/SuBSENSE.{h,cpp} (the class USTC_BGS type 36 instantiates, ustc_src/ustc_bgs.cpp:68)
-class SuBSENSEBGS : public HipBGSBase {
- public:
-  SuBSENSEBGS() : HipBGSBase(BGS_SUBSENSE, "SuBSENSEBGS"), showOutput(true) {}
-  ~SuBSENSEBGS() override {}
- private:
-  bool showOutput;
-  void saveConfig() override {  // SuBSENSE.cpp:47-60
-    XmlConfig fs;
-    fs.beginWrite();
-    fs.writeReal("fRelLBSPThreshold", params_.lbsp_rel_threshold);
-    fs.writeInt("nDescDistThresholdOffset", params_.subsense_desc_dist_threshold_offset);
-    fs.writeInt("nMinColorDistThreshold", params_.subsense_min_color_dist_threshold);
-    fs.writeInt("nBGSamples", params_.subsense_n_samples);
-    fs.writeInt("nRequiredBGSamples", params_.subsense_n_required);
-    fs.writeInt("nSamplesForMovingAvgs", params_.subsense_samples_for_moving_avgs);
-    fs.writeInt("showOutput", showOutput);
-    fs.save(configPath());
-  }
-  void loadConfig() override {  // SuBSENSE.cpp:62-75 (read every frame; the model itself is built once, on the first frame)
-    XmlConfig fs;
-    fs.load(configPath());
-    params_.lbsp_rel_threshold = (float)fs.readReal("fRelLBSPThreshold", 0.333f);
-    params_.subsense_desc_dist_threshold_offset = fs.readInt("nDescDistThresholdOffset", 3);
-    params_.subsense_min_color_dist_threshold = fs.readInt("nMinColorDistThreshold", 30);
-    params_.subsense_n_samples = fs.readInt("nBGSamples", 50);
-    params_.subsense_n_required = fs.readInt("nRequiredBGSamples", 2);
-    params_.subsense_samples_for_moving_avgs = fs.readInt("nSamplesForMovingAvgs", 100);
-    showOutput = fs.readInt("showOutput", true);
-  }
-};
-
-// package_bgs/pl/LOBSTER.{h,cpp}: like SuBSENSEBGS, the parameters are handed to the model once, when it is built on the first frame
-class LOBSTERBGS : public HipBGSBase {
- public:
-  LOBSTERBGS() : HipBGSBase(BGS_LOBSTER, "LOBSTERBGS"), showOutput(true) {}
-  ~LOBSTERBGS() override {}
- private:
-  bool showOutput;
-  void saveConfig() override {  // LOBSTER.cpp:47-58
-    XmlConfig fs;
-    fs.beginWrite();
-    fs.writeReal("fRelLBSPThreshold", params_.lbsp_rel_threshold);
-    fs.writeInt("nLBSPThresholdOffset", params_.lbsp_threshold_offset);
-    fs.writeInt("nDescDistThreshold", params_.subsense_desc_dist_threshold_offset);
-    fs.writeInt("nColorDistThreshold", params_.subsense_min_color_dist_threshold);
-    fs.writeInt("nBGSamples", params_.subsense_n_samples);
-    fs.writeInt("nRequiredBGSamples", params_.subsense_n_required);
-    fs.writeInt("showOutput", showOutput);
-    fs.save(configPath());
-  }
-  void loadConfig() override {  // :60-73
-    XmlConfig fs;
-    fs.load(configPath());
-    params_.lbsp_rel_threshold = (float)fs.readReal("fRelLBSPThreshold", 0.365f);
-    params_.lbsp_threshold_offset = fs.readInt("nLBSPThresholdOffset", 0);
-    params_.subsense_desc_dist_threshold_offset = fs.readInt("nDescDistThreshold", 4);
-    params_.subsense_min_color_dist_threshold = fs.readInt("nColorDistThreshold", 30);
-    params_.subsense_n_samples = fs.readInt("nBGSamples", 35);
-    params_.subsense_n_required = fs.readInt("nRequiredBGSamples", 2);
-    showOutput = fs.readInt("showOutput", true);
-  }
-};
-
-// package_bgs/dp/DP*BGS.{h,cpp}: the wrapper reads its XML every frame but hands the values to the model only once, inside
-// `if(firstTime)` (e.g. DPZivkovicAGMMBGS.cpp:48-65) - later edits of the file change what saveConfig would write, not the
-// running model.  Mirrored: the values go into params_ only while firstTime is true.
-#define BGS_HIP_DP_CLASS(Class, ALGO, WRITE_BODY, READ_BODY)                  \
-  class Class : public HipBGSBase {                                           \
-   public:                                                                     \
-    Class() : HipBGSBase(ALGO, #Class), showOutput(true) {                    \
-      threshold = params_.dp_threshold, alpha = params_.dp_alpha, gaussians = params_.dp_gaussians; \
-      learningFrames = params_.learning_frames, samplingRate = params_.dp_sampling_rate; \
-    }                                                                          \
-    BGS_HIP_BANNER_DTOR(Class)                                                \
-   private:                                                                    \
-    double threshold, alpha;                                                   \
-    int gaussians, learningFrames, samplingRate;                               \
-    bool showOutput;                                                           \
-    void saveConfig() override {                                               \
-      XmlConfig fs;                                                            \
-      fs.beginWrite();                                                         \
-      WRITE_BODY fs.writeInt("showOutput", showOutput);                       \
-      fs.save(configPath());                                                   \
-    }                                                                          \
-    void loadConfig() override {                                               \
-      XmlConfig fs;                                                            \
-      fs.load(configPath());                                                   \
-      READ_BODY showOutput = fs.readInt("showOutput", true);                  \
-      if (firstTime) {                                                         \
-        params_.dp_threshold = (float)threshold, params_.dp_alpha = (float)alpha, params_.dp_gaussians = gaussians; \
-        params_.learning_frames = learningFrames, params_.dp_sampling_rate = samplingRate; \
-      }                                                                        \
-    }                                                                          \
-  };
-
-// DPZivkovicAGMMBGS.cpp:82-104
-BGS_HIP_DP_CLASS(DPZivkovicAGMMBGS, BGS_DP_ZIVKOVIC_AGMM,
-                 fs.writeReal("threshold", threshold); fs.writeReal("alpha", alpha); fs.writeInt("gaussians", gaussians);,
-                 threshold = fs.readReal("threshold", 25.0f); alpha = fs.readReal("alpha", 0.001f); gaussians = fs.readInt("gaussians", 3);)
-// DPGrimsonGMMBGS.cpp:84-105
-BGS_HIP_DP_CLASS(DPGrimsonGMMBGS, BGS_DP_GRIMSON_GMM,
-                 fs.writeReal("threshold", threshold); fs.writeReal("alpha", alpha); fs.writeInt("gaussians", gaussians);,
-                 threshold = fs.readReal("threshold", 9.0); alpha = fs.readReal("alpha", 0.01); gaussians = fs.readInt("gaussians", 3);)
-// DPWrenGABGS.cpp:83-104
-BGS_HIP_DP_CLASS(DPWrenGABGS, BGS_DP_WREN_GA,
-                 fs.writeReal("threshold", threshold); fs.writeReal("alpha", alpha); fs.writeInt("learningFrames", learningFrames);,
-                 threshold = fs.readReal("threshold", 12.25f); alpha = fs.readReal("alpha", 0.005f); learningFrames = fs.readInt("learningFrames", 30);)
-// DPMeanBGS.cpp:84-105 (threshold is an int there)
-BGS_HIP_DP_CLASS(DPMeanBGS, BGS_DP_MEAN,
-                 fs.writeInt("threshold", (int)threshold); fs.writeReal("alpha", alpha); fs.writeInt("learningFrames", learningFrames);,
-                 threshold = fs.readInt("threshold", 2700); alpha = fs.readReal("alpha", 1e-6f); learningFrames = fs.readInt("learningFrames", 30);)
-// DPAdaptiveMedianBGS.cpp:83-104
-BGS_HIP_DP_CLASS(DPAdaptiveMedianBGS, BGS_DP_ADAPTIVE_MEDIAN,
-                 fs.writeInt("threshold", (int)threshold); fs.writeInt("samplingRate", samplingRate); fs.writeInt("learningFrames", learningFrames);,
-                 threshold = fs.readInt("threshold", 40); samplingRate = fs.readInt("samplingRate", 7); learningFrames = fs.readInt("learningFrames", 30);)
-#undef BGS_HIP_DP_CLASS
+#include "bgs_classes.inc"
 
 #undef BGS_HIP_BANNER_DTOR
 
