@@ -97,12 +97,12 @@ def test_product_never_touches_the_oracle():
 
 
 def test_reference_side_adapter_shares_the_tested_class_list():
-    """integration/HipBGS.h (cv::Mat + CvFileStorage, for the reference tree) and tracking_amd/host/bgs_host.h (compiled and tested
+    """tracking_amd/host/HipBGS.h (cv::Mat + CvFileStorage, for the reference tree) and tracking_amd/host/bgs_host.h (compiled and tested
     here) include the same per-class list, and that list holds every class the ABI has an algorithm id for."""
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     inc = open(os.path.join(root, "tracking_amd", "host", "bgs_classes.inc")).read()
-    for f in (os.path.join(root, "integration", "HipBGS.h"), os.path.join(root, "tracking_amd", "host", "bgs_host.h")):
+    for f in (os.path.join(root, "tracking_amd", "host", "HipBGS.h"), os.path.join(root, "tracking_amd", "host", "bgs_host.h")):
         assert '#include "bgs_classes.inc"' in open(f).read(), f
     names = set(re.findall(r"^class (\w+) : public HipBGSBase", inc, re.M)) | set(re.findall(r"^BGS_HIP_DP_CLASS\((\w+),", inc, re.M))
     want = {"FrameDifferenceBGS", "StaticFrameDifferenceBGS", "WeightedMovingMeanBGS", "WeightedMovingVarianceBGS", "AdaptiveBackgroundLearning",
