@@ -320,7 +320,7 @@ def test_device_batch_matches_oracle(name, borrow):
         keep.append(d_frames)  # borrowed history must stay alive
         d_fg = torch.full((S, H, W), 9, dtype=torch.uint8, device="cuda")
         d_bg = torch.full((S, H, W, 1 if algo == capi.ASBL else 3), 9, dtype=torch.uint8, device="cuda")
-        has_bits = algo not in (capi.ASBL, capi.GMG)  # the stencil / median paths write the byte mask only
+        has_bits = True  # (the stencil / median / sample-consensus paths pack the finished byte mask)
         d_bits = torch.zeros((S, H * W // 64), dtype=torch.int64, device="cuda") if has_bits else None
         flags = eng.process_batch_device(d_frames, d_fg, d_bg, d_bits)
         torch.cuda.synchronize()
@@ -1017,3 +1017,22 @@ def test_large_batches_match_single_stream_engines(algo, S, T):
             singles[k].process_batch_device(clips[k][t:t + 1], fg1, None, None)
             torch.cuda.synchronize()
             assert torch.equal(fg[s], fg1[0]), (t, s)
+
+
+@pytest.mark.parametrize("algo", [capi.SUBSENSE, capi.LOBSTER])
+def test_sample_consensus_models_packed_mask(algo):
+    """bgs_process_batch_device with d_bits for SuBSENSE / LOBSTER: the bit mask MaskGather ships equals the byte mask."""
+    torch = _torch()
+    S, T, H, W = 2, 5, 48, 64
+    eng = Engine(algo, n_streams=S)
+    eng.set_geometry(H, W, 3)
+    clips = np.stack([synth.random_frames(T, H, W, 3, seed=300 + s) for s in range(S)])
+    clips[:, 2:] = clips[:, :1]  # repeat the first frame so that part of the mask goes to background
+    for t in range(T):
+        d_frames = torch.from_numpy(np.ascontiguousarray(clips[:, t])).cuda()
+        d_fg = torch.empty((S, H, W), dtype=torch.uint8, device="cuda")
+        d_bits = torch.zeros((S, H * W // 64), dtype=torch.int64, device="cuda")
+        eng.process_batch_device(d_frames, d_fg, None, d_bits)
+        torch.cuda.synchronize()
+        bits = np.unpackbits(d_bits.cpu().numpy().view(np.uint8).reshape(S, -1), axis=1, bitorder="little").reshape(S, H, W)
+        assert np.array_equal(bits != 0, d_fg.cpu().numpy() != 0), t

@@ -599,7 +599,7 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
       break;
     }
     case BGS_GMG: {
-      if (d_bits) return fail(BGS_ERR_UNSUPPORTED, "GMG writes the byte mask only");
+      if (d_bits && !d_fg) return fail(BGS_ERR_UNSUPPORTED, "GMG: the packed mask is made from the byte mask, pass d_fg too");
       const size_t P = e->n * e->S;
       if (t == 0) hipLaunchKernelGGL(bgs::gmg_clear_kernel, dim3(blocks_for(npix)), dim3(bgs::kBlock), 0, s, e->gmg_nfeat + off, npix);  // initialize(): nfeatures = 0
       bgs::GmgArgs g{};
@@ -618,21 +618,24 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
         } else {
           HIP_TRY(hipMemcpyAsync(d_fg, e->bgstate + off, npix, hipMemcpyDeviceToDevice, s));
         }
+        if (d_bits) hipLaunchKernelGGL(bgs::mask_pack_kernel, dim3(blocks_for(npix)), dim3(bgs::kBlock), 0, s, (const uint8_t*)d_fg, d_bits, npix);
       }
       flags = BGS_FG_VALID;  // no getBackgroundImage for GMG (GMG.cpp:59): img_bgmodel ends up empty
       break;
     }
     case BGS_SUBSENSE: {
-      if (d_bits) return fail(BGS_ERR_UNSUPPORTED, "SuBSENSE writes the byte mask only");
       int rc = ss_process(e, first, count, d_frames, d_fg, d_bg, s, t);
       if (rc) return rc;
+      if (d_bits)  // the mask is also model state (m_oLastFGMask): pack it from there
+        hipLaunchKernelGGL(bgs::mask_pack_kernel, dim3(blocks_for(npix)), dim3(bgs::kBlock), 0, s, (const uint8_t*)(e->ss->u8[SS_LASTFG] + off), d_bits, npix);
       flags = BGS_FG_VALID | BGS_BG_VALID;
       break;
     }
     case BGS_LOBSTER: {
-      if (d_bits) return fail(BGS_ERR_UNSUPPORTED, "LOBSTER writes the byte mask only");
       int rc = lob_process(e, first, count, d_frames, d_fg, d_bg, s, t);
       if (rc) return rc;
+      if (d_bits)
+        hipLaunchKernelGGL(bgs::mask_pack_kernel, dim3(blocks_for(npix)), dim3(bgs::kBlock), 0, s, (const uint8_t*)(e->ss->u8[SS_LASTFG] + off), d_bits, npix);
       flags = BGS_FG_VALID | BGS_BG_VALID;
       break;
     }
@@ -691,6 +694,10 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
           hipLaunchKernelGGL((bgs::asbl_kernel<3>), grid, dim3(bgs::kBlock), 0, s, q);
         else
           hipLaunchKernelGGL((bgs::asbl_kernel<1>), grid, dim3(bgs::kBlock), 0, s, q);
+      }
+      if (d_bits) {
+        if (!d_fg) return fail(BGS_ERR_UNSUPPORTED, "AdaptiveSelectiveBackgroundLearning: the packed mask is made from the byte mask, pass d_fg too");
+        hipLaunchKernelGGL(bgs::mask_pack_kernel, dim3(blocks_for(npix)), dim3(bgs::kBlock), 0, s, (const uint8_t*)d_fg, d_bits, npix);
       }
       for (int i = first; i < first + count; ++i) {
         e->flip[i] = (uint8_t)(cur ^ 1);

@@ -319,6 +319,13 @@ __global__ __launch_bounds__(kBlock) void median_kernel(const MorphArgs a) {
   a.dst[img + (size_t)y * a.cols + x] = (uint8_t)lo;
 }
 
+// byte mask -> bit mask (bit i of word j = pixel 64 j + i is non-zero): one wave ballot per word; n % 64 == 0
+__global__ __launch_bounds__(kBlock) void mask_pack_kernel(const uint8_t* src, uint64_t* dst, size_t n) {
+  const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const unsigned long long w = __ballot(p < n && src[p] != 0);
+  if ((threadIdx.x & (kWave - 1)) == 0 && p < n) dst[p >> 6] = w;
+}
+
 // host side: one launch over `count` images stored back to back
 inline void morph_launch(const MorphArgs& a, int count, hipStream_t s) {
   if (a.op == 2)
