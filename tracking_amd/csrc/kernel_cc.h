@@ -13,7 +13,7 @@
 //   cc_merge     union(p, n) for the links not covered by a run: span boundaries, N, and the upper diagonals (atomicMin on the larger root)
 //   cc_compress  every pixel now holds its component's root
 //   cc_count / cc_scan / cc_scatter   roots -> dense ids in raster order (wave ballot + popcount prefix, two-level scan)
-//   cc_boxes     atomicMin/Max/Add into the component's box, merged per lane run and per wave first
+//   cc_boxes     atomicMin/Max/Add into the component's box, merged per lane run, per wave and per workgroup (LDS table) first
 //   cc_finish    (minx, miny, maxx, maxy) -> (x, y, w, h)
 #pragma once
 #include "bgs_device.h"
@@ -178,17 +178,45 @@ __global__ __launch_bounds__(kBlock) void cc_scatter_kernel(const int* L, size_t
   }
 }
 
-// Boxes: a wave walks 1024 consecutive pixels (16 per lane, coalesced).  A lane keeps one open accumulator and flushes
-// it with atomics only when its component changes; at the end the wave merges the open accumulators of lanes that hold
-// the same component (one butterfly per distinct component) so that a big blob costs one set of atomics per wave
-// instead of one per pixel (1080p: full mask 2.0 -> 0.3 ms, percolating random mask 50 -> 2.5 ms, blob mask 0.84 -> 0.12 ms).
-constexpr int kCcBoxPer = 16;
+// Boxes: a wave walks 1024 consecutive pixels (16 per lane, coalesced).  A lane keeps one open accumulator and flushes it
+// when its component changes; at the end the wave merges the open accumulators of lanes that hold the same component (one
+// butterfly per distinct component).  Flushes go to a 128-entry table in LDS (open addressing on the component id, LDS
+// atomics), and the workgroup issues one set of global atomics per component it met - so a mask that is mostly one giant
+// component (a model's first frames) no longer funnels every flush through the same five global addresses.
+constexpr int kCcBoxPer = 16, kCcSlots = 128;
 
 __device__ __forceinline__ void cc_box_atomics(CcBox* b, int mnx, int mny, int mxx, int mxy, int cnt) {
   atomicMin(&b->x, mnx), atomicMin(&b->y, mny), atomicMax(&b->w, mxx), atomicMax(&b->h, mxy), atomicAdd(&b->area, cnt);
 }
 
+struct CcTable {
+  int id[kCcSlots];
+  int box[kCcSlots][5];
+};
+
+__device__ __forceinline__ void cc_table_add(CcTable& t, CcBox* boxes, int id, int mnx, int mny, int mxx, int mxy, int cnt) {
+  int slot = (int)(((unsigned)id * 2654435761u) >> 25);  // 7 bits
+  for (int probe = 0; probe < 8; ++probe) {
+    const int old = atomicCAS(&t.id[slot], -1, id);
+    if (old == -1 || old == id) {
+      atomicMin(&t.box[slot][0], mnx), atomicMin(&t.box[slot][1], mny), atomicMax(&t.box[slot][2], mxx), atomicMax(&t.box[slot][3], mxy);
+      atomicAdd(&t.box[slot][4], cnt);
+      return;
+    }
+    slot = (slot + 1) & (kCcSlots - 1);
+  }
+  cc_box_atomics(boxes + id, mnx, mny, mxx, mxy, cnt);  // table crowded around this hash: go straight to memory
+}
+
 __global__ __launch_bounds__(kBlock) void cc_boxes_kernel(const int* L, const int* id, int rows, int cols, int img_rows, CcBox* boxes, int max_boxes) {
+  __shared__ CcTable tab;
+  if (threadIdx.x < kCcSlots) {
+    tab.id[threadIdx.x] = -1;
+    tab.box[threadIdx.x][0] = tab.box[threadIdx.x][1] = 0x7fffffff;
+    tab.box[threadIdx.x][2] = tab.box[threadIdx.x][3] = -1;
+    tab.box[threadIdx.x][4] = 0;
+  }
+  __syncthreads();
   const size_t N = (size_t)rows * cols;
   const int lane = threadIdx.x & (kWave - 1);
   const size_t wave0 = ((size_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave) * (kWave * kCcBoxPer);
@@ -198,7 +226,7 @@ __global__ __launch_bounds__(kBlock) void cc_boxes_kernel(const int* L, const in
     const int l = p < N ? L[p] : -1;
     if (l < 0) continue;
     if (l != cl) {  // a different component than the one this lane has open
-      if (cid >= 0 && cid < max_boxes) cc_box_atomics(boxes + cid, mnx, mny, mxx, mxy, cnt);
+      if (cid >= 0 && cid < max_boxes) cc_table_add(tab, boxes, cid, mnx, mny, mxx, mxy, cnt);
       cl = l, cid = id[l];
       mnx = mny = 0x7fffffff, mxx = mxy = -1, cnt = 0;
     }
@@ -218,9 +246,12 @@ __global__ __launch_bounds__(kBlock) void cc_boxes_kernel(const int* L, const in
       c = max(c, __shfl_xor(c, o)), d = max(d, __shfl_xor(d, o));
       e += __shfl_xor(e, o);
     }
-    if (lane == leader) cc_box_atomics(boxes + lid, a, b, c, d, e);
+    if (lane == leader) cc_table_add(tab, boxes, lid, a, b, c, d, e);
     pending &= ~__ballot(mine);
   }
+  __syncthreads();
+  if (threadIdx.x < kCcSlots && tab.id[threadIdx.x] >= 0)
+    cc_box_atomics(boxes + tab.id[threadIdx.x], tab.box[threadIdx.x][0], tab.box[threadIdx.x][1], tab.box[threadIdx.x][2], tab.box[threadIdx.x][3], tab.box[threadIdx.x][4]);
 }
 
 __global__ __launch_bounds__(kBlock) void cc_finish_kernel(CcBox* boxes, const int* count, int max_boxes, int imgN) {
