@@ -118,29 +118,28 @@ __global__ __launch_bounds__(kBlock) void cc_count_kernel(const int* L, size_t N
   if (threadIdx.x == 0) blockCount[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// exclusive scan of blockCount[nb] in place by one workgroup; total -> *count
+// exclusive scan of blockCount[nb] in place by one workgroup (each lane owns a contiguous slice, one scan of the 256 slice
+// sums in between); total -> *count
 __global__ __launch_bounds__(kBlock) void cc_scan_kernel(int* blockCount, int nb, int* count) {
   __shared__ int part[kBlock];
-  __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
+  const int per = (nb + kBlock - 1) / kBlock, lo = min((int)threadIdx.x * per, nb), hi = min(lo + per, nb);
+  int sum = 0;
+  for (int i = lo; i < hi; ++i) sum += blockCount[i];
+  part[threadIdx.x] = sum;
   __syncthreads();
-  for (int base = 0; base < nb; base += kBlock) {
-    const int i = base + threadIdx.x;
-    const int v = i < nb ? blockCount[i] : 0;
-    part[threadIdx.x] = v;
+  for (int o = 1; o < kBlock; o <<= 1) {  // Hillis-Steele inclusive scan of the slice sums
+    const int t = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
     __syncthreads();
-    for (int o = 1; o < kBlock; o <<= 1) {  // Hillis-Steele inclusive scan
-      const int t = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
-      __syncthreads();
-      part[threadIdx.x] += t;
-      __syncthreads();
-    }
-    if (i < nb) blockCount[i] = carry + part[threadIdx.x] - v;
-    __syncthreads();
-    if (threadIdx.x == kBlock - 1) carry += part[kBlock - 1];
+    part[threadIdx.x] += t;
     __syncthreads();
   }
-  if (threadIdx.x == 0) *count = carry;
+  int run = part[threadIdx.x] - sum;
+  for (int i = lo; i < hi; ++i) {
+    const int v = blockCount[i];
+    blockCount[i] = run;
+    run += v;
+  }
+  if (threadIdx.x == kBlock - 1) *count = part[kBlock - 1];
 }
 
 // dense id of every root, in raster order; the boxes start empty
