@@ -102,6 +102,7 @@ struct bgs_engine {
   uint8_t *h_in = nullptr, *h_fg = nullptr, *h_bg = nullptr;
   uint8_t *d_in = nullptr, *d_fg = nullptr, *d_bg = nullptr;
   hipStream_t stream = nullptr;
+  hipEvent_t band_ev[8] = {nullptr};  // bgs_process: one event per output band
 
   // dominant-kernel timing
   bool timing = false;
@@ -130,6 +131,8 @@ void free_all(bgs_engine* e) {
   if (e->d_stat) (void)hipFree(e->d_stat), e->d_stat = nullptr;
   if (e->h_stat) (void)hipHostFree(e->h_stat), e->h_stat = nullptr;
   if (e->stat_ev) (void)hipEventDestroy(e->stat_ev), e->stat_ev = nullptr;
+  for (auto& ev : e->band_ev)
+    if (ev) (void)hipEventDestroy(ev), ev = nullptr;
 }
 
 int check_params(bgs_algo algo, const bgs_params& p) {
@@ -975,11 +978,17 @@ int bgs_process(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols
   if (rc) return rc;
   HIP_TRY(hipSetDevice(e->device));
   const size_t rb = (size_t)cols * channels, fb = e->n * channels;
-  for (int y = 0; y < rows; ++y) std::memcpy(e->h_in + (size_t)y * rb, in + (size_t)y * in_step, rb);
   // history-keeping algorithms receive the upload straight in their ring slot (zero-copy history)
   uint8_t* dst = e->d_in;
   if (e->nring) dst = e->ring[e->seen[stream] % e->nring] + (size_t)stream * fb;
-  HIP_TRY(hipMemcpyAsync(dst, e->h_in, fb, hipMemcpyHostToDevice, e->stream));
+  // staging is pipelined: while the DMA engine moves band k, the CPU copies band k+1 of the caller's (pageable, possibly
+  // strided) image into the pinned buffer
+  const int bands = rows >= 64 ? 8 : 1;
+  for (int b = 0; b < bands; ++b) {
+    const int y0 = (int)((int64_t)rows * b / bands), y1 = (int)((int64_t)rows * (b + 1) / bands);
+    for (int y = y0; y < y1; ++y) std::memcpy(e->h_in + (size_t)y * rb, in + (size_t)y * in_step, rb);
+    HIP_TRY(hipMemcpyAsync(dst + (size_t)y0 * rb, e->h_in + (size_t)y0 * rb, (size_t)(y1 - y0) * rb, hipMemcpyHostToDevice, e->stream));
+  }
   uint32_t flags = 0;
   const bool saved_borrow = e->borrow;
   e->borrow = false;
@@ -987,13 +996,26 @@ int bgs_process(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols
   e->borrow = saved_borrow;
   if (rc) return rc;
   const int bg_ch = e->algo == BGS_ASBL ? 1 : channels;
-  if (fg && (flags & BGS_FG_VALID)) HIP_TRY(hipMemcpyAsync(e->h_fg, e->d_fg, e->n, hipMemcpyDeviceToHost, e->stream));
-  if (bg && (flags & BGS_BG_VALID)) HIP_TRY(hipMemcpyAsync(e->h_bg, e->d_bg, e->n * bg_ch, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  if (fg && (flags & BGS_FG_VALID))
-    for (int y = 0; y < rows; ++y) std::memcpy(fg + (size_t)y * fg_step, e->h_fg + (size_t)y * cols, (size_t)cols);
-  if (bg && (flags & BGS_BG_VALID))
-    for (int y = 0; y < rows; ++y) std::memcpy(bg + (size_t)y * bg_step, e->h_bg + (size_t)y * cols * bg_ch, (size_t)cols * bg_ch);
+  // the way back is pipelined the same way when there is a background image to return (6 MB at 1080p): band k is copied out to
+  // the caller's image while band k+1 is still on the bus; a mask alone (2 MB) is not worth the events
+  const bool out_fg = fg && (flags & BGS_FG_VALID), out_bg = bg && (flags & BGS_BG_VALID);
+  const int obands = out_bg ? bands : 1;
+  for (int b = 0; b < obands; ++b) {
+    const int y0 = (int)((int64_t)rows * b / obands), y1 = (int)((int64_t)rows * (b + 1) / obands);
+    if (out_fg) HIP_TRY(hipMemcpyAsync(e->h_fg + (size_t)y0 * cols, e->d_fg + (size_t)y0 * cols, (size_t)(y1 - y0) * cols, hipMemcpyDeviceToHost, e->stream));
+    if (out_bg)
+      HIP_TRY(hipMemcpyAsync(e->h_bg + (size_t)y0 * cols * bg_ch, e->d_bg + (size_t)y0 * cols * bg_ch, (size_t)(y1 - y0) * cols * bg_ch, hipMemcpyDeviceToHost, e->stream));
+    if (!e->band_ev[b]) HIP_TRY(hipEventCreateWithFlags(&e->band_ev[b], hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(e->band_ev[b], e->stream));
+  }
+  for (int b = 0; b < obands; ++b) {
+    const int y0 = (int)((int64_t)rows * b / obands), y1 = (int)((int64_t)rows * (b + 1) / obands);
+    HIP_TRY(hipEventSynchronize(e->band_ev[b]));
+    if (out_fg)
+      for (int y = y0; y < y1; ++y) std::memcpy(fg + (size_t)y * fg_step, e->h_fg + (size_t)y * cols, (size_t)cols);
+    if (out_bg)
+      for (int y = y0; y < y1; ++y) std::memcpy(bg + (size_t)y * bg_step, e->h_bg + (size_t)y * cols * bg_ch, (size_t)cols * bg_ch);
+  }
   if (out_flags) *out_flags = flags;
   return BGS_OK;
 }
