@@ -6,7 +6,9 @@ TAG=$1; KERN=$2; CTRS=$3; shift 3; [ "$1" == "--" ] && shift
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT/raw -o pmc -- python3 "$@" > $OUT/run.log 2>&1
+# FETCH_SIZE and WRITE_SIZE do not fit one pass ("Request exceeds the capabilities of the hardware": rocprofv3 aborts and then
+# hangs in its finaliser) - pass them in separate invocations; the timeout keeps a bad counter set from eating the whole call
+timeout -k 5 150 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $OUT/raw -o pmc -- python3 "$@" > $OUT/run.log 2>&1
 python3 - "$OUT" "$KERN" <<'PY'
 import csv, glob, sys, collections
 out, kern = sys.argv[1], sys.argv[2]
