@@ -26,6 +26,8 @@ struct SsDevice {
   bgs::SsScalars* sc = nullptr;
   int* changed = nullptr;
   int* h_changed = nullptr;  // pinned
+  hipStream_t side = nullptr;  // phase B runs here, beside the post-processing chain (both only need phase A)
+  hipEvent_t evA = nullptr, evB = nullptr;
   uint64_t *mbits = nullptr, *rbits = nullptr;  // flood fill: bit-packed mask / reached set, [S][rows][W64]
   std::vector<uint8_t> pp;   // per stream: which copy of Dlast / RawST is current
   int use3x3 = 1, lrScaling = 0, medK = 9;
@@ -39,6 +41,9 @@ struct SsDevice {
     for (auto& q : u8)
       if (q) (void)hipFree(q), q = nullptr;
     if (h_changed) (void)hipHostFree(h_changed);
+    if (side) (void)hipStreamDestroy(side), side = nullptr;
+    if (evA) (void)hipEventDestroy(evA), evA = nullptr;
+    if (evB) (void)hipEventDestroy(evB), evB = nullptr;
     color = lut = lastColor = curColor = nullptr, desc = lastDesc = req = curDesc = nullptr, dsLT = dsST = nullptr, sc = nullptr, changed = h_changed = nullptr, mbits = rbits = nullptr;
   }
 };
@@ -190,7 +195,22 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
     const dim3 tilesA((e->cols + bgs::kSsTW - 1) / bgs::kSsTW, (e->rows + bgs::kSsATH - 1) / bgs::kSsATH, count);
     SS_LAUNCH(ss_phase_a_kernel, tilesA, block, s, a);
   }
-  SS_LAUNCH(ss_phase_b_kernel, tiles, block, s, a);
+  // Phase B (the scattered sample writes) and the post-processing chain both depend on phase A only, and the next frame depends
+  // on both: phase B goes to a side stream and rejoins at the end, so its memory-bound scatter overlaps the LDS-bound morphology.
+  static const bool overlap = !(getenv("BGS_SS_OVERLAP") && atoi(getenv("BGS_SS_OVERLAP")) == 0);
+  if (overlap && !d->side) {
+    HIP_TRY(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&d->evA, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&d->evB, hipEventDisableTiming));
+  }
+  if (overlap) {
+    HIP_TRY(hipEventRecord(d->evA, s));
+    HIP_TRY(hipStreamWaitEvent(d->side, d->evA, 0));
+    SS_LAUNCH(ss_phase_b_kernel, tiles, block, d->side, a);
+    HIP_TRY(hipEventRecord(d->evB, d->side));
+  } else {
+    SS_LAUNCH(ss_phase_b_kernel, tiles, block, s, a);
+  }
   hipLaunchKernelGGL(bgs::ss_blink_kernel, dim3(blocks_for(npix)), block, 0, s, a, npix);
   uint8_t *raw = d->u8[SS_RAW] + off, *t1 = d->u8[SS_T1] + off, *t3 = d->u8[SS_T3] + off, *t4 = d->u8[SS_T4] + off;
   uint8_t* lastFG = d->u8[SS_LASTFG] + off;
@@ -222,6 +242,7 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
     SS_LAUNCH(ss_downsample_kernel, dim3(blocks_for(dsn), 1, count), block, s, a);
   }
   hipLaunchKernelGGL(bgs::ss_frame_level_kernel, dim3(count), dim3(256), 0, s, a);
+  if (overlap) HIP_TRY(hipStreamWaitEvent(s, d->evB, 0));  // the refresh below and the next frame need phase B's writes
   SS_LAUNCH(ss_refresh_kernel, dim3(blocks_for(N), 1, count), block, s, a, 1);  // refreshModel(0.1f) if asked (:680)
   if (d_bg) SS_LAUNCH(ss_background_kernel, dim3(blocks_for(N * e->ch), 1, count), block, s, a);
   HIP_TRY(hipGetLastError());
