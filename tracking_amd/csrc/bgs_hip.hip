@@ -97,6 +97,7 @@ struct bgs_engine {
   int probe_max = 8;               // placement probe: candidates tried at allocation (<= 1: off)
   float probe_ms[16] = {0};         // what the probe measured (diagnostics)
   int probe_n = 0, probe_pick = -1;
+  bool poison = false;             // BGS_DEBUG_POISON: every fresh device buffer is filled with 0xA5 (see dmalloc)
 
   // host staging (bgs_process)
   uint8_t *h_in = nullptr, *h_fg = nullptr, *h_bg = nullptr;
@@ -146,6 +147,21 @@ int check_params(bgs_algo algo, const bgs_params& p) {
   if (algo == BGS_DP_ADAPTIVE_MEDIAN && p.dp_sampling_rate == 0) return fail(BGS_ERR_UNSUPPORTED, "AdaptiveMedian samplingRate 0 (frame_num %% 0)");
   return BGS_OK;
 }
+
+// Every model / history / staging buffer of an engine comes from here.  Nothing may rely on what a fresh allocation holds:
+// each model is initialised at a stream's first frame ON THE LAUNCH STREAM (mog2_clear, mog1_clear_kernel, gmg_clear_kernel,
+// dp_gmm_clear_kernel, ss_init_streams, ...).  BGS_DEBUG_POISON=1 makes a violation deterministic instead of timing- and
+// allocator-dependent: the buffer is filled with 0xA5 (a NaN-free but wildly wrong float, a mode count of 165) before first use.
+int dmalloc(bgs_engine* e, void** p, size_t bytes) {
+  HIP_TRY(hipMalloc(p, bytes));
+  if (e->poison) HIP_TRY(hipMemsetAsync(*p, 0xA5, bytes, e->stream));  // allocate() drains e->stream before it returns
+  return BGS_OK;
+}
+#define DMALLOC(ptr, bytes)                               \
+  do {                                                    \
+    int rc__ = dmalloc(e, (void**)&(ptr), (bytes));       \
+    if (rc__) return rc__;                                \
+  } while (0)
 
 struct Timed {
   bgs_engine* e;
@@ -242,17 +258,17 @@ size_t mog2_state_bytes(const bgs_engine* e) {
 int mog2_allocate(bgs_engine* e) {
   const size_t P = e->n * e->S, bytes = mog2_state_bytes(e);
   HIP_TRY(hipMalloc((void**)&e->d_stat, 2 * sizeof(unsigned)));
-  HIP_TRY(hipMemset(e->d_stat, 0, 2 * sizeof(unsigned)));
+  HIP_TRY(hipMemsetAsync(e->d_stat, 0, 2 * sizeof(unsigned), e->stream));  // ordered: allocate() drains e->stream before it returns
   HIP_TRY(hipHostMalloc((void**)&e->h_stat, 2 * sizeof(unsigned), hipHostMallocDefault));
   HIP_TRY(hipEventCreateWithFlags(&e->stat_ev, hipEventDisableTiming));
   if (!e->mog2_tiled) {
-    HIP_TRY(hipMalloc((void**)&e->mog2_state, bytes));
-    HIP_TRY(hipMalloc((void**)&e->mog2_nmodes, P));
+    DMALLOC(e->mog2_state, bytes);
+    DMALLOC(e->mog2_nmodes, P);
     return BGS_OK;
   }
   const int tries = std::min(e->probe_max, 16);
   if (tries <= 1 || bytes < ((size_t)768 << 20)) {
-    HIP_TRY(hipMalloc((void**)&e->mog2_state, bytes));
+    DMALLOC(e->mog2_state, bytes);
     return BGS_OK;
   }
   uint8_t* d_frame = nullptr;
@@ -300,6 +316,31 @@ int mog2_allocate(bgs_engine* e) {
       // no early exit inside a round: there are more than two speed classes (2.83 / 2.55 / 2.30 ms have been seen side by
       // side), so every candidate is measured and the fastest kept
     }
+    if (getenv("BGS_DEBUG_PROBE") && atoi(getenv("BGS_DEBUG_PROBE")) >= 2 && !rc) {
+      // de-confounding pass: the same candidates again, in REVERSE order and then in the original order, so a
+      // "fast placement" that is really "measured first after idle" shows up as such
+      for (int pass = 0; pass < 2; ++pass) {
+        fprintf(stderr, "[bgs] placement probe re-time (%s order), ms/launch by candidate:", pass == 0 ? "reverse" : "forward");
+        float again[16] = {0};
+        for (int j = 0; j < n; ++j) {
+          const int i = pass == 0 ? n - 1 - j : j;
+          e->mog2_state = cand[i];
+          bgs::Mog2Args m{};
+          mog2_fill_args(e, m, 0.05);
+          m.frame = d_frame, m.state_off = 0, m.npix = P;
+          for (int q = 0; q < 2; ++q) (void)launch_mog2(e, m, e->stream, false);
+          (void)hipEventRecord(ev0, e->stream);
+          for (int q = 0; q < 4; ++q) (void)launch_mog2(e, m, e->stream, false);
+          (void)hipEventRecord(ev1, e->stream);
+          (void)hipEventSynchronize(ev1);
+          float ms = 0;
+          (void)hipEventElapsedTime(&ms, ev0, ev1);
+          again[i] = ms / 4;
+        }
+        for (int i = 0; i < n; ++i) fprintf(stderr, " %.3f", again[i]);
+        fprintf(stderr, "\n");
+      }
+    }
     for (int i = 0; i < n; ++i) {
       if (i == best && !rc) {
         if (keep) (void)hipFree(keep);
@@ -331,10 +372,7 @@ int mog2_allocate(bgs_engine* e) {
 template <class Run>
 int probe_allocate(bgs_engine* e, void** out, size_t bytes, Run run) {
   const int tries = std::min(e->probe_max, 16);
-  if (tries <= 1 || bytes < ((size_t)768 << 20)) {
-    HIP_TRY(hipMalloc(out, bytes));
-    return BGS_OK;
-  }
+  if (tries <= 1 || bytes < ((size_t)768 << 20)) return dmalloc(e, out, bytes);
   hipEvent_t ev0, ev1;
   HIP_TRY(hipEventCreate(&ev0));
   HIP_TRY(hipEventCreate(&ev1));
@@ -389,6 +427,7 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
   HIP_TRY(hipSetDevice(e->device));
   e->rows = rows, e->cols = cols, e->ch = ch, e->n = (size_t)rows * cols;
   const size_t P = e->n * e->S, fb = P * ch;
+  if (!e->stream) HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   switch (e->algo) {
     case BGS_FRAME_DIFF: e->nring = 2; break;
     case BGS_WMM:
@@ -412,20 +451,19 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
     case BGS_DP_ADAPTIVE_MEDIAN: e->state_ch = 3; break;  // bgstate = the median image
     default: return fail(BGS_ERR_UNSUPPORTED, "algorithm %d is not implemented in this build", (int)e->algo);
   }
-  for (int i = 0; i < e->nring; ++i) HIP_TRY(hipMalloc((void**)&e->ring[i], fb));
-  if (e->state_ch) HIP_TRY(hipMalloc((void**)&e->bgstate, P * e->state_ch));
-  if (e->algo == BGS_ASBL) HIP_TRY(hipMalloc((void**)&e->bgstate2, P));
-  if (e->algo == BGS_SIGMA_DELTA) HIP_TRY(hipMalloc((void**)&e->bgstate2, P * 3));  // Vt
+  for (int i = 0; i < e->nring; ++i) DMALLOC(e->ring[i], fb);
+  if (e->state_ch) DMALLOC(e->bgstate, P * e->state_ch);
+  if (e->algo == BGS_ASBL) DMALLOC(e->bgstate2, P);
+  if (e->algo == BGS_SIGMA_DELTA) DMALLOC(e->bgstate2, P * 3);  // Vt
   if (e->algo == BGS_GMG) {
     const size_t F = (size_t)e->p.gmg_max_features;
-    HIP_TRY(hipMalloc((void**)&e->gmg_colors, P * F * sizeof(int32_t)));
-    HIP_TRY(hipMalloc((void**)&e->gmg_weights, P * F * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&e->gmg_nfeat, P));
+    DMALLOC(e->gmg_colors, P * F * sizeof(int32_t));
+    DMALLOC(e->gmg_weights, P * F * sizeof(float));
+    DMALLOC(e->gmg_nfeat, P);
   }
   if (e->algo == BGS_MOG1) {
     const size_t planes = ch == 3 ? bgs::mog1_planes<3>() : bgs::mog1_planes<1>();
     const size_t tiles = (P + bgs::kMog1Tile - 1) / bgs::kMog1Tile;
-    if (!e->stream) HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     const size_t bytes = tiles * planes * bgs::kMog1Tile * sizeof(float);
     uint8_t* d_zero = nullptr;  // a black frame for the probe launches
     const bool probing = e->probe_max > 1 && bytes >= ((size_t)768 << 20);
@@ -449,7 +487,6 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
     if (d_zero) (void)hipFree(d_zero);
     if (rc) return rc;
   }
-  if (!e->stream) HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   if (e->algo == BGS_MOG2) {
     int rc = mog2_allocate(e);
     if (rc) return rc;
@@ -466,7 +503,9 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
     int rc = lob_allocate(e);
     if (rc) return rc;
   }
-  if (!e->stream) HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  // Whatever allocation enqueued on e->stream (statistics counters, poison fills) is complete before the caller's first
+  // launch - which may come on ANOTHER stream (device path) that nothing else orders against this one.
+  HIP_TRY(hipStreamSynchronize(e->stream));
   return BGS_OK;
 }
 
@@ -476,9 +515,9 @@ int ensure_staging(bgs_engine* e) {
   HIP_TRY(hipHostMalloc((void**)&e->h_in, fb, hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&e->h_fg, e->n, hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&e->h_bg, fb, hipHostMallocDefault));
-  HIP_TRY(hipMalloc((void**)&e->d_in, fb));
-  HIP_TRY(hipMalloc((void**)&e->d_fg, e->n));
-  HIP_TRY(hipMalloc((void**)&e->d_bg, fb));
+  DMALLOC(e->d_in, fb);
+  DMALLOC(e->d_fg, e->n);
+  DMALLOC(e->d_bg, fb);
   return BGS_OK;
 }
 
@@ -887,6 +926,7 @@ int bgs_create(bgs_algo algo, const bgs_params* params, int hip_device, int n_st
   if (const char* env = getenv("BGS_XCD_SWIZZLE")) e->xcd_swizzle = atoi(env);
   if (const char* env = getenv("BGS_MOG2_SPARSE")) e->mog2_sparse = atoi(env);
   if (const char* env = getenv("BGS_PLACEMENT_PROBE")) e->probe_max = atoi(env);
+  if (const char* env = getenv("BGS_DEBUG_POISON")) e->poison = atoi(env) != 0;
   *out = e;
   return BGS_OK;
 }

@@ -54,9 +54,9 @@ int dp_allocate(bgs_engine* e) {
     });
     if (d_zero) (void)hipFree(d_zero);
     if (rc) return rc;
-    if (!probing) HIP_TRY(hipMemset(e->dp_state, 0, bytes));  // InitModel of the GMMs: everything 0 (the probe hands its pick over zeroed)
   }
-  if (e->bgstate) HIP_TRY(hipMemset(e->bgstate, 0, P * e->state_ch));
+  // Nothing is initialised here: InitModel runs in dp_process at a stream's first frame, on the launch stream (an
+  // allocation-time memset on another stream is not ordered before a kernel on the caller's / a non-blocking stream).
   return BGS_OK;
 }
 
@@ -69,6 +69,8 @@ int dp_process(bgs_engine* e, int first, int count, int64_t t, const uint8_t* d_
   a.low = p.dp_threshold, a.high = 2 * a.low, a.alpha = p.dp_alpha;  // HighThreshold = 2*LowThreshold, e.g. DPZivkovicAGMMBGS.cpp:58
   a.update = 0, a.xcd_swizzle = e->xcd_swizzle;
   const unsigned blocks = blocks_for(a.npix);
+  if (t == 0 && (e->algo == BGS_DP_ZIVKOVIC_AGMM || e->algo == BGS_DP_GRIMSON_GMM))  // InitModel: all modes and counts 0
+    hipLaunchKernelGGL(bgs::dp_gmm_clear_kernel, dim3(blocks), dim3(bgs::kBlock), 0, s, a, dp_planes_of(e));
   if (t == 0 && (e->algo == BGS_DP_WREN_GA || e->algo == BGS_DP_MEAN))  // InitModel from the first frame
     hipLaunchKernelGGL(bgs::dp_init_kernel, dim3(blocks), dim3(bgs::kBlock), 0, s, a, e->algo == BGS_DP_WREN_GA ? 4 : 3, 36.0f);
   if (t == 0 && e->algo == BGS_DP_ADAPTIVE_MEDIAN)

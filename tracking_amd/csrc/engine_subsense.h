@@ -68,23 +68,23 @@ int ss_allocate(bgs_engine* e) {
       return fail(BGS_ERR_UNSUPPORTED, "SuBSENSE frame-level analysis: rows and cols must be multiples of 8 (cv::resize INTER_AREA with an integer ratio)");
   }
   const size_t N = e->n, P = N * e->S, nS = (size_t)p.subsense_n_samples, C = (size_t)e->ch;
-  HIP_TRY(hipMalloc((void**)&d->color, P * nS * C));
-  HIP_TRY(hipMalloc((void**)&d->desc, P * nS * C * 2));
-  HIP_TRY(hipMalloc((void**)&d->lastColor, P * C));
-  HIP_TRY(hipMalloc((void**)&d->lastDesc, P * C * 2));
-  HIP_TRY(hipMalloc((void**)&d->req, P * 2 * 2));
-  HIP_TRY(hipMalloc((void**)&d->lut, (size_t)e->S * 256));
-  HIP_TRY(hipMalloc((void**)&d->sc, (size_t)e->S * sizeof(bgs::SsScalars)));
-  HIP_TRY(hipMalloc((void**)&d->changed, sizeof(int)));
+  DMALLOC(d->color, P * nS * C);
+  DMALLOC(d->desc, P * nS * C * 2);
+  DMALLOC(d->lastColor, P * C);
+  DMALLOC(d->lastDesc, P * C * 2);
+  DMALLOC(d->req, P * 2 * 2);
+  DMALLOC(d->lut, (size_t)e->S * 256);
+  DMALLOC(d->sc, (size_t)e->S * sizeof(bgs::SsScalars));
+  DMALLOC(d->changed, sizeof(int));
   const size_t words = (size_t)e->S * e->rows * ((e->cols + 63) / 64);
-  HIP_TRY(hipMalloc((void**)&d->mbits, words * 8));
-  HIP_TRY(hipMalloc((void**)&d->rbits, words * 8));
+  DMALLOC(d->mbits, words * 8);
+  DMALLOC(d->rbits, words * 8);
   HIP_TRY(hipHostMalloc((void**)&d->h_changed, sizeof(int), hipHostMallocDefault));
-  for (auto& q : d->f32) HIP_TRY(hipMalloc((void**)&q, P * sizeof(float)));
-  for (auto& q : d->u8) HIP_TRY(hipMalloc((void**)&q, P));
+  for (auto& q : d->f32) DMALLOC(q, P * sizeof(float));
+  for (auto& q : d->u8) DMALLOC(q, P);
   const size_t ds = (size_t)(e->rows / 8) * (e->cols / 8) * C * e->S + 4;
-  HIP_TRY(hipMalloc((void**)&d->dsLT, ds * sizeof(float)));
-  HIP_TRY(hipMalloc((void**)&d->dsST, ds * sizeof(float)));
+  DMALLOC(d->dsLT, ds * sizeof(float));
+  DMALLOC(d->dsST, ds * sizeof(float));
   d->pp.assign(e->S, 0);
   return BGS_OK;
 }
@@ -310,16 +310,16 @@ int lob_allocate(bgs_engine* e) {
   SsDevice* d = new SsDevice();
   e->ss = d;
   const size_t N = e->n, P = N * e->S, nS = (size_t)p.subsense_n_samples, C = (size_t)e->ch;
-  HIP_TRY(hipMalloc((void**)&d->color, P * nS * C));
-  HIP_TRY(hipMalloc((void**)&d->desc, P * nS * C * 2));
-  HIP_TRY(hipMalloc((void**)&d->lastColor, P * C));
-  HIP_TRY(hipMalloc((void**)&d->lastDesc, P * C * 2));
-  HIP_TRY(hipMalloc((void**)&d->curColor, P * C));
-  HIP_TRY(hipMalloc((void**)&d->curDesc, P * C * 2));
-  HIP_TRY(hipMalloc((void**)&d->req, P * 2 * 2));
-  HIP_TRY(hipMalloc((void**)&d->lut, (size_t)e->S * 256));
-  HIP_TRY(hipMalloc((void**)&d->u8[SS_LASTFG], P));
-  HIP_TRY(hipMalloc((void**)&d->u8[SS_RAW], P));
+  DMALLOC(d->color, P * nS * C);
+  DMALLOC(d->desc, P * nS * C * 2);
+  DMALLOC(d->lastColor, P * C);
+  DMALLOC(d->lastDesc, P * C * 2);
+  DMALLOC(d->curColor, P * C);
+  DMALLOC(d->curDesc, P * C * 2);
+  DMALLOC(d->req, P * 2 * 2);
+  DMALLOC(d->lut, (size_t)e->S * 256);
+  DMALLOC(d->u8[SS_LASTFG], P);
+  DMALLOC(d->u8[SS_RAW], P);
   d->medK = 9;  // DEFAULT_MEDIAN_BLUR_KERNEL_SIZE, BackgroundSubtractorLBSP.cpp:17
   d->pp.assign(e->S, 0);
   return BGS_OK;

@@ -358,6 +358,16 @@ __global__ __launch_bounds__(kBlock) void dp_median_kernel(const DpArgs a) {
   }
 }
 
+// Zivkovic / Grimson InitModel (dp/ZivkovicAGMM.cpp:77-97, GrimsonGMM.cpp:93-117): every mode field and the mode count of
+// the launch's pixels = 0.  Runs on the launch stream at a stream's first frame, like mog2_clear_kernel / mog1_clear_kernel.
+__global__ __launch_bounds__(kBlock) void dp_gmm_clear_kernel(const DpArgs a, int planes) {
+  const size_t gp = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (gp >= a.npix) return;
+  float* st = dp_plane0(a, gp, planes);
+  for (int q = 0; q < planes; ++q) st[q * kDpTile] = 0.f;
+  a.bstate[(size_t)a.first * a.n + gp] = 0;
+}
+
 // WrenGA / Mean: model = the first frame (InitModel); one lane per pixel
 __global__ __launch_bounds__(kBlock) void dp_init_kernel(const DpArgs a, int planes, float var0) {
   const size_t gp = (size_t)blockIdx.x * kBlock + threadIdx.x;
