@@ -236,6 +236,10 @@ int64_t bgs_frames_seen(const bgs_engine* e, int stream);
  * with HIP events on the launch stream when timing is enabled (bench.py's roofline leg). */
 int bgs_enable_kernel_timing(bgs_engine* e, int on);
 int bgs_kernel_timing(bgs_engine* e, double* avg_ms, int64_t* launches, const char** kernel_name);
+/* The same measurement launch by launch: copies the durations (ms) of the first min(cap, launches) timed launches since the
+ * last reset into ms[] and returns how many were written (negative = error).  bench.py commits the series behind its
+ * burst / sustained figures from this (profiles/rNN_mog2_launch_series.csv). */
+int64_t bgs_kernel_timing_series(bgs_engine* e, float* ms, int64_t cap);
 
 void bgs_destroy(bgs_engine* e);
 

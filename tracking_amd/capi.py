@@ -96,6 +96,7 @@ SYMBOLS = [
     ("bgs_frames_seen", C.c_int64, [_P, C.c_int]),
     ("bgs_enable_kernel_timing", C.c_int, [_P, C.c_int]),
     ("bgs_kernel_timing", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_char_p)]),
+    ("bgs_kernel_timing_series", C.c_int64, [_P, C.POINTER(C.c_float), C.c_int64]),
     ("bgs_destroy", None, [_P]),
     ("bgs_last_error", C.c_char_p, []),
     ("bgs_lbsp_describe_device", C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),

@@ -250,11 +250,94 @@ size_t mog2_state_bytes(const bgs_engine* e) {
   return P * bgs::kMog2Planes * sizeof(float);
 }
 
-// Model allocation with a PLACEMENT PROBE.  Measured on MI355X: the same kernel on the same layout runs in
-// one of two modes, ~5.5 TB/s or ~6.1 TB/s, depending only on which physical VRAM pages hipMalloc handed out (a physically
-// contiguous block always lands in the slow mode).  The model lives for the life of the stream, so it pays to look: allocate
-// 8 candidates, time the real update kernel on each (zero model, zero frame, dense traffic), keep the fastest, free the
-// rest.  Costs ~0.2 s and, transiently, 8x the model's memory; skipped for models too small to be HBM-bound.
+// Model allocation with a PLACEMENT PROBE for the big, long-lived models (MOG2, MOG1, dp GMMs).
+// Measured on MI355X (profiles/r02_placement_probe.txt): the same kernel on the same layout streams a multi-GB
+// model at one of 2-3 speeds (32 x 1080p MOG2: 2.185 / 2.40 / 2.43 ms per dense launch) depending only on which physical VRAM
+// hipMalloc handed out.  The speed belongs to the ALLOCATION: re-timing the same candidates in reverse and again in forward
+// order gives the same numbers per candidate (BGS_DEBUG_PROBE=2), and the first candidate measured is usually not the fast
+// one.  The model lives as long as the camera stream, so it pays to look: allocate candidates one after the other (the
+// losers stay allocated meanwhile, otherwise hipMalloc would hand the same pages out again), time `run` on each - one dense
+// pass of the kernel that will stream the buffer, on e->stream - and keep the fastest.
+//   * stops at the first candidate within 2 % of `expect_ms` (the fast class, when the caller knows it): usually the 2nd;
+//   * never takes more than the device has to spare: a further candidate is only tried while free memory stays above
+//     max(2 GiB, 1/16 of the device) AFTER it, so co-resident engines are not pushed out of memory;
+//   * skipped below 768 MB (such a model is not HBM-bound: it sits in the 256 MiB Infinity Cache for a good part).
+// The buffer is handed over with unspecified contents: every model is initialised at its first frame on the launch stream.
+template <class Run>
+int probe_allocate(bgs_engine* e, void** out, size_t bytes, double expect_ms, Run run) {
+  const int tries = std::min(e->probe_max, 16);
+  if (tries <= 1 || bytes < ((size_t)768 << 20)) return dmalloc(e, out, bytes);
+  hipEvent_t ev0, ev1;
+  HIP_TRY(hipEventCreate(&ev0));
+  HIP_TRY(hipEventCreate(&ev1));
+  const int debug = getenv("BGS_DEBUG_PROBE") ? atoi(getenv("BGS_DEBUG_PROBE")) : 0;
+  void* cand[16] = {nullptr};
+  int n = 0, best = -1, rc = BGS_OK;
+  float tmin = 1e30f;
+  auto time_one = [&](void* buf, float* ms_out) -> int {
+    int r = BGS_OK;
+    for (int i = 0; i < 2 && !r; ++i) r = run(buf);
+    (void)hipEventRecord(ev0, e->stream);
+    for (int i = 0; i < 4 && !r; ++i) r = run(buf);
+    (void)hipEventRecord(ev1, e->stream);
+    if (r) return r;
+    if (hipEventSynchronize(ev1) != hipSuccess) return fail(BGS_ERR_HIP, "placement probe failed: %s", hipGetErrorString(hipGetLastError()));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    *ms_out = ms / 4;
+    return BGS_OK;
+  };
+  for (; n < tries; ++n) {
+    if (n > 0) {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) break;
+      if (free_b < bytes + std::max((size_t)2 << 30, total_b / 16)) break;  // leave the device room to breathe
+    }
+    if (hipMalloc(&cand[n], bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      cand[n] = nullptr;
+      break;  // out of memory: settle for what we have
+    }
+    (void)hipMemsetAsync(cand[n], 0, bytes, e->stream);
+    rc = time_one(cand[n], &e->probe_ms[n]);
+    if (rc) {
+      ++n;
+      break;
+    }
+    if (e->probe_ms[n] < tmin) tmin = e->probe_ms[n], best = n;
+    if (expect_ms > 0 && e->probe_ms[n] <= 1.02 * expect_ms && debug < 2) {
+      ++n;
+      break;
+    }
+  }
+  if (debug) {
+    fprintf(stderr, "[bgs] placement probe (%zu MB, expected %.3f): %d candidates, ms per dense launch:", bytes >> 20, expect_ms, n);
+    for (int i = 0; i < n; ++i) fprintf(stderr, " %.3f%s", e->probe_ms[i], i == best ? "*" : "");
+    fprintf(stderr, "\n");
+  }
+  if (debug >= 2 && !rc) {  // de-confounding passes: the same candidates again, in reverse and then in the original order
+    for (int pass = 0; pass < 2; ++pass) {
+      float again[16] = {0};
+      for (int j = 0; j < n; ++j) {
+        const int i = pass == 0 ? n - 1 - j : j;
+        (void)time_one(cand[i], &again[i]);
+      }
+      fprintf(stderr, "[bgs] placement probe re-time (%s order), ms by candidate:", pass == 0 ? "reverse" : "forward");
+      for (int i = 0; i < n; ++i) fprintf(stderr, " %.3f", again[i]);
+      fprintf(stderr, "\n");
+    }
+  }
+  e->probe_n = n, e->probe_pick = best;
+  for (int i = 0; i < n; ++i)
+    if (cand[i] && (i != best || rc)) (void)hipFree(cand[i]);
+  (void)hipEventDestroy(ev0), (void)hipEventDestroy(ev1);
+  if (rc) return rc;
+  if (best < 0) return fail(BGS_ERR_NOMEM, "out of device memory for the model (%zu bytes)", bytes);
+  if (e->poison) HIP_TRY(hipMemsetAsync(cand[best], 0xA5, bytes, e->stream));
+  *out = cand[best];
+  return BGS_OK;
+}
+
 int mog2_allocate(bgs_engine* e) {
   const size_t P = e->n * e->S, bytes = mog2_state_bytes(e);
   HIP_TRY(hipMalloc((void**)&e->d_stat, 2 * sizeof(unsigned)));
@@ -266,154 +349,29 @@ int mog2_allocate(bgs_engine* e) {
     DMALLOC(e->mog2_nmodes, P);
     return BGS_OK;
   }
-  const int tries = std::min(e->probe_max, 16);
-  if (tries <= 1 || bytes < ((size_t)768 << 20)) {
-    DMALLOC(e->mog2_state, bytes);
-    return BGS_OK;
+  const bool probing = e->probe_max > 1 && bytes >= ((size_t)768 << 20);
+  uint8_t* d_frame = nullptr;  // a black frame for the probe launches
+  if (probing) {
+    HIP_TRY(hipMalloc((void**)&d_frame, P * 3));
+    HIP_TRY(hipMemsetAsync(d_frame, 0, P * 3, e->stream));
   }
-  uint8_t* d_frame = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_frame, P * 3));
-  HIP_TRY(hipMemsetAsync(d_frame, 0, P * 3, e->stream));
-  hipEvent_t ev0, ev1;
-  HIP_TRY(hipEventCreate(&ev0));
-  HIP_TRY(hipEventCreate(&ev1));
-  float* cand[16] = {nullptr};
   const int saved_sparse = e->mog2_sparse;
   e->mog2_sparse = 0;  // probe with the dense traffic pattern: that is what a busy scene produces
-  // A dense launch moves 206 B/pixel; on a good placement this part sustains ~6.15 TB/s.  Now and then all
-  // candidates of a round come out slow (seen: eight at 2.45 ms where 2.2 ms is normal), so a round whose best is more than
-  // 6 % off that mark is followed by another one - up to three - keeping the best buffer found so far.
+  // a dense launch moves 206 B/pixel; on a good placement this part sustains ~6.15 TB/s
   const double expect_ms = 206.0 * (double)P / 6.15e12 * 1e3;
-  int n = 0, best = 0, rc = BGS_OK;
-  float* keep = nullptr;
-  float keep_ms = 1e30f;
-  for (int round = 0; round < 3 && !rc; ++round) {
-    n = 0, best = -1;
-    for (; n < tries; ++n) {
-      if (hipMalloc((void**)&cand[n], bytes) != hipSuccess) {
-        (void)hipGetLastError();
-        cand[n] = nullptr;
-        break;  // out of memory: settle for what we have
-      }
-      e->mog2_state = cand[n];
-      bgs::Mog2Args m{};
-      mog2_fill_args(e, m, 0.05);
-      m.frame = d_frame, m.state_off = 0, m.npix = P;
-      mog2_clear(e, m, e->stream);
-      for (int i = 0; i < 2 && !rc; ++i) rc = launch_mog2(e, m, e->stream, false);
-      (void)hipEventRecord(ev0, e->stream);
-      for (int i = 0; i < 4 && !rc; ++i) rc = launch_mog2(e, m, e->stream, false);
-      (void)hipEventRecord(ev1, e->stream);
-      if (rc || hipEventSynchronize(ev1) != hipSuccess) {
-        rc = rc ? rc : fail(BGS_ERR_HIP, "placement probe failed: %s", hipGetErrorString(hipGetLastError()));
-        ++n;
-        break;
-      }
-      float ms = 0;
-      (void)hipEventElapsedTime(&ms, ev0, ev1);
-      e->probe_ms[n] = ms / 4;
-      if (ms / 4 < keep_ms) keep_ms = ms / 4, best = n;
-      // no early exit inside a round: there are more than two speed classes (2.83 / 2.55 / 2.30 ms have been seen side by
-      // side), so every candidate is measured and the fastest kept
-    }
-    if (getenv("BGS_DEBUG_PROBE") && atoi(getenv("BGS_DEBUG_PROBE")) >= 2 && !rc) {
-      // de-confounding pass: the same candidates again, in REVERSE order and then in the original order, so a
-      // "fast placement" that is really "measured first after idle" shows up as such
-      for (int pass = 0; pass < 2; ++pass) {
-        fprintf(stderr, "[bgs] placement probe re-time (%s order), ms/launch by candidate:", pass == 0 ? "reverse" : "forward");
-        float again[16] = {0};
-        for (int j = 0; j < n; ++j) {
-          const int i = pass == 0 ? n - 1 - j : j;
-          e->mog2_state = cand[i];
-          bgs::Mog2Args m{};
-          mog2_fill_args(e, m, 0.05);
-          m.frame = d_frame, m.state_off = 0, m.npix = P;
-          for (int q = 0; q < 2; ++q) (void)launch_mog2(e, m, e->stream, false);
-          (void)hipEventRecord(ev0, e->stream);
-          for (int q = 0; q < 4; ++q) (void)launch_mog2(e, m, e->stream, false);
-          (void)hipEventRecord(ev1, e->stream);
-          (void)hipEventSynchronize(ev1);
-          float ms = 0;
-          (void)hipEventElapsedTime(&ms, ev0, ev1);
-          again[i] = ms / 4;
-        }
-        for (int i = 0; i < n; ++i) fprintf(stderr, " %.3f", again[i]);
-        fprintf(stderr, "\n");
-      }
-    }
-    for (int i = 0; i < n; ++i) {
-      if (i == best && !rc) {
-        if (keep) (void)hipFree(keep);
-        keep = cand[i];
-      } else if (cand[i]) {
-        (void)hipFree(cand[i]);
-      }
-      cand[i] = nullptr;
-    }
-    if (getenv("BGS_DEBUG_PROBE")) {
-      fprintf(stderr, "[bgs] placement probe round %d: %d candidates, ms/launch:", round, n);
-      for (int i = 0; i < n; ++i) fprintf(stderr, " %.3f%s", e->probe_ms[i], i == best ? "*" : "");
-      fprintf(stderr, "  (kept %.3f, expected %.3f)\n", keep_ms, expect_ms);
-    }
-    if (!keep || keep_ms <= 1.06 * expect_ms || bytes < ((size_t)2 << 30)) break;
-  }
+  float* saved_state = e->mog2_state;
+  int rc = probe_allocate(e, (void**)&e->mog2_state, bytes, expect_ms, [&](void* cand) -> int {
+    e->mog2_state = (float*)cand;
+    bgs::Mog2Args m{};
+    mog2_fill_args(e, m, 0.05);
+    m.frame = d_frame, m.state_off = 0, m.npix = P;
+    const int r = launch_mog2(e, m, e->stream, false);
+    e->mog2_state = saved_state;
+    return r;
+  });
   e->mog2_sparse = saved_sparse;
-  e->probe_n = n, e->probe_pick = best;
-  e->mog2_state = rc ? nullptr : keep;
-  if (rc && keep) (void)hipFree(keep);
-  (void)hipFree(d_frame);
-  (void)hipEventDestroy(ev0), (void)hipEventDestroy(ev1);
-  if (!rc && !e->mog2_state) return fail(BGS_ERR_NOMEM, "out of device memory for the MOG2 model (%zu bytes)", bytes);
+  if (d_frame) (void)hipFree(d_frame);
   return rc;
-}
-
-// The placement probe of mog2_allocate for any other big, long-lived model: `run(candidate)` must enqueue ONE dense pass of the
-// kernel that will stream the buffer (on e->stream) and return a bgs status.  Picks the fastest of up to probe_max candidates.
-template <class Run>
-int probe_allocate(bgs_engine* e, void** out, size_t bytes, Run run) {
-  const int tries = std::min(e->probe_max, 16);
-  if (tries <= 1 || bytes < ((size_t)768 << 20)) return dmalloc(e, out, bytes);
-  hipEvent_t ev0, ev1;
-  HIP_TRY(hipEventCreate(&ev0));
-  HIP_TRY(hipEventCreate(&ev1));
-  void* cand[16] = {nullptr};
-  int n = 0, best = 0, rc = BGS_OK;
-  float tmin = 1e30f;
-  for (; n < tries; ++n) {
-    if (hipMalloc(&cand[n], bytes) != hipSuccess) {
-      (void)hipGetLastError();
-      break;  // out of memory: settle for what we have
-    }
-    (void)hipMemsetAsync(cand[n], 0, bytes, e->stream);
-    for (int i = 0; i < 2 && !rc; ++i) rc = run(cand[n]);
-    (void)hipEventRecord(ev0, e->stream);
-    for (int i = 0; i < 4 && !rc; ++i) rc = run(cand[n]);
-    (void)hipEventRecord(ev1, e->stream);
-    if (rc || hipEventSynchronize(ev1) != hipSuccess) {
-      rc = rc ? rc : fail(BGS_ERR_HIP, "placement probe failed: %s", hipGetErrorString(hipGetLastError()));
-      ++n;
-      break;
-    }
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, ev0, ev1);
-    e->probe_ms[n] = ms / 4;
-    if (ms < tmin) tmin = ms, best = n;
-  }
-  e->probe_n = n, e->probe_pick = best;
-  for (int i = 0; i < n; ++i)
-    if (i != best || rc) (void)hipFree(cand[i]);
-  (void)hipEventDestroy(ev0), (void)hipEventDestroy(ev1);
-  if (rc) return rc;
-  if (!n) return fail(BGS_ERR_NOMEM, "out of device memory for the model (%zu bytes)", bytes);
-  HIP_TRY(hipMemsetAsync(cand[best], 0, bytes, e->stream));  // hand the model over in its initial (all-zero) state
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  *out = cand[best];
-  if (getenv("BGS_DEBUG_PROBE")) {
-    fprintf(stderr, "[bgs] placement probe (%zu MB):", bytes >> 20);
-    for (int i = 0; i < n; ++i) fprintf(stderr, " %.3f%s", e->probe_ms[i], i == best ? "*" : "");
-    fprintf(stderr, " ms per dense launch\n");
-  }
-  return BGS_OK;
 }
 
 #include "engine_subsense.h"
@@ -471,7 +429,7 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
       HIP_TRY(hipMalloc((void**)&d_zero, P * ch));
       HIP_TRY(hipMemsetAsync(d_zero, 0, P * ch, e->stream));
     }
-    int rc = probe_allocate(e, (void**)&e->mog1_state, bytes, [&](void* cand) -> int {
+    int rc = probe_allocate(e, (void**)&e->mog1_state, bytes, 0.0, [&](void* cand) -> int {
       bgs::Mog1Args m{};
       m.state = (float*)cand, m.state_off = 0, m.npix = P, m.frame = d_zero, m.fg = nullptr, m.fg_bits = nullptr;
       m.alpha = 0.05f, m.T = 0.7f, m.vT = 6.25f, m.w0 = 0.05f, m.sk0 = 0.001f, m.var0 = 900.f, m.minVar = 225.f;
@@ -1195,6 +1153,19 @@ int bgs_kernel_timing(bgs_engine* e, double* avg_ms, int64_t* launches, const ch
   if (launches) *launches = (int64_t)e->events.size();
   if (kernel_name) *kernel_name = e->kernel_name;
   return BGS_OK;
+}
+
+int64_t bgs_kernel_timing_series(bgs_engine* e, float* ms, int64_t cap) {
+  if (!e || !ms || cap < 0) return fail(BGS_ERR_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(e->device));
+  int64_t n = 0;
+  for (auto& ev : e->events) {
+    if (n >= cap) break;
+    HIP_TRY(hipEventSynchronize(ev.second));
+    HIP_TRY(hipEventElapsedTime(&ms[n], ev.first, ev.second));
+    ++n;
+  }
+  return n;
 }
 
 void bgs_destroy(bgs_engine* e) {

@@ -37,9 +37,9 @@ int dp_allocate(bgs_engine* e) {
     if (probing) {
       HIP_TRY(hipMalloc((void**)&d_zero, P * 3));
       HIP_TRY(hipMemsetAsync(d_zero, 0, P * 3, e->stream));
-      if (e->bgstate) HIP_TRY(hipMemsetAsync(e->bgstate, 0, P * e->state_ch, e->stream));
+      if (e->bgstate) HIP_TRY(hipMemsetAsync(e->bgstate, 0, P * e->state_ch, e->stream));  // the probe kernels read the mode counts
     }
-    int rc = probe_allocate(e, (void**)&e->dp_state, bytes, [&](void* cand) -> int {
+    int rc = probe_allocate(e, (void**)&e->dp_state, bytes, 0.0, [&](void* cand) -> int {
       bgs::DpArgs a{};
       a.frame = d_zero, a.state = (float*)cand, a.bstate = e->bgstate, a.fg = nullptr, a.fg_bits = nullptr;
       a.n = e->n, a.npix = P, a.first = 0, a.low = 25.f, a.high = 50.f, a.alpha = 0.01f, a.update = 0, a.xcd_swizzle = e->xcd_swizzle;

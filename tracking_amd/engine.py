@@ -114,6 +114,14 @@ class Engine:
         capi.check(capi.lib().bgs_kernel_timing(self._h, C.byref(ms), C.byref(n), C.byref(name)))
         return ms.value, n.value, (name.value or b"").decode()
 
+    def kernel_timing_series(self, cap=16384):
+        """Per-launch durations (ms) of the dominant kernel since timing was enabled."""
+        buf = (C.c_float * cap)()
+        n = capi.lib().bgs_kernel_timing_series(self._h, buf, cap)
+        if n < 0:
+            capi.check(int(n))
+        return np.frombuffer(buf, dtype=np.float32, count=int(n)).copy()
+
 
 # -- stand-alone device primitives ---------------------------------------------------------------------------------
 def lbsp_describe_device(img, lut, out=None, device=0, hip_stream=None):
