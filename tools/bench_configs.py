@@ -209,6 +209,17 @@ def main():
         run_subsense(2)
         run_subsense(2, kind="smooth")
         return
+    if args.only == "byte":  # the byte-stream kernels only, no CPU leg (kernel iteration)
+        run(capi.WMV, "WeightedMovingVarianceBGS", 2160, 3840, S, 10, cpu_frames=0)
+        run(capi.WMV, "WeightedMovingVarianceBGS (S_sat: every pixel moves)", 2160, 3840, S, 10, cpu_frames=0, kind="sat")
+        run(capi.ABL, "AdaptiveBackgroundLearning", 2160, 3840, S, 10, borrow=False, cpu_frames=0)
+        run(capi.ABL, "AdaptiveBackgroundLearning (S_sat)", 2160, 3840, S, 10, borrow=False, cpu_frames=0, kind="sat")
+        run(capi.WMM, "WeightedMovingMeanBGS (+bg)", 2160, 3840, S, 13, want_bg=True, cpu_frames=0)
+        run(capi.WMM, "WeightedMovingMeanBGS (mask only)", 2160, 3840, S, 10, cpu_frames=0)
+        run(capi.FRAME_DIFF, "FrameDifferenceBGS", 2160, 3840, S, 7, cpu_frames=0)
+        run(capi.SIGMA_DELTA, "SigmaDeltaBGS", 2160, 3840, S, 16, borrow=False, cpu_frames=0)
+        run(capi.ASBL, "AdaptiveSelectiveBackgroundLearning", 2160, 3840, S, 6, borrow=False, cpu_frames=0)
+        return
     if args.only == "lbsp":
         run_lbsp()
         return

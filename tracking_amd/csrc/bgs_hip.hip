@@ -74,6 +74,10 @@ struct bgs_engine {
   // byte state (SFD background, ABL/ASBL background): [S][n*state_ch]
   uint8_t* bgstate = nullptr;
   int state_ch = 0;
+  uint8_t* abl_lut = nullptr;   // ABL: 256 x 256 table of background bytes for the current alpha (kernel_pointwise.h)
+  double abl_lut_alpha = 0;     // the alpha it was built for
+  bool abl_lut_valid = false;
+  int n_cu = 256;
   uint8_t* bgstate2 = nullptr;  // ASBL: second buffer of the ping-pong pair (the 3x3 median reads neighbours' OLD background)
   std::vector<uint8_t> flip;    // ASBL: which buffer holds the current background, per stream
   float* mog1_state = nullptr;  // MOG1 model (kernel_mog1.h, tiled)
@@ -118,6 +122,7 @@ void ss_free(bgs_engine* e);  // engine_subsense.h
 void free_all(bgs_engine* e) {
   for (auto& r : e->ring)
     if (r) (void)hipFree(r), r = nullptr;
+  if (e->abl_lut) (void)hipFree(e->abl_lut), e->abl_lut = nullptr, e->abl_lut_valid = false;
   void* dev[] = {e->dp_state, e->gmg_colors, e->gmg_weights, e->gmg_nfeat, e->bgstate, e->bgstate2, e->mog1_state, e->mog2_state, e->mog2_nmodes, e->d_in, e->d_fg, e->d_bg};
   for (void* d : dev)
     if (d) (void)hipFree(d);
@@ -377,6 +382,17 @@ int mog2_allocate(bgs_engine* e) {
 #include "engine_subsense.h"
 #include "engine_dp.h"
 
+// (Re)build ABL's lookup table for the current alpha on e->stream.  Called when the geometry is set and when bgs_set_params
+// changes alpha; both drain the device first / the stream after, so no launch on any stream sees a half-written table.
+int abl_build_lut(bgs_engine* e) {
+  if (!e->abl_lut) HIP_TRY(hipMalloc((void**)&e->abl_lut, 256 * 256));
+  hipLaunchKernelGGL(bgs::abl_lut_kernel, dim3(256), dim3(bgs::kBlock), 0, e->stream, e->abl_lut, e->p.alpha, 1 - e->p.alpha);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->abl_lut_alpha = e->p.alpha, e->abl_lut_valid = true;
+  return BGS_OK;
+}
+
 int allocate(bgs_engine* e, int rows, int cols, int ch) {
   if (rows <= 0 || cols <= 0) return fail(BGS_ERR_INVALID, "bad geometry %dx%d", rows, cols);
   if (ch != 1 && ch != 3) return fail(BGS_ERR_UNSUPPORTED, "channels must be 1 or 3, got %d", ch);
@@ -411,6 +427,12 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
   }
   for (int i = 0; i < e->nring; ++i) DMALLOC(e->ring[i], fb);
   if (e->state_ch) DMALLOC(e->bgstate, P * e->state_ch);
+  if (e->algo == BGS_ABL) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, e->device) == hipSuccess && prop.multiProcessorCount > 0) e->n_cu = prop.multiProcessorCount;
+    int rc = abl_build_lut(e);
+    if (rc) return rc;
+  }
   if (e->algo == BGS_ASBL) DMALLOC(e->bgstate2, P);
   if (e->algo == BGS_SIGMA_DELTA) DMALLOC(e->bgstate2, P * 3);  // Vt
   if (e->algo == BGS_GMG) {
@@ -590,8 +612,23 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
         a.alpha = p.alpha, a.beta = 1 - p.alpha;
         const int64_t cnt = e->counter[first];
         a.update = ((p.limit > 0 && p.limit < cnt) || p.limit == -1) ? 1 : 0;
-        const int G = pick_group(a, C);
-        LAUNCH_FRAME_KERNEL(abl_kernel, "abl_kernel");
+        const int G = pick_group(a, C, 4);  // 4 pixels per lane: 42 VGPRs -> two 1024-lane workgroups per CU (16: 128 VGPRs, one); measured 0.126 vs 0.134 ms
+        {
+          Timed t__(e, s, "abl_kernel");
+          const size_t per_tile = (size_t)bgs::kAblBlock * G, ntiles = (npix + per_tile - 1) / per_tile;
+          // persistent: exactly as many workgroups as are resident at once (1 or 2 per CU, by registers), each walking its share of the tiles
+          const dim3 block(bgs::kAblBlock);
+#define ABL_CASE(GV, CV, UV)                                                                                                               \
+  if (G == GV && C == CV && (a.update != 0) == UV) {                                                                                       \
+    static int per_cu = 0;                                                                                                                 \
+    if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bgs::abl_kernel<GV, CV, UV>, bgs::kAblBlock, 0) != hipSuccess || per_cu < 1)) per_cu = 1; \
+    const dim3 grid((unsigned)std::min<size_t>(ntiles, (size_t)per_cu * e->n_cu));                                                        \
+    hipLaunchKernelGGL((bgs::abl_kernel<GV, CV, UV>), grid, block, 0, s, a, (const uint8_t*)e->abl_lut);                                   \
+  }
+          ABL_CASE(16, 3, true) ABL_CASE(4, 3, true) ABL_CASE(1, 3, true) ABL_CASE(16, 1, true) ABL_CASE(4, 1, true) ABL_CASE(1, 1, true)
+          ABL_CASE(16, 3, false) ABL_CASE(4, 3, false) ABL_CASE(1, 3, false) ABL_CASE(16, 1, false) ABL_CASE(4, 1, false) ABL_CASE(1, 1, false)
+#undef ABL_CASE
+        }
         if (a.update && p.limit > 0 && p.limit < cnt)
           for (int i = first; i < first + count; ++i) e->counter[i]++;
       }
@@ -912,6 +949,12 @@ int bgs_set_params(bgs_engine* e, const bgs_params* params) {
       p.dp_sampling_rate = old.dp_sampling_rate, p.learning_frames = old.learning_frames;
     }
     if (e->algo == BGS_GMG) p.gmg_max_features = old.gmg_max_features;  // sizes the histogram planes
+    if (e->algo == BGS_ABL && (!e->abl_lut_valid || p.alpha != e->abl_lut_alpha)) {
+      // a launch still in flight on some stream may be reading the table: let the device drain before it is rewritten
+      if (hipSetDevice(e->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(BGS_ERR_HIP, "device sync failed");
+      rc = abl_build_lut(e);
+      if (rc) return rc;
+    }
   }
   return BGS_OK;
 }

@@ -192,27 +192,60 @@ __global__ __launch_bounds__(kBlock) void wmv_kernel(const FrameArgs a) {
   gray_thr_store<G, C>(d, a, p0, active, a.fg_bits != nullptr);
 }
 
-template <int G, int C>
-__global__ __launch_bounds__(kBlock) void abl_kernel(const FrameArgs a) {
-  const size_t p0 = (xcd_block(a.xcd_swizzle) * kBlock + threadIdx.x) * G;
-  const bool active = p0 < a.npix;
-  PxGroup<G, C> d;
-  if (active) {
-    PxGroup<G, C> x, bgq;
-    x.load(a.cur + p0 * C);
-    bgq.load(a.p1 + p0 * C);
-#pragma unroll
-    for (int i = 0; i < G * C; ++i) {
-      const int xi = x.b.get(i), bi = bgq.b.get(i);
-      if (a.update) bgq.b.set(i, sat_u8(add_weighted(to_unit(xi), a.alpha, to_unit(bi), a.beta) * 255.f));  // :54-58
-      // :50, :64-65: saturate(|i/255 - b/255| * 255) in float == |i - b| for all 65 536 byte pairs (checked exhaustively,
-      // CPU test test_unit_absdiff_is_integer_absdiff), so the float round trip is skipped
-      d.b.set(i, abs(xi - bi));
+// AdaptiveBackgroundLearning.  The new background byte, sat_u8(addWeighted(i/255, alpha, b/255, 1-alpha) * 255) (:54-58), is a
+// pure function of the two bytes for a fixed alpha, and its f64 arithmetic (~25 VALU instructions per byte) made the kernel
+// issue-bound at 0.52-0.58 of the HBM peak (profiles/r01_bench_configs.txt; a 10 B/pixel stream leaves ~20 lane-instructions
+// per byte before VALU issue, not HBM, sets the time).  So the 256 x 256 answers are tabulated ONCE per alpha by abl_lut_kernel
+// - with exactly that arithmetic - and the frame kernel looks them up in LDS:
+//   * table in LDS with a row stride of 260 bytes (65 dwords: rows of neighbouring background values start on different banks);
+//   * 1024-lane persistent workgroups (2 per CU at 65 KB of LDS each) that walk the launch tile by tile, so the 64 KB table load
+//     is paid once per workgroup, not once per 12 KB of frame;
+//   * per byte: one ds_read_u8 + ~8 integer instructions (the mask side |i - b| -> gray -> threshold was integer already).
+constexpr int kAblLutStride = 260;
+constexpr int kAblBlock = 1024;
+
+// lut[b * 256 + x] = the background byte AdaptiveBackgroundLearning.cpp:54-58 produces from input byte x and background byte b
+__global__ __launch_bounds__(kBlock) void abl_lut_kernel(uint8_t* lut, double alpha, double beta) {
+  const int x = threadIdx.x, b = blockIdx.x;
+  lut[b * 256 + x] = (uint8_t)sat_u8(add_weighted(to_unit(x), alpha, to_unit(b), beta) * 255.f);
+}
+
+template <int G, int C, bool UPDATE>
+__global__ __launch_bounds__(kAblBlock) void abl_kernel(const FrameArgs a, const uint8_t* __restrict__ lut) {
+  __shared__ uint8_t T[UPDATE ? 256 * kAblLutStride : 16];
+  if constexpr (UPDATE) {
+    const uint4* src = reinterpret_cast<const uint4*>(lut);
+    for (int i = threadIdx.x; i < 256 * 16; i += kAblBlock) {  // 16 x 16-byte pieces per row; 260 = 65 dwords keeps dword alignment
+      const uint4 v = src[i];
+      uint32_t* dst = reinterpret_cast<uint32_t*>(T + (i >> 4) * kAblLutStride + (i & 15) * 16);
+      dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
     }
-    if (a.update) bgq.store(a.state_out + p0 * C);
-    if (a.bg) bgq.store(a.bg + p0 * C);
+    __syncthreads();
   }
-  gray_thr_store<G, C>(d, a, p0, active, a.fg_bits != nullptr);
+  const size_t per_tile = (size_t)kAblBlock * G;
+  const size_t ntiles = (a.npix + per_tile - 1) / per_tile;
+  const bool packed = a.fg_bits != nullptr;
+  for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const size_t p0 = (tile * kAblBlock + threadIdx.x) * G;
+    const bool active = p0 < a.npix;
+    PxGroup<G, C> d;
+    if (active) {
+      PxGroup<G, C> x, bgq;
+      x.load(a.cur + p0 * C);
+      bgq.load(a.p1 + p0 * C);
+#pragma unroll
+      for (int i = 0; i < G * C; ++i) {
+        const int xi = x.b.get(i), bi = bgq.b.get(i);
+        if constexpr (UPDATE) bgq.b.set(i, T[bi * kAblLutStride + xi]);  // :54-58
+        // :50, :64-65: saturate(|i/255 - b/255| * 255) in float == |i - b| for all 65 536 byte pairs (checked exhaustively,
+        // CPU test test_unit_absdiff_is_integer_absdiff), so the float round trip is skipped
+        d.b.set(i, abs(xi - bi));
+      }
+      if constexpr (UPDATE) bgq.store(a.state_out + p0 * C);
+      if (a.bg) bgq.store(a.bg + p0 * C);
+    }
+    gray_thr_store<G, C>(d, a, p0, active, packed);
+  }
 }
 
 // K-N4 SigmaDeltaBGS::process over sdLaMa091 (package_bgs/bl/SigmaDeltaBGS.cpp:41-52, sdLaMa091.cpp:529-633): pure byte arithmetic,
