@@ -334,6 +334,23 @@ def test_subsense_golden_frames(golden_frames):
     check_subsense_state(eng, orc, golden_frames.shape[1], golden_frames.shape[2])
 
 
+def test_subsense_flood_fill_finish_kernel_path(golden_frames, tmp_path):
+    """BGS_SS_FLOOD_BATCH=0: no batch launches at all, SuBSENSE's hole filling is done entirely by ss_flood_finish_kernel (the
+    path that otherwise only runs for masks the 12-launch batch does not converge on).  The knob is read once per process,
+    hence the child process."""
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from gpu_helpers import run_pair, check_subsense_state, capi\n"
+            "f = np.load(%r)['frames'][:10]\n"
+            "eng, orc, _ = run_pair(capi.SUBSENSE, f)\n"
+            "check_subsense_state(eng, orc, f.shape[1], f.shape[2])\n"
+            "print('finish-kernel path OK')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)),
+                                                   os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frames_96x80.npz"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BGS_SS_FLOOD_BATCH="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "finish-kernel path OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_subsense_qvga_with_frame_level_block():
     """320x240 = QVGA: learning-rate scaling + auto model reset enabled; a scene cut at frame 12 triggers refreshModel(0.1)."""
     a = synth.numpy_frames("surv", 30, 240, 320, seed=21) // 6          # dark scene, long enough for ST (1/25) and LT (1/30) to part
@@ -407,10 +424,12 @@ def test_subsense_rejects_unsupported_inputs():
         Engine(capi.SUBSENSE).process(np.zeros((243, 325, 3), np.uint8))  # >= QVGA and not a multiple of 8
 
 
-@pytest.mark.parametrize("shape", [(64, 64), (37, 53), (1, 1), (3, 200), (130, 257), (200, 70)])
+@pytest.mark.parametrize("shape", [(64, 64), (37, 53), (1, 1), (3, 200), (130, 257), (200, 70), (300, 520)])
 def test_floodfill_from_origin_vs_oracle(shape):
     """cv::floodFill(mask, Point(0,0), 255): mazes with long snaking corridors, enclosed holes, origin on either value,
-    sizes that are not multiples of the 64x64 bit-packed tile."""
+    sizes that are not multiples of the 64x64 bit-packed tile.  The serpentine walls make the fill cross tile borders far more
+    often than the fixed batch of relaxation launches covers (kSsFloodBatch = 12), so ss_flood_finish_kernel does the rest
+    (at 300x520: 45 tiles over the finish kernel's 16 waves)."""
     torch = _torch()
     from tracking_amd.engine import mask_morph_device, MORPH_FLOODFILL_ORIGIN, MORPH_MEDIAN_BINARY
     rng = np.random.default_rng(shape[0] * 1000 + shape[1])

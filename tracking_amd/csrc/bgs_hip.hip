@@ -1254,22 +1254,20 @@ int bgs_mask_morph_device(int hip_device, const void* d_src, void* d_dst, int ro
   if (op == 4) {  // cv::floodFill(img, Point(0,0), 255)
     const int W64 = (cols + 63) / 64, tilesY = (rows + 63) / 64;
     uint64_t *mb = nullptr, *rb = nullptr;
-    int* ch = nullptr;
+    int* fl = nullptr;
     HIP_TRY(hipMalloc((void**)&mb, (size_t)rows * W64 * 8));
     HIP_TRY(hipMalloc((void**)&rb, (size_t)rows * W64 * 8));
-    HIP_TRY(hipMalloc((void**)&ch, sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&fl, bgs::kSsFloodFlags * sizeof(int)));
+    (void)hipMemsetAsync(fl, 0, bgs::kSsFloodFlags * sizeof(int), s);
     hipLaunchKernelGGL(bgs::ss_flood_pack_kernel, dim3(blocks_for((size_t)rows * W64 * bgs::kWave)), dim3(bgs::kBlock), 0, s, (const uint8_t*)d_src, mb, rb, rows, cols, W64);
     hipLaunchKernelGGL(bgs::ss_flood_seed_kernel, dim3(1), dim3(bgs::kBlock), 0, s, (const uint64_t*)mb, rb, rows, cols, W64);
-    int h = 1;
-    for (long it = 0; it < (long)rows * W64 + 8 && h; ++it) {  // every launch that changes anything reaches at least one new word
-      (void)hipMemsetAsync(ch, 0, sizeof(int), s);
-      hipLaunchKernelGGL(bgs::ss_flood_kernel, dim3(blocks_for((size_t)tilesY * W64 * bgs::kWave)), dim3(bgs::kBlock), 0, s, (const uint64_t*)mb, rb, rows, W64, ch);
-      (void)hipMemcpyAsync(&h, ch, sizeof(int), hipMemcpyDeviceToHost, s);
-      (void)hipStreamSynchronize(s);
-    }
+    // the same host-free sequence as SuBSENSE's post-processing (engine_subsense.h): a fixed batch, then the finish kernel
+    for (int k = 0; k < bgs::kSsFloodBatch; ++k)
+      hipLaunchKernelGGL(bgs::ss_flood_kernel, dim3(blocks_for((size_t)tilesY * W64 * bgs::kWave)), dim3(bgs::kBlock), 0, s, (const uint64_t*)mb, rb, rows, W64, fl, k);
+    hipLaunchKernelGGL(bgs::ss_flood_finish_kernel, dim3(1), dim3(1024), 0, s, (const uint64_t*)mb, rb, rows, W64, fl, bgs::kSsFloodBatch);
     hipLaunchKernelGGL(bgs::ss_flood_paint_kernel, dim3(blocks_for((size_t)rows * cols)), dim3(bgs::kBlock), 0, s, (const uint8_t*)d_src, (const uint64_t*)rb, (uint8_t*)d_dst, rows, cols, W64);
     hipError_t er = hipStreamSynchronize(s);
-    (void)hipFree(mb), (void)hipFree(rb), (void)hipFree(ch);
+    (void)hipFree(mb), (void)hipFree(rb), (void)hipFree(fl);
     if (er != hipSuccess) return fail(BGS_ERR_HIP, "flood fill failed: %s", hipGetErrorString(er));
     return BGS_OK;
   }

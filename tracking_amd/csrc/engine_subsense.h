@@ -2,8 +2,11 @@
 // its anonymous namespace, after bgs_engine / fail() / HIP_TRY / Timed are defined.
 // One ss_process() call = SuBSENSEBGS::process (package_bgs/pl/SuBSENSE.cpp:21-45) for streams [first, first+count).
 //
-// Everything runs on the launch stream; the frame-level block (BackgroundSubtractorSuBSENSE.cpp:643-699) runs on the device
-// so there is no host round trip except the flood fill's convergence flag (:630).
+// Everything is enqueued on the launch stream and NOTHING waits for the device: the frame-level block
+// (BackgroundSubtractorSuBSENSE.cpp:643-699) runs on the device, the flood fill (:630) is a fixed batch of launches that stop
+// working on a device-side flag (kernel_subsense.h: ss_flood_kernel / ss_flood_finish_kernel), per-stream constants travel in
+// kernel arguments.  Calls on one engine must come from one host thread at a time; ranges of streams in flight on different
+// HIP streams must be disjoint (flood flags are per stream; the side stream and its two events are shared, which only serialises).
 
 enum { SS_R, SS_V, SS_T, SS_DLAST0, SS_DLAST1, SS_DMINLT, SS_DMINST, SS_RAWLT, SS_RAWST0, SS_RAWST1, SS_FINLT, SS_FINST, SS_NF32 };
 enum { SS_UNSTABLE, SS_BLINKS, SS_LASTFG, SS_LASTRAW, SS_LASTRAWBLINK, SS_LASTDILINV, SS_RAW, SS_T1, SS_T2, SS_T3, SS_T4, SS_NU8 };
@@ -24,8 +27,7 @@ struct SsDevice {
   uint8_t* u8[SS_NU8] = {nullptr};
   float *dsLT = nullptr, *dsST = nullptr;
   bgs::SsScalars* sc = nullptr;
-  int* changed = nullptr;
-  int* h_changed = nullptr;  // pinned
+  int* flood_flags = nullptr;  // [S][kSsFloodFlags], see ss_flood_kernel
   hipStream_t side = nullptr;  // phase B runs here, beside the post-processing chain (both only need phase A)
   hipEvent_t evA = nullptr, evB = nullptr;
   uint64_t *mbits = nullptr, *rbits = nullptr;  // flood fill: bit-packed mask / reached set, [S][rows][W64]
@@ -33,18 +35,17 @@ struct SsDevice {
   int use3x3 = 1, lrScaling = 0, medK = 9;
   float capLo0 = 4.f, capHi0 = 512.f;
   void release() {
-    void* p[] = {color, lut, lastColor, curColor, desc, lastDesc, curDesc, req, dsLT, dsST, sc, changed, mbits, rbits};
+    void* p[] = {color, lut, lastColor, curColor, desc, lastDesc, curDesc, req, dsLT, dsST, sc, flood_flags, mbits, rbits};
     for (void* q : p)
       if (q) (void)hipFree(q);
     for (auto& q : f32)
       if (q) (void)hipFree(q), q = nullptr;
     for (auto& q : u8)
       if (q) (void)hipFree(q), q = nullptr;
-    if (h_changed) (void)hipHostFree(h_changed);
     if (side) (void)hipStreamDestroy(side), side = nullptr;
     if (evA) (void)hipEventDestroy(evA), evA = nullptr;
     if (evB) (void)hipEventDestroy(evB), evB = nullptr;
-    color = lut = lastColor = curColor = nullptr, desc = lastDesc = req = curDesc = nullptr, dsLT = dsST = nullptr, sc = nullptr, changed = h_changed = nullptr, mbits = rbits = nullptr;
+    color = lut = lastColor = curColor = nullptr, desc = lastDesc = req = curDesc = nullptr, dsLT = dsST = nullptr, sc = nullptr, flood_flags = nullptr, mbits = rbits = nullptr;
   }
 };
 
@@ -75,11 +76,10 @@ int ss_allocate(bgs_engine* e) {
   DMALLOC(d->req, P * 2 * 2);
   DMALLOC(d->lut, (size_t)e->S * 256);
   DMALLOC(d->sc, (size_t)e->S * sizeof(bgs::SsScalars));
-  DMALLOC(d->changed, sizeof(int));
+  DMALLOC(d->flood_flags, (size_t)e->S * bgs::kSsFloodFlags * sizeof(int));
   const size_t words = (size_t)e->S * e->rows * ((e->cols + 63) / 64);
   DMALLOC(d->mbits, words * 8);
   DMALLOC(d->rbits, words * 8);
-  HIP_TRY(hipHostMalloc((void**)&d->h_changed, sizeof(int), hipHostMallocDefault));
   for (auto& q : d->f32) DMALLOC(q, P * sizeof(float));
   for (auto& q : d->u8) DMALLOC(q, P);
   const size_t ds = (size_t)(e->rows / 8) * (e->cols / 8) * C * e->S + 4;
@@ -134,12 +134,10 @@ int ss_init_streams(bgs_engine* e, int first, int count, const uint8_t* d_frames
   ss_initial_lut(e->p, e->ch, lut);
   bgs::SsScalars sc0{};
   sc0.autoReset = d->lrScaling, sc0.capLo = d->capLo0, sc0.capHi = d->capHi0;
-  for (int i = first; i < first + count; ++i) {
-    HIP_TRY(hipMemcpyAsync(d->lut + (size_t)i * 256, lut, 256, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d->sc + i, &sc0, sizeof(sc0), hipMemcpyHostToDevice, s));
-    d->pp[i] = 0;
-  }
-  HIP_TRY(hipStreamSynchronize(s));  // lut / sc0 live on this stack frame
+  bgs::SsLut256 lutv;
+  std::memcpy(lutv.v, lut, 256);
+  hipLaunchKernelGGL(bgs::ss_init_consts_kernel, dim3(count), dim3(bgs::kBlock), 0, s, d->lut, d->sc, lutv, sc0, first);
+  for (int i = first; i < first + count; ++i) d->pp[i] = 0;
   auto fillf = [&](int idx, float v) -> hipError_t {
     uint32_t bits;
     std::memcpy(&bits, &v, 4);
@@ -224,13 +222,11 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
   hipLaunchKernelGGL(bgs::ss_flood_pack_kernel, dim3(blocks_for((size_t)e->rows * W64 * bgs::kWave), 1, count), block, 0, s, (const uint8_t*)t1, mbits, rbits, e->rows, e->cols, W64);
   hipLaunchKernelGGL(bgs::ss_flood_seed_kernel, dim3(count), block, 0, s, (const uint64_t*)mbits, rbits, e->rows, e->cols, W64);
   const dim3 fgrid(blocks_for((size_t)tilesY * W64 * bgs::kWave), 1, count);
-  for (long it = 0; it < (long)e->rows * W64 + 8; it += 4) {  // runs until no tile changed; 4 launches per flag check (typical masks: 1-3 checks)
-    HIP_TRY(hipMemsetAsync(d->changed, 0, sizeof(int), s));
-    for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(bgs::ss_flood_kernel, fgrid, block, 0, s, (const uint64_t*)mbits, rbits, e->rows, W64, d->changed);
-    HIP_TRY(hipMemcpyAsync(d->h_changed, d->changed, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    if (!*d->h_changed) break;
-  }
+  int* fl = d->flood_flags + (size_t)first * bgs::kSsFloodFlags;
+  HIP_TRY(hipMemsetAsync(fl, 0, (size_t)count * bgs::kSsFloodFlags * sizeof(int), s));
+  static const int batch = getenv("BGS_SS_FLOOD_BATCH") ? std::max(0, std::min(bgs::kSsFloodBatch, atoi(getenv("BGS_SS_FLOOD_BATCH")))) : bgs::kSsFloodBatch;  // test knob: 0/1 force the finish kernel to do the work
+  for (int k = 0; k < batch; ++k) hipLaunchKernelGGL(bgs::ss_flood_kernel, fgrid, block, 0, s, (const uint64_t*)mbits, rbits, e->rows, W64, fl, k);
+  hipLaunchKernelGGL(bgs::ss_flood_finish_kernel, dim3(count), dim3(1024), 0, s, (const uint64_t*)mbits, rbits, e->rows, W64, fl, batch);
   // erode x3 :632 -> t3
   ss_morph(t1, t3, e->rows, e->cols, count, 0, 7, s);  // erode x3 = one 7x7 box
   hipLaunchKernelGGL(bgs::ss_combine_kernel, dim3(blocks_for(npix)), block, 0, s, a, (const uint8_t*)t1, (const uint64_t*)rbits, W64, (const uint8_t*)t3, t4, npix);  // :631-634
@@ -348,8 +344,9 @@ int lob_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, ui
       const long r = std::lrint((double)f);
       lut[v] = (uint8_t)std::min<long>(std::max<long>(r, 0), 255);
     }
-    for (int i = first; i < first + count; ++i) HIP_TRY(hipMemcpyAsync(d->lut + (size_t)i * 256, lut, 256, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));  // lut lives on this stack frame
+    bgs::SsLut256 lutv;
+    std::memcpy(lutv.v, lut, 256);
+    hipLaunchKernelGGL(bgs::ss_init_consts_kernel, dim3(count), block, 0, s, d->lut, (bgs::SsScalars*)nullptr, lutv, bgs::SsScalars{}, first);
     HIP_TRY(hipMemsetAsync(d->u8[SS_LASTFG] + off, 0, npix, s));
     HIP_TRY(hipMemsetAsync(d->color + off * nS * C, 0, npix * nS * C, s));
     HIP_TRY(hipMemsetAsync(d->desc + off * nS * C, 0, npix * nS * C * 2, s));

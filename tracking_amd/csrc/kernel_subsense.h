@@ -659,6 +659,18 @@ __global__ __launch_bounds__(kBlock) void ss_blink_kernel(const SsArgs a, size_t
   a.lastRaw[g] = raw;
 }
 
+// Per-stream constants of a freshly constructed model, handed over BY VALUE in the kernel arguments (no host buffer has to
+// outlive the launch, so the first frame needs no stream synchronisation): the 256-entry LBSP threshold LUT and the
+// frame-level scalars.  One workgroup per stream of the launch.
+struct SsLut256 {
+  uint8_t v[256];
+};
+__global__ __launch_bounds__(kBlock) void ss_init_consts_kernel(uint8_t* lut_all, SsScalars* sc_all, const SsLut256 lut, const SsScalars sc0, int first) {
+  const int stream = first + blockIdx.x;
+  lut_all[(size_t)stream * 256 + threadIdx.x] = lut.v[threadIdx.x];
+  if (sc_all && threadIdx.x == 0) sc_all[stream] = sc0;
+}
+
 // flood fill from (0,0) (:630) on BIT-PACKED rows: one 64-bit word = 64 pixels, one wave = one 64x64 tile, lane = row.
 //   mbits[y][w] bit i = (mask(y, 64w+i) == seed value)      rbits = pixels reached so far
 // Inside a row the fill is carry arithmetic ((m + r) ripples a seed through its run of 1s); between rows it is a wave
@@ -719,25 +731,28 @@ __global__ __launch_bounds__(kBlock) void ss_flood_seed_kernel(const uint64_t* m
   }
 }
 
-__global__ __launch_bounds__(kBlock) void ss_flood_kernel(const uint64_t* mbits, uint64_t* rbits, int rows, int W64, int* changed) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const int tilesY = (rows + 63) / 64;
-  const size_t tile = (size_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
-  if (tile >= (size_t)tilesY * W64) return;  // whole wave
-  const int ty = (int)(tile / W64), w = (int)(tile % W64), y = ty * 64 + lane;
-  const size_t base = (size_t)blockIdx.z * rows * W64;
-  const uint64_t* mb = mbits + base;
-  uint64_t* rb = rbits + base;
+// One relaxation of one 64x64 tile (one wave, lane = row): halos from the neighbouring tiles as they stand in memory, then the
+// tile runs to its fixed point in registers.  Returns true (wave-uniform) if any row of the tile gained pixels.
+// COHERENT: reads of the reached set bypass the CU's vector L1 (agent-scope atomic loads) - needed when the SAME kernel relaxes
+// tiles repeatedly (ss_flood_finish_kernel); across kernel launches the caches are invalidated anyway.
+template <bool COHERENT>
+__device__ __forceinline__ bool ss_flood_tile(const uint64_t* mb, uint64_t* rb, int rows, int W64, int ty, int w, int lane) {
+  auto rd = [&](size_t idx) -> uint64_t {
+    if constexpr (COHERENT)
+      return __hip_atomic_load(reinterpret_cast<unsigned long long*>(rb + idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      return rb[idx];
+  };
+  const int y = ty * 64 + lane;
   const bool in = y < rows;
   const uint64_t m = in ? mb[(size_t)y * W64 + w] : 0;
-  const uint64_t r0 = in ? rb[(size_t)y * W64 + w] : 0;
-  // halos from the neighbouring tiles as they stand in memory (constant during this launch)
+  const uint64_t r0 = in ? rd((size_t)y * W64 + w) : 0;
   uint64_t side = 0;
-  if (in && w > 0 && (rb[(size_t)y * W64 + w - 1] >> 63)) side |= 1ull;
-  if (in && w < W64 - 1 && (rb[(size_t)y * W64 + w + 1] & 1ull)) side |= 1ull << 63;
+  if (in && w > 0 && (rd((size_t)y * W64 + w - 1) >> 63)) side |= 1ull;
+  if (in && w < W64 - 1 && (rd((size_t)y * W64 + w + 1) & 1ull)) side |= 1ull << 63;
   uint64_t vert = 0;
-  if (lane == 0 && y > 0 && in) vert = rb[(size_t)(y - 1) * W64 + w];
-  if (lane == 63 && y + 1 < rows) vert = rb[(size_t)(y + 1) * W64 + w];
+  if (lane == 0 && y > 0 && in) vert = rd((size_t)(y - 1) * W64 + w);
+  if (lane == 63 && y + 1 < rows) vert = rd((size_t)(y + 1) * W64 + w);
   uint64_t r = ss_hfill(r0 | ((side | vert) & m), m);
   for (;;) {
     const uint32_t lo = (uint32_t)r, hi = (uint32_t)(r >> 32);
@@ -750,9 +765,47 @@ __global__ __launch_bounds__(kBlock) void ss_flood_kernel(const uint64_t* mbits,
     r = rn;
     if (!__any(ch)) break;
   }
-  if (in && r != r0) {
-    rb[(size_t)y * W64 + w] = r;
-    *changed = 1;
+  const bool grew = in && r != r0;
+  if (grew) {
+    if constexpr (COHERENT)
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(rb + (size_t)y * W64 + w), r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      rb[(size_t)y * W64 + w] = r;
+  }
+  return __any(grew);
+}
+
+// The flood fill runs WITHOUT a host round trip: the host enqueues a fixed batch of kSsFloodBatch relaxation launches plus one
+// ss_flood_finish_kernel.  flags[stream][k] = "launch k changed something in this image"; launch k of an image returns at once when
+// launch k-1 changed nothing (the fill has converged: typical masks need 2-6 launches, the wavefront crosses a tile per launch
+// from every side), and the finish kernel only works when the last batch launch still changed something - then ONE workgroup
+// per image keeps relaxing all tiles until nothing changes (slow, but any mask converges; spiral masks in the tests).
+constexpr int kSsFloodBatch = 12;
+constexpr int kSsFloodFlags = kSsFloodBatch + 1;  // per stream; the last one: "the finish kernel had to work" (diagnostics)
+
+__global__ __launch_bounds__(kBlock) void ss_flood_kernel(const uint64_t* mbits, uint64_t* rbits, int rows, int W64, int* flags, int k) {
+  int* fl = flags + (size_t)blockIdx.z * kSsFloodFlags;
+  if (k > 0 && fl[k - 1] == 0) return;  // converged in an earlier launch (stream order makes fl[k-1] final)
+  const int lane = threadIdx.x & (kWave - 1);
+  const int tilesY = (rows + 63) / 64;
+  const size_t tile = (size_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+  if (tile >= (size_t)tilesY * W64) return;  // whole wave
+  const size_t base = (size_t)blockIdx.z * rows * W64;
+  if (ss_flood_tile<false>(mbits + base, rbits + base, rows, W64, (int)(tile / W64), (int)(tile % W64), lane) && lane == 0) fl[k] = 1;
+}
+
+__global__ __launch_bounds__(1024) void ss_flood_finish_kernel(const uint64_t* mbits, uint64_t* rbits, int rows, int W64, int* flags, int batch) {
+  int* fl = flags + (size_t)blockIdx.x * kSsFloodFlags;
+  if (batch > 0 && fl[batch - 1] == 0) return;  // the batch converged: the usual case
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwaves = blockDim.x / kWave;
+  const int ntiles = ((rows + 63) / 64) * W64;
+  const size_t base = (size_t)blockIdx.x * rows * W64;
+  if (threadIdx.x == 0) fl[kSsFloodBatch] = 1;
+  for (;;) {
+    bool ch = false;
+    for (int tile = wave; tile < ntiles; tile += nwaves) ch |= ss_flood_tile<true>(mbits + base, rbits + base, rows, W64, tile / W64, tile % W64, lane);
+    __threadfence();
+    if (!__syncthreads_or(ch)) break;
   }
 }
 
