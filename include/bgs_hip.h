@@ -295,6 +295,28 @@ int bgs_mask_components_batch_device(int hip_device, const void* d_masks, int im
                                      int32_t* d_labels, bgs_box* d_boxes, int max_boxes, int32_t* d_offsets, void* d_work,
                                      void* hip_stream);
 
+/* ---- N2: blob list hand-off (ustc_src/trackingMain.cpp:166: the blob detector consumes the mask right after FG detection) ----
+ * OpenCV-legacy's detectors turn each foreground region into a CvBlob {x, y, w, h, ID} from the region's bounding rectangle
+ * and its coordinate moments (centre = centroid, size = 4 sigma; recalled from modules/legacy/src/enteringblobdetection.cpp,
+ * not in the tree).  Both are produced here, per component, so the caller can apply either convention
+ * (tracking_amd/host/blob.h: blob_from_box / blob_from_moments). */
+typedef struct bgs_moments {
+  int64_t sx, sy;   /* sum of x, sum of y over the component's pixels (image coordinates) */
+  int64_t sxx, syy; /* sum of x*x, sum of y*y */
+} bgs_moments;
+/* bgs_mask_components_batch_device plus the moments of every component (d_moments [max_boxes], same order as d_boxes;
+ * NULL = not wanted).  No labels output. */
+int bgs_mask_blobs_batch_device(int hip_device, const void* d_masks, int images, int rows, int cols, int connectivity,
+                                bgs_box* d_boxes, bgs_moments* d_moments, int max_boxes, int32_t* d_offsets, void* d_work,
+                                void* hip_stream);
+/* Host path: components of the foreground mask that the LAST bgs_process call of `stream` produced, computed on the device
+ * copy of that mask (bgs_process keeps it even when its `fg` argument is NULL, so a caller that only wants blobs moves no
+ * mask over PCIe); components narrower than min_w or lower than min_h are dropped; host arrays boxes / moments (optional)
+ * [max_boxes] receive the first max_boxes survivors in raster order of their first pixel, *count their number.  Synchronous.
+ * BGS_ERR_STATE if that call produced no valid mask (warm-up frame) or another stream has been processed since. */
+int bgs_last_mask_blobs(bgs_engine* e, int stream, int connectivity, int min_w, int min_h, bgs_box* boxes, bgs_moments* moments,
+                        int max_boxes, int32_t* count);
+
 #ifdef __cplusplus
 }
 #endif

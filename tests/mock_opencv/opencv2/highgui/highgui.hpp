@@ -1,0 +1,3 @@
+// declaration-only mock, see ../../README.md
+#pragma once
+#include "../opencv.hpp"

@@ -5,6 +5,7 @@ import os
 import re
 import subprocess
 
+import numpy as np
 import pytest
 
 from tracking_amd import capi
@@ -109,3 +110,53 @@ def test_reference_side_adapter_shares_the_tested_class_list():
             "AdaptiveSelectiveBackgroundLearning", "MixtureOfGaussianV1BGS", "MixtureOfGaussianV2BGS", "GMG", "SigmaDeltaBGS", "SuBSENSEBGS", "LOBSTERBGS",
             "DPZivkovicAGMMBGS", "DPGrimsonGMMBGS", "DPWrenGABGS", "DPMeanBGS", "DPAdaptiveMedianBGS"}
     assert names == want, names ^ want
+
+
+def test_reference_side_adapters_compile(tmp_path):
+    """tracking_amd/host/HipBGS.h and HipFGDetector.h (what a maintainer adds to the reference tree: cv::Mat, CvFileStorage, CvFGDetector,
+    CvBlobSeq) are syntax-checked as -std=gnu++0x - the reference's CMakeLists.txt:5 - against the declaration-only OpenCV mock in
+    tests/mock_opencv.  Nothing is linked or run: OpenCV itself is absent from this image."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tu = tmp_path / "adapters.cpp"
+    tu.write_text('#include "HipBGS.h"\n#include "HipFGDetector.h"\n'
+                  'IBGS* make(int i) { return i ? (IBGS*)new hipbgs::MixtureOfGaussianV2BGS : (IBGS*)new hipbgs::SuBSENSEBGS(); }\n'
+                  'CvFGDetector* make_fg() { return new HipFGDetector(36); }\n'
+                  'int blobs(HipFGDetector* d, CvBlobSeq* s) { return d->GetBlobs(s) + d->GetBlobs(s, 4, false); }\n')
+    r = subprocess.run(["g++", "-std=gnu++0x", "-fsyntax-only", "-Wall", "-I" + os.path.join(root, "tests", "mock_opencv"), "-I" + os.path.join(root, "include"),
+                        "-I" + os.path.join(root, "tracking_amd", "host"), str(tu)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_blob_conversions_on_known_shapes(tmp_path):
+    """tracking_amd/host/blob_convert.h: a filled w x h rectangle at (x0, y0) gives, from its box, centre (x0 + w/2, y0 + h/2) and size
+    (w, h); from its moments, the centroid (x0 + (w-1)/2, y0 + (h-1)/2) and 4 sigma of a discrete uniform: 4 sqrt((w^2-1)/12)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include "blob.h"
+using namespace bgs_hip;
+int main() {
+  const int x0 = 10, y0 = 20, w = 7, h = 4;
+  bgs_box b = {x0, y0, w, h, w * h, y0 * 100 + x0};
+  bgs_moments m = {0, 0, 0, 0};
+  for (int y = y0; y < y0 + h; ++y) for (int x = x0; x < x0 + w; ++x) m.sx += x, m.sy += y, m.sxx += x * x, m.syy += y * y;
+  CvBlob a = cvBlob(0, 0, 0, 0), c = cvBlob(0, 0, 0, 0);
+  bgs_hip_convert::blob_from_box(b, a);
+  bgs_hip_convert::blob_from_moments(b, m, c);
+  std::printf("%.6f %.6f %.6f %.6f | %.6f %.6f %.6f %.6f\n", a.x, a.y, a.w, a.h, c.x, c.y, c.w, c.h);
+  CvBlobSeq s; s.AddBlob(&a); c.ID = 5; s.AddBlob(&c);
+  std::printf("%d %d %d\n", s.GetBlobNum(), s.GetBlobByID(5) == s.GetBlob(1), s.GetBlob(2) == 0);
+  s.DelBlob(0); std::printf("%d %d\n", s.GetBlobNum(), s.GetBlob(0)->ID);
+  return 0;
+}''')
+    exe = tmp_path / "t"
+    subprocess.run(["g++", "-std=c++14", "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "tracking_amd", "host"), "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
+    box, mom = [[float(v) for v in part.split()] for part in out[0].split("|")]
+    assert box == [13.5, 22.0, 7.0, 4.0]
+    want = [10 + 3.0, 20 + 1.5, 4 * np.sqrt((49 - 1) / 12.0), 4 * np.sqrt((16 - 1) / 12.0)]
+    assert np.allclose(mom, want, atol=1e-5), (mom, want)
+    assert out[1].split() == ["2", "1", "1"] and out[2].split() == ["1", "5"]

@@ -132,3 +132,128 @@ def test_ustc_bgs_rejects_types_outside_the_path(demo, tmp_path, golden_frames):
     golden_frames[:2].tofile(raw)
     r = subprocess.run([demo, raw, "80", "96", "2", os.path.join(str(tmp_path), "out"), "23"], cwd=str(tmp_path), capture_output=True, text=True)
     assert r.returncode == 1 and "outside the package_bgs hot path" in r.stdout
+
+
+def _oracle_blobs(mask, min_w=5, min_h=5, connectivity=8):
+    """(boxes[k] as pyoracle.BOX_DTYPE, moments int64 [k][4]) of the oracle's components of `mask`, smaller ones dropped."""
+    from oracle import pyoracle
+    labels, boxes, n = pyoracle.components(mask, connectivity)
+    keep = [b for b in boxes if b["w"] >= min_w and b["h"] >= min_h]
+    ys, xs = np.nonzero(labels >= 0)
+    roots = labels[ys, xs]
+    mom = []
+    for b in keep:
+        sel = roots == b["root"]
+        x, y = xs[sel].astype(np.int64), ys[sel].astype(np.int64)
+        mom.append([x.sum(), y.sum(), (x * x).sum(), (y * y).sum()])
+    return keep, np.array(mom, np.int64).reshape(-1, 4)
+
+
+@pytest.mark.gpu
+def test_last_mask_blobs_match_oracle_components(golden_frames):
+    """N2, C ABI: bgs_last_mask_blobs on the device copy of the mask == the oracle's connected components of the oracle's mask
+    (rectangles, areas, first pixels, coordinate moments), with and without the mask also being returned to the host."""
+    from oracle import pyoracle
+    from tracking_amd import Engine, capi
+    eng, orc = Engine(capi.MOG2), pyoracle.Oracle(capi.MOG2)
+    seen_blobs = 0
+    for t, f in enumerate(golden_frames[:12]):
+        ofg, _ = orc.process(f)
+        if t % 2:
+            flags = eng.process_mask_only_on_device(f)  # fg = NULL: nothing but rectangles crosses PCIe
+            assert flags & capi.FG_VALID
+        else:
+            fg, _ = eng.process(f)
+            assert np.array_equal(fg, ofg)
+        for conn, mw, mh in ((8, 5, 5), (4, 0, 0), (8, 2, 3)):
+            boxes, mom, n = eng.last_mask_blobs(connectivity=conn, min_w=mw, min_h=mh, max_boxes=4096)
+            want, wmom = _oracle_blobs(ofg, mw, mh, conn)
+            assert n == len(want), (t, conn, n, len(want))
+            assert np.array_equal(boxes, np.array([[b[k] for k in ("x", "y", "w", "h", "area", "root")] for b in want], np.int32).reshape(-1, 6)), (t, conn)
+            assert np.array_equal(mom, wmom), (t, conn)
+            seen_blobs += n
+    assert seen_blobs > 20
+    # truncation: count still says how many there are
+    boxes, _, n = eng.last_mask_blobs(connectivity=4, max_boxes=3)
+    assert n > 3 and len(boxes) == 3
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_last_mask_blobs_needs_a_valid_mask(golden_frames):
+    from tracking_amd import Engine, capi
+    eng = Engine(capi.FRAME_DIFF, n_streams=2)
+    eng.process(golden_frames[0])  # warm-up frame: outputs untouched, no mask
+    with pytest.raises(Exception):
+        eng.last_mask_blobs()
+    eng.process(golden_frames[1])
+    eng.last_mask_blobs()
+    eng.process(golden_frames[0], stream=1)
+    with pytest.raises(Exception):
+        eng.last_mask_blobs(stream=0)  # the device mask now belongs to stream 1 (and that was a warm-up frame)
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_mask_blobs_batch_device_vs_oracle():
+    import torch
+    from tracking_amd.engine import mask_blobs_batch_device
+    rng = np.random.default_rng(5)
+    masks = np.zeros((3, 120, 200), np.uint8)
+    for k in range(3):
+        for _ in range(25):
+            y, x = rng.integers(0, 110), rng.integers(0, 180)
+            masks[k, y:y + rng.integers(1, 30), x:x + rng.integers(1, 40)] = 255
+        masks[k][rng.random(masks[k].shape) < 0.01] = 255
+    boxes, mom, off = mask_blobs_batch_device(torch.from_numpy(masks).cuda(), 8)
+    boxes, mom = boxes.cpu().numpy(), mom.cpu().numpy()
+    for k in range(3):
+        want, wmom = _oracle_blobs(masks[k], 0, 0, 8)
+        got = boxes[off[k]:off[k + 1]]
+        assert len(got) == len(want)
+        assert np.array_equal(got, np.array([[b[q] for q in ("x", "y", "w", "h", "area", "root")] for b in want], np.int32).reshape(-1, 6))
+        assert np.array_equal(mom[off[k]:off[k + 1]], wmom)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["box", "moments"])
+def test_hipfgdetector_blob_list(demo, tmp_path, golden_frames, mode):
+    """N2, C++ mirror: HipFGDetector(5).Process + GetBlobs through the demo harness; the printed CvBlob {x, y, w, h, ID} list of every
+    frame equals what blob_convert.h's formulas give on the oracle's components of the oracle's mask (regions >= 5 x 5, raster order,
+    IDs counting up; the harness prints the list back to front like ustc_src/trackingMain.cpp:184-190)."""
+    from oracle import pyoracle
+    from tracking_amd import capi
+    os.makedirs(tmp_path / "config")
+    frames = golden_frames[:10]
+    raw = os.path.join(str(tmp_path), "frames.raw")
+    frames.tofile(raw)
+    n, rows, cols = frames.shape[:3]
+    r = subprocess.run([demo, raw, str(rows), str(cols), str(n), os.path.join(str(tmp_path), "out"), "5", mode], cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.split("\n") if l.startswith("frame ") or l.startswith("pBlob")]
+    o = pyoracle.Oracle(capi.MOG2)
+    next_id, pos, total = 0, 0, 0
+    for t in range(n):
+        fg, _ = o.process(frames[t])
+        want, wmom = _oracle_blobs(fg, 5, 5, 8)
+        assert lines[pos] == "frame %d blobs %d" % (t, len(want)), (lines[pos], len(want))
+        pos += 1
+        exp = []
+        for b, m in zip(want, wmom):
+            if mode == "box":
+                x, y, w, h = b["x"] + 0.5 * b["w"], b["y"] + 0.5 * b["h"], float(b["w"]), float(b["h"])
+            else:
+                a = float(b["area"])
+                mx, my = m[0] / a, m[1] / a
+                x, y = mx, my
+                w, h = 4 * np.sqrt(max(m[2] / a - mx * mx, 0)), 4 * np.sqrt(max(m[3] / a - my * my, 0))
+            exp.append((x, y, w, h, next_id))
+            next_id += 1
+        for e in reversed(exp):
+            vals = lines[pos].replace("pBlob x,y,w,h,id is ", "").split(" , ")
+            pos += 1
+            got = [float(v) for v in vals[:4]]
+            assert np.allclose(got, e[:4], rtol=1e-5, atol=1e-4), (t, got, e)
+            assert int(vals[4]) == e[4]
+        total += len(exp)
+    assert total > 5

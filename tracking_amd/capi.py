@@ -106,6 +106,8 @@ SYMBOLS = [
     ("bgs_mask_components_device", C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P]),
     ("bgs_mask_components_batch_workspace", C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     ("bgs_mask_components_batch_device", C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P]),
+    ("bgs_mask_blobs_batch_device", C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P]),
+    ("bgs_last_mask_blobs", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_int32)]),
 ]
 
 _lib = None

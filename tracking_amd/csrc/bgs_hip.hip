@@ -108,6 +108,9 @@ struct bgs_engine {
   uint8_t *d_in = nullptr, *d_fg = nullptr, *d_bg = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t band_ev[8] = {nullptr};  // bgs_process: one event per output band
+  int last_fg_stream = -1;            // bgs_last_mask_blobs: whose mask d_fg holds (-1: none valid)
+  void* cc_work = nullptr;            // its device scratch: workspace | boxes | moments | count
+  int cc_cap = 0;                     // boxes the scratch has room for
 
   // dominant-kernel timing
   bool timing = false;
@@ -123,6 +126,8 @@ void free_all(bgs_engine* e) {
   for (auto& r : e->ring)
     if (r) (void)hipFree(r), r = nullptr;
   if (e->abl_lut) (void)hipFree(e->abl_lut), e->abl_lut = nullptr, e->abl_lut_valid = false;
+  if (e->cc_work) (void)hipFree(e->cc_work), e->cc_work = nullptr, e->cc_cap = 0;
+  e->last_fg_stream = -1;
   void* dev[] = {e->dp_state, e->gmg_colors, e->gmg_weights, e->gmg_nfeat, e->bgstate, e->bgstate2, e->mog1_state, e->mog2_state, e->mog2_nmodes, e->d_in, e->d_fg, e->d_bg};
   for (void* d : dev)
     if (d) (void)hipFree(d);
@@ -1033,9 +1038,11 @@ int bgs_process(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols
   uint32_t flags = 0;
   const bool saved_borrow = e->borrow;
   e->borrow = false;
-  rc = process_range(e, stream, 1, dst, fg ? e->d_fg : nullptr, bg ? e->d_bg : nullptr, nullptr, e->stream, &flags);
+  e->last_fg_stream = -1;
+  rc = process_range(e, stream, 1, dst, e->d_fg, bg ? e->d_bg : nullptr, nullptr, e->stream, &flags);  // the mask stays on the device for bgs_last_mask_blobs
   e->borrow = saved_borrow;
   if (rc) return rc;
+  if (flags & BGS_FG_VALID) e->last_fg_stream = stream;
   const int bg_ch = e->algo == BGS_ASBL ? 1 : channels;
   // the way back is pipelined the same way when there is a background image to return (6 MB at 1080p): band k is copied out to
   // the caller's image while band k+1 is still on the bus; a mask alone (2 MB) is not worth the events
@@ -1307,7 +1314,8 @@ size_t bgs_mask_components_batch_workspace(int images, int rows, int cols) {
 
 // images stacked back to back are labelled as one tall image whose links never cross an image boundary
 static int cc_run(int hip_device, const void* d_mask, int images, int rows, int cols, int connectivity, int32_t* d_labels, bgs_box* d_boxes, int max_boxes,
-                  int32_t* d_count, int32_t* d_offsets, void* d_work, void* hip_stream) {
+                  int32_t* d_count, int32_t* d_offsets, void* d_work, void* hip_stream, bgs_moments* d_moments = nullptr) {
+  static_assert(sizeof(bgs_moments) == sizeof(bgs::CcMoments), "bgs_moments layout");
   static_assert(sizeof(bgs_box) == sizeof(bgs::CcBox), "bgs_box layout");
   if (!d_mask || !d_boxes || (!d_count && !d_offsets) || images <= 0 || rows <= 0 || cols <= 0 || max_boxes < 0 || (connectivity != 4 && connectivity != 8))
     return fail(BGS_ERR_INVALID, "bgs_mask_components: bad argument");
@@ -1328,6 +1336,7 @@ static int cc_run(int hip_device, const void* d_mask, int images, int rows, int 
   const int conn8 = connectivity == 8, allRows = rows * images;
   const dim3 grid(blocks_for(n)), block(bgs::kBlock);
   if (d_offsets) HIP_TRY(hipMemsetAsync(d_offsets, 0, ((size_t)images + 1) * sizeof(int32_t), s));
+  if (d_moments && max_boxes > 0) HIP_TRY(hipMemsetAsync(d_moments, 0, (size_t)max_boxes * sizeof(bgs_moments), s));
   hipLaunchKernelGGL(bgs::cc_init_kernel, grid, block, 0, s, (const uint8_t*)d_mask, L, allRows, cols, rows, conn8);
   hipLaunchKernelGGL(bgs::cc_merge_kernel, grid, block, 0, s, L, allRows, cols, rows, conn8);
   hipLaunchKernelGGL(bgs::cc_compress_kernel, grid, block, 0, s, L, n);
@@ -1335,7 +1344,7 @@ static int cc_run(int hip_device, const void* d_mask, int images, int rows, int 
   hipLaunchKernelGGL(bgs::cc_scan_kernel, dim3(1), block, 0, s, blockCount, nb, total);
   hipLaunchKernelGGL(bgs::cc_scatter_kernel, dim3(nb), block, 0, s, (const int*)L, n, (const int*)blockCount, id, (bgs::CcBox*)d_boxes, max_boxes, (int*)d_offsets, imgN);
   if (max_boxes > 0) {
-    hipLaunchKernelGGL(bgs::cc_boxes_kernel, dim3(blocks_for((n + bgs::kCcBoxPer - 1) / bgs::kCcBoxPer)), block, 0, s, (const int*)L, (const int*)id, allRows, cols, rows, (bgs::CcBox*)d_boxes, max_boxes);
+    hipLaunchKernelGGL(bgs::cc_boxes_kernel, dim3(blocks_for((n + bgs::kCcBoxPer - 1) / bgs::kCcBoxPer)), block, 0, s, (const int*)L, (const int*)id, allRows, cols, rows, (bgs::CcBox*)d_boxes, max_boxes, (bgs::CcMoments*)d_moments);
     hipLaunchKernelGGL(bgs::cc_finish_kernel, dim3(blocks_for((size_t)max_boxes)), block, 0, s, (bgs::CcBox*)d_boxes, (const int*)total, max_boxes, (int)imgN);
   }
   if (d_offsets) hipLaunchKernelGGL(bgs::cc_offsets_kernel, dim3(1), dim3(1), 0, s, (int*)d_offsets, images);
@@ -1360,6 +1369,55 @@ int bgs_mask_components_batch_device(int hip_device, const void* d_masks, int im
                                      int max_boxes, int32_t* d_offsets, void* d_work, void* hip_stream) {
   if (!d_offsets) return fail(BGS_ERR_INVALID, "bgs_mask_components_batch_device: d_offsets is NULL");
   return cc_run(hip_device, d_masks, images, rows, cols, connectivity, d_labels, d_boxes, max_boxes, nullptr, d_offsets, d_work, hip_stream);
+}
+
+int bgs_mask_blobs_batch_device(int hip_device, const void* d_masks, int images, int rows, int cols, int connectivity, bgs_box* d_boxes, bgs_moments* d_moments,
+                                int max_boxes, int32_t* d_offsets, void* d_work, void* hip_stream) {
+  if (!d_offsets) return fail(BGS_ERR_INVALID, "bgs_mask_blobs_batch_device: d_offsets is NULL");
+  return cc_run(hip_device, d_masks, images, rows, cols, connectivity, nullptr, d_boxes, max_boxes, nullptr, d_offsets, d_work, hip_stream, d_moments);
+}
+
+int bgs_last_mask_blobs(bgs_engine* e, int stream, int connectivity, int min_w, int min_h, bgs_box* boxes, bgs_moments* moments, int max_boxes, int32_t* count) {
+  if (!e || !count || max_boxes < 0 || (max_boxes > 0 && !boxes)) return fail(BGS_ERR_INVALID, "bgs_last_mask_blobs: bad argument");
+  *count = 0;
+  if (stream < 0 || stream >= e->S) return fail(BGS_ERR_INVALID, "stream %d outside 0..%d", stream, e->S - 1);
+  if (!e->n || e->last_fg_stream != stream)
+    return fail(BGS_ERR_STATE, "bgs_last_mask_blobs: the last bgs_process call left no valid mask of stream %d on the device", stream);
+  HIP_TRY(hipSetDevice(e->device));
+  // device scratch, grown on demand: [workspace][boxes cap][moments cap][count]; more components than `cap` are counted but not kept
+  const int cap = std::max(max_boxes, 1024);
+  const size_t ws = (bgs_mask_components_workspace(e->rows, e->cols) + 15) & ~(size_t)15;
+  if (!e->cc_work || e->cc_cap < cap) {
+    if (e->cc_work) (void)hipFree(e->cc_work), e->cc_work = nullptr;
+    HIP_TRY(hipMalloc(&e->cc_work, ws + (size_t)cap * (sizeof(bgs_box) + sizeof(bgs_moments)) + 16));
+    e->cc_cap = cap;
+  }
+  bgs_box* d_boxes = (bgs_box*)((char*)e->cc_work + ws);
+  bgs_moments* d_mom = (bgs_moments*)(d_boxes + e->cc_cap);
+  int32_t* d_count = (int32_t*)(d_mom + e->cc_cap);
+  int rc = cc_run(e->device, e->d_fg, 1, e->rows, e->cols, connectivity, nullptr, d_boxes, e->cc_cap, d_count, nullptr, e->cc_work, e->stream, d_mom);
+  if (rc) return rc;
+  int32_t n = 0;
+  HIP_TRY(hipMemcpyAsync(&n, d_count, sizeof(n), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  n = std::min(n, e->cc_cap);
+  std::vector<bgs_box> hb((size_t)n);
+  std::vector<bgs_moments> hm((size_t)n);
+  if (n) {
+    HIP_TRY(hipMemcpy(hb.data(), d_boxes, (size_t)n * sizeof(bgs_box), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hm.data(), d_mom, (size_t)n * sizeof(bgs_moments), hipMemcpyDeviceToHost));
+  }
+  int kept = 0;
+  for (int i = 0; i < n; ++i) {
+    if (hb[i].w < min_w || hb[i].h < min_h) continue;
+    if (kept < max_boxes) {
+      boxes[kept] = hb[i];
+      if (moments) moments[kept] = hm[i];
+    }
+    ++kept;
+  }
+  *count = kept;
+  return BGS_OK;
 }
 
 }  // extern "C"

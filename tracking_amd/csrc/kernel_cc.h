@@ -24,6 +24,12 @@ struct CcBox {
   int x, y, w, h, area, root;  // during accumulation: x,y = min corner, w,h = max corner
 };
 
+// first and second moments of a component's pixel coordinates (image-relative): what OpenCV-legacy's blob detectors derive a
+// CvBlob's centre and size from (N2, include/bgs_hip.h: bgs_moments)
+struct CcMoments {
+  long long sx, sy, sxx, syy;
+};
+
 constexpr int kCcPerBlock = kBlock * 4;  // pixels per workgroup in the counting kernels
 
 __device__ __forceinline__ int cc_find(const int* L, int p) {
@@ -207,7 +213,10 @@ __device__ __forceinline__ void cc_table_add(CcTable& t, CcBox* boxes, int id, i
   cc_box_atomics(boxes + id, mnx, mny, mxx, mxy, cnt);  // table crowded around this hash: go straight to memory
 }
 
-__global__ __launch_bounds__(kBlock) void cc_boxes_kernel(const int* L, const int* id, int rows, int cols, int img_rows, CcBox* boxes, int max_boxes) {
+// `moments` (optional, zeroed by the caller): coordinate sums per component.  They skip the LDS table: one set of four 64-bit
+// global atomics per (wave, component) - a wave meets few components, and a mask that is one giant component still only
+// issues N/1024 of them per address.
+__global__ __launch_bounds__(kBlock) void cc_boxes_kernel(const int* L, const int* id, int rows, int cols, int img_rows, CcBox* boxes, int max_boxes, CcMoments* moments) {
   __shared__ CcTable tab;
   if (threadIdx.x < kCcSlots) {
     tab.id[threadIdx.x] = -1;
@@ -220,17 +229,28 @@ __global__ __launch_bounds__(kBlock) void cc_boxes_kernel(const int* L, const in
   const int lane = threadIdx.x & (kWave - 1);
   const size_t wave0 = ((size_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave) * (kWave * kCcBoxPer);
   int cid = -1, cl = -1, mnx = 0x7fffffff, mny = 0x7fffffff, mxx = -1, mxy = -1, cnt = 0;
+  unsigned long long sx = 0, sy = 0, sxx = 0, syy = 0;
+  auto flush_moments = [&](int c, unsigned long long a, unsigned long long b, unsigned long long q, unsigned long long r) {
+    CcMoments* m = moments + c;
+    atomicAdd((unsigned long long*)&m->sx, a), atomicAdd((unsigned long long*)&m->sy, b);
+    atomicAdd((unsigned long long*)&m->sxx, q), atomicAdd((unsigned long long*)&m->syy, r);
+  };
   for (int k = 0; k < kCcBoxPer; ++k) {
     const size_t p = wave0 + (size_t)k * kWave + lane;
     const int l = p < N ? L[p] : -1;
     if (l < 0) continue;
     if (l != cl) {  // a different component than the one this lane has open
-      if (cid >= 0 && cid < max_boxes) cc_table_add(tab, boxes, cid, mnx, mny, mxx, mxy, cnt);
+      if (cid >= 0 && cid < max_boxes) {
+        cc_table_add(tab, boxes, cid, mnx, mny, mxx, mxy, cnt);
+        if (moments) flush_moments(cid, sx, sy, sxx, syy);
+      }
       cl = l, cid = id[l];
       mnx = mny = 0x7fffffff, mxx = mxy = -1, cnt = 0;
+      sx = sy = sxx = syy = 0;
     }
     const int yy = (int)(p / cols), x = (int)(p - (size_t)yy * cols), y = yy % img_rows;
     mnx = min(mnx, x), mny = min(mny, y), mxx = max(mxx, x), mxy = max(mxy, y), cnt++;
+    if (moments) sx += (unsigned)x, sy += (unsigned)y, sxx += (unsigned long long)x * (unsigned)x, syy += (unsigned long long)y * (unsigned)y;
   }
   if (cid >= max_boxes) cid = -1;
   unsigned long long pending = __ballot(cid >= 0);
@@ -246,6 +266,15 @@ __global__ __launch_bounds__(kBlock) void cc_boxes_kernel(const int* L, const in
       e += __shfl_xor(e, o);
     }
     if (lane == leader) cc_table_add(tab, boxes, lid, a, b, c, d, e);
+    if (moments) {  // wave-uniform
+      unsigned long long m0 = mine ? sx : 0, m1 = mine ? sy : 0, m2 = mine ? sxx : 0, m3 = mine ? syy : 0;
+#pragma unroll
+      for (int o = kWave / 2; o > 0; o >>= 1) {
+        m0 += (unsigned long long)__shfl_xor((long long)m0, o), m1 += (unsigned long long)__shfl_xor((long long)m1, o);
+        m2 += (unsigned long long)__shfl_xor((long long)m2, o), m3 += (unsigned long long)__shfl_xor((long long)m3, o);
+      }
+      if (lane == leader) flush_moments(lid, m0, m1, m2, m3);
+    }
     pending &= ~__ballot(mine);
   }
   __syncthreads();

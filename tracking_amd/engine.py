@@ -76,6 +76,25 @@ class Engine:
             bg = bg[:, :, 0]
         return (fg if f & capi.FG_VALID else None), (bg if (bg is not None and f & capi.BG_VALID) else None)
 
+    def process_mask_only_on_device(self, frame, stream=0):
+        """bgs_process with fg = bg = NULL: the mask stays on the device (for last_mask_blobs).  Returns the out_flags."""
+        rows, cols = frame.shape[:2]
+        ch = 1 if frame.ndim == 2 else frame.shape[2]
+        frame = np.ascontiguousarray(frame)
+        flags = C.c_uint32(0)
+        capi.check(capi.lib().bgs_process(self._h, stream, frame.ctypes.data_as(C.c_void_p), rows, cols, ch, frame.strides[0], None, 0, None, 0, C.byref(flags)))
+        return flags.value
+
+    def last_mask_blobs(self, stream=0, connectivity=8, min_w=0, min_h=0, max_boxes=4096):
+        """bgs_last_mask_blobs: (boxes int32 [k][6] = BOX_FIELDS, moments int64 [k][4] = sx, sy, sxx, syy, count) of the mask the
+        last process() call of `stream` left on the device; k = min(count, max_boxes)."""
+        boxes = np.zeros((max(max_boxes, 1), 6), np.int32)
+        mom = np.zeros((max(max_boxes, 1), 4), np.int64)
+        n = C.c_int32(0)
+        capi.check(capi.lib().bgs_last_mask_blobs(self._h, stream, connectivity, min_w, min_h, boxes.ctypes.data_as(C.c_void_p), mom.ctypes.data_as(C.c_void_p), max_boxes, C.byref(n)))
+        k = min(n.value, max_boxes)
+        return boxes[:k], mom[:k], n.value
+
     # -- device path -----------------------------------------------------------
     @staticmethod
     def _ptr(t):
@@ -204,3 +223,20 @@ def mask_components_batch_device(masks, connectivity=8, max_boxes=65536, want_la
                                                            C.c_void_p(offsets.data_ptr()), C.c_void_p(work.data_ptr()), C.c_void_p(hip_stream)))
     off = offsets.cpu()
     return labels, boxes[:min(int(off[-1]), max_boxes)], off
+
+
+def mask_blobs_batch_device(masks, connectivity=8, max_boxes=65536, device=0, hip_stream=None):
+    """bgs_mask_blobs_batch_device: boxes int32 [k][6], moments int64 [k][4] (sx, sy, sxx, syy), offsets int32 [images+1]."""
+    import torch
+    images, rows, cols = masks.shape
+    if hip_stream is None:
+        hip_stream = torch.cuda.current_stream().cuda_stream
+    boxes = torch.zeros((max(max_boxes, 1), 6), dtype=torch.int32, device=masks.device)
+    mom = torch.zeros((max(max_boxes, 1), 4), dtype=torch.int64, device=masks.device)
+    offsets = torch.zeros(images + 1, dtype=torch.int32, device=masks.device)
+    work = torch.empty(capi.lib().bgs_mask_components_batch_workspace(images, rows, cols), dtype=torch.uint8, device=masks.device)
+    capi.check(capi.lib().bgs_mask_blobs_batch_device(device, C.c_void_p(masks.data_ptr()), images, rows, cols, connectivity, C.c_void_p(boxes.data_ptr()),
+                                                      C.c_void_p(mom.data_ptr()), max_boxes, C.c_void_p(offsets.data_ptr()), C.c_void_p(work.data_ptr()), C.c_void_p(hip_stream)))
+    off = offsets.cpu()
+    k = min(int(off[-1]), max_boxes)
+    return boxes[:k], mom[:k], off

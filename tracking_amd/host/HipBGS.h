@@ -12,7 +12,8 @@
 // Build: -I<repo>/include -I<repo>/tracking_amd/host  -L<repo>/tracking_amd/lib -lbgs_hip
 //
 // This file needs OpenCV 2.4 headers, which the build image of this repository does not have: it is checked for syntax against
-// a declaration-only mock only, the logic it shares with bgs_host.h is what the tests exercise.
+// a declaration-only mock (tests/mock_opencv, test_reference_side_adapters_compile in tests/test_capi_cpu.py, -std=gnu++0x like the
+// reference's CMakeLists.txt:5); the logic it shares with bgs_host.h is what the tests exercise.
 #pragma once
 #include <iostream>
 #include <string>
@@ -95,6 +96,20 @@ class HipBGSBase : public IBGS {
     firstTime = false;
   }
   void setDevice(int d) { device_ = d; }  // which HIP device the lazily created engine uses (default 0)
+  // N2 blob hand-off: connected components of the mask the last process() call produced, found on the device copy of that
+  // mask (bgs_last_mask_blobs); components smaller than min_w x min_h are dropped.  Returns how many there are.
+  int lastMaskBlobs(int connectivity, int min_w, int min_h, std::vector<bgs_box>& boxes, std::vector<bgs_moments>& moments) {
+    if (!engine_) fail();
+    int32_t n = 0;
+    boxes.resize(256), moments.resize(256);
+    for (int pass = 0; pass < 2; ++pass) {  // second pass only if the first buffer was too small
+      if (bgs_last_mask_blobs(engine_, 0, connectivity, min_w, min_h, &boxes[0], &moments[0], (int)boxes.size(), &n)) fail();
+      if (n <= (int)boxes.size()) break;
+      boxes.resize(n), moments.resize(n);
+    }
+    boxes.resize(n), moments.resize(n);
+    return n;
+  }
 
  protected:
   HipBGSBase(bgs_algo algo, const char* name, bool clears_bg = false) : firstTime(true), algo_(algo), name_(name), clears_bg_(clears_bg), device_(0), engine_(0) {

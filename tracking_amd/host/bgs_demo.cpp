@@ -4,7 +4,8 @@
 // frames.raw = n_frames x rows x cols x 3 bytes (BGR).  For every class enabled in ./config/FrameProcessor.xml the mask of
 // each frame is appended to <out_prefix>.<ClassName>.raw (frames whose output the class leaves untouched are written as 0x07).
 // With a 6th argument the frames go through USTC_BGS(type) instead (ustc_src/ustc_bgs.cpp) and GetMask() of every frame is
-// written to <out_prefix>.ustc.raw.
+// written to <out_prefix>.ustc.raw.  With a 7th argument ("box" or "moments") the detector is a HipFGDetector and every frame's blob
+// list (GetBlobs) is printed like ustc_src/trackingMain.cpp:189-190 prints the tracker's: "pBlob x,y,w,h,id is ...".
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -35,15 +36,25 @@ int main(int argc, char** argv) {
     std::ifstream in(argv[1], std::ios::binary);
     if (!in) throw Exception(BGS_ERR_INVALID, std::string("cannot open ") + argv[1]);
     if (argc >= 7) {  // the tracker's FG detector: Process(frame) then GetMask(), trackingMain.cpp:152-166
-      USTC_BGS fg(std::atoi(argv[6]));
+      HipFGDetector fg(std::atoi(argv[6]));
+      const bool want_blobs = argc >= 8, from_moments = want_blobs && std::string(argv[7]) == "moments";
       std::ofstream out((prefix + ".ustc.raw").c_str(), std::ios::binary);
       Image frame(rows, cols, 3);
+      CvBlobSeq blobs;
       for (int t = 0; t < n; ++t) {
         in.read((char*)frame.data, (size_t)rows * cols * 3);
         if (!in) throw Exception(BGS_ERR_INVALID, "short read on frame file");
         fg.Process(frame);
         const Image* m = fg.GetMask();
         dump(out, m ? *m : Image(), rows, cols);
+        if (want_blobs) {
+          fg.GetBlobs(&blobs, 8, from_moments);
+          std::printf("frame %d blobs %d\n", t, blobs.GetBlobNum());
+          for (int i = blobs.GetBlobNum(); i > 0; i--) {  // trackingMain.cpp:184-190
+            CvBlob* pBlob = blobs.GetBlob(i - 1);
+            std::printf("pBlob x,y,w,h,id is %.9g , %.9g , %.9g , %.9g , %d\n", pBlob->x, pBlob->y, pBlob->w, pBlob->h, pBlob->ID);
+          }
+        }
       }
       fg.Release();
       return 0;

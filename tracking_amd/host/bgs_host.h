@@ -193,6 +193,21 @@ class HipBGSBase : public IBGS {
   }
   // which HIP device the lazily created engine uses (default 0); the reference has no such notion
   void setDevice(int d) { device_ = d; }
+  // N2 blob hand-off: connected components of the mask the last process() call produced, found on the device copy of that
+  // mask (bgs_last_mask_blobs); components smaller than min_w x min_h are dropped.  Returns how many there are.
+  int lastMaskBlobs(int connectivity, int min_w, int min_h, std::vector<bgs_box>& boxes, std::vector<bgs_moments>& moments) {
+    if (!engine_) throw Exception(BGS_ERR_STATE, std::string(name_) + ": no frame processed yet");
+    int32_t n = 0;
+    boxes.resize(256), moments.resize(256);
+    for (int pass = 0; pass < 2; ++pass) {  // second pass only if the first buffer was too small
+      int rc = bgs_last_mask_blobs(engine_, 0, connectivity, min_w, min_h, boxes.data(), moments.data(), (int)boxes.size(), &n);
+      if (rc) throw Exception(rc, std::string(name_) + ": " + bgs_last_error());
+      if (n <= (int)boxes.size()) break;
+      boxes.resize(n), moments.resize(n);
+    }
+    boxes.resize(n), moments.resize(n);
+    return n;
+  }
 
  protected:
   HipBGSBase(bgs_algo algo, const char* name, bool clears_bg = false) : firstTime(true), algo_(algo), name_(name), clears_bg_(clears_bg) {

@@ -6,6 +6,7 @@
 // throw instead of silently running something else.
 #pragma once
 #include "bgs_host.h"
+#include "blob.h"
 
 namespace bgs_hip {
 
@@ -49,6 +50,41 @@ class USTC_BGS {
     if (img_mask.empty()) std::cout << "img_mask is empty " << frameNum << std::endl;
     frameNum++;
   }
+};
+
+// N2: the FG detector with the blob list hand-off.  USTC_BGS hands the tracker a full mask (GetMask) and OpenCV-legacy's
+// CvBlobDetector extracts the foreground regions from it on the CPU (ustc_src/trackingMain.cpp:56-57, :166).  With the mask
+// already in HBM the regions are found there (kernel_cc.h) and only their rectangles and moments come back: GetBlobs() fills a
+// CvBlobSeq with one CvBlob {x, y, w, h, ID} per region of at least CV_BLOB_MINW x CV_BLOB_MINH pixels, in raster order of the
+// regions' first pixels, IDs counting up from the detector's own counter (CvBlobTrackerAuto1 numbers new blobs the same way).
+class HipFGDetector : public USTC_BGS {
+ public:
+  explicit HipFGDetector(int type) : USTC_BGS(type), nextBlobID(0) {}
+  int nextBlobID;
+
+  // fromMoments: centre = centroid, size = 4 sigma (blob_from_moments); otherwise the bounding rectangle (blob_from_box)
+  int GetBlobs(CvBlobSeq* pBlobs, int connectivity = 8, bool fromMoments = true) {
+    pBlobs->Clear();
+    if (frameNum == 0 || img_mask.empty()) return 0;
+    HipBGSBase* h = dynamic_cast<HipBGSBase*>(bgs);
+    if (!h) throw Exception(BGS_ERR_STATE, "HipFGDetector: the IBGS object is not a libbgs_hip class");
+    h->lastMaskBlobs(connectivity, CV_BLOB_MINW, CV_BLOB_MINH, boxes_, moments_);
+    for (size_t i = 0; i < boxes_.size(); ++i) {
+      CvBlob b = cvBlob(0, 0, 0, 0);
+      if (fromMoments)
+        bgs_hip_convert::blob_from_moments(boxes_[i], moments_[i], b);
+      else
+        bgs_hip_convert::blob_from_box(boxes_[i], b);
+      b.ID = nextBlobID++;
+      pBlobs->AddBlob(&b);
+    }
+    return pBlobs->GetBlobNum();
+  }
+  const std::vector<bgs_box>& lastBoxes() const { return boxes_; }
+
+ private:
+  std::vector<bgs_box> boxes_;
+  std::vector<bgs_moments> moments_;
 };
 
 }  // namespace bgs_hip
