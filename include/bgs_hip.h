@@ -317,6 +317,40 @@ int bgs_mask_blobs_batch_device(int hip_device, const void* d_masks, int images,
 int bgs_last_mask_blobs(bgs_engine* e, int stream, int connectivity, int min_w, int min_h, bgs_box* boxes, bgs_moments* moments,
                         int max_boxes, int32_t* count);
 
+/* ---- N3: frame preparation on the device (the step BEFORE the path) --------------------------------------------------------
+ * What VideoCapture::start (VideoCapture.cpp:158-207: cvResize to input_resize_percent, cvFlip(frame, frame, 0), ROI view) and
+ * PreProcessor::process (PreProcessor.cpp:46-77: optional cv::equalizeHist, optional cv::GaussianBlur 7x7 sigma 1.5) do to a
+ * captured frame before FrameProcessor hands it to every IBGS::process, in that order, as one device pass over frames that
+ * are already in HBM (a decoder's output) or as a host-buffer convenience.  Flip and ROI are exact by definition; resize,
+ * equalizeHist and GaussianBlur restate OpenCV 2.4's 8-bit fixed-point arithmetic from recall (unpinned). */
+typedef struct bgs_ingest {
+  uint32_t struct_size;     /* sizeof(bgs_ingest) */
+  int32_t resize_percent;   /* VideoCapture input_resize_percent; 100 = same size; output = (cols*pct/100, rows*pct/100) */
+  int32_t flip;             /* VideoCapture enableFlip: rows reversed (cvFlip mode 0) */
+  int32_t roi_x0, roi_y0, roi_x1, roi_y1; /* VideoCapture ROI in the resized, flipped frame; used when x1 > x0 and y1 > y0 */
+  int32_t equalize_hist;    /* PreProcessor equalizeHist: 1-channel frames only (cv::equalizeHist asserts CV_8UC1) */
+  int32_t gaussian_blur;    /* PreProcessor gaussianBlur */
+} bgs_ingest;
+int bgs_ingest_default(bgs_ingest* cfg); /* the reference's defaults: 100 %, nothing else */
+/* geometry of the prepared frame; BGS_ERR_INVALID for a ROI outside the resized frame or an empty result */
+int bgs_ingest_size(const bgs_ingest* cfg, int src_rows, int src_cols, int* rows, int* cols);
+/* bytes of device scratch bgs_ingest_device needs for `images` frames (0 when the configuration needs none) */
+size_t bgs_ingest_workspace(const bgs_ingest* cfg, int images, int src_rows, int src_cols, int channels);
+/* d_src: [images] frames of src_rows x src_cols x channels uint8, rows src_step bytes apart, images src_rows*src_step apart.
+ * d_dst: [images][rows][cols][channels] contiguous (bgs_ingest_size) - what bgs_process_batch_device takes.  Asynchronous on
+ * hip_stream; d_work may be NULL when bgs_ingest_workspace is 0. */
+int bgs_ingest_device(int hip_device, const bgs_ingest* cfg, const void* d_src, int images, int src_rows, int src_cols, int channels,
+                      size_t src_step, void* d_dst, void* d_work, void* hip_stream);
+/* Make the frame preparation part of the engine's host path: from now on bgs_process takes the RAW captured frame (any size, but
+ * the same size every call) and fg / bg come out in the prepared geometry (bgs_ingest_size), which is also the engine's geometry.
+ * Flip and ROI alone are folded into the pinned staging copy (no device work at all); resize / equalizeHist / GaussianBlur run
+ * as bgs_ingest_device between the upload and the model kernel.  Must be called before the first frame; cfg NULL switches it off. */
+int bgs_set_ingest(bgs_engine* e, const bgs_ingest* cfg);
+/* Host buffers in, host buffers out (PreProcessor::process / VideoCapture's frame preparation as one call): uploads, runs
+ * bgs_ingest_device, downloads.  dst: rows x cols x channels, rows dst_step bytes apart.  Synchronous. */
+int bgs_ingest_host(int hip_device, const bgs_ingest* cfg, const uint8_t* src, int src_rows, int src_cols, int channels, size_t src_step,
+                    uint8_t* dst, size_t dst_step);
+
 #ifdef __cplusplus
 }
 #endif

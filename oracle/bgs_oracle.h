@@ -49,6 +49,14 @@ void orc_erode3x3(const uint8_t* src, uint8_t* dst, int rows, int cols, int iter
 void orc_dilate3x3(const uint8_t* src, uint8_t* dst, int rows, int cols, int iterations);
 void orc_floodfill_from_origin(uint8_t* img, int rows, int cols, uint8_t newval);
 
+/* N3 frame preparation (ingest_oracle.c) */
+void orc_ingest_size(const bgs_ingest* c, int src_rows, int src_cols, int* rows, int* cols);
+int orc_ingest(const bgs_ingest* c, const uint8_t* src, int src_rows, int src_cols, int ch, size_t src_step, uint8_t* dst);
+void orc_resize_linear_u8(const uint8_t* src, int srows, int scols, int ch, size_t sstep, uint8_t* dst, int drows, int dcols);
+void orc_equalize_hist_u8(uint8_t* img, size_t total);
+int orc_gaussian7_kernel(int ik[7]);
+void orc_gaussian_blur7_u8(const uint8_t* src, uint8_t* dst, int rows, int cols, int ch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,16 @@ def lib():
         l.orc_floodfill_from_origin.restype = None
         l.orc_components.argtypes = [_P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int]
         l.orc_components.restype = C.c_int
+        l.orc_ingest_size.argtypes = [_P, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        l.orc_ingest_size.restype = None
+        l.orc_ingest.argtypes = [_P, _P, C.c_int, C.c_int, C.c_int, C.c_size_t, _P]
+        l.orc_resize_linear_u8.argtypes = [_P, C.c_int, C.c_int, C.c_int, C.c_size_t, _P, C.c_int, C.c_int]
+        l.orc_resize_linear_u8.restype = None
+        l.orc_equalize_hist_u8.argtypes = [_P, C.c_size_t]
+        l.orc_equalize_hist_u8.restype = None
+        l.orc_gaussian7_kernel.argtypes = [_P]
+        l.orc_gaussian_blur7_u8.argtypes = [_P, _P, C.c_int, C.c_int, C.c_int]
+        l.orc_gaussian_blur7_u8.restype = None
         _lib = l
     return _lib
 
@@ -220,3 +230,25 @@ def ref_sigmadelta_clip(frames, amp=1, vmin=15, vmax=255):
         frames.tofile(fin)
         subprocess.run([_REF_SDLAMA, fin, str(rows), str(cols), str(n), str(amp), str(vmin), str(vmax), fout], check=True)
         return np.fromfile(fout, np.uint8).reshape(n - 1, rows, cols)
+
+
+# ---- N3 frame preparation (ingest_oracle.c) ----
+
+def ingest(cfg, frame):
+    """cfg: tracking_amd.capi.BgsIngest.  frame: HxW or HxWxC uint8.  Returns the prepared frame (or None where the reference fails)."""
+    f = np.ascontiguousarray(frame)
+    rows, cols = f.shape[:2]
+    ch = 1 if f.ndim == 2 else f.shape[2]
+    r, c = C.c_int(0), C.c_int(0)
+    lib().orc_ingest_size(C.byref(cfg), rows, cols, C.byref(r), C.byref(c))
+    if r.value < 1 or c.value < 1:
+        return None
+    out = np.empty((r.value, c.value) if f.ndim == 2 else (r.value, c.value, ch), np.uint8)
+    rc = lib().orc_ingest(C.byref(cfg), _ptr(f), rows, cols, ch, f.strides[0], _ptr(out))
+    return out if rc == 0 else None
+
+
+def gaussian7_kernel():
+    ik = (C.c_int * 7)()
+    smooth = lib().orc_gaussian7_kernel(ik)
+    return list(ik), bool(smooth)

@@ -405,3 +405,85 @@ def test_morphology_oracle_vs_scipy():
         want = b.copy()
         want[lab == lab[0, 0]] = 255
         assert np.array_equal(pyoracle.floodfill_from_origin(b, 255), want), shape
+
+
+# ---- N3 frame preparation (oracle/ingest_oracle.c): the restated OpenCV pieces against independent formulations ----
+
+def _ingest_cfg(**kw):
+    from tracking_amd import capi
+    return capi.default_ingest(**kw)
+
+
+def test_ingest_gaussian_kernel_takes_the_fixed_point_path():
+    """cv::GaussianBlur on 8U only runs in fixed point when getKernelType calls the float kernel smooth (|sum - 1| within FLT_EPSILON):
+    the restatement checks that condition for (7, 1.5) and this pins the integer kernel it derives."""
+    ik, smooth = pyoracle.gaussian7_kernel()
+    assert smooth
+    assert ik == [9, 28, 55, 69, 55, 28, 9]  # sums to 253, not 256: each 8-bit coefficient is rounded on its own (as recalled, nothing renormalises)
+    want = np.exp(-0.5 * (np.arange(7) - 3.0) ** 2 / 1.5 ** 2)
+    assert ik == [int(round(v)) for v in want / want.sum() * 256]
+
+
+@pytest.mark.parametrize("shape", [(40, 60, 3), (9, 5, 1), (1, 1, 3), (3, 70, 3), (64, 64, 1)])
+def test_ingest_blur_vs_scipy(shape):
+    from scipy import ndimage
+    rng = np.random.default_rng(shape[0] * 100 + shape[1])
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    got = pyoracle.ingest(_ingest_cfg(gaussian_blur=1), img if shape[2] == 3 else img[:, :, 0])
+    ik, _ = pyoracle.gaussian7_kernel()
+    t = ndimage.correlate1d(img.astype(np.int64), np.array(ik, np.int64), axis=1, mode="mirror")   # BORDER_REFLECT_101
+    t = ndimage.correlate1d(t, np.array(ik, np.int64), axis=0, mode="mirror")
+    want = np.clip((t + (1 << 15)) >> 16, 0, 255).astype(np.uint8)
+    assert np.array_equal(got.reshape(shape), want)
+
+
+def test_ingest_equalize_vs_numpy():
+    rng = np.random.default_rng(3)
+    for img in (rng.integers(30, 200, (50, 70), dtype=np.uint8), np.full((8, 9), 77, np.uint8), (rng.random((40, 40)) < 0.5).astype(np.uint8) * 255):
+        got = pyoracle.ingest(_ingest_cfg(equalize_hist=1), img)
+        hist = np.bincount(img.ravel(), minlength=256)
+        i = int(np.flatnonzero(hist)[0])
+        if hist[i] == img.size:
+            want = np.full_like(img, i)
+        else:
+            scale = np.float32(255.0) / np.float32(img.size - hist[i])
+            csum = np.cumsum(hist[i + 1:]).astype(np.float32)
+            lut = np.zeros(256, np.uint8)
+            lut[i + 1:] = np.clip(np.rint(csum * scale), 0, 255).astype(np.uint8)
+            want = lut[img]
+        assert np.array_equal(got, want)
+    assert pyoracle.ingest(_ingest_cfg(equalize_hist=1), np.zeros((4, 4, 3), np.uint8)) is None  # cv::equalizeHist asserts CV_8UC1
+
+
+def test_ingest_flip_roi_and_identity_resize_are_exact():
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    assert np.array_equal(pyoracle.ingest(_ingest_cfg(), img), img)  # cvResize to the same size: every coefficient is (2048, 0)
+    assert np.array_equal(pyoracle.ingest(_ingest_cfg(flip=1), img), img[::-1])
+    c = _ingest_cfg(flip=1, roi_x0=5, roi_y0=7, roi_x1=40, roi_y1=30)
+    assert np.array_equal(pyoracle.ingest(c, img), img[::-1][7:30, 5:40])
+    assert pyoracle.ingest(_ingest_cfg(roi_x0=5, roi_y0=7, roi_x1=60, roi_y1=30), img) is None  # cvSetImageROI outside the frame
+
+
+@pytest.mark.parametrize("pct", [50, 25, 75, 130, 33])
+def test_ingest_resize_vs_float_bilinear(pct):
+    """R1 against the textbook float formula (half-pixel centres, clamped taps): the 11-bit fixed point stays within 1 grey level;
+    50 % of an even-sized frame is exactly the rounded 2x2 block mean (INTER_AREA's fast path)."""
+    rng = np.random.default_rng(pct)
+    img = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+    got = pyoracle.ingest(_ingest_cfg(resize_percent=pct), img)
+    rh, rw = 48 * pct // 100, 64 * pct // 100
+    assert got.shape == (rh, rw, 3)
+    if pct == 50:
+        b = img.astype(np.int32)
+        assert np.array_equal(got, ((b[0::2, 0::2] + b[0::2, 1::2] + b[1::2, 0::2] + b[1::2, 1::2] + 2) >> 2).astype(np.uint8))
+        return
+    ys = (np.arange(rh) + 0.5) * (48 / rh) - 0.5
+    xs = (np.arange(rw) + 0.5) * (64 / rw) - 0.5
+    y0, x0 = np.floor(ys).astype(int), np.floor(xs).astype(int)
+    fy, fx = (ys - y0)[:, None, None], (xs - x0)[None, :, None]
+    yc0, yc1 = np.clip(y0, 0, 47), np.clip(y0 + 1, 0, 47)
+    xc0, xc1 = np.clip(x0, 0, 63), np.clip(x0 + 1, 0, 63)
+    f = img.astype(np.float64)
+    want = (f[yc0][:, xc0] * (1 - fx) + f[yc0][:, xc1] * fx) * (1 - fy) + (f[yc1][:, xc0] * (1 - fx) + f[yc1][:, xc1] * fx) * fy
+    assert np.max(np.abs(got.astype(np.float64) - want)) <= 1.0

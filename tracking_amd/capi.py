@@ -107,6 +107,12 @@ SYMBOLS = [
     ("bgs_mask_components_batch_workspace", C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     ("bgs_mask_components_batch_device", C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P]),
     ("bgs_mask_blobs_batch_device", C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P]),
+    ("bgs_ingest_default", C.c_int, [_P]),
+    ("bgs_ingest_size", C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("bgs_ingest_workspace", C.c_size_t, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("bgs_ingest_device", C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, _P, _P, _P]),
+    ("bgs_set_ingest", C.c_int, [_P, _P]),
+    ("bgs_ingest_host", C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_size_t, _P, C.c_size_t]),
     ("bgs_last_mask_blobs", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_int32)]),
 ]
 
@@ -136,6 +142,20 @@ def check(rc):
     if rc < 0:
         raise BgsError(rc, last_error())
     return rc
+
+
+class BgsIngest(C.Structure):
+    """struct bgs_ingest, field for field (N3 frame preparation)."""
+    _fields_ = [("struct_size", C.c_uint32), ("resize_percent", C.c_int32), ("flip", C.c_int32), ("roi_x0", C.c_int32), ("roi_y0", C.c_int32),
+                ("roi_x1", C.c_int32), ("roi_y1", C.c_int32), ("equalize_hist", C.c_int32), ("gaussian_blur", C.c_int32)]
+
+
+def default_ingest(**kw):
+    c = BgsIngest()
+    check(lib().bgs_ingest_default(C.byref(c)))
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
 
 
 def default_params(algo):

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "kernel_gmg.h"
+#include "kernel_ingest.h"
 #include "kernel_cc.h"
 #include "kernel_dp.h"
 #include "kernel_mog1.h"
@@ -108,6 +109,10 @@ struct bgs_engine {
   uint8_t *d_in = nullptr, *d_fg = nullptr, *d_bg = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t band_ev[8] = {nullptr};  // bgs_process: one event per output band
+  bool ingest_on = false;             // bgs_set_ingest: bgs_process takes raw frames
+  bgs_ingest ingest{};
+  int raw_rows = 0, raw_cols = 0;     // geometry of the raw frames (fixed by the first one)
+  uint8_t *h_raw = nullptr, *d_raw = nullptr, *d_ingest_ws = nullptr;  // raw staging for configurations that need device work
   int last_fg_stream = -1;            // bgs_last_mask_blobs: whose mask d_fg holds (-1: none valid)
   void* cc_work = nullptr;            // its device scratch: workspace | boxes | moments | count
   int cc_cap = 0;                     // boxes the scratch has room for
@@ -127,6 +132,9 @@ void free_all(bgs_engine* e) {
     if (r) (void)hipFree(r), r = nullptr;
   if (e->abl_lut) (void)hipFree(e->abl_lut), e->abl_lut = nullptr, e->abl_lut_valid = false;
   if (e->cc_work) (void)hipFree(e->cc_work), e->cc_work = nullptr, e->cc_cap = 0;
+  if (e->h_raw) (void)hipHostFree(e->h_raw), e->h_raw = nullptr;
+  if (e->d_raw) (void)hipFree(e->d_raw), e->d_raw = nullptr;
+  if (e->d_ingest_ws) (void)hipFree(e->d_ingest_ws), e->d_ingest_ws = nullptr;
   e->last_fg_stream = -1;
   void* dev[] = {e->dp_state, e->gmg_colors, e->gmg_weights, e->gmg_nfeat, e->bgstate, e->bgstate2, e->mog1_state, e->mog2_state, e->mog2_nmodes, e->d_in, e->d_fg, e->d_bg};
   for (void* d : dev)
@@ -817,6 +825,46 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
 
 }  // namespace
 
+// N3 (bgs_ingest_*, bgs_set_ingest): geometry of the frame preparation
+namespace {
+struct IngestPlan {
+  int rw, rh, rows, cols, x0, y0, mode;
+  double scale_x, scale_y;
+};
+int ingest_plan(const bgs_ingest* c, int src_rows, int src_cols, IngestPlan* pl) {
+  if (!c || c->struct_size != sizeof(bgs_ingest)) return fail(BGS_ERR_INVALID, "bgs_ingest.struct_size mismatch");
+  if (src_rows <= 0 || src_cols <= 0 || c->resize_percent <= 0) return fail(BGS_ERR_INVALID, "bad ingest geometry");
+  pl->rw = (int)(((int64_t)src_cols * c->resize_percent) / 100), pl->rh = (int)(((int64_t)src_rows * c->resize_percent) / 100);  // VideoCapture.cpp:142
+  if (pl->rw < 1 || pl->rh < 1) return fail(BGS_ERR_INVALID, "resize to %d %% leaves no pixels", c->resize_percent);
+  const bool roi = c->roi_x1 > c->roi_x0 && c->roi_y1 > c->roi_y0;
+  pl->x0 = roi ? c->roi_x0 : 0, pl->y0 = roi ? c->roi_y0 : 0;
+  pl->cols = roi ? c->roi_x1 - c->roi_x0 : pl->rw, pl->rows = roi ? c->roi_y1 - c->roi_y0 : pl->rh;
+  if (pl->x0 < 0 || pl->y0 < 0 || pl->x0 + pl->cols > pl->rw || pl->y0 + pl->rows > pl->rh)
+    return fail(BGS_ERR_INVALID, "ROI (%d,%d)-(%d,%d) outside the %dx%d frame (cvSetImageROI would fail)", c->roi_x0, c->roi_y0, c->roi_x1, c->roi_y1, pl->rw, pl->rh);
+  pl->scale_x = 1. / ((double)pl->rw / src_cols), pl->scale_y = 1. / ((double)pl->rh / src_rows);
+  const int isx = (int)std::lrint(pl->scale_x), isy = (int)std::lrint(pl->scale_y);
+  const bool area_fast = std::fabs(pl->scale_x - isx) < 2.220446049250313e-16 && std::fabs(pl->scale_y - isy) < 2.220446049250313e-16;
+  pl->mode = (pl->rw == src_cols && pl->rh == src_rows) ? 0 : (area_fast && isx == 2 && isy == 2) ? 2 : 1;
+  return BGS_OK;
+}
+// cv::getGaussianKernel(7, 1.5, CV_32F) -> the integer kernel of the 8-bit fixed-point filter (R3, kernel_ingest.h)
+void gaussian7_kernel(int ik[7]) {
+  float cf[7];
+  const double sigma = 1.5, scale2X = -0.5 / (sigma * sigma);
+  double sum = 0;
+  for (int i = 0; i < 7; ++i) {
+    const double x = i - 3.0;
+    cf[i] = (float)std::exp(scale2X * x * x);
+    sum += cf[i];
+  }
+  sum = 1. / sum;
+  for (int i = 0; i < 7; ++i) {
+    cf[i] = (float)(cf[i] * sum);
+    ik[i] = (int)std::lrintf(cf[i] * 256.f);
+  }
+}
+}  // namespace
+
 extern "C" {
 
 int bgs_abi_version(void) { return BGS_ABI_VERSION; }
@@ -1018,6 +1066,19 @@ int bgs_process(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols
   if (!in || rows <= 0 || cols <= 0) return BGS_OK;  // if(img_input.empty()) return;
   if (channels != 1 && channels != 3) return fail(BGS_ERR_UNSUPPORTED, "channels must be 1 or 3");
   if (in_step < (size_t)cols * channels) return fail(BGS_ERR_INVALID, "in_step %zu < cols*channels", in_step);
+  // N3: with bgs_set_ingest the caller hands over the RAW captured frame; everything below runs in the prepared geometry
+  IngestPlan pl{};
+  const bool ingest = e->ingest_on;
+  const int raw_rows = rows, raw_cols = cols;
+  if (ingest) {
+    int rc0 = ingest_plan(&e->ingest, rows, cols, &pl);
+    if (rc0) return rc0;
+    if (e->ingest.equalize_hist && channels != 1) return fail(BGS_ERR_UNSUPPORTED, "equalizeHist needs a 1-channel frame (cv::equalizeHist asserts CV_8UC1, PreProcessor.cpp:64)");
+    if (e->raw_rows && (e->raw_rows != rows || e->raw_cols != cols)) return fail(BGS_ERR_GEOMETRY, "raw frames were %dx%d, now %dx%d", e->raw_rows, e->raw_cols, rows, cols);
+    e->raw_rows = rows, e->raw_cols = cols;
+    rows = pl.rows, cols = pl.cols;
+  }
+  const bool ingest_on_device = ingest && (pl.mode != 0 || e->ingest.equalize_hist || e->ingest.gaussian_blur);
   int rc = bgs_set_geometry(e, rows, cols, channels);
   if (rc) return rc;
   rc = ensure_staging(e);
@@ -1027,13 +1088,37 @@ int bgs_process(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols
   // history-keeping algorithms receive the upload straight in their ring slot (zero-copy history)
   uint8_t* dst = e->d_in;
   if (e->nring) dst = e->ring[e->seen[stream] % e->nring] + (size_t)stream * fb;
-  // staging is pipelined: while the DMA engine moves band k, the CPU copies band k+1 of the caller's (pageable, possibly
-  // strided) image into the pinned buffer
-  const int bands = rows >= 64 ? 8 : 1;
-  for (int b = 0; b < bands; ++b) {
-    const int y0 = (int)((int64_t)rows * b / bands), y1 = (int)((int64_t)rows * (b + 1) / bands);
-    for (int y = y0; y < y1; ++y) std::memcpy(e->h_in + (size_t)y * rb, in + (size_t)y * in_step, rb);
-    HIP_TRY(hipMemcpyAsync(dst + (size_t)y0 * rb, e->h_in + (size_t)y0 * rb, (size_t)(y1 - y0) * rb, hipMemcpyHostToDevice, e->stream));
+  if (ingest_on_device) {
+    // resize / equalizeHist / GaussianBlur: the raw frame goes up as it is, the preparation runs between the upload and the model kernel
+    const size_t raw_rb = (size_t)raw_cols * channels, raw_bytes = raw_rb * raw_rows;
+    if (!e->h_raw) {
+      HIP_TRY(hipHostMalloc((void**)&e->h_raw, raw_bytes, hipHostMallocDefault));
+      HIP_TRY(hipMalloc((void**)&e->d_raw, raw_bytes));
+      const size_t ws = bgs_ingest_workspace(&e->ingest, 1, raw_rows, raw_cols, channels);
+      if (ws) HIP_TRY(hipMalloc((void**)&e->d_ingest_ws, ws));
+    }
+    const int bands = raw_rows >= 64 ? 8 : 1;
+    for (int b = 0; b < bands; ++b) {
+      const int y0 = (int)((int64_t)raw_rows * b / bands), y1 = (int)((int64_t)raw_rows * (b + 1) / bands);
+      for (int y = y0; y < y1; ++y) std::memcpy(e->h_raw + (size_t)y * raw_rb, in + (size_t)y * in_step, raw_rb);
+      HIP_TRY(hipMemcpyAsync(e->d_raw + (size_t)y0 * raw_rb, e->h_raw + (size_t)y0 * raw_rb, (size_t)(y1 - y0) * raw_rb, hipMemcpyHostToDevice, e->stream));
+    }
+    rc = bgs_ingest_device(e->device, &e->ingest, e->d_raw, 1, raw_rows, raw_cols, channels, raw_rb, dst, e->d_ingest_ws, e->stream);
+    if (rc) return rc;
+  } else {
+    // staging is pipelined: while the DMA engine moves band k, the CPU copies band k+1 of the caller's (pageable, possibly
+    // strided) image into the pinned buffer.  Flip (rows reversed) and ROI (a window of the raw frame) cost nothing extra: they
+    // only change which source row and column each staged row starts at.
+    const int bands = rows >= 64 ? 8 : 1;
+    for (int b = 0; b < bands; ++b) {
+      const int y0 = (int)((int64_t)rows * b / bands), y1 = (int)((int64_t)rows * (b + 1) / bands);
+      for (int y = y0; y < y1; ++y) {
+        size_t sy = (size_t)y, sx = 0;
+        if (ingest) sy = (size_t)(e->ingest.flip ? pl.rh - 1 - (y + pl.y0) : y + pl.y0), sx = (size_t)pl.x0 * channels;
+        std::memcpy(e->h_in + (size_t)y * rb, in + sy * in_step + sx, rb);
+      }
+      HIP_TRY(hipMemcpyAsync(dst + (size_t)y0 * rb, e->h_in + (size_t)y0 * rb, (size_t)(y1 - y0) * rb, hipMemcpyHostToDevice, e->stream));
+    }
   }
   uint32_t flags = 0;
   const bool saved_borrow = e->borrow;
@@ -1047,7 +1132,7 @@ int bgs_process(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols
   // the way back is pipelined the same way when there is a background image to return (6 MB at 1080p): band k is copied out to
   // the caller's image while band k+1 is still on the bus; a mask alone (2 MB) is not worth the events
   const bool out_fg = fg && (flags & BGS_FG_VALID), out_bg = bg && (flags & BGS_BG_VALID);
-  const int obands = out_bg ? bands : 1;
+  const int obands = out_bg ? (rows >= 64 ? 8 : 1) : 1;
   for (int b = 0; b < obands; ++b) {
     const int y0 = (int)((int64_t)rows * b / obands), y1 = (int)((int64_t)rows * (b + 1) / obands);
     if (out_fg) HIP_TRY(hipMemcpyAsync(e->h_fg + (size_t)y0 * cols, e->d_fg + (size_t)y0 * cols, (size_t)(y1 - y0) * cols, hipMemcpyDeviceToHost, e->stream));
@@ -1418,6 +1503,136 @@ int bgs_last_mask_blobs(bgs_engine* e, int stream, int connectivity, int min_w, 
   }
   *count = kept;
   return BGS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------- N3: ingest
+
+int bgs_set_ingest(bgs_engine* e, const bgs_ingest* c) {
+  if (!e) return fail(BGS_ERR_INVALID, "engine is NULL");
+  if (e->n) return fail(BGS_ERR_INVALID, "bgs_set_ingest must come before the first frame (it decides the engine's geometry)");
+  if (!c) {
+    e->ingest_on = false;
+    return BGS_OK;
+  }
+  if (c->struct_size != sizeof(bgs_ingest)) return fail(BGS_ERR_INVALID, "bgs_ingest.struct_size mismatch");
+  if (c->resize_percent <= 0) return fail(BGS_ERR_INVALID, "resize_percent must be positive");
+  e->ingest = *c, e->ingest_on = true;
+  return BGS_OK;
+}
+
+int bgs_ingest_default(bgs_ingest* c) {
+  if (!c) return fail(BGS_ERR_INVALID, "cfg is NULL");
+  std::memset(c, 0, sizeof(*c));
+  c->struct_size = (uint32_t)sizeof(*c);
+  c->resize_percent = 100;  // config/VideoCapture.xml, config/PreProcessor.xml: everything else off
+  return BGS_OK;
+}
+
+int bgs_ingest_size(const bgs_ingest* c, int src_rows, int src_cols, int* rows, int* cols) {
+  IngestPlan pl;
+  int rc = ingest_plan(c, src_rows, src_cols, &pl);
+  if (rc) return rc;
+  if (rows) *rows = pl.rows;
+  if (cols) *cols = pl.cols;
+  return BGS_OK;
+}
+
+size_t bgs_ingest_workspace(const bgs_ingest* c, int images, int src_rows, int src_cols, int channels) {
+  IngestPlan pl;
+  if (images <= 0 || ingest_plan(c, src_rows, src_cols, &pl)) return 0;
+  size_t need = 0;
+  if (c->equalize_hist) need += (size_t)images * 256 * (sizeof(unsigned) + 1);
+  if (c->gaussian_blur) need += (size_t)images * pl.rows * pl.cols * channels;  // the frame before the blur
+  return need ? need + 64 : 0;
+}
+
+int bgs_ingest_device(int hip_device, const bgs_ingest* c, const void* d_src, int images, int src_rows, int src_cols, int channels, size_t src_step, void* d_dst,
+                      void* d_work, void* hip_stream) {
+  IngestPlan pl;
+  int rc = ingest_plan(c, src_rows, src_cols, &pl);
+  if (rc) return rc;
+  if (!d_src || !d_dst || images <= 0 || images > 65535) return fail(BGS_ERR_INVALID, "bgs_ingest_device: bad argument");
+  if (channels != 1 && channels != 3) return fail(BGS_ERR_UNSUPPORTED, "channels must be 1 or 3");
+  if (src_step < (size_t)src_cols * channels) return fail(BGS_ERR_INVALID, "src_step %zu < src_cols*channels", src_step);
+  if (c->equalize_hist && channels != 1) return fail(BGS_ERR_UNSUPPORTED, "equalizeHist needs a 1-channel frame (cv::equalizeHist asserts CV_8UC1, PreProcessor.cpp:64)");
+  const size_t ws = bgs_ingest_workspace(c, images, src_rows, src_cols, channels);
+  if (ws && !d_work) return fail(BGS_ERR_INVALID, "bgs_ingest_device: this configuration needs %zu bytes of d_work", ws);
+  HIP_TRY(hipSetDevice(hip_device));
+  hipStream_t s = (hipStream_t)hip_stream;
+  const size_t n = (size_t)pl.rows * pl.cols;
+  // workspace: [hist][lut][pad to 16][pre-blur frames]
+  unsigned* hist = (unsigned*)d_work;
+  uint8_t* lut = (uint8_t*)d_work + (c->equalize_hist ? (size_t)images * 256 * sizeof(unsigned) : 0);
+  uint8_t* pre = (uint8_t*)(((uintptr_t)(lut + (c->equalize_hist ? (size_t)images * 256 : 0)) + 15) & ~(uintptr_t)15);
+  uint8_t* geom_out = c->gaussian_blur ? pre : (uint8_t*)d_dst;
+  bgs::IngestArgs a{};
+  a.src = (const uint8_t*)d_src, a.dst = geom_out, a.src_rows = src_rows, a.src_cols = src_cols, a.rw = pl.rw, a.rh = pl.rh, a.rows = pl.rows, a.cols = pl.cols;
+  a.x0 = pl.x0, a.y0 = pl.y0, a.flip = c->flip != 0, a.mode = pl.mode, a.src_step = src_step, a.scale_x = pl.scale_x, a.scale_y = pl.scale_y;
+  const dim3 grid(blocks_for(n), 1, images), block(bgs::kBlock);
+  if (channels == 3)
+    hipLaunchKernelGGL((bgs::ingest_geom_kernel<3>), grid, block, 0, s, a);
+  else
+    hipLaunchKernelGGL((bgs::ingest_geom_kernel<1>), grid, block, 0, s, a);
+  if (c->equalize_hist) {
+    HIP_TRY(hipMemsetAsync(hist, 0, (size_t)images * 256 * sizeof(unsigned), s));
+    hipLaunchKernelGGL(bgs::ingest_hist_kernel, dim3(std::min<unsigned>(blocks_for(n), 1024), 1, images), block, 0, s, (const uint8_t*)geom_out, n, hist);
+    hipLaunchKernelGGL(bgs::ingest_lut_kernel, dim3(images), block, 0, s, (const unsigned*)hist, lut, (unsigned)n);
+    hipLaunchKernelGGL(bgs::ingest_apply_lut_kernel, grid, block, 0, s, geom_out, n, (const uint8_t*)lut);
+  }
+  if (c->gaussian_blur) {
+    bgs::BlurArgs b{};
+    b.src = pre, b.dst = (uint8_t*)d_dst, b.rows = pl.rows, b.cols = pl.cols;
+    gaussian7_kernel(b.k);
+    const dim3 bgrid((pl.cols + bgs::kBlurTW - 1) / bgs::kBlurTW, (pl.rows + bgs::kBlurTH - 1) / bgs::kBlurTH, images);
+    if (channels == 3)
+      hipLaunchKernelGGL((bgs::ingest_blur7_kernel<3>), bgrid, block, 0, s, b);
+    else
+      hipLaunchKernelGGL((bgs::ingest_blur7_kernel<1>), bgrid, block, 0, s, b);
+  }
+  HIP_TRY(hipGetLastError());
+  return BGS_OK;
+}
+
+int bgs_ingest_host(int hip_device, const bgs_ingest* c, const uint8_t* src, int src_rows, int src_cols, int channels, size_t src_step, uint8_t* dst, size_t dst_step) {
+  IngestPlan pl;
+  int rc = ingest_plan(c, src_rows, src_cols, &pl);
+  if (rc) return rc;
+  if (!src || !dst) return fail(BGS_ERR_INVALID, "bgs_ingest_host: NULL buffer");
+  if (channels != 1 && channels != 3) return fail(BGS_ERR_UNSUPPORTED, "channels must be 1 or 3");
+  const size_t out_row = (size_t)pl.cols * channels;
+  if (dst_step < out_row) return fail(BGS_ERR_INVALID, "dst_step %zu < cols*channels", dst_step);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(BGS_ERR_HIP, "no HIP device visible: libbgs_hip has no CPU path");
+  HIP_TRY(hipSetDevice(hip_device));
+  const size_t in_bytes = (size_t)src_rows * src_cols * channels, out_bytes = (size_t)pl.rows * out_row, ws = bgs_ingest_workspace(c, 1, src_rows, src_cols, channels);
+  uint8_t *d_in = nullptr, *d_out = nullptr, *d_ws = nullptr;
+  hipStream_t s = nullptr;
+  auto cleanup = [&]() {
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (d_ws) (void)hipFree(d_ws);
+    if (s) (void)hipStreamDestroy(s);
+  };
+  hipError_t er = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (er == hipSuccess) er = hipMalloc((void**)&d_in, in_bytes);
+  if (er == hipSuccess) er = hipMalloc((void**)&d_out, out_bytes);
+  if (er == hipSuccess && ws) er = hipMalloc((void**)&d_ws, ws);
+  // rows are packed on the way up (the caller's step may exceed the row), one 2-D copy each way
+  if (er == hipSuccess) er = hipMemcpy2DAsync(d_in, (size_t)src_cols * channels, src, src_step, (size_t)src_cols * channels, src_rows, hipMemcpyHostToDevice, s);
+  if (er != hipSuccess) {
+    cleanup();
+    return fail(BGS_ERR_HIP, "bgs_ingest_host: %s", hipGetErrorString(er));
+  }
+  rc = bgs_ingest_device(hip_device, c, d_in, 1, src_rows, src_cols, channels, (size_t)src_cols * channels, d_out, d_ws, s);
+  if (!rc) {
+    er = hipMemcpy2DAsync(dst, dst_step, d_out, out_row, out_row, pl.rows, hipMemcpyDeviceToHost, s);
+    if (er == hipSuccess) er = hipStreamSynchronize(s);
+    if (er != hipSuccess) rc = fail(BGS_ERR_HIP, "bgs_ingest_host: %s", hipGetErrorString(er));
+  } else {
+    (void)hipStreamSynchronize(s);
+  }
+  cleanup();
+  return rc;
 }
 
 }  // extern "C"

@@ -46,6 +46,11 @@ class Engine:
     def set_option(self, option, value):
         capi.check(capi.lib().bgs_set_option(self._h, option, int(value)))
 
+    def set_ingest(self, cfg):
+        """bgs_set_ingest: process() then takes raw captured frames and returns outputs in the prepared geometry."""
+        capi.check(capi.lib().bgs_set_ingest(self._h, C.byref(cfg) if cfg is not None else None))
+        self._ingest = cfg
+
     def set_geometry(self, rows, cols, channels):
         capi.check(capi.lib().bgs_set_geometry(self._h, rows, cols, channels))
 
@@ -63,12 +68,17 @@ class Engine:
         if frame.strides[-1] != 1 or (frame.ndim == 3 and frame.strides[1] != ch):
             frame = np.ascontiguousarray(frame)
         step = frame.strides[0]
+        in_rows, in_cols = rows, cols
+        if getattr(self, "_ingest", None) is not None:  # outputs come out in the prepared geometry
+            r, c = C.c_int(0), C.c_int(0)
+            capi.check(capi.lib().bgs_ingest_size(C.byref(self._ingest), rows, cols, C.byref(r), C.byref(c)))
+            rows, cols = r.value, c.value
         fg = np.empty((rows, cols), np.uint8)
         bg_ch = 1 if self.algo == capi.ASBL else ch
         bg = np.empty((rows, cols, bg_ch), np.uint8) if want_bg else None
         flags = C.c_uint32(0)
         capi.check(capi.lib().bgs_process(
-            self._h, stream, frame.ctypes.data_as(C.c_void_p), rows, cols, ch, step,
+            self._h, stream, frame.ctypes.data_as(C.c_void_p), in_rows, in_cols, ch, step,
             fg.ctypes.data_as(C.c_void_p), cols,
             bg.ctypes.data_as(C.c_void_p) if bg is not None else None, cols * bg_ch, C.byref(flags)))
         f = flags.value
@@ -240,3 +250,35 @@ def mask_blobs_batch_device(masks, connectivity=8, max_boxes=65536, device=0, hi
     off = offsets.cpu()
     k = min(int(off[-1]), max_boxes)
     return boxes[:k], mom[:k], off
+
+
+# -- N3 frame preparation ------------------------------------------------------------------------------------------------
+def ingest_device(cfg, frames, device=0, hip_stream=None):
+    """bgs_ingest_device: frames torch CUDA uint8 [images][rows][cols][C] (or [images][rows][cols]); returns the prepared frames."""
+    import torch
+    images, rows, cols = frames.shape[:3]
+    ch = 1 if frames.dim() == 3 else frames.shape[3]
+    r, c = C.c_int(0), C.c_int(0)
+    capi.check(capi.lib().bgs_ingest_size(C.byref(cfg), rows, cols, C.byref(r), C.byref(c)))
+    out = torch.empty((images, r.value, c.value) if frames.dim() == 3 else (images, r.value, c.value, ch), dtype=torch.uint8, device=frames.device)
+    ws = capi.lib().bgs_ingest_workspace(C.byref(cfg), images, rows, cols, ch)
+    work = torch.empty(max(ws, 1), dtype=torch.uint8, device=frames.device)
+    if hip_stream is None:
+        hip_stream = torch.cuda.current_stream().cuda_stream
+    capi.check(capi.lib().bgs_ingest_device(device, C.byref(cfg), C.c_void_p(frames.data_ptr()), images, rows, cols, ch, frames.stride(1),
+                                            C.c_void_p(out.data_ptr()), C.c_void_p(work.data_ptr()) if ws else None, C.c_void_p(hip_stream)))
+    return out
+
+
+def ingest_host(cfg, frame, device=0):
+    """bgs_ingest_host: frame numpy uint8 HxW or HxWxC (any row stride); returns the prepared frame."""
+    rows, cols = frame.shape[:2]
+    ch = 1 if frame.ndim == 2 else frame.shape[2]
+    if frame.strides[-1] != 1 or (frame.ndim == 3 and frame.strides[1] != ch):
+        frame = np.ascontiguousarray(frame)
+    r, c = C.c_int(0), C.c_int(0)
+    capi.check(capi.lib().bgs_ingest_size(C.byref(cfg), rows, cols, C.byref(r), C.byref(c)))
+    out = np.empty((r.value, c.value) if frame.ndim == 2 else (r.value, c.value, ch), np.uint8)
+    capi.check(capi.lib().bgs_ingest_host(device, C.byref(cfg), frame.ctypes.data_as(C.c_void_p), rows, cols, ch, frame.strides[0],
+                                          out.ctypes.data_as(C.c_void_p), out.strides[0]))
+    return out

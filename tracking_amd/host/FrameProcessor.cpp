@@ -6,7 +6,7 @@
 namespace bgs_hip {
 
 FrameProcessor::FrameProcessor()
-    : frameToStop(0), firstTime(true), frameNumber(0), duration(0), tictoc(""), enablePreProcessor(true), frameDifference(nullptr),
+    : frameToStop(0), firstTime(true), frameNumber(0), duration(0), tictoc(""), preProcessor(nullptr), enablePreProcessor(true), frameDifference(nullptr),
       enableFrameDifferenceBGS(false), staticFrameDifference(nullptr), enableStaticFrameDifferenceBGS(false), weightedMovingMean(nullptr),
       enableWeightedMovingMeanBGS(false), weightedMovingVariance(nullptr), enableWeightedMovingVarianceBGS(false), mixtureOfGaussianV1BGS(nullptr),
       enableMixtureOfGaussianV1BGS(false), mixtureOfGaussianV2BGS(nullptr), enableMixtureOfGaussianV2BGS(false), adaptiveBackgroundLearning(nullptr),
@@ -29,6 +29,7 @@ FrameProcessor::FrameProcessor()
 FrameProcessor::~FrameProcessor() { std::cout << "~FrameProcessor()" << std::endl; }
 
 void FrameProcessor::init() {  // FrameProcessor.cpp:35-155
+  if (enablePreProcessor) preProcessor = new PreProcessor;
   if (enableFrameDifferenceBGS) frameDifference = new FrameDifferenceBGS;
   if (enableStaticFrameDifferenceBGS) staticFrameDifference = new StaticFrameDifferenceBGS;
   if (enableWeightedMovingMeanBGS) weightedMovingMean = new WeightedMovingMeanBGS;
@@ -57,7 +58,7 @@ void FrameProcessor::process(std::string name, IBGS* bgs, const Image& img_input
 
 void FrameProcessor::process(const Image& img_input) {  // :169-340
   frameNumber++;
-  if (enablePreProcessor) img_input.copyTo(img_prep);  // PreProcessor default: img_input.copyTo(img_output) (PreProcessor.cpp:56)
+  if (enablePreProcessor) preProcessor->process(img_input, img_prep);  // :173-174
   // with enablePreProcessor = 0 img_prep stays empty and every class returns at `if(img_input.empty()) return;`
   if (enableFrameDifferenceBGS) process("FrameDifferenceBGS", frameDifference, img_prep, img_framediff);
   if (enableStaticFrameDifferenceBGS) process("StaticFrameDifferenceBGS", staticFrameDifference, img_prep, img_staticfdiff);
@@ -98,6 +99,7 @@ void FrameProcessor::finish() {  // :342-482 (reverse order of init)
   delete weightedMovingMean, weightedMovingMean = nullptr;
   delete staticFrameDifference, staticFrameDifference = nullptr;
   delete frameDifference, frameDifference = nullptr;
+  delete preProcessor, preProcessor = nullptr;  // :480-481
 }
 
 void FrameProcessor::tic(std::string value) {  // :484-488

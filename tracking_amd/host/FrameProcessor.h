@@ -6,13 +6,14 @@
 //   ./config/FrameProcessor.xml (tictoc + enable*)    FrameProcessor.cpp:496-610
 //
 // Same control flow as the reference: one IBGS instance per enabled class, created in init(), fed the same
-// pre-processed frame in the reference's order, one mask per class kept in a member image.  The PreProcessor default
-// (a plain copy of the BGR input, PreProcessor.cpp:56) is the identity here; its optional filters are out of scope.
+// pre-processed frame in the reference's order, one mask per class kept in a member image.  The PreProcessor (PreProcessor.h:
+// copy, optional equalizeHist / GaussianBlur from ./config/PreProcessor.xml) is created in init() like the reference's (:37-38).
 #pragma once
 #include <chrono>
 #include <string>
 
 #include "bgs_host.h"
+#include "PreProcessor.h"
 
 namespace bgs_hip {
 
@@ -46,6 +47,7 @@ class FrameProcessor : public IFrameProcessor {
   std::chrono::steady_clock::time_point t0;
   std::string tictoc;
 
+  PreProcessor* preProcessor;
   bool enablePreProcessor;
   FrameDifferenceBGS* frameDifference;
   bool enableFrameDifferenceBGS;

@@ -61,6 +61,7 @@ int main(int argc, char** argv) {
     }
     FrameProcessor* fp = new FrameProcessor;
     fp->init();
+    FramePrep prep;  // VideoCapture's resize / flip / ROI from ./config/VideoCapture.xml (defaults: none); BGSLIB_RAW geometry in, prepared out
     const char* names[] = {"FrameDifferenceBGS", "StaticFrameDifferenceBGS", "WeightedMovingMeanBGS", "WeightedMovingVarianceBGS",
                            "MixtureOfGaussianV1BGS", "MixtureOfGaussianV2BGS", "AdaptiveBackgroundLearning", "AdaptiveSelectiveBackgroundLearning",
                            "GMG", "DPAdaptiveMedianBGS", "DPGrimsonGMMBGS", "DPZivkovicAGMMBGS", "DPMeanBGS", "DPWrenGABGS", "SigmaDeltaBGS", "SuBSENSEBGS", "LOBSTERBGS"};
@@ -72,8 +73,10 @@ int main(int argc, char** argv) {
     for (int t = 0; t < n; ++t) {
       in.read((char*)frame.data, (size_t)rows * cols * 3);
       if (!in) throw Exception(BGS_ERR_INVALID, "short read on frame file");
-      fp->process(frame);
-      for (size_t i = 0; i < outs.size(); ++i) dump(outs[i], *masks[i], rows, cols);
+      Image img_input;
+      prep.process(frame, img_input);  // VideoCapture.cpp:164-203
+      fp->process(img_input);
+      for (size_t i = 0; i < outs.size(); ++i) dump(outs[i], *masks[i], img_input.rows, img_input.cols);
     }
     fp->finish();
     delete fp;
