@@ -131,17 +131,25 @@ def main():
     ap.add_argument("--settle", type=int, default=340, help="untimed launches after model saturation and before the W warm-up steps, so that the timed K steps see the sustained clocks")
     ap.add_argument("--sustain", type=int, default=200, help="further launches after the timed K, reported as roofline.sustained")
     ap.add_argument("--series", default="", help="write the per-launch kernel durations (settle, warmup, timed, sustain) to this CSV")
+    ap.add_argument("--rehearse", action="store_true", help="N > 1 control flow on one GPU: all ranks on cuda:0, gloo, masks via host (not a benchmark)")
     ap.add_argument("--px", type=int, default=0, help="MOG2 pixels per lane (tuning; 0 = default = 1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # --rehearse: the N > 1 control flow on ONE GPU (every rank on cuda:0, `gloo` instead of RCCL, the packed masks go through a
+    # host copy): RCCL refuses two ranks on one device, and this box has one.  Numbers from it are not benchmark results.
+    rehearse = args.rehearse and world > 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # the process group comes up before this process makes its first GPU call
+        if rehearse:
+            dist.init_process_group("gloo")
+            local = 0
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libbgs_hip has no CPU path")
@@ -163,11 +171,14 @@ def main():
     fg = torch.empty((S, ROWS, COLS), dtype=torch.uint8, device=dev)
     bg = torch.empty((S, ROWS, COLS, CH), dtype=torch.uint8, device=dev) if args.with_bg else None
     words = ROWS * COLS // 64
-    gather = MaskGather(S, words, dev) if world > 1 else None
+    gather = MaskGather(S, words, "cpu" if rehearse else dev) if world > 1 else None
+    bits_dev = torch.empty((S, words), dtype=torch.int64, device=dev) if rehearse else None
 
     def step(t):
-        bits = gather.next_buffer() if gather else None
+        bits = bits_dev if rehearse else (gather.next_buffer() if gather else None)
         eng.process_batch_device(pool[t % period], fg, bg, bits)
+        if rehearse:
+            gather.next_buffer().copy_(bits_dev)  # synchronous D2H: rehearsal only
         if gather:
             gather.post()
 
@@ -205,7 +216,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     # sustained leg (untimed by the contract's clock, reported beside it): SUSTAIN further launches of the same step
@@ -294,7 +305,7 @@ def main():
             "config": {"workload": "MixtureOfGaussianV2BGS (MOG2 K=5, alpha=0.05, threshold 15) on 1920x1080x3 uint8, %s synthetic input, %d streams per GPU batched in one launch "
                                    "(BASELINE configs[1] geometry x %d = the per-GPU share of configs[4]); frames resident in HBM" % ("S_sat" if args.input == "sat" else "S_surv", S, S),
                        "streams_per_gpu": S, "rows": ROWS, "cols": COLS, "channels": CH, "K": 5, "input": args.input,
-                       "mask_gather": "RCCL gather of bit-packed masks to rank 0 every step, overlapped" if world > 1 else "none (1 GPU)"},
+                       "mask_gather": ("REHEARSAL: gloo gather through host copies, all ranks on one GPU - not a benchmark" if rehearse else "RCCL gather of bit-packed masks to rank 0 every step, overlapped") if world > 1 else "none (1 GPU)"},
             "streams_1080p30": round(mpix / (ROWS * COLS / 1e6) / 30.0, 1),
             "frames_per_s": round(mpix * 1e6 / (ROWS * COLS), 1),
             "mean_live_modes_stream0": live_modes,
