@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbgs_hip.so")
+LIB_PATH = os.environ.get("BGS_LIB_PATH") or os.path.join(_HERE, "lib", "libbgs_hip.so")  # BGS_LIB_PATH: A/B builds of the same ABI (tools/)
 
 # bgs_algo (include/bgs_hip.h)
 FRAME_DIFF, STATIC_FRAME_DIFF, WMM, WMV, ABL, ASBL, MOG2, MOG1, GMG, SUBSENSE, LBSP_DESC, SIGMA_DELTA = range(12)

@@ -21,8 +21,10 @@ enum { SS_UNSTABLE, SS_BLINKS, SS_LASTFG, SS_LASTRAW, SS_LASTRAWBLINK, SS_LASTDI
   } while (0)
 
 struct SsDevice {
-  uint8_t *color = nullptr, *lut = nullptr, *lastColor = nullptr, *curColor = nullptr;  // cur*: LOBSTER scratch (kernel_subsense.h)
-  uint16_t *desc = nullptr, *lastDesc = nullptr, *req = nullptr, *curDesc = nullptr;
+  void* samples = nullptr;  // records of colour + descriptor (kernel_subsense.h: SsSample, ss_rec)
+  int nSpad = 0, pixelMajor = 0;
+  uint8_t *lut = nullptr, *lastColor = nullptr, *curColor = nullptr;  // cur*: LOBSTER scratch (kernel_subsense.h)
+  uint16_t *lastDesc = nullptr, *req = nullptr, *curDesc = nullptr;
   float* f32[SS_NF32] = {nullptr};
   uint8_t* u8[SS_NU8] = {nullptr};
   float *dsLT = nullptr, *dsST = nullptr;
@@ -35,7 +37,7 @@ struct SsDevice {
   int use3x3 = 1, lrScaling = 0, medK = 9;
   float capLo0 = 4.f, capHi0 = 512.f;
   void release() {
-    void* p[] = {color, lut, lastColor, curColor, desc, lastDesc, curDesc, req, dsLT, dsST, sc, flood_flags, mbits, rbits};
+    void* p[] = {samples, lut, lastColor, curColor, lastDesc, curDesc, req, dsLT, dsST, sc, flood_flags, mbits, rbits};
     for (void* q : p)
       if (q) (void)hipFree(q);
     for (auto& q : f32)
@@ -45,7 +47,7 @@ struct SsDevice {
     if (side) (void)hipStreamDestroy(side), side = nullptr;
     if (evA) (void)hipEventDestroy(evA), evA = nullptr;
     if (evB) (void)hipEventDestroy(evB), evB = nullptr;
-    color = lut = lastColor = curColor = nullptr, desc = lastDesc = req = curDesc = nullptr, dsLT = dsST = nullptr, sc = nullptr, flood_flags = nullptr, mbits = rbits = nullptr;
+    samples = nullptr, lut = lastColor = curColor = nullptr, lastDesc = req = curDesc = nullptr, dsLT = dsST = nullptr, sc = nullptr, flood_flags = nullptr, mbits = rbits = nullptr;
   }
 };
 
@@ -69,8 +71,8 @@ int ss_allocate(bgs_engine* e) {
       return fail(BGS_ERR_UNSUPPORTED, "SuBSENSE frame-level analysis: rows and cols must be multiples of 8 (cv::resize INTER_AREA with an integer ratio)");
   }
   const size_t N = e->n, P = N * e->S, nS = (size_t)p.subsense_n_samples, C = (size_t)e->ch;
-  DMALLOC(d->color, P * nS * C);
-  DMALLOC(d->desc, P * nS * C * 2);
+  d->pixelMajor = 0, d->nSpad = (int)nS;  // sample-major planes (kernel_subsense.h: layout note)
+  DMALLOC(d->samples, P * (size_t)d->nSpad * (C == 3 ? 16 : 4));
   DMALLOC(d->lastColor, P * C);
   DMALLOC(d->lastDesc, P * C * 2);
   DMALLOC(d->req, P * 2 * 2);
@@ -92,7 +94,7 @@ int ss_allocate(bgs_engine* e) {
 void ss_fill_args(const bgs_engine* e, bgs::SsArgs& a, int first, int cur_pp, unsigned frameIndex) {
   const SsDevice* d = e->ss;
   const bgs_params& p = e->p;
-  a.color = d->color, a.desc = d->desc, a.lastColor = d->lastColor, a.lastDesc = d->lastDesc, a.req = d->req, a.lut = d->lut, a.sc = d->sc;
+  a.samples = d->samples, a.nSpad = d->nSpad, a.pixelMajor = d->pixelMajor, a.lastColor = d->lastColor, a.lastDesc = d->lastDesc, a.req = d->req, a.lut = d->lut, a.sc = d->sc;
   a.R = d->f32[SS_R], a.V = d->f32[SS_V], a.T = d->f32[SS_T];
   a.DlastOld = d->f32[cur_pp ? SS_DLAST1 : SS_DLAST0], a.DlastNew = d->f32[cur_pp ? SS_DLAST0 : SS_DLAST1];
   a.RawSTOld = d->f32[cur_pp ? SS_RAWST1 : SS_RAWST0], a.RawSTNew = d->f32[cur_pp ? SS_RAWST0 : SS_RAWST1];
@@ -129,7 +131,7 @@ void ss_initial_lut(const bgs_params& p, int channels, uint8_t lut[256]) {
 
 int ss_init_streams(bgs_engine* e, int first, int count, const uint8_t* d_frames, hipStream_t s) {
   SsDevice* d = e->ss;
-  const size_t N = e->n, off = N * first, npix = N * count, nS = (size_t)e->p.subsense_n_samples, C = (size_t)e->ch;
+  const size_t N = e->n, off = N * first, npix = N * count, C = (size_t)e->ch;
   uint8_t lut[256];
   ss_initial_lut(e->p, e->ch, lut);
   bgs::SsScalars sc0{};
@@ -153,8 +155,7 @@ int ss_init_streams(bgs_engine* e, int first, int count, const uint8_t* d_frames
     HIP_TRY(hipMemsetAsync(d->dsLT + dsn * first, 0, dsn * count * sizeof(float), s));
     HIP_TRY(hipMemsetAsync(d->dsST + dsn * first, 0, dsn * count * sizeof(float), s));
   }
-  HIP_TRY(hipMemsetAsync(d->color + off * nS * C, 0, npix * nS * C, s));
-  HIP_TRY(hipMemsetAsync(d->desc + off * nS * C, 0, npix * nS * C * 2, s));
+  HIP_TRY(hipMemsetAsync((uint8_t*)d->samples + off * (size_t)d->nSpad * (C == 3 ? 16 : 4), 0, npix * (size_t)d->nSpad * (C == 3 ? 16 : 4), s));
   // first-frame descriptors (:229-243) with the initial LUT, border = 0; LastColor interior = frame
   bgs::LbspArgs la{};
   la.img = d_frames, la.desc = d->lastDesc + off * C, la.rows = e->rows, la.cols = e->cols;
@@ -276,8 +277,6 @@ int64_t ss_get_state(bgs_engine* e, int stream, const char* plane, void* dst, si
                      {"lastraw", d->u8[SS_LASTRAW] + off, N},
                      {"lastcolor", d->lastColor + off * C, N * C},
                      {"lastdesc", d->lastDesc + off * C, N * 2 * C},
-                     {"color", d->color + off * nS * C, N * nS * C},
-                     {"desc", d->desc + off * nS * C, N * nS * 2 * C},
                      {"lut", d->lut + (size_t)stream * 256, 256}};
   for (const Ent& t : tab)
     if (!strcmp(plane, t.name)) {
@@ -285,6 +284,26 @@ int64_t ss_get_state(bgs_engine* e, int stream, const char* plane, void* dst, si
       if (hipMemcpy(dst, t.p, t.bytes, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
       return (int64_t)t.bytes;
     }
+  if (!strcmp(plane, "color") || !strcmp(plane, "desc")) {  // canonical export: color u8 [nS][N][C], desc u16 [nS][N][C], whatever the record layout
+    const bool wantColor = !strcmp(plane, "color");
+    const size_t need = N * nS * C * (wantColor ? 1 : 2), recB = C == 3 ? 16 : 4;
+    if (cap < need) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
+    const size_t per = d->pixelMajor ? (size_t)d->nSpad : nS;  // records per pixel held on the device
+    std::vector<uint8_t> recs(N * per * recB);
+    if (hipMemcpy(recs.data(), (const uint8_t*)d->samples + off * per * recB, recs.size(), hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+    for (size_t k = 0; k < nS; ++k)
+      for (size_t px = 0; px < N; ++px) {  // export: [nS][N][C], whatever the device order
+        const uint8_t* r = recs.data() + (d->pixelMajor ? px * per + k : k * N + px) * recB;
+        const size_t o = k * N + px;
+        for (size_t c = 0; c < C; ++c) {
+          if (wantColor)
+            ((uint8_t*)dst)[o * C + c] = r[c];
+          else
+            std::memcpy((uint8_t*)dst + (o * C + c) * 2, r + (C == 3 ? 4 + 2 * c : 2), 2);
+        }
+      }
+    return (int64_t)need;
+  }
   if (!strcmp(plane, "scalars")) {
     if (cap < 7 * sizeof(double)) return fail(BGS_ERR_STATE, "buffer too small for plane scalars");
     bgs::SsScalars sc;
@@ -306,8 +325,8 @@ int lob_allocate(bgs_engine* e) {
   SsDevice* d = new SsDevice();
   e->ss = d;
   const size_t N = e->n, P = N * e->S, nS = (size_t)p.subsense_n_samples, C = (size_t)e->ch;
-  DMALLOC(d->color, P * nS * C);
-  DMALLOC(d->desc, P * nS * C * 2);
+  d->pixelMajor = 0, d->nSpad = (int)nS;  // LOBSTER: sample-major (kernel_subsense.h)
+  DMALLOC(d->samples, P * nS * (C == 3 ? 16 : 4));
   DMALLOC(d->lastColor, P * C);
   DMALLOC(d->lastDesc, P * C * 2);
   DMALLOC(d->curColor, P * C);
@@ -324,7 +343,7 @@ int lob_allocate(bgs_engine* e) {
 void lob_fill_args(const bgs_engine* e, bgs::SsArgs& a, int first, unsigned frameIndex) {
   const SsDevice* d = e->ss;
   const bgs_params& p = e->p;
-  a.color = d->color, a.desc = d->desc, a.lastColor = d->lastColor, a.lastDesc = d->lastDesc, a.req = d->req, a.lut = d->lut;
+  a.samples = d->samples, a.nSpad = d->nSpad, a.pixelMajor = d->pixelMajor, a.lastColor = d->lastColor, a.lastDesc = d->lastDesc, a.req = d->req, a.lut = d->lut;
   a.lastFG = d->u8[SS_LASTFG], a.raw = d->u8[SS_RAW];
   a.rows = e->rows, a.cols = e->cols, a.nS = p.subsense_n_samples, a.nReq = p.subsense_n_required;
   a.nMinColor = p.subsense_min_color_dist_threshold, a.nDescOff = p.subsense_desc_dist_threshold_offset;
@@ -348,8 +367,7 @@ int lob_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, ui
     std::memcpy(lutv.v, lut, 256);
     hipLaunchKernelGGL(bgs::ss_init_consts_kernel, dim3(count), block, 0, s, d->lut, (bgs::SsScalars*)nullptr, lutv, bgs::SsScalars{}, first);
     HIP_TRY(hipMemsetAsync(d->u8[SS_LASTFG] + off, 0, npix, s));
-    HIP_TRY(hipMemsetAsync(d->color + off * nS * C, 0, npix * nS * C, s));
-    HIP_TRY(hipMemsetAsync(d->desc + off * nS * C, 0, npix * nS * C * 2, s));
+    HIP_TRY(hipMemsetAsync((uint8_t*)d->samples + off * nS * (C == 3 ? 16 : 4), 0, npix * nS * (C == 3 ? 16 : 4), s));
     bgs::LbspArgs la{};
     la.img = d_frames, la.desc = d->lastDesc + off * C, la.rows = e->rows, la.cols = e->cols;
     std::memcpy(la.lut, lut, 256);

@@ -15,9 +15,15 @@
 // stood at the start of the frame, then apply all sample writes, the highest source pixel index winning a conflict);
 // a pixel reads its random neighbour's D_last / raw-segmentation means from the previous frame's copy.
 //
-// Layout per stream: colour samples u8 [nS][N][3], descriptor samples u16 [nS][N][3] (one contiguous plane per sample index,
-// so the early-exit sample loop reads one coalesced row of each plane per iteration), ten f32 maps [N] (+2 second copies),
-// byte maps [N].  The current frame's 5x5 neighbourhood is staged through LDS once per workgroup (phase A: 64x32 pixel tile +
+// Background samples are RECORDS: colour and LBSP descriptor of one sample of one pixel together in 16 bytes (BGR: b g r 0 |
+// d0 d1 | d2 0 | 0; 4 bytes for gray: c 0 | d), one vector load per sample in the sample-consensus loops, one store per model
+// update.  Order: SAMPLE-MAJOR [nS][N], one plane per sample index (ss_rec; a pixel-major order is kept selectable there).
+// Round 2 measured the alternatives on 8 x 1080p S_surv (profiles/r02_subsense_phase_a_pmc.txt): planar colour / descriptor
+// arrays (six loads per sample): phase A 2.95 ms, whole step 4.60; these records: 2.96 / 4.42 (phase B's scattered writes are one
+// store each); pixel-major [N][nS] with one load per sample: 3.2-3.6 (1024 resident lanes each want their own line kept, the L1
+// holds 256); pixel-major with 64-byte batches into registers: 3.06, line requests halved (TCP_TCC_READ_REQ 178 M -> 95 M per
+// launch) but +45 % memory and more instructions.  The kernel is VALU-bound, none of this is what limits it.
+// Ten f32 maps [N] (+2 second copies), byte maps [N].  The current frame's 5x5 neighbourhood is staged through LDS once per workgroup (phase A: 64x32 pixel tile +
 // halo 2, with an LDS work queue over its pixels; phase B and LOBSTER's phase A: 64x4).
 //   lob_phase_a_kernel   LOBSTER's operator()                     BackgroundSubtractorLOBSTER.cpp:172-284 (shares phase B, refresh, background)
 #pragma once
@@ -37,8 +43,8 @@ struct SsScalars {
 
 struct SsArgs {
   const uint8_t* frame;  // [S][N][3]
-  uint8_t* color;        // [S][nS][N][3]
-  uint16_t* desc;        // [S][nS][N][3]
+  void* samples;         // records (SsSample<C>), see ss_rec(): SuBSENSE pixel-major [S][N][nSpad], LOBSTER sample-major [S][nS][N]
+  int nSpad, pixelMajor; // records per pixel in the pixel-major order (nS rounded up to a whole batch of 4)
   float *R, *V, *T, *DlastOld, *DlastNew, *DminLT, *DminST, *RawLT, *RawSTOld, *RawSTNew, *FinLT, *FinST;  // [S][N]
   uint8_t *unstable, *blinks, *lastFG, *lastRaw, *lastRawBlink, *lastDilInv, *lastColor;                  // [S][N] ([S][N][3])
   uint16_t* lastDesc;    // [S][N][3]
@@ -76,6 +82,56 @@ __device__ __constant__ const int8_t kSsN5[24][2] = {{-2, 2},  {-1, 2},  {0, 2},
 #define SS_REQ_VALID 0x8000u
 __device__ __forceinline__ uint16_t ss_req(unsigned slot, int code) { return (uint16_t)(SS_REQ_VALID | (slot << 8) | (unsigned)code); }
 
+// One background sample: colour c[C] + descriptor d[C], packed (see the layout note at the top of the file).
+template <int C>
+struct SsSample;
+template <>
+struct SsSample<3> {
+  uint4 v;
+  static constexpr size_t kBytes = 16;
+  __device__ __forceinline__ int color(int c) const { return (int)((v.x >> (8 * c)) & 0xffu); }
+  __device__ __forceinline__ unsigned desc(int c) const { return c == 0 ? (v.y & 0xffffu) : c == 1 ? (v.y >> 16) : (v.z & 0xffffu); }
+  __device__ __forceinline__ static SsSample make(const int (&col)[3], const unsigned (&d)[3]) {
+    SsSample r;
+    r.v = make_uint4((uint32_t)col[0] | ((uint32_t)col[1] << 8) | ((uint32_t)col[2] << 16), (d[0] & 0xffffu) | (d[1] << 16), d[2] & 0xffffu, 0u);
+    return r;
+  }
+  __device__ __forceinline__ static SsSample load(const void* base, size_t rec) {
+    SsSample r;
+    r.v = reinterpret_cast<const uint4*>(base)[rec];
+    return r;
+  }
+  __device__ __forceinline__ void store(void* base, size_t rec) const { reinterpret_cast<uint4*>(base)[rec] = v; }
+};
+template <>
+struct SsSample<1> {
+  uint32_t v;
+  static constexpr size_t kBytes = 4;
+  __device__ __forceinline__ int color(int) const { return (int)(v & 0xffu); }
+  __device__ __forceinline__ unsigned desc(int) const { return v >> 16; }
+  __device__ __forceinline__ static SsSample make(const int (&col)[1], const unsigned (&d)[1]) {
+    SsSample r;
+    r.v = (uint32_t)col[0] | (d[0] << 16);
+    return r;
+  }
+  __device__ __forceinline__ static SsSample load(const void* base, size_t rec) {
+    SsSample r;
+    r.v = reinterpret_cast<const uint32_t*>(base)[rec];
+    return r;
+  }
+  __device__ __forceinline__ void store(void* base, size_t rec) const { reinterpret_cast<uint32_t*>(base)[rec] = v; }
+};
+
+// Pins the point where a prefetched sample is first "used": an empty asm that reads and re-defines its registers.  Without it the
+// compiler is free to copy the freshly loaded registers at once, which puts the s_waitcnt right behind the load.
+__device__ __forceinline__ void ss_wait_here(SsSample<3>& s) { asm volatile("" : "+v"(s.v.x), "+v"(s.v.y), "+v"(s.v.z), "+v"(s.v.w)); }
+__device__ __forceinline__ void ss_wait_here(SsSample<1>& s) { asm volatile("" : "+v"(s.v)); }
+
+// record index of sample k of pixel p (0..N) of absolute stream `stream`
+__device__ __forceinline__ size_t ss_rec(const SsArgs& a, int stream, size_t N, size_t p, int k) {
+  return a.pixelMajor ? ((size_t)stream * N + p) * (size_t)a.nSpad + (size_t)k : ((size_t)stream * (size_t)a.nS + (size_t)k) * N + p;
+}
+
 // ----------------------------------------------------------------------------------------------- phase A
 // One workgroup owns a 64 x 32 pixel tile (8 pixels per lane) and works in three stages:
 //   1. per pixel (static lane<->pixel map): thresholds from R / unstable, the three intra-LBSP descriptors -> LDS context;
@@ -87,6 +143,16 @@ __device__ __forceinline__ uint16_t ss_req(unsigned slot, int code) { return (ui
 // The result of a pixel does not depend on when or where it is processed: every model read is of start-of-frame state.
 constexpr int kSsATH = 32, kSsAPix = kSsTW * kSsATH, kSsRefill = 16;
 constexpr uint32_t kSsNotInterior = 0xffffffffu;
+
+#ifdef BGS_EXP_COUNT  // counting build (tools/exp_phase_a.sh): never defined in the product build
+__device__ unsigned long long g_exp_cnt[8];
+#define EXP_COUNT(i, v)                                                      \
+  do {                                                                       \
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_exp_cnt[i], (unsigned long long)(v)); \
+  } while (0)
+#else
+#define EXP_COUNT(i, v)
+#endif
 
 template <int C>
 __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
@@ -137,8 +203,6 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
     }
   };
   auto interior_of = [&](int x, int y) { return x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2; };  // LBSP::validateROI; border pixels are never touched
-  const size_t sbase = (size_t)stream * a.nS * N;
-  const size_t sstride = N * C;
 
   // ---- stage 1: thresholds and intra descriptors
   {
@@ -178,18 +242,27 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
   __syncthreads();
 
   // ---- stage 2: sample consensus, lanes fed from the queue
+  // rocprofv3 (round 2, 8 x 1080p S_surv): 21 samples are tested per pixel and 2.6 of them get as far as the inter-LBSP step; the
+  // kernel is VALU-bound (VALU active 71 % of the time, 4 700 VALU instructions per pixel, of which ~80 per loop iteration in the
+  // rejection tests) - experiments that only changed the memory side (one load per sample instead of six, pixel-major batches,
+  // deeper prefetch) or only ran the inter-LBSP step less often (parking) left its 2.95 ms where they were.  So the rejection
+  // tests are written for instruction count: the three colour distances with v_sad_u8 on masked words, the three intra
+  // descriptor distances from two XORs, and the per-channel colour test folded into the bound on sd (sd >= cd, see below).
   {
     const int lane = threadIdx.x & (kWave - 1);
     bool active = false, qempty = false;
     int q = 0, idx = 0, good = 0;
     uint32_t minDesc = maxDesc, minSum = maxColor, colorThr = 0, descThr = 0;
-    int cur[C], bc[C], nbc[C];
-    unsigned intra[C], bd[C], nbd[C];
+    int cur[C];
+    unsigned intra[C];
     uint32_t nb[C][8];
-    const uint8_t* cp = a.color;
-    const uint16_t* dp = a.desc;
+    uint32_t curm[C];  // the current colour, channel c alone in byte c of a word (BGR); the gray value (gray)
+    uint32_t iy = 0, iz = 0;  // intra descriptors as the records hold them: d0 | d1 << 16, d2
+    size_t rec = 0;  // record of the NEXT sample to request for this lane's pixel
+    SsSample<C> smp{}, nsmp{};
 #pragma unroll
-    for (int c = 0; c < C; ++c) cur[c] = bc[c] = nbc[c] = 0, intra[c] = bd[c] = nbd[c] = 0;
+    for (int c = 0; c < C; ++c) cur[c] = 0, intra[c] = 0, curm[c] = 0;
+    const size_t sbase = (size_t)stream * a.nS * N;  // sample-major planes (ss_rec)
     for (;;) {
       const unsigned long long idle = __ballot(!active);
       const int nidle = __popcll(idle);
@@ -209,28 +282,36 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
             descThr = ctx[q][2], colorThr = c1 >> 16;
             intra[0] = c0 & 0xffffu;
             if constexpr (C == 3) intra[1] = c0 >> 16, intra[2] = c1 & 0xffffu;
+            iy = c0, iz = c1 & 0xffffu;
             gather(ly, lx, cur, nb);
-            const size_t p = (size_t)(y0 + ly) * a.cols + (x0 + lx);
-            cp = a.color + (sbase + p) * C, dp = a.desc + (sbase + p) * C;
 #pragma unroll
-            for (int c = 0; c < C; ++c) bc[c] = nbc[c] = cp[c], bd[c] = nbd[c] = dp[c];
+            for (int c = 0; c < C; ++c) curm[c] = (uint32_t)cur[c] << (8 * c);
+            const size_t p = (size_t)(y0 + ly) * a.cols + (x0 + lx);
+            rec = sbase + p;
+            smp = nsmp = SsSample<C>::load(a.samples, rec);
             idx = 0, good = 0, minDesc = maxDesc, minSum = maxColor;
+#ifdef BGS_EXP_NOLOOP  // timing experiments only (never defined in the product build): queue + gather, no sample tests
+            idx = a.nS;
+#endif
             active = true;
           }
         }
       }
+      EXP_COUNT(0, 1);  // wave-iterations
       if (active) {
         if (good < a.nReq && idx < a.nS) {  // :469-497 (BGR) / :334-357 (gray); sample idx+1 is in flight while idx is tested
-          if (idx + 1 < a.nS) {
-            cp += sstride, dp += sstride;
-#pragma unroll
-            for (int c = 0; c < C; ++c) nbc[c] = cp[c], nbd[c] = dp[c];
-          }
+#ifndef BGS_EXP_NOLOAD
+          // Unconditional (the last trip re-reads its own record) so that the loaded registers ARE nsmp: under a condition the
+          // compiler merged them with the old value through copies placed right behind the load - with an s_waitcnt vmcnt(0)
+          // in front - and every trip paid the full memory latency (found in the ISA, round 2).
+          rec += (idx + 1 < a.nS) ? N : 0;
+          nsmp = SsSample<C>::load(a.samples, rec);
+#endif
           if constexpr (C == 1) {
-            const int bcc = bc[0];
+            const int bcc = smp.color(0);
+            const unsigned bdc = smp.desc(0);
             const uint32_t cd = (uint32_t)abs(cur[0] - bcc);
             if (cd <= colorThr) {
-              const unsigned bdc = bd[0];
               const uint32_t intraD = (uint32_t)__popc(intra[0] ^ bdc);
               const unsigned inter = ss_lbsp(nb[0], bcc, lut[bcc]);
               const uint32_t dd = (intraD + (uint32_t)__popc(inter ^ bdc)) / 2;
@@ -245,30 +326,41 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
               }
             }
           } else {
-            // The reference walks the channels in order and drops the sample at the first failed test (:474-491); a sample
-            // is kept only if every test passes, so the tests may run in any order.  Cheap exact rejections first (colour
-            // distances, then lower bounds from the intra half of the descriptor distance: dd >= intraD/2 and sd grows
-            // with dd); the three inter-LBSP descriptors are computed only for samples that can still pass.
+            // The reference walks the channels in order and drops the sample at the first failed test (:474-491); a sample is kept
+            // only if every test passes, so the tests may run in any order.  Exact rejections first, from what costs least:
+            // lower bounds with the intra half of the descriptor distance alone (dd >= intraD/2, and sd grows with dd).  The
+            // per-channel colour test cd <= scColorThr is implied by the one on the bound lbsd = min(255, k + cd): either
+            // lbsd = k + cd >= cd, or lbsd = 255 <= scColorThr and cd <= 255.
             const uint32_t totColorThr = colorThr * 3, totDescThr = descThr * 3, scColorThr = totColorThr / 2;
-            uint32_t cd[3], intraD[3], lbDesc = 0, lbSum = 0;
-            bool ok = true;
+            const uint32_t sx = smp.v.x, sy = smp.v.y, sz = smp.v.z;
+            uint32_t cd[3], intraD[3], lbdd[3], lbsd[3];
+            cd[0] = __builtin_amdgcn_sad_u8(curm[0], sx & 0x0000ffu, 0u);
+            cd[1] = __builtin_amdgcn_sad_u8(curm[1], sx & 0x00ff00u, 0u);
+            cd[2] = __builtin_amdgcn_sad_u8(curm[2], sx & 0xff0000u, 0u);
+            const uint32_t xy = iy ^ sy;
+            intraD[0] = (uint32_t)__popc(xy & 0xffffu), intraD[1] = (uint32_t)__popc(xy >> 16), intraD[2] = (uint32_t)__popc(iz ^ sz);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-              cd[c] = (uint32_t)abs(cur[c] - bc[c]);
-              intraD[c] = (uint32_t)__popc(intra[c] ^ bd[c]);
-              const uint32_t lbdd = intraD[c] / 2;
-              uint32_t lbsd = (lbdd / 2) * (255 / 16) + cd[c];
-              lbsd = lbsd < 255 ? lbsd : 255;
-              ok = ok && cd[c] <= scColorThr && lbsd <= scColorThr;
-              lbDesc += lbdd, lbSum += lbsd;
+              lbdd[c] = intraD[c] >> 1;
+              lbsd[c] = min((lbdd[c] >> 1) * (255 / 16) + cd[c], 255u);
             }
-            ok = ok && lbDesc <= totDescThr && lbSum <= totColorThr;
-            if (ok) {
+            bool ok = max(max(lbsd[0], lbsd[1]), lbsd[2]) <= scColorThr && lbdd[0] + lbdd[1] + lbdd[2] <= totDescThr && lbsd[0] + lbsd[1] + lbsd[2] <= totColorThr;
+#ifdef BGS_EXP_COUNT
+            {
+              const unsigned long long okm = __ballot(ok);
+              if (okm && (unsigned)(__ffsll((long long)okm) - 1) == (threadIdx.x & 63u)) atomicAdd(&g_exp_cnt[2], 1ull), atomicAdd(&g_exp_cnt[3], (unsigned long long)__popcll(okm));
+            }
+#endif
+#ifdef BGS_EXP_NOEXP
+            ok = false;
+#endif
+            if (ok) {  // the inter-LBSP descriptors: only for samples that can still pass
               uint32_t totDesc = 0, totSum = 0;
 #pragma unroll
               for (int c = 0; c < 3; ++c) {
-                const unsigned inter = ss_lbsp(nb[c], bc[c], lut[bc[c]]);
-                const uint32_t interD = (uint32_t)__popc(inter ^ bd[c]);
+                const int bcc = smp.color(c);
+                const unsigned inter = ss_lbsp(nb[c], bcc, lut[bcc]);
+                const uint32_t interD = (uint32_t)__popc(inter ^ smp.desc(c));
                 const uint32_t dd = (intraD[c] + interD) / 2;
                 uint32_t sd = (dd / 2) * (255 / 16) + cd[c];
                 sd = sd < 255 ? sd : 255;
@@ -283,8 +375,8 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
             }
           }
           idx++;
-#pragma unroll
-          for (int c = 0; c < C; ++c) bc[c] = nbc[c], bd[c] = nbd[c];
+          ss_wait_here(nsmp);  // the wait for sample idx+1 belongs HERE, behind the tests of sample idx
+          smp = nsmp;
         }
         if (!(good < a.nReq && idx < a.nS)) {
           ctx[q][2] = (uint32_t)good | (minDesc << 8) | (minSum << 16);
@@ -478,20 +570,19 @@ __global__ __launch_bounds__(kBlock) void lob_phase_a_kernel(const SsArgs a) {
   }
   const uint32_t colorThr = (uint32_t)a.nMinColor, descThr = (uint32_t)a.nDescOff;
   const uint32_t descThr3 = descThr * 3, colorThr3 = colorThr * 3, scDesc = descThr3 / 2, scColor = colorThr3 / 2;  // :225-228
-  const size_t sbase = (size_t)stream * a.nS * N, sstride = N * C;
-  const uint8_t* cp = a.color + (sbase + p) * C;
-  const uint16_t* dp = a.desc + (sbase + p) * C;
+  size_t rec = ss_rec(a, stream, N, p, 0);
+  const size_t rstep = a.pixelMajor ? 1 : N;
   int good = 0, idx = 0;
-  int bc[C], nbc[C];
-  unsigned bd[C], nbd[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) bc[c] = nbc[c] = cp[c], bd[c] = nbd[c] = dp[c];
+  int bc[C];
+  unsigned bd[C];
+  SsSample<C> smp = SsSample<C>::load(a.samples, rec), nsmp = smp;
   while (good < a.nReq && idx < a.nS) {  // :192-205 (gray) / :241-258 (BGR); sample idx+1 is in flight while idx is tested (the loop is latency-bound)
     if (idx + 1 < a.nS) {
-      cp += sstride, dp += sstride;
-#pragma unroll
-      for (int c = 0; c < C; ++c) nbc[c] = cp[c], nbd[c] = dp[c];
+      rec += rstep;
+      nsmp = SsSample<C>::load(a.samples, rec);
     }
+#pragma unroll
+    for (int c = 0; c < C; ++c) bc[c] = smp.color(c), bd[c] = smp.desc(c);
     if constexpr (C == 1) {
       const int bcc = bc[0];
       const uint32_t cd = (uint32_t)abs(cur[0] - bcc);
@@ -521,8 +612,7 @@ __global__ __launch_bounds__(kBlock) void lob_phase_a_kernel(const SsArgs a) {
       if (ok && totD <= descThr3 && totC <= colorThr3) good++;
     }
     idx++;
-#pragma unroll
-    for (int c = 0; c < C; ++c) bc[c] = nbc[c], bd[c] = nbd[c];
+    smp = nsmp;
   }
   uint16_t reqSelf = 0, reqNbr = 0;
   if (good >= a.nReq) {
@@ -574,10 +664,7 @@ __global__ __launch_bounds__(kBlock) void ss_phase_b_kernel(const SsArgs a) {
   const int x = x0 + lx, y = y0 + ly;
   if (!(x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2)) return;
   const size_t p = (size_t)y * a.cols + x;
-  const size_t sbase = (size_t)stream * a.nS * N;
-  uint8_t* cp = a.color + (sbase + p) * C;
-  uint16_t* dp = a.desc + (sbase + p) * C;
-  const size_t sstride = N * C;
+
 #pragma unroll
   for (int dy = -2; dy <= 2; ++dy)
 #pragma unroll
@@ -588,9 +675,11 @@ __global__ __launch_bounds__(kBlock) void ss_phase_b_kernel(const SsArgs a) {
       for (int q = 0; q < 2; ++q) {  // self request first, then the neighbour request
         const uint32_t r = (both >> (16 * q)) & 0xffffu;
         if ((r & (SS_REQ_VALID | 0x1fu)) != aimed) continue;
-        const size_t o = (size_t)((r >> 8) & 0x3fu) * sstride;
+        int col[C];
+        unsigned dsc[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) cp[o + c] = lc[ly + 2 + dy][lx + 2 + dx][c], dp[o + c] = ld[ly + 2 + dy][lx + 2 + dx][c];
+        for (int c = 0; c < C; ++c) col[c] = lc[ly + 2 + dy][lx + 2 + dx][c], dsc[c] = ld[ly + 2 + dy][lx + 2 + dx][c];
+        SsSample<C>::make(col, dsc).store(a.samples, ss_rec(a, stream, N, p, (int)((r >> 8) & 0x3fu)));  // one 16-byte (4-byte) store per update
       }
     }
 }
@@ -611,7 +700,6 @@ __global__ __launch_bounds__(kBlock) void ss_refresh_kernel(const SsArgs a, int 
   const int nRefresh = mode == 1 ? (int)(0.1f * a.nS) : a.nS;
   const uint32_t fr = a.frameIndex;
   const int start = mode == 1 ? (int)(ss_rand(fr, 0xFFFFFFFFu, 0) % (uint32_t)a.nS) : 0;
-  const size_t sbase = (size_t)stream * a.nS * N;
   for (int m = 0; m < nRefresh; ++m) {
     int r = 1 + (int)(ss_rand(fr, (uint32_t)p, 16u + (uint32_t)m) % 512u), xs, ys = 0;  // RandUtils.h:28-48
     bool stop = false;
@@ -627,9 +715,11 @@ __global__ __launch_bounds__(kBlock) void ss_refresh_kernel(const SsArgs a, int 
     xs = min(max(xs + x - 3, 2), a.cols - 3), ys = min(max(ys + y - 3, 2), a.rows - 3);
     const size_t j = sN + (size_t)ys * a.cols + xs;
     if (!a.lastFG[j]) {
-      const size_t dst = (sbase + (size_t)((start + m) % a.nS) * N + p) * C;
+      int col[C];
+      unsigned dsc[C];
 #pragma unroll
-      for (int c = 0; c < C; ++c) a.color[dst + c] = a.lastColor[j * C + c], a.desc[dst + c] = a.lastDesc[j * C + c];
+      for (int c = 0; c < C; ++c) col[c] = a.lastColor[j * C + c], dsc[c] = a.lastDesc[j * C + c];
+      SsSample<C>::make(col, dsc).store(a.samples, ss_rec(a, stream, N, p, (start + m) % a.nS));
     }
   }
 }
@@ -947,9 +1037,12 @@ __global__ __launch_bounds__(kBlock) void ss_background_kernel(const SsArgs a) {
   const size_t N = (size_t)a.rows * a.cols;
   const size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x;  // byte index inside one [N][C] image
   if (e >= N * C) return;
-  const uint8_t* base = a.color + (size_t)stream * a.nS * N * C + e;
+  const size_t p = e / C;
+  const int c = (int)(e - p * C);
+  // the colour word of a record is its first dword: one 4-byte load per sample
+  const uint32_t* base = reinterpret_cast<const uint32_t*>(a.samples);
   float acc = 0;
-  for (int k = 0; k < a.nS; ++k) acc += div_rn((float)base[(size_t)k * N * C], (float)a.nS);
+  for (int k = 0; k < a.nS; ++k) acc += div_rn((float)((base[ss_rec(a, stream, N, p, k) * (SsSample<C>::kBytes / 4)] >> (8 * c)) & 0xffu), (float)a.nS);
   a.bgimg[(size_t)blockIdx.z * N * C + e] = (uint8_t)sat_u8(acc);
 }
 
