@@ -577,10 +577,8 @@ __global__ __launch_bounds__(kBlock) void lob_phase_a_kernel(const SsArgs a) {
   unsigned bd[C];
   SsSample<C> smp = SsSample<C>::load(a.samples, rec), nsmp = smp;
   while (good < a.nReq && idx < a.nS) {  // :192-205 (gray) / :241-258 (BGR); sample idx+1 is in flight while idx is tested (the loop is latency-bound)
-    if (idx + 1 < a.nS) {
-      rec += rstep;
-      nsmp = SsSample<C>::load(a.samples, rec);
-    }
+    rec += (idx + 1 < a.nS) ? rstep : 0;  // unconditional, see phase A: the loaded registers must BE nsmp for the load to stay in flight
+    nsmp = SsSample<C>::load(a.samples, rec);
 #pragma unroll
     for (int c = 0; c < C; ++c) bc[c] = smp.color(c), bd[c] = smp.desc(c);
     if constexpr (C == 1) {
@@ -612,6 +610,7 @@ __global__ __launch_bounds__(kBlock) void lob_phase_a_kernel(const SsArgs a) {
       if (ok && totD <= descThr3 && totC <= colorThr3) good++;
     }
     idx++;
+    ss_wait_here(nsmp);
     smp = nsmp;
   }
   uint16_t reqSelf = 0, reqNbr = 0;
