@@ -148,4 +148,44 @@ __device__ __forceinline__ unsigned ss_lbsp(const uint32_t (&nb)[8], int ref, in
   return (acc & 0xffu) | ((acc >> 8) & 0xff00u);
 }
 
+// The 5x5 double-cross neighbourhood of one pixel out of a halo'd LDS tile, with dword reads.
+// The tile rows hold interleaved C-channel bytes starting at an arbitrary byte alignment (`shift` of row ry, 0..3; the rows
+// were filled with ALIGNED dword loads from the image, so the first wanted byte of a row sits `shift` bytes into it).  For tile
+// pixel (ly, lx) - halo 2, so its own bytes start at shift + (lx + 2) * C of row ly + 2 - the window of row ry is the 5*C bytes
+// of pixels lx .. lx+4 of that row: WD + 1 dword reads and WD v_alignbyte put them at byte 0 of w[r][...]
+// (round 1 read every byte on its own: 51 ds_read_u8 + address arithmetic per pixel and channel set).
+template <int C>
+struct LbspWin {
+  static constexpr int WD = (5 * C + 3) / 4;  // dwords per window row: 4 (BGR, 15 bytes), 2 (gray, 5 bytes)
+  uint32_t w[5][WD];
+  // row_dw: LDS row pitch in dwords; s0 / sstep: shift of tile row ry is (s0 + ry * sstep) & 3
+  __device__ __forceinline__ void load(const uint32_t* tile, int row_dw, int ly, int lx, int s0, int sstep) {
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      const int ry = ly + r;  // tile rows ly .. ly+4 = image rows y-2 .. y+2
+      const int b0 = ((s0 + ry * sstep) & 3) + lx * C, sh = b0 & 3;
+      const uint32_t* q = tile + ry * row_dw + (b0 >> 2);
+      uint32_t d[WD + 1];
+#pragma unroll
+      for (int j = 0; j <= WD; ++j) d[j] = q[j];
+#pragma unroll
+      for (int j = 0; j < WD; ++j) w[r][j] = __builtin_amdgcn_alignbyte(d[j + 1], d[j], (uint32_t)sh);
+    }
+  }
+  // byte (dx, dy, c) of the window, dx, dy in -2..2: compile-time position
+  static constexpr int pos(int dx, int c) { return (dx + 2) * C + c; }
+  __device__ __forceinline__ int centre(int c) const { return (int)((w[2][pos(0, c) >> 2] >> (8 * (pos(0, c) & 3))) & 0xffu); }
+  // the 16 neighbours of channel c packed as ss_lbsp wants them: dword k = neighbour k << 16 | neighbour 8+k (one v_perm_b32 each)
+  __device__ __forceinline__ void pack(int c, uint32_t (&nb)[8]) const {
+    constexpr int dx[16] = {-1, 1, 1, -1, 1, 0, -1, 0, -2, 2, 2, -2, 0, 0, 2, -2}, dy[16] = {1, -1, 1, -1, 0, -1, 0, 1, -2, 2, -2, 2, 2, -2, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int pa = pos(dx[k], c), pb = pos(dx[8 + k], c);
+      // v_perm_b32 D, S0, S1, sel: selector 0-3 = bytes of S1, 4-7 = bytes of S0, 0x0c = constant 0
+      const uint32_t sel = 0x0c000c00u | ((uint32_t)(4 + (pa & 3)) << 16) | (uint32_t)(pb & 3);
+      nb[k] = __builtin_amdgcn_perm(w[dy[k] + 2][pa >> 2], w[dy[8 + k] + 2][pb >> 2], sel);
+    }
+  }
+};
+
 }  // namespace bgs

@@ -149,6 +149,11 @@ struct LbspArgs {
   uint8_t lut[256];    // absolute threshold per centre value
 };
 
+// Round 2: the neighbourhood now comes out of the LDS tile with dword reads (LbspWin: 25 ds_read_b32 + 20 v_alignbyte + one
+// v_perm per packed pair instead of 51 ds_read_u8) - and the kernel's time did not move (16 x 1080p in one launch: 0.234 ms,
+// 142 Gpixel/s), nor did staging the output through LDS for whole-dword stores (0.28 ms).  With the compare compiled out the
+// same launch takes 0.086 ms: the kernel is bound by ss_lbsp itself - 16 comparisons per channel at 2 packed instructions per
+// neighbour, ~120 VALU instructions per pixel - which no access pattern changes.
 constexpr int kLbspTW = 64, kLbspTH = 16;  // output tile; 256 lanes, each 4 rows of one column
 
 // bit 15..0 -> (dx, dy) of LBSP_16bits_dbcross_3ch3t.i:27-43
@@ -197,19 +202,13 @@ __global__ __launch_bounds__(kBlock) void lbsp_kernel(const LbspArgs a) {
       for (int c = 0; c < C; ++c) out[c] = 0;
       continue;
     }
-    auto at = [&](int ry, int rx, int c) -> int {  // pixel (ry, rx) of the halo'd tile, channel c
-      const uint8_t* rowp = reinterpret_cast<const uint8_t*>(tile[ry]);
-      const long row0 = (long)(y0 + ry - 2) * a.cols * C;  // interior pixels only read unclamped rows
-      const int shift = (int)((row0 + rb) & 3L);
-      return rowp[shift + rx * C + c];
-    };
+    LbspWin<C> win;  // dword reads of the LDS tile + v_alignbyte / v_perm packing (bgs_device.h) instead of 51 byte reads
+    win.load(&tile[0][0], ROWB / 4, ly, lx, (int)(((long)(y0 - 2) * a.cols * C + rb) & 3L), (a.cols * C) & 3);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      const int ref = at(ly + 2, lx + 2, c);
+      const int ref = win.centre(c);
       uint32_t nb[8];  // two neighbours per dword, as ss_lbsp wants them (bit 15-k in the high half, bit 7-k in the low half)
-#pragma unroll
-      for (int b = 0; b < 8; ++b)
-        nb[b] = ((uint32_t)at(ly + 2 + kLbspDy[b], lx + 2 + kLbspDx[b], c) << 16) | (uint32_t)at(ly + 2 + kLbspDy[8 + b], lx + 2 + kLbspDx[8 + b], c);
+      win.pack(c, nb);
       out[c] = (uint16_t)ss_lbsp(nb, ref, lut[ref]);
     }
   }

@@ -191,15 +191,16 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
     const int shift = (int)(((long)(y0 + ry - 2) * a.cols * C + rb) & 3L);
     return rowp[shift + rx * C + c];
   };
-  // current colour and the 16 LBSP neighbours (packed as ss_lbsp wants them) of tile pixel (ly, lx)
+  // current colour and the 16 LBSP neighbours (packed as ss_lbsp wants them) of tile pixel (ly, lx): dword reads of the LDS
+  // tile + v_alignbyte / v_perm (bgs_device.h: LbspWin) instead of one ds_read_u8 per byte
+  const int rowShift0 = (int)(((long)(y0 - 2) * a.cols * C + rb) & 3L), rowShiftStep = (a.cols * C) & 3;
   auto gather = [&](int ly, int lx, int (&cur)[C], uint32_t (&nb)[C][8]) {
-    const int8_t dxs[16] = {-1, 1, 1, -1, 1, 0, -1, 0, -2, 2, 2, -2, 0, 0, 2, -2}, dys[16] = {1, -1, 1, -1, 0, -1, 0, 1, -2, 2, -2, 2, 2, -2, 0, 0};
+    LbspWin<C> win;
+    win.load(&tile[0][0], ROWB / 4, ly, lx, rowShift0, rowShiftStep);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      cur[c] = at(ly + 2, lx + 2, c);
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        nb[c][k] = ((uint32_t)at(ly + 2 + dys[k], lx + 2 + dxs[k], c) << 16) | (uint32_t)at(ly + 2 + dys[8 + k], lx + 2 + dxs[8 + k], c);
+      cur[c] = win.centre(c);
+      win.pack(c, nb[c]);
     }
   };
   auto interior_of = [&](int x, int y) { return x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2; };  // LBSP::validateROI; border pixels are never touched
@@ -553,20 +554,16 @@ __global__ __launch_bounds__(kBlock) void lob_phase_a_kernel(const SsArgs a) {
     a.req[i * 2] = 0, a.req[i * 2 + 1] = 0;
     return;
   }
-  auto at = [&](int ry, int rx, int c) -> int {
-    const uint8_t* rowp = reinterpret_cast<const uint8_t*>(tile[ry]);
-    const int shift = (int)(((long)(y0 + ry - 2) * a.cols * C + rb) & 3L);
-    return rowp[shift + rx * C + c];
-  };
-  const int8_t dxs[16] = {-1, 1, 1, -1, 1, 0, -1, 0, -2, 2, 2, -2, 0, 0, 2, -2}, dys[16] = {1, -1, 1, -1, 0, -1, 0, 1, -2, 2, -2, 2, 2, -2, 0, 0};
   int cur[C];
   uint32_t nb[C][8];
+  {
+    LbspWin<C> win;
+    win.load(&tile[0][0], ROWB / 4, ly, lx, (int)(((long)(y0 - 2) * a.cols * C + rb) & 3L), (a.cols * C) & 3);
 #pragma unroll
-  for (int c = 0; c < C; ++c) {
-    cur[c] = at(ly + 2, lx + 2, c);
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-      nb[c][k] = ((uint32_t)at(ly + 2 + dys[k], lx + 2 + dxs[k], c) << 16) | (uint32_t)at(ly + 2 + dys[8 + k], lx + 2 + dxs[8 + k], c);
+    for (int c = 0; c < C; ++c) {
+      cur[c] = win.centre(c);
+      win.pack(c, nb[c]);
+    }
   }
   const uint32_t colorThr = (uint32_t)a.nMinColor, descThr = (uint32_t)a.nDescOff;
   const uint32_t descThr3 = descThr * 3, colorThr3 = colorThr * 3, scDesc = descThr3 / 2, scColor = colorThr3 / 2;  // :225-228
