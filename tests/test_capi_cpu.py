@@ -160,3 +160,26 @@ int main() {
     want = [10 + 3.0, 20 + 1.5, 4 * np.sqrt((49 - 1) / 12.0), 4 * np.sqrt((16 - 1) / 12.0)]
     assert np.allclose(mom, want, atol=1e-5), (mom, want)
     assert out[1].split() == ["2", "1", "1"] and out[2].split() == ["1", "5"]
+
+
+def test_ingest_and_blob_structs_match_c(tmp_path):
+    """bgs_ingest (ctypes mirror capi.BgsIngest), bgs_box and bgs_moments (numpy int32 x 6 / int64 x 4 rows in the bindings) have the
+    layout the C compiler gives them; bgs_ingest_default / bgs_ingest_size / bgs_ingest_workspace answer without a GPU."""
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "bgs_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(bgs_ingest), offsetof(bgs_ingest, roi_x0), '
+                   'offsetof(bgs_ingest, gaussian_blur), sizeof(bgs_box), sizeof(bgs_moments));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    size, roi, blur, box, mom = map(int, subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split())
+    assert size == C.sizeof(capi.BgsIngest) and roi == capi.BgsIngest.roi_x0.offset and blur == capi.BgsIngest.gaussian_blur.offset
+    assert box == 6 * 4 and mom == 4 * 8
+    c = capi.default_ingest()
+    assert (c.struct_size, c.resize_percent, c.flip, c.equalize_hist, c.gaussian_blur) == (size, 100, 0, 0, 0)
+    r, k = C.c_int(0), C.c_int(0)
+    assert capi.lib().bgs_ingest_size(C.byref(c), 1080, 1920, C.byref(r), C.byref(k)) == 0 and (r.value, k.value) == (1080, 1920)
+    c2 = capi.default_ingest(resize_percent=50, roi_x0=10, roi_y0=20, roi_x1=110, roi_y1=70, gaussian_blur=1)
+    assert capi.lib().bgs_ingest_size(C.byref(c2), 1080, 1920, C.byref(r), C.byref(k)) == 0 and (r.value, k.value) == (50, 100)
+    assert capi.lib().bgs_ingest_workspace(C.byref(c2), 4, 1080, 1920, 3) >= 4 * 50 * 100 * 3
+    assert capi.lib().bgs_ingest_workspace(C.byref(c), 4, 1080, 1920, 3) == 0
+    bad = capi.default_ingest(roi_x0=10, roi_y0=20, roi_x1=5000, roi_y1=70)
+    assert capi.lib().bgs_ingest_size(C.byref(bad), 1080, 1920, C.byref(r), C.byref(k)) == capi.ERR_INVALID
