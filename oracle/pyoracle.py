@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libbgs_oracle.so")
+_LIB = os.environ.get("BGS_ORACLE_LIB") or os.path.join(_HERE, "libbgs_oracle.so")  # BGS_ORACLE_LIB: e.g. an ASan/UBSan build (tools/sanitize_cpu.sh)
 _REF_LBSP = os.path.join(_HERE, "_ref", "libref_lbsp.so")
 _REF_SDLAMA = os.path.join(_HERE, "_ref", "ref_sdlama_cli")
 

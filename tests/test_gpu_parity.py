@@ -660,3 +660,33 @@ def test_model_sizing_parameters_are_frozen_after_the_first_frame(golden_frames)
             fg, bg = eng.process(f)
             ofg, obg = orc.process(f)
             assert np.array_equal(fg, ofg), (algo, t)
+
+
+@pytest.mark.parametrize("algo", [capi.MOG2, capi.SUBSENSE, capi.DP_ZIVKOVIC_AGMM, capi.ABL])
+def test_disjoint_stream_ranges_in_flight_on_two_hip_streams(algo):
+    """bgs_process_range_device for streams [0, 2) on one HIP stream and [2, 4) on another, enqueued back to back without any
+    synchronisation in between, frame after frame: every stream must equal its own oracle.  (What the header allows: ranges in
+    flight at once must be disjoint; per-range state - SuBSENSE's flood-fill flags, frame counters, first-frame initialisation on
+    the launch stream - must not be shared.)"""
+    torch = _torch()
+    H, W, S, T = 48, 64, 4, 6
+    clips = np.stack([synth.random_frames(T, H, W, 3, seed=300 + s) for s in range(S)])  # [S][T][H][W][3]
+    dev = torch.from_numpy(clips).cuda()
+    eng = Engine(algo, n_streams=S)
+    eng.set_geometry(H, W, 3)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    fg = torch.empty((T, S, H, W), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for t in range(T):
+        fa, fb = dev[0:2, t].contiguous(), dev[2:4, t].contiguous()
+        torch.cuda.synchronize()  # the frame copies above ran on torch's default stream
+        eng.process_batch_device(fa, fg[t, 0:2], None, None, hip_stream=s1.cuda_stream, first=0, count=2)
+        eng.process_batch_device(fb, fg[t, 2:4], None, None, hip_stream=s2.cuda_stream, first=2, count=2)
+    torch.cuda.synchronize()
+    got = fg.cpu().numpy()
+    for s in range(S):
+        orc = pyoracle.Oracle(algo)
+        for t in range(T):
+            ofg, _ = orc.process(clips[s, t], want_bg=False)
+            assert np.array_equal(got[t, s], ofg), (s, t, int((got[t, s] != ofg).sum()))
+    eng.close()

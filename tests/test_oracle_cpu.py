@@ -487,3 +487,20 @@ def test_ingest_resize_vs_float_bilinear(pct):
     f = img.astype(np.float64)
     want = (f[yc0][:, xc0] * (1 - fx) + f[yc0][:, xc1] * fx) * (1 - fy) + (f[yc1][:, xc0] * (1 - fx) + f[yc1][:, xc1] * fx) * fy
     assert np.max(np.abs(got.astype(np.float64) - want)) <= 1.0
+
+
+def test_cpu_code_is_clean_under_asan_and_ubsan():
+    """tools/sanitize_cpu.sh: the oracle's C code (through these same CPU tests) and the host-side C++ mirror (XML handling, set-up, the
+    no-GPU exception path) under AddressSanitizer + UndefinedBehaviorSanitizer.  GPU sanitizers do not exist on this pool; this is the
+    CPU half."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not shutil.which("gcc") or not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no libasan in this image")
+    if os.environ.get("BGS_ORACLE_LIB"):
+        pytest.skip("already running inside the sanitizer run")
+    r = subprocess.run(["bash", os.path.join(root, "tools", "sanitize_cpu.sh")], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "oracle under ASan+UBSan: OK" in r.stdout and "host mirror under ASan+UBSan: OK" in r.stdout
