@@ -111,7 +111,7 @@ def surv_leg(local, S, fg, steps=200, sparse=1):
     mpix = steps * S * ROWS * COLS / dt / 1e6
     out = {"mpixels_per_s": round(mpix, 1), "streams_1080p30": round(mpix / (ROWS * COLS / 1e6) / 30.0, 1), "kernel_ms": round(ms, 4),
            "mean_live_modes_stream0": round(float(nm.mean()), 3), "foreground_ratio": round(float((fg != 0).float().mean()), 4),
-           # bytes model of a scene with n live modes per pixel, 8 + 28 n (frame 3 + nmodes 1+1 + mask 1 + 2 spare; 28 = r/w of {w, var, mu[3]} ... per mode)
+           # SURVEY.md §8(d) asks for its bytes model `8 + 28 n` (n = mean live modes) beside the S_surv rate
            "bytes_model_per_pixel": round(8 + 28 * float(nm.mean()), 1), "bytes_model_GBps": round((8 + 28 * float(nm.mean())) * S * ROWS * COLS / (ms * 1e-3) / 1e9, 1),
            "sparse_mode": sparse,
            "note": "S_surv input, %d streams; BGS_OPT_MOG2_SPARSE=%d (1 = unchanged planes not written back, 2/4 = also planes of absent modes not read, per wave / per lane, 3 = automatic choice between 1 and 4 [default])" % (S, sparse)}
