@@ -29,5 +29,6 @@ for t in range(n):
 torch.cuda.synchronize()
 lib.bgs_debug_counters(out, 1)
 px = S * rows * cols * n
+print("refills per pixel-round (x64/px) %.2f, lanes refilled per refill %.1f" % (out[4] * 64 / px, out[5] / max(out[4], 1)))
 print("per pixel: wave-iterations x64 %.2f  active lane-trips %.2f  (utilisation %.2f)  inter-LBSP wave-iterations x64 %.2f  lanes needing it %.2f"
       % (out[0] * 64 / px, out[1] / px, out[1] / (out[0] * 64.0), out[2] * 64 / px, out[3] / px))

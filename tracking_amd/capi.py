@@ -127,6 +127,8 @@ def lib():
             raise ImportError("libbgs_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` (%s)" % LIB_PATH)
         l = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
+            if os.environ.get("BGS_LIB_PATH") and os.environ.get("BGS_LIB_PARTIAL_ABI") and not hasattr(l, name):
+                continue  # A/B against an older build of the library (tools/): entry points it lacks simply stay unbound
             fn = getattr(l, name)  # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args

@@ -269,6 +269,8 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
       const int nidle = __popcll(idle);
       if (qempty && nidle == kWave) break;
       if (!qempty && nidle >= a.refill) {  // wave-uniform
+        EXP_COUNT(4, 1);
+        EXP_COUNT(5, nidle);
         const int leader = __ffsll((long long)idle) - 1;
         unsigned base = 0;
         if (lane == leader) base = atomicAdd(&qhead, (unsigned)nidle);
