@@ -33,11 +33,19 @@ constexpr int kGmgFast = 8;
 __device__ __forceinline__ void gmg_fast(const GmgArgs& a, bool active, size_t sp, size_t p0, int nf, int color) {
   int c[kGmgFast];
   float w[kGmgFast];
+  // All 16 loads are issued back to back and waited for once.  They are UNCONDITIONAL on purpose: written as `if (i < nf) load`
+  // the compiler merged every loaded value with the default through a copy and put s_waitcnt vmcnt(0) behind each pair - eight
+  // serial memory round trips (round 2, found in the ISA like SuBSENSE's prefetch).  Entries past the count re-read the last
+  // valid one (same cache line, no extra traffic) and are zeroed afterwards.
+  const int lastValid = max(nf - 1, 0);
 #pragma unroll
   for (int i = 0; i < kGmgFast; ++i) {
-    c[i] = 0, w[i] = 0.f;
-    if (active && i < nf) c[i] = a.colors[(size_t)i * a.plane + sp], w[i] = a.weights[(size_t)i * a.plane + sp];
+    const size_t o = (size_t)min(i, lastValid) * a.plane + sp;
+    c[i] = a.colors[o], w[i] = a.weights[o];
   }
+#pragma unroll
+  for (int i = 0; i < kGmgFast; ++i)
+    if (!(active && i < nf)) c[i] = 0, w[i] = 0.f;
   int idx = -1;
   float wfound = 0.f;
 #pragma unroll
