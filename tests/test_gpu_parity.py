@@ -336,7 +336,7 @@ def test_subsense_golden_frames(golden_frames):
 
 def test_subsense_flood_fill_finish_kernel_path(golden_frames, tmp_path):
     """BGS_SS_FLOOD_BATCH=0: no batch launches at all, SuBSENSE's hole filling is done entirely by ss_flood_finish_kernel (the
-    path that otherwise only runs for masks the 12-launch batch does not converge on).  The knob is read once per process,
+    path that otherwise only runs for masks the batch of relaxation launches does not converge on).  The knob is read once per process,
     hence the child process."""
     import subprocess
     import sys
@@ -428,7 +428,7 @@ def test_subsense_rejects_unsupported_inputs():
 def test_floodfill_from_origin_vs_oracle(shape):
     """cv::floodFill(mask, Point(0,0), 255): mazes with long snaking corridors, enclosed holes, origin on either value,
     sizes that are not multiples of the 64x64 bit-packed tile.  The serpentine walls make the fill cross tile borders far more
-    often than the fixed batch of relaxation launches covers (kSsFloodBatch = 12), so ss_flood_finish_kernel does the rest
+    often than the fixed batch of relaxation launches covers (kSsFloodBatch x kSsFloodRounds tile steps), so ss_flood_finish_kernel does the rest
     (at 300x520: 45 tiles over the finish kernel's 16 waves)."""
     torch = _torch()
     from tracking_amd.engine import mask_morph_device, MORPH_FLOODFILL_ORIGIN, MORPH_MEDIAN_BINARY

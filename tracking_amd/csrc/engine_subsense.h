@@ -304,6 +304,13 @@ int64_t ss_get_state(bgs_engine* e, int stream, const char* plane, void* dst, si
       }
     return (int64_t)need;
   }
+  if (!strcmp(plane, "floodflags")) {  // diagnostics: which launches of the last flood fill still changed something, [kSsFloodFlags] int32; the last one = the finish kernel had to work
+    if (e->algo != BGS_SUBSENSE) return fail(BGS_ERR_STATE, "floodflags: SuBSENSE only");
+    const size_t nb = (size_t)bgs::kSsFloodFlags * sizeof(int);
+    if (cap < nb) return fail(BGS_ERR_STATE, "buffer too small for plane floodflags");
+    if (hipMemcpy(dst, d->flood_flags + (size_t)stream * bgs::kSsFloodFlags, nb, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+    return (int64_t)nb;
+  }
   if (!strcmp(plane, "scalars")) {
     if (cap < 7 * sizeof(double)) return fail(BGS_ERR_STATE, "buffer too small for plane scalars");
     bgs::SsScalars sc;

@@ -865,10 +865,10 @@ __device__ __forceinline__ bool ss_flood_tile(const uint64_t* mb, uint64_t* rb, 
 
 // The flood fill runs WITHOUT a host round trip: the host enqueues a fixed batch of kSsFloodBatch relaxation launches plus one
 // ss_flood_finish_kernel.  flags[stream][k] = "launch k changed something in this image"; launch k of an image returns at once when
-// launch k-1 changed nothing (the fill has converged: typical masks need 2-6 launches, the wavefront crosses a tile per launch
-// from every side), and the finish kernel only works when the last batch launch still changed something - then ONE workgroup
+// launch k-1 changed nothing (the fill has converged: typical masks need 2-4 launches, the wavefront crosses up to kSsFloodRounds
+// tiles per launch from every side), and the finish kernel only works when the last batch launch still changed something - then ONE workgroup
 // per image keeps relaxing all tiles until nothing changes (slow, but any mask converges; spiral masks in the tests).
-constexpr int kSsFloodBatch = 12;
+constexpr int kSsFloodBatch = 8, kSsFloodRounds = 4;
 constexpr int kSsFloodFlags = kSsFloodBatch + 1;  // per stream; the last one: "the finish kernel had to work" (diagnostics)
 
 __global__ __launch_bounds__(kBlock) void ss_flood_kernel(const uint64_t* mbits, uint64_t* rbits, int rows, int W64, int* flags, int k) {
@@ -879,7 +879,15 @@ __global__ __launch_bounds__(kBlock) void ss_flood_kernel(const uint64_t* mbits,
   const size_t tile = (size_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
   if (tile >= (size_t)tilesY * W64) return;  // whole wave
   const size_t base = (size_t)blockIdx.z * rows * W64;
-  if (ss_flood_tile<false>(mbits + base, rbits + base, rows, W64, (int)(tile / W64), (int)(tile % W64), lane) && lane == 0) fl[k] = 1;
+  // kSsFloodRounds relaxations per launch: all tiles of the launch are resident at once (510 per 1080p image), so a tile that
+  // re-reads its neighbours' halos (past the L1: COHERENT) sees what they reached a moment ago and the wavefront crosses up to
+  // kSsFloodRounds tiles per launch instead of one.  An all-background 1080p mask (the common case: the fill has to come in
+  // from the ring to the centre, 9 tiles) needed 9-12 launches with one relaxation each; stale reads only delay, never break, a
+  // monotone fill.
+  bool grew = false;
+  for (int round = 0; round < kSsFloodRounds; ++round)
+    grew |= ss_flood_tile<true>(mbits + base, rbits + base, rows, W64, (int)(tile / W64), (int)(tile % W64), lane);
+  if (grew && lane == 0) fl[k] = 1;
 }
 
 __global__ __launch_bounds__(1024) void ss_flood_finish_kernel(const uint64_t* mbits, uint64_t* rbits, int rows, int W64, int* flags, int batch) {
