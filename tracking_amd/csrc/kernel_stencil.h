@@ -229,11 +229,15 @@ constexpr int kBoxTW = 64, kBoxTH = 16;
 // n iterations of the 3x3 erode/dilate equal one (2n+1)x(2n+1) box: cells outside the image never take part
 // (morphologyDefaultBorderValue) and the image is convex, so the iterated and the one-shot minimum run over the same cells
 // (OpenCV itself folds iterations of a rectangular element into one larger element).  Median: BORDER_REPLICATE.
+// OPT / RT: operation and radius as compile-time constants (-1: take them from the arguments).  The post-processing chains use
+// a handful of shapes over and over (3x3 / 7x7 erode and dilate, binary medians 7 .. 13): with constant trip counts the two
+// passes unroll and the per-cell `op` tests disappear.
+template <int OPT, int RT>
 __global__ __launch_bounds__(kBlock) void morph_box_kernel(const MorphArgs a) {
   constexpr int LW = kBoxTW + 2 * kMorphMaxR + 2;
   __shared__ uint8_t t[kBoxTH + 2 * kMorphMaxR][LW];
   __shared__ uint8_t v[kBoxTH][LW];
-  const int R = a.ksize / 2, op = a.op;
+  const int R = RT >= 0 ? RT : a.ksize / 2, op = OPT >= 0 ? OPT : a.op;
   const int x0 = blockIdx.x * kBoxTW, y0 = blockIdx.y * kBoxTH;
   const size_t img = (size_t)blockIdx.z * a.rows * a.cols;
   const int HW = kBoxTW + 2 * R, HH = kBoxTH + 2 * R;
@@ -256,6 +260,7 @@ __global__ __launch_bounds__(kBlock) void morph_box_kernel(const MorphArgs a) {
     for (int r = 0; r < 4; ++r) {
       const int ry = strip * 4 + r;
       int acc = op == 0 ? 255 : 0;
+#pragma unroll
       for (int dy = 0; dy <= 2 * R; ++dy) {
         const int c = t[ry + dy][cx];
         acc = op == 0 ? min(acc, c) : op == 1 ? max(acc, c) : acc + c;
@@ -267,11 +272,12 @@ __global__ __launch_bounds__(kBlock) void morph_box_kernel(const MorphArgs a) {
   const int ly = threadIdx.x / (kBoxTW / 4), xs = (threadIdx.x % (kBoxTW / 4)) * 4;  // horizontal pass: four pixels of one row
   const int y = y0 + ly, x = x0 + xs;
   if (y >= a.rows || x >= a.cols) return;
-  const int need = (a.ksize * a.ksize) / 2 + 1;
+  const int need = ((2 * R + 1) * (2 * R + 1)) / 2 + 1;
   uint32_t packed = 0;
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
     int acc = op == 0 ? 255 : 0;
+#pragma unroll
     for (int dx = 0; dx <= 2 * R; ++dx) {
       const int c = v[ly][xs + o + dx];
       acc = op == 0 ? min(acc, c) : op == 1 ? max(acc, c) : acc + c;
@@ -329,8 +335,19 @@ __global__ __launch_bounds__(kBlock) void mask_pack_kernel(const uint8_t* src, u
 inline void morph_launch(const MorphArgs& a, int count, hipStream_t s) {
   if (a.op == 2)
     hipLaunchKernelGGL(median_kernel, dim3((a.cols + kMorphTW - 1) / kMorphTW, (a.rows + kMorphTH - 1) / kMorphTH, count), dim3(kBlock), 0, s, a);
-  else
-    hipLaunchKernelGGL(morph_box_kernel, dim3((a.cols + kBoxTW - 1) / kBoxTW, (a.rows + kBoxTH - 1) / kBoxTH, count), dim3(kBlock), 0, s, a);
+  else {
+    const dim3 grid((a.cols + kBoxTW - 1) / kBoxTW, (a.rows + kBoxTH - 1) / kBoxTH, count), block(kBlock);
+    const int R = a.ksize / 2;
+#define MORPH_CASE(OPV, RV) \
+  if (a.op == OPV && R == RV) {                                                       \
+    hipLaunchKernelGGL((morph_box_kernel<OPV, RV>), grid, block, 0, s, a);            \
+    return;                                                                           \
+  }
+    MORPH_CASE(0, 1) MORPH_CASE(1, 1) MORPH_CASE(0, 3) MORPH_CASE(1, 3)                 // 3x3 and (3 iterations =) 7x7 erode / dilate
+    MORPH_CASE(3, 3) MORPH_CASE(3, 4) MORPH_CASE(3, 5) MORPH_CASE(3, 6)                 // binary medians 7 (GMG), 9 (LOBSTER, SuBSENSE), 11, 13
+#undef MORPH_CASE
+    hipLaunchKernelGGL((morph_box_kernel<-1, -1>), grid, block, 0, s, a);
+  }
 }
 
 }  // namespace bgs
