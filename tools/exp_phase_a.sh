@@ -1,3 +1,3 @@
 set -o pipefail
-timeout -k 10 600 python -m pytest tests -m gpu -x -q -k "morphology or floodfill or subsense_golden or subsense_qvga or subsense_large or lobster_golden or gmg or GMG" 2>&1 | tail -2
-for k in subsense8 subsense; do timeout -k 10 300 python tools/bench_configs.py --only $k 2>&1 | grep -v amdgpu.ids; done
+timeout -k 10 900 python -m pytest tests -m gpu -x -q -k "subsense or lobster or sample_consensus or large_batches or disjoint" 2>&1 | tail -3
+for k in subsense8 subsense lobster pipeline; do timeout -k 10 300 python tools/bench_configs.py --only $k 2>&1 | grep -v amdgpu.ids; done

@@ -188,7 +188,7 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
   bgs::SsArgs a{};
   ss_fill_args(e, a, first, cur, (unsigned)(t + 1));
   a.frame = d_frames, a.fg = d_fg, a.bgimg = d_bg;
-  const dim3 tiles((e->cols + bgs::kSsTW - 1) / bgs::kSsTW, (e->rows + bgs::kSsTH - 1) / bgs::kSsTH, count), block(bgs::kBlock);
+  const dim3 tilesB((e->cols + bgs::kSsTW - 1) / bgs::kSsTW, (e->rows + bgs::kSsBTH - 1) / bgs::kSsBTH, count), block(bgs::kBlock);
   {
     Timed tm(e, s, "ss_phase_a_kernel");
     const dim3 tilesA((e->cols + bgs::kSsTW - 1) / bgs::kSsTW, (e->rows + bgs::kSsATH - 1) / bgs::kSsATH, count);
@@ -205,10 +205,10 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
   if (overlap) {
     HIP_TRY(hipEventRecord(d->evA, s));
     HIP_TRY(hipStreamWaitEvent(d->side, d->evA, 0));
-    SS_LAUNCH(ss_phase_b_kernel, tiles, block, d->side, a);
+    SS_LAUNCH(ss_phase_b_kernel, tilesB, block, d->side, a);
     HIP_TRY(hipEventRecord(d->evB, d->side));
   } else {
-    SS_LAUNCH(ss_phase_b_kernel, tiles, block, s, a);
+    SS_LAUNCH(ss_phase_b_kernel, tilesB, block, s, a);
   }
   hipLaunchKernelGGL(bgs::ss_blink_kernel, dim3(blocks_for(npix)), block, 0, s, a, npix);
   uint8_t *raw = d->u8[SS_RAW] + off, *t1 = d->u8[SS_T1] + off, *t3 = d->u8[SS_T3] + off, *t4 = d->u8[SS_T4] + off;
@@ -394,11 +394,12 @@ int lob_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, ui
   a.frame = d_frames, a.fg = d_fg, a.bgimg = d_bg;
   a.lastColor = d->curColor, a.lastDesc = d->curDesc;  // phase A writes / phase B reads what a requesting pixel copies into the model
   const dim3 tiles((e->cols + bgs::kSsTW - 1) / bgs::kSsTW, (e->rows + bgs::kSsTH - 1) / bgs::kSsTH, count);
+  const dim3 tilesB((e->cols + bgs::kSsTW - 1) / bgs::kSsTW, (e->rows + bgs::kSsBTH - 1) / bgs::kSsBTH, count);
   {
     Timed tm(e, s, "lob_phase_a_kernel");
     SS_LAUNCH(lob_phase_a_kernel, tiles, block, s, a);
   }
-  SS_LAUNCH(ss_phase_b_kernel, tiles, block, s, a);
+  SS_LAUNCH(ss_phase_b_kernel, tilesB, block, s, a);
   uint8_t* lastFG = d->u8[SS_LASTFG] + off;
   ss_morph(d->u8[SS_RAW] + off, lastFG, e->rows, e->cols, count, 3, d->medK, s);  // cv::medianBlur(oCurrFGMask, m_oLastFGMask, 9) :281
   if (d_fg) HIP_TRY(hipMemcpyAsync(d_fg, lastFG, npix, hipMemcpyDeviceToDevice, s));  // :282

@@ -634,15 +634,29 @@ __global__ __launch_bounds__(kBlock) void lob_phase_a_kernel(const SsArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------------- phase B
+// Applies the sample writes phase A decided, in the reference's order: sources in raster order, a source's self update before its
+// neighbour diffusion, a later write to the same (pixel, sample slot) replacing an earlier one.
+// Round 1 PULLED: every pixel looked at the requests of the 25 sources around it (50 LDS reads and tests per pixel, 0.47 ms on
+// 8 x 1080p - the second-largest kernel of the step - for writes that a few percent of the pixels make).  Now the requests are
+// PUSHED: a workgroup owns a 64 x 16 tile of TARGETS, collects the requests of the tile + halo whose target lies inside the tile into
+// a list in LDS, and one lane per list entry decides whether its request is the last one in that order for its (target, slot) - it
+// looks at the up to 50 requests that could aim at the same target - and if so performs the write.  Same result, the work follows
+// the number of requests instead of the number of pixels.
+constexpr int kSsBTH = 16;
+
 template <int C>
 __global__ __launch_bounds__(kBlock) void ss_phase_b_kernel(const SsArgs a) {
-  constexpr int HW = kSsTW + 4, HH = kSsTH + 4;
+  constexpr int HW = kSsTW + 4, HH = kSsBTH + 4;
   __shared__ uint32_t rq[HH][HW];     // both requests of a source pixel in one dword
   __shared__ uint8_t lc[HH][HW][C];   // what a requesting source writes: its current colour / intra descriptor (phase A left
-  __shared__ uint16_t ld[HH][HW][C];  // them in lastColor / lastDesc); staged so that the writes below wait on no load
+  __shared__ uint16_t ld[HH][HW][C];  // them in lastColor / lastDesc)
+  __shared__ uint32_t list[HH * HW * 2];  // ly << 16 | lx << 8 | q of every request whose target is in this tile
+  __shared__ unsigned nlist;
   const int stream = a.first + blockIdx.z;
   const size_t N = (size_t)a.rows * a.cols, sN = (size_t)stream * N;
-  const int x0 = blockIdx.x * kSsTW, y0 = blockIdx.y * kSsTH;
+  const int x0 = blockIdx.x * kSsTW, y0 = blockIdx.y * kSsBTH;
+  if (threadIdx.x == 0) nlist = 0;
+  __syncthreads();
   for (int i = threadIdx.x; i < HH * HW; i += kBlock) {
     const int ly = i / HW, lx = i - ly * HW;
     const int y = y0 + ly - 2, x = x0 + lx - 2;
@@ -653,33 +667,46 @@ __global__ __launch_bounds__(kBlock) void ss_phase_b_kernel(const SsArgs a) {
       if (v) {
 #pragma unroll
         for (int c = 0; c < C; ++c) lc[ly][lx][c] = a.lastColor[src * C + c], ld[ly][lx][c] = a.lastDesc[src * C + c];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {  // self request first, then the neighbour request
+          const uint32_t r = (v >> (16 * q)) & 0xffffu;
+          if (!(r & SS_REQ_VALID)) continue;
+          const int code = (int)(r & 0x1fu), tly = ly + code / 5 - 2, tlx = lx + code % 5 - 2;  // code = (dy + 2) * 5 + (dx + 2) of the target
+          if (tly >= 2 && tly < 2 + kSsBTH && tlx >= 2 && tlx < 2 + kSsTW) list[atomicAdd(&nlist, 1u)] = ((uint32_t)ly << 16) | ((uint32_t)lx << 8) | (uint32_t)q;
+        }
       }
     }
     rq[ly][lx] = v;
   }
   __syncthreads();
-  const int lx = threadIdx.x % kSsTW, ly = threadIdx.x / kSsTW;
-  const int x = x0 + lx, y = y0 + ly;
-  if (!(x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2)) return;
-  const size_t p = (size_t)y * a.cols + x;
-
+  const unsigned n = nlist;
+  for (unsigned e = threadIdx.x; e < n; e += kBlock) {
+    const uint32_t ent = list[e];
+    const int ly = (int)(ent >> 16), lx = (int)((ent >> 8) & 0xffu), q = (int)(ent & 1u);
+    const uint32_t r = (rq[ly][lx] >> (16 * q)) & 0xffffu;
+    const int code = (int)(r & 0x1fu), tly = ly + code / 5 - 2, tlx = lx + code % 5 - 2;
+    const uint32_t slot = (r >> 8) & 0x3fu;
+    const int key = (ly * HW + lx) * 2 + q;  // position in the reference's order of writes
+    bool last = true;
 #pragma unroll
-  for (int dy = -2; dy <= 2; ++dy)
+    for (int dy = -2; dy <= 2; ++dy)
 #pragma unroll
-    for (int dx = -2; dx <= 2; ++dx) {  // sources in raster order: a later source overwrites an earlier one, as in the reference's loop
-      const uint32_t both = rq[ly + 2 + dy][lx + 2 + dx];
-      const uint32_t aimed = SS_REQ_VALID | (uint32_t)(12 - 5 * dy - dx);  // the code of a request whose target is this pixel
+      for (int dx = -2; dx <= 2; ++dx) {
+        const int sy = tly + dy, sx = tlx + dx;  // inside the halo'd tile: the target is inside the tile
+        const uint32_t both = rq[sy][sx];
+        const uint32_t aimed = SS_REQ_VALID | (slot << 8) | (uint32_t)(12 - 5 * dy - dx);  // a request of (sy, sx) for this target and slot
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {  // self request first, then the neighbour request
-        const uint32_t r = (both >> (16 * q)) & 0xffffu;
-        if ((r & (SS_REQ_VALID | 0x1fu)) != aimed) continue;
-        int col[C];
-        unsigned dsc[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) col[c] = lc[ly + 2 + dy][lx + 2 + dx][c], dsc[c] = ld[ly + 2 + dy][lx + 2 + dx][c];
-        SsSample<C>::make(col, dsc).store(a.samples, ss_rec(a, stream, N, p, (int)((r >> 8) & 0x3fu)));  // one 16-byte (4-byte) store per update
+        for (int qq = 0; qq < 2; ++qq)
+          if (((both >> (16 * qq)) & (SS_REQ_VALID | 0x3f00u | 0x1fu)) == aimed && (sy * HW + sx) * 2 + qq > key) last = false;
       }
-    }
+    if (!last) continue;
+    int col[C];
+    unsigned dsc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) col[c] = lc[ly][lx][c], dsc[c] = ld[ly][lx][c];
+    const size_t p = (size_t)(y0 + tly - 2) * a.cols + (size_t)(x0 + tlx - 2);
+    SsSample<C>::make(col, dsc).store(a.samples, ss_rec(a, stream, N, p, (int)slot));  // one 16-byte (4-byte) store per update
+  }
 }
 
 // ----------------------------------------------------------------------------------------------- refreshModel :249-291
