@@ -1,0 +1,200 @@
+"""bgs_process_clip_device: nframes consecutive frames of every stream in one call.  MixtureOfGaussianV2BGS fuses runs of
+8 / 4 / 2 frames into one launch that keeps the model in registers; the contract is that NOTHING observable changes: masks,
+bit-packed masks, backgrounds, model state and frame counts equal the frame-by-frame path and the CPU oracle, for every
+sparse level, clip length and starting point."""
+import numpy as np
+import pytest
+
+from gpu_helpers import ALGOS, _params, _torch, check_mog2_state, check_state
+from oracle import pyoracle
+from tools import synth
+from tracking_amd import Engine, capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _clips(kind, S, T, H, W, seed):
+    if kind == "random":
+        return np.stack([synth.random_frames(T, H, W, 3, seed=seed + s) for s in range(S)])
+    return np.stack([synth.numpy_frames(kind, T, H, W, seed=seed + s) for s in range(S)])  # [S][T][H][W][3]
+
+
+def _run_clip(eng, clips, t0, n, want_bg=True):
+    """frames t0..t0+n of every stream through ONE clip call; returns fg [n][S][H][W], bits, bg, flags."""
+    torch = _torch()
+    S, _, H, W, _ = clips.shape
+    d_frames = torch.from_numpy(np.ascontiguousarray(clips[:, t0:t0 + n].transpose(1, 0, 2, 3, 4))).cuda()  # [n][S][H][W][3]
+    d_fg = torch.full((n, S, H, W), 9, dtype=torch.uint8, device="cuda")
+    d_bg = torch.full((n, S, H, W, 3), 9, dtype=torch.uint8, device="cuda") if want_bg else None
+    d_bits = torch.zeros((n, S, H * W // 64), dtype=torch.int64, device="cuda")
+    flags = eng.process_clip_device(d_frames, n, d_fg, d_bg, d_bits)
+    torch.cuda.synchronize()
+    bits = np.unpackbits(d_bits.cpu().numpy().view(np.uint8).reshape(n, S, -1), axis=2, bitorder="little").reshape(n, S, H, W)
+    return d_fg.cpu().numpy(), bits, (d_bg.cpu().numpy() if want_bg else None), flags
+
+
+@pytest.mark.parametrize("kind", ["sat", "surv", "random"])
+@pytest.mark.parametrize("sparse", [0, 1, 2, 3, 4])
+def test_mog2_clip_equals_oracle_frame_by_frame(kind, sparse):
+    """15 frames as clips of 1 + 8 + 4 + 2 (a 15-frame call splits into 8 + 4 + 2 + 1 by itself): every mask, background and the
+    final model against the oracle fed one frame at a time."""
+    S, T, H, W = 3, 30, 16, 64
+    clips = _clips(kind, S, T, H, W, seed=900)
+    eng = Engine(capi.MOG2, n_streams=S)
+    eng.set_geometry(H, W, 3)
+    eng.set_option(capi.OPT_MOG2_SPARSE, sparse)
+    orcs = [pyoracle.Oracle(capi.MOG2) for _ in range(S)]
+    t0 = 0
+    for n in (1, 8, 4, 2, 15):
+        fg, bits, bg, flags = _run_clip(eng, clips, t0, n)
+        assert len(flags) == n and all(f == (capi.FG_VALID | capi.BG_VALID) for f in flags)
+        for j in range(n):
+            for s in range(S):
+                ofg, obg = orcs[s].process(clips[s, t0 + j])
+                assert np.array_equal(fg[j, s], ofg), (t0 + j, s, int((fg[j, s] != ofg).sum()))
+                assert np.array_equal(bits[j, s] * 255, np.where(ofg != 0, 255, 0)), (t0 + j, s)
+                assert np.array_equal(bg[j, s], obg), (t0 + j, s)
+        t0 += n
+        for s in range(S):
+            assert eng.frames_seen(s) == t0
+            check_mog2_state(eng, orcs[s], H * W, stream=s)
+
+
+@pytest.mark.parametrize("alpha", [-1.0, 0.05, 0.002])
+def test_mog2_clip_learning_rate_schedule(alpha):
+    """alpha < 0 = the automatic rate 1/min(2n, history): a different rate for every frame inside one launch; the first frame of a
+    stream (clear + rate 1/2) is part of the first clip."""
+    S, T, H, W = 2, 24, 8, 64
+    clips = _clips("surv", S, T, H, W, seed=77)
+    p = _params(capi.MOG2, alpha=alpha)
+    eng = Engine(capi.MOG2, params=p, n_streams=S)
+    eng.set_geometry(H, W, 3)
+    orcs = [pyoracle.Oracle(capi.MOG2, params=p) for _ in range(S)]
+    t0 = 0
+    for n in (8, 8, 8):
+        fg, _, bg, _ = _run_clip(eng, clips, t0, n)
+        for j in range(n):
+            for s in range(S):
+                ofg, obg = orcs[s].process(clips[s, t0 + j])
+                assert np.array_equal(fg[j, s], ofg), (t0 + j, s)
+                assert np.array_equal(bg[j, s], obg), (t0 + j, s)
+        t0 += n
+    for s in range(S):
+        check_mog2_state(eng, orcs[s], H * W, stream=s)
+
+
+def test_mog2_clip_fused_equals_unfused_bitwise():
+    """The same 23-frame clip with BGS_OPT_CLIP_FUSE 1 and 0, shadows delivered (no threshold), a sub-range of the streams: masks
+    and every model plane identical bit for bit (not just within the float tolerance)."""
+    S, T, H, W = 5, 23, 24, 64
+    clips = _clips("surv", S, T, H, W, seed=5)
+    p = _params(capi.MOG2, enable_threshold=0)
+    res = []
+    for fuse in (1, 0):
+        eng = Engine(capi.MOG2, params=p, n_streams=S)
+        eng.set_geometry(H, W, 3)
+        eng.set_option(capi.OPT_CLIP_FUSE, fuse)
+        torch = _torch()
+        sub = clips[1:4]
+        d_frames = torch.from_numpy(np.ascontiguousarray(sub.transpose(1, 0, 2, 3, 4))).cuda()
+        d_fg = torch.zeros((T, 3, H, W), dtype=torch.uint8, device="cuda")
+        eng.process_clip_device(d_frames, T, d_fg, None, None, first=1, count=3)
+        torch.cuda.synchronize()
+        n = H * W
+        planes = [eng.get_state(pl, sh, dt, stream=2) for pl, sh, dt in (("w", (5, n), np.float32), ("var", (5, n), np.float32), ("mu", (5, 3, n), np.float32), ("nmodes", (n,), np.uint8))]
+        assert [eng.frames_seen(s) for s in range(S)] == [0, T, T, T, 0]
+        res.append((d_fg.cpu().numpy(), planes))
+    assert np.array_equal(res[0][0], res[1][0])
+    assert set(np.unique(res[0][0])) <= {0, 127, 255}
+    for a, b in zip(res[0][1], res[1][1]):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def test_mog2_clip_then_single_frames_then_host_path():
+    """Clip calls mix freely with the other entry points on the same engine."""
+    S, T, H, W = 1, 14, 16, 64
+    clips = _clips("sat", S, T, H, W, seed=11)
+    eng = Engine(capi.MOG2)
+    eng.set_geometry(H, W, 3)
+    orc = pyoracle.Oracle(capi.MOG2)
+    fg, _, _, _ = _run_clip(eng, clips, 0, 8)
+    for j in range(8):
+        assert np.array_equal(fg[j, 0], orc.process(clips[0, j])[0])
+    for t in range(8, 11):
+        g, b = eng.process(clips[0, t])
+        ofg, obg = orc.process(clips[0, t])
+        assert np.array_equal(g, ofg) and np.array_equal(b, obg)
+    fg, _, _, _ = _run_clip(eng, clips, 11, 3)
+    for j in range(3):
+        assert np.array_equal(fg[j, 0], orc.process(clips[0, 11 + j])[0])
+    check_mog2_state(eng, orc, H * W)
+
+
+@pytest.mark.parametrize("name", ["FrameDifferenceBGS", "WeightedMovingVarianceBGS", "MixtureOfGaussianV1BGS", "DPZivkovicAGMMBGS", "GMG", "SigmaDeltaBGS"])
+def test_clip_call_of_the_other_classes_is_the_frame_by_frame_path(name):
+    torch = _torch()
+    algo = ALGOS[name]
+    S, T, H, W = 2, 7, 16, 64
+    clips = _clips("random", S, T, H, W, seed=300)
+    eng = Engine(algo, n_streams=S)
+    eng.set_geometry(H, W, 3)
+    orcs = [pyoracle.Oracle(algo) for _ in range(S)]
+    d_frames = torch.from_numpy(np.ascontiguousarray(clips.transpose(1, 0, 2, 3, 4))).cuda()
+    d_fg = torch.full((T, S, H, W), 9, dtype=torch.uint8, device="cuda")
+    flags = eng.process_clip_device(d_frames, T, d_fg)
+    torch.cuda.synchronize()
+    fg = d_fg.cpu().numpy()
+    for t in range(T):
+        for s in range(S):
+            ofg, _ = orcs[s].process(clips[s, t])
+            assert bool(flags[t] & capi.FG_VALID) == (ofg is not None), (t, s)
+            if ofg is not None:
+                assert np.array_equal(fg[t, s], ofg), (t, s)
+            else:
+                assert (fg[t, s] == 9).all()
+    for s in range(S):
+        check_state(name, eng, orcs[s], H * W, stream=s)
+
+
+def test_clip_argument_errors():
+    torch = _torch()
+    eng = Engine(capi.MOG2, n_streams=2)
+    with pytest.raises(capi.BgsError):
+        eng.process_clip_device(torch.zeros(8, device="cuda", dtype=torch.uint8), 1)  # geometry not set
+    eng.set_geometry(8, 64, 3)
+    d = torch.zeros((2, 2, 8, 64, 3), dtype=torch.uint8, device="cuda")
+    with pytest.raises(capi.BgsError):
+        eng.process_clip_device(d, 0)
+    with pytest.raises(capi.BgsError):
+        eng.process_clip_device(d, 2, first=1, count=2)
+    eng.process_clip_device(d[:, :1], 2, first=0, count=1)
+    with pytest.raises(capi.BgsError):  # stream 0 is two frames ahead of stream 1 now
+        eng.process_clip_device(d, 2)
+
+
+def test_mog2_clip_full_size_1080p_sampled_parity():
+    """4 x 1080p streams, 12 frames as 8 + 4: packed masks against the frame-by-frame engine on every pixel, and the oracle on a
+    sampled band of rows of one stream."""
+    torch = _torch()
+    S, T, H, W = 4, 12, 1080, 1920
+    frames = synth.s_surv(T, H, W, seed=31, device="cuda")  # [T][H][W][3] on the device
+    d_frames = torch.stack([torch.roll(frames, shifts=17 * s, dims=2) for s in range(S)], dim=1).contiguous()  # [T][S][H][W][3]
+    a, b = Engine(capi.MOG2, n_streams=S), Engine(capi.MOG2, n_streams=S)
+    for e in (a, b):
+        e.set_geometry(H, W, 3)
+    fg_a = torch.zeros((T, S, H, W), dtype=torch.uint8, device="cuda")
+    fg_b = torch.zeros_like(fg_a)
+    a.process_clip_device(d_frames, T, fg_a)
+    for t in range(T):
+        b.process_batch_device(d_frames[t], fg_b[t])
+    torch.cuda.synchronize()
+    assert torch.equal(fg_a, fg_b)
+    n = H * W
+    for pl, sh, dt in (("w", (5, n), np.float32), ("mu", (5, 3, n), np.float32), ("nmodes", (n,), np.uint8)):
+        assert np.array_equal(a.get_state(pl, sh, dt, stream=3).view(np.uint8), b.get_state(pl, sh, dt, stream=3).view(np.uint8)), pl
+    r0, r1 = 500, 516
+    orc = pyoracle.Oracle(capi.MOG2)
+    band = d_frames[:, 1, r0:r1].cpu().numpy()
+    for t in range(T):
+        ofg, _ = orc.process(np.ascontiguousarray(band[t]))
+        assert np.array_equal(fg_a[t, 1, r0:r1].cpu().numpy(), ofg), t

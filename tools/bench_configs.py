@@ -199,6 +199,38 @@ def run_cc():
         print("connected components 1920x1080 %-12s: %d components, %.3f ms per mask (incl. count read-back) -> %.1f Mpix/s" % (name, n, ms, 1080 * 1920 / ms / 1e3))
 
 
+def run_clip(S=32, rows=1080, cols=1920, kind="sat", steps=24, Ts=(1, 2, 4, 8)):
+    """bgs_process_clip_device on the bench geometry: T frames of every stream per launch, the model held in registers."""
+    dev = torch.device("cuda", 0)
+    P = 16  # a pool of 16 time steps; S_sat has period 5, so a clip may start at any multiple of 5... the pool is walked cyclically in whole clips
+    pool = torch.empty((P, S, rows, cols, 3), dtype=torch.uint8, device=dev)
+    gen = synth.s_sat if kind == "sat" else synth.s_surv
+    for s in range(S):
+        pool[:, s] = gen(P, rows, cols, seed=4321 + s, device=dev)
+    px = S * rows * cols
+    for T in Ts:
+        e = Engine(capi.MOG2, n_streams=S)
+        e.set_geometry(rows, cols, 3)
+        bits = torch.empty((T, S, rows * cols // 64), dtype=torch.int64, device=dev)
+        for t in range(0, 64, T):  # saturate the mixture (every mode of every pixel live on S_sat)
+            e.process_clip_device(pool[(t % P):(t % P) + T], T, None, None, bits)
+        torch.cuda.synchronize()
+        e.enable_kernel_timing(True)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            t = (64 + i * T) % P
+            e.process_clip_device(pool[t:t + T], T, None, None, bits)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        ms, n, kname = e.kernel_timing()
+        moved = 201.0 / T + 3 + 1 / 8.0
+        print("MOG2 clip T=%d (%s) %dx%d x%d streams: %-18s %.3f ms per launch = %.3f ms per frame step -> %7.1f Gpix/s = %6.0f 1080p frames/s; "
+              "206 B/px/frame algorithmic -> %.2f of 8 TB/s; bytes actually moved (dense model) %.1f B/px/frame -> %.2f TB/s; wall %.1f Gpix/s"
+              % (T, kind, cols, rows, S, kname, ms, ms / T, px * T / ms / 1e6, px * T / ms * 1e3 / (rows * cols), 206.0 * px * T / ms / 1e9 / 8.0, moved,
+                 moved * px * T / ms / 1e9, px * T * steps / wall / 1e9))
+        e.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=8)
@@ -219,6 +251,13 @@ def main():
         run(capi.FRAME_DIFF, "FrameDifferenceBGS", 2160, 3840, S, 7, cpu_frames=0)
         run(capi.SIGMA_DELTA, "SigmaDeltaBGS", 2160, 3840, S, 16, borrow=False, cpu_frames=0)
         run(capi.ASBL, "AdaptiveSelectiveBackgroundLearning", 2160, 3840, S, 6, borrow=False, cpu_frames=0)
+        return
+    if args.only in ("clip8sat", "clip8surv"):  # one short leg, for counter passes
+        run_clip(kind=args.only[5:], steps=6, Ts=(8,))
+        return
+    if args.only == "clip":
+        run_clip(kind="sat")
+        run_clip(kind="surv")
         return
     if args.only == "lbsp":
         run_lbsp()

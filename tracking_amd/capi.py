@@ -15,7 +15,7 @@ FRAME_DIFF, STATIC_FRAME_DIFF, WMM, WMV, ABL, ASBL, MOG2, MOG1, GMG, SUBSENSE, L
 DP_ZIVKOVIC_AGMM, DP_GRIMSON_GMM, DP_WREN_GA, DP_MEAN, DP_ADAPTIVE_MEDIAN = range(12, 17)
 LOBSTER = 17
 FG_VALID, BG_VALID = 1, 2
-OPT_BORROW_FRAMES, OPT_MOG2_PIXELS_PER_LANE, OPT_MOG2_TILED, OPT_XCD_SWIZZLE, OPT_PLACEMENT_PROBE, OPT_MOG2_SPARSE = 1, 2, 3, 4, 5, 6
+OPT_BORROW_FRAMES, OPT_MOG2_PIXELS_PER_LANE, OPT_MOG2_TILED, OPT_XCD_SWIZZLE, OPT_PLACEMENT_PROBE, OPT_MOG2_SPARSE, OPT_CLIP_FUSE = 1, 2, 3, 4, 5, 6, 7
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_GEOMETRY, ERR_HIP, ERR_NOMEM, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
 
@@ -92,6 +92,7 @@ SYMBOLS = [
     ("bgs_process", C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_size_t, _P, C.c_size_t, _P, C.c_size_t, C.POINTER(C.c_uint32)]),
     ("bgs_process_batch_device", C.c_int, [_P, _P, _P, _P, _P, _P, C.POINTER(C.c_uint32)]),
     ("bgs_process_range_device", C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.POINTER(C.c_uint32)]),
+    ("bgs_process_clip_device", C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.POINTER(C.c_uint32)]),
     ("bgs_get_state", C.c_int64, [_P, C.c_int, C.c_char_p, _P, C.c_size_t]),
     ("bgs_frames_seen", C.c_int64, [_P, C.c_int]),
     ("bgs_enable_kernel_timing", C.c_int, [_P, C.c_int]),

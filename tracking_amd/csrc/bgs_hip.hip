@@ -94,6 +94,7 @@ struct bgs_engine {
   int mog2_px = 0;                 // pixels per lane, 0 = widest the alignment allows
   int xcd_swizzle = 1;             // XCD-aware block order (kernel_mog2.h): 0 off, 1 model kernels (MOG2, MOG1, dp), 2 also the byte-stream kernels
   int mog2_sparse = 3;             // data-dependent plane skipping (kernel_mog2.h): 0 dense, 1 stores, 2 stores+loads per wave, 4 per lane, 3 = choose 1 or 4 from the scene
+  bool clip_fuse = true;           // MOG2 clip calls keep the model in registers across frames (option 7; results identical either way)
   int mog2_sparse_now = 1;         // what auto mode currently runs
   unsigned* d_stat = nullptr;      // device: {sampled waves, sparse waves}
   unsigned* h_stat = nullptr;      // pinned copy
@@ -198,6 +199,28 @@ struct Timed {
   }
 };
 
+void mog2_stat_poll(bgs_engine* e, hipStream_t s) {
+  // Automatic sparse level (results are identical either way, only speed differs): skipping the loads of absent modes
+  // makes the plane loads wait for the nmodes load, which pays only when a good part of the waves can skip something.
+  // The kernel samples "largest nmodes in the wave < K-1" on every 64th block; the host reads the two counters back
+  // without ever blocking (event query) and switches with hysteresis.
+  if (e->stat_pending && hipEventQuery(e->stat_ev) == hipSuccess) {
+    e->stat_pending = false;
+    const unsigned total = e->h_stat[0], sparse_waves = e->h_stat[1];
+    if (total >= 64) {
+      const float frac = (float)sparse_waves / (float)total;
+      if (frac > 0.30f) e->mog2_sparse_now = 4;
+      if (frac < 0.15f) e->mog2_sparse_now = 1;
+    }
+  }
+  if (!e->stat_pending) {
+    (void)hipMemcpyAsync(e->h_stat, e->d_stat, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s);
+    (void)hipMemsetAsync(e->d_stat, 0, 2 * sizeof(unsigned), s);
+    (void)hipEventRecord(e->stat_ev, s);
+    e->stat_pending = true;
+  }
+}
+
 int launch_mog2(bgs_engine* e, bgs::Mog2Args& a, hipStream_t s, bool timed = true) {
   const bgs_params& p = e->p;
   // shadow test only when it can change the delivered mask: not thresholded, or the threshold separates shadow from foreground
@@ -222,27 +245,7 @@ int launch_mog2(bgs_engine* e, bgs::Mog2Args& a, hipStream_t s, bool timed = tru
   if (PX == PXV && tiled == TL) hipLaunchKernelGGL((bgs::mog2_update_kernel<PXV, TL>), grid, block, 0, s, a);
   MOG2_CASE(4, true) MOG2_CASE(2, true) MOG2_CASE(1, true) MOG2_CASE(4, false) MOG2_CASE(2, false) MOG2_CASE(1, false)
 #undef MOG2_CASE
-  if (a.stat) {
-    // Automatic sparse level (results are identical either way, only speed differs): skipping the loads of absent modes
-    // makes the plane loads wait for the nmodes load, which pays only when a good part of the waves can skip something.
-    // The kernel samples "largest nmodes in the wave < K-1" on every 64th block; the host reads the two counters back
-    // without ever blocking (event query) and switches with hysteresis.
-    if (e->stat_pending && hipEventQuery(e->stat_ev) == hipSuccess) {
-      e->stat_pending = false;
-      const unsigned total = e->h_stat[0], sparse_waves = e->h_stat[1];
-      if (total >= 64) {
-        const float frac = (float)sparse_waves / (float)total;
-        if (frac > 0.30f) e->mog2_sparse_now = 4;
-        if (frac < 0.15f) e->mog2_sparse_now = 1;
-      }
-    }
-    if (!e->stat_pending) {
-      (void)hipMemcpyAsync(e->h_stat, e->d_stat, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s);
-      (void)hipMemsetAsync(e->d_stat, 0, 2 * sizeof(unsigned), s);
-      (void)hipEventRecord(e->stat_ev, s);
-      e->stat_pending = true;
-    }
-  }
+  if (a.stat) mog2_stat_poll(e, s);
   return BGS_OK;
 }
 
@@ -260,6 +263,30 @@ void mog2_clear(bgs_engine* e, const bgs::Mog2Args& m, hipStream_t s) {
     hipLaunchKernelGGL((bgs::mog2_clear_kernel<true>), dim3(blocks_for(m.npix)), dim3(bgs::kBlock), 0, s, m);
   else
     hipLaunchKernelGGL((bgs::mog2_clear_kernel<false>), dim3(blocks_for(m.npix)), dim3(bgs::kBlock), 0, s, m);
+}
+
+// One launch over `fuse` (2, 4 or 8) consecutive frames of streams whose model starts at c.m.state_off (kernel_mog2.h, clip launches)
+int launch_mog2_clip(bgs_engine* e, bgs::Mog2ClipArgs& c, int fuse, hipStream_t s) {
+  const bgs_params& p = e->p;
+  bgs::Mog2Args& a = c.m;
+  a.shadow = p.mog2_detect_shadows && (!p.enable_threshold || ((p.mog2_shadow_value > p.threshold) != (255 > p.threshold)));
+  a.want_bg = a.bgimg != nullptr, a.packed = a.fg_bits != nullptr;
+  a.xcd_swizzle = e->xcd_swizzle;
+  a.sparse = e->mog2_sparse == 3 ? e->mog2_sparse_now : e->mog2_sparse;
+  a.stat = e->mog2_sparse == 3 ? e->d_stat : nullptr;
+  if (a.packed && a.npix % 64) return fail(BGS_ERR_UNSUPPORTED, "packed mask needs pixels %% 64 == 0");
+  Timed t(e, s, "mog2_clip_kernel");
+  const dim3 grid(blocks_for(a.npix)), block(bgs::kBlock);
+  unsigned every = 1;
+  while (grid.x / every > 256) every <<= 1;
+  a.stat_mask = every - 1;
+  const bool tiled = e->mog2_tiled;
+#define MOG2_CLIP_CASE(TL, TV) \
+  if (tiled == TL && fuse == TV) hipLaunchKernelGGL((bgs::mog2_clip_kernel<TL, TV>), grid, block, 0, s, c);
+  MOG2_CLIP_CASE(true, 2) MOG2_CLIP_CASE(true, 4) MOG2_CLIP_CASE(true, 8) MOG2_CLIP_CASE(false, 2) MOG2_CLIP_CASE(false, 4) MOG2_CLIP_CASE(false, 8)
+#undef MOG2_CLIP_CASE
+  if (a.stat) mog2_stat_poll(e, s);
+  return BGS_OK;
 }
 
 size_t mog2_state_bytes(const bgs_engine* e) {
@@ -823,6 +850,61 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
   return BGS_OK;
 }
 
+
+// bgs_process_clip_device: `nframes` consecutive frames of streams [first, first+count).  Every algorithm: frame by frame
+// through process_range (the same launches as nframes range calls).  MOG2: runs of 8 / 4 / 2 frames go through ONE launch
+// that keeps the model in registers (kernel_mog2.h); what is left over takes the single-frame kernel.
+int process_clip(bgs_engine* e, int first, int count, int nframes, const uint8_t* d_frames, uint8_t* d_fg, uint8_t* d_bg, uint64_t* d_bits, hipStream_t s,
+                 uint32_t* out_flags) {
+  if (nframes < 1) return fail(BGS_ERR_INVALID, "nframes must be >= 1");
+  if (!e->n) return fail(BGS_ERR_INVALID, "geometry not set: call bgs_set_geometry or bgs_process first");
+  if (first < 0 || count <= 0 || first + count > e->S) return fail(BGS_ERR_INVALID, "stream range [%d,%d) outside 0..%d", first, first + count, e->S);
+  if (!d_frames) return fail(BGS_ERR_INVALID, "d_frames is NULL");
+  const bgs_params& p = e->p;
+  const size_t npix = e->n * count, C = (size_t)e->ch;
+  if (d_bits && npix % 64) return fail(BGS_ERR_UNSUPPORTED, "packed mask needs rows*cols %% 64 == 0");
+  const size_t words = npix / 64;
+  // lr >= 1 re-initialises the model on every frame (needToInitialize): nothing to keep in registers
+  const bool fuse_ok = e->algo == BGS_MOG2 && e->clip_fuse && p.alpha < 1;
+  int t = 0;
+  while (t < nframes) {
+    const int left = nframes - t;
+    const int fuse = !fuse_ok ? 1 : left >= 8 ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1;
+    const uint8_t* fr = d_frames + (size_t)t * npix * C;
+    uint8_t* fg = d_fg ? d_fg + (size_t)t * npix : nullptr;
+    uint8_t* bg = d_bg ? d_bg + (size_t)t * npix * C : nullptr;
+    uint64_t* bits = d_bits ? d_bits + (size_t)t * words : nullptr;
+    if (fuse == 1) {
+      int rc = process_range(e, first, count, fr, fg, bg, bits, s, out_flags ? out_flags + t : nullptr);
+      if (rc) return rc;
+    } else {
+      const int64_t seen = e->seen[first];
+      for (int i = first; i < first + count; ++i)
+        if (e->seen[i] != seen) return fail(BGS_ERR_INVALID, "streams %d and %d are not in lock-step (%lld vs %lld frames)", first, i, (long long)seen, (long long)e->seen[i]);
+      HIP_TRY(hipSetDevice(e->device));
+      bgs::Mog2ClipArgs c{};
+      c.m.state_off = e->n * first, c.m.npix = npix;
+      mog2_fill_args(e, c.m, 0.0);
+      if (seen == 0) mog2_clear(e, c.m, s);  // needToInitialize on a stream's first frame
+      for (int j = 0; j < fuse; ++j) {       // the learning rate of each frame, as the single-frame path computes it
+        const int64_t nf = seen + j + 1;
+        const double lr = (p.alpha >= 0 && nf > 1) ? p.alpha : 1. / (double)std::min<int64_t>(2 * nf, p.mog2_history);
+        c.alphaT[j] = (float)lr, c.alpha1[j] = 1.f - c.alphaT[j], c.prune[j] = (float)(-lr * (double)p.mog2_ct);
+      }
+      c.m.frame = fr, c.m.fg = fg, c.m.bgimg = bg, c.m.fg_bits = bits;
+      c.frame_stride = npix * 3, c.fg_stride = npix, c.bg_stride = npix * 3, c.bits_stride = words;
+      int rc = launch_mog2_clip(e, c, fuse, s);
+      if (rc) return rc;
+      HIP_TRY(hipGetLastError());
+      for (int i = first; i < first + count; ++i) e->seen[i] += fuse;
+      if (out_flags)
+        for (int j = 0; j < fuse; ++j) out_flags[t + j] = BGS_FG_VALID | BGS_BG_VALID;
+    }
+    t += fuse;
+  }
+  return BGS_OK;
+}
+
 }  // namespace
 
 // N3 (bgs_ingest_*, bgs_set_ingest): geometry of the frame preparation
@@ -974,6 +1056,7 @@ int bgs_create(bgs_algo algo, const bgs_params* params, int hip_device, int n_st
   if (const char* env = getenv("BGS_XCD_SWIZZLE")) e->xcd_swizzle = atoi(env);
   if (const char* env = getenv("BGS_MOG2_SPARSE")) e->mog2_sparse = atoi(env);
   if (const char* env = getenv("BGS_PLACEMENT_PROBE")) e->probe_max = atoi(env);
+  if (const char* env = getenv("BGS_CLIP_FUSE")) e->clip_fuse = atoi(env) != 0;
   if (const char* env = getenv("BGS_DEBUG_POISON")) e->poison = atoi(env) != 0;
   *out = e;
   return BGS_OK;
@@ -1039,6 +1122,7 @@ int bgs_set_option(bgs_engine* e, int option, int64_t value) {
       return BGS_OK;
     case 4: e->xcd_swizzle = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return BGS_OK;
     case 6: e->mog2_sparse = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 4); return BGS_OK;
+    case 7: e->clip_fuse = value != 0; return BGS_OK;
     case 5:
       if (e->n) return fail(BGS_ERR_INVALID, "the placement probe runs when the geometry is set");
       e->probe_max = (int)value;
@@ -1051,6 +1135,12 @@ int bgs_process_range_device(bgs_engine* e, int first, int count, const void* d_
                              uint32_t* out_flags) {
   if (!e) return fail(BGS_ERR_INVALID, "engine is NULL");
   return process_range(e, first, count, (const uint8_t*)d_frames, (uint8_t*)d_fg, (uint8_t*)d_bg, (uint64_t*)d_fg_bits, (hipStream_t)hip_stream, out_flags);
+}
+
+int bgs_process_clip_device(bgs_engine* e, int first, int count, int nframes, const void* d_frames, void* d_fg, void* d_bg, void* d_fg_bits,
+                            void* hip_stream, uint32_t* out_flags) {
+  if (!e) return fail(BGS_ERR_INVALID, "engine is NULL");
+  return process_clip(e, first, count, nframes, (const uint8_t*)d_frames, (uint8_t*)d_fg, (uint8_t*)d_bg, (uint64_t*)d_fg_bits, (hipStream_t)hip_stream, out_flags);
 }
 
 int bgs_process_batch_device(bgs_engine* e, const void* d_frames, void* d_fg, void* d_bg, void* d_fg_bits, void* hip_stream, uint32_t* out_flags) {

@@ -116,7 +116,9 @@ __device__ __forceinline__ bool mog2_shadow(const Mog2Px& s, int nmodes, float x
 
 // One pixel of MOG2Invoker::operator() — same statement order as the reference so every float rounds identically.
 // Returns the raw mask value (0 background, shadow_val, 255 foreground) before the wrapper's threshold.
-__device__ __forceinline__ int mog2_pixel(Mog2Px& s, int& nmodes_io, float x0, float x1, float x2, const Mog2Args& a, unsigned& dirty) {
+// alphaT / alpha1 / prune are the learning-rate terms of THIS frame (they differ between the frames of a clip launch).
+__device__ __forceinline__ int mog2_pixel(Mog2Px& s, int& nmodes_io, float x0, float x1, float x2, const Mog2Args& a, unsigned& dirty,
+                                          const float alphaT, const float alpha1, const float prune) {
   bool background = false, fitsPDF = false;
   int nmodes = nmodes_io;
   const int nNewModes = nmodes;
@@ -124,7 +126,7 @@ __device__ __forceinline__ int mog2_pixel(Mog2Px& s, int& nmodes_io, float x0, f
 #pragma unroll
   for (int mode = 0; mode < kMog2K; ++mode) {
     if (mode < nmodes) {  // nmodes shrinks inside the loop when a mode is pruned (reference quirk)
-      float weight = a.alpha1 * s.w[mode] + a.prune;
+      float weight = alpha1 * s.w[mode] + prune;
       bool matched = false;
       if (!fitsPDF) {
         const float var = s.var[mode];
@@ -134,8 +136,8 @@ __device__ __forceinline__ int mog2_pixel(Mog2Px& s, int& nmodes_io, float x0, f
         if (dist2 < a.Tg * var) {
           fitsPDF = true;
           matched = true;
-          weight += a.alphaT;
-          const float k = div_rn(a.alphaT, weight);
+          weight += alphaT;
+          const float k = div_rn(alphaT, weight);
           s.m0[mode] -= k * d0;
           s.m1[mode] -= k * d1;
           s.m2[mode] -= k * d2;
@@ -146,7 +148,7 @@ __device__ __forceinline__ int mog2_pixel(Mog2Px& s, int& nmodes_io, float x0, f
           dirty |= 1u << mode;  // mean / variance of this mode changed
         }
       }
-      const bool pruned = weight < -a.prune;
+      const bool pruned = weight < -prune;
       if (pruned) nmodes--;
       // The reference stores the weight at gmm[mode - swap_count] after the bubble; storing it first and letting it
       // travel with the swaps is the same thing.  The bubble compares the UNPRUNED weight, as the reference does.
@@ -172,19 +174,19 @@ __device__ __forceinline__ int mog2_pixel(Mog2Px& s, int& nmodes_io, float x0, f
 #pragma unroll
     for (int k = 0; k < kMog2K; ++k) {
       if (k == mode) {
-        s.w[k] = (nmodes == 1) ? 1.f : a.alphaT;
+        s.w[k] = (nmodes == 1) ? 1.f : alphaT;
         s.m0[k] = x0, s.m1[k] = x1, s.m2[k] = x2;
         s.var[k] = a.varInit;
         dirty |= 1u << k;
       } else if (nmodes != 1 && k < nmodes - 1) {
-        s.w[k] *= a.alpha1;
+        s.w[k] *= alpha1;
       }
     }
     bool moving = true;
 #pragma unroll
     for (int i = kMog2K - 1; i > 0; --i) {
       if (i <= nmodes - 1) {
-        moving = moving && !(a.alphaT < s.w[i - 1]);
+        moving = moving && !(alphaT < s.w[i - 1]);
         if (moving) mog2_swap(s, i, i - 1), dirty |= 3u << (i - 1);
       }
     }
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(kBlock) void mog2_update_kernel(const Mog2Args a) {
       float worig[kMog2K];
 #pragma unroll
       for (int k = 0; k < kMog2K; ++k) worig[k] = s.w[k];
-      const int raw = mog2_pixel(s, nm, x0, x1, x2, a, dirty_m);
+      const int raw = mog2_pixel(s, nm, x0, x1, x2, a, dirty_m, a.alphaT, a.alpha1, a.prune);
 #pragma unroll
       for (int k = 0; k < kMog2K; ++k) dirty_w |= (unsigned)(s.w[k] != worig[k]) << k;
       const int m = thr_bin(raw, a.thr, a.enable_thr);
@@ -385,6 +387,113 @@ __global__ __launch_bounds__(kBlock) void mog2_update_kernel(const Mog2Args a) {
     // every lane of the wave takes part (inactive tail lanes contribute 0); npix % 64 == 0 is checked by the host
     store_packed_mask<PX>(a.fg_bits, p0, bits, active);
   }
+}
+
+// ---- clip launches: T consecutive frames of every stream in ONE launch (bgs_process_clip_device) -------------------------
+// The model of a pixel is loaded once, updated T times in registers in frame order with exactly the statements of the
+// single-frame kernel, and written back once: model traffic per frame drops from 201 B/pixel to 201/T, the frame and mask bytes
+// stay (4 B/pixel/frame).  Results are those of T successive single-frame launches, bit for bit: a pixel's update depends on
+// nothing but its own model and its own input.  One pixel per lane; npix % 64 == 0 when masks are bit-packed (then a wave is
+// active or idle as a whole, which the cross-lane packing needs).
+// Slots at index >= nmodes are all-zero in memory ever since mog2_clear (nmodes never shrinks), so the slots a lane does not
+// load are exactly the zeros it holds for them; a mode created in such a slot during the clip is written back like any other
+// changed plane.
+constexpr int kMog2ClipMax = 8;
+struct Mog2ClipArgs {
+  Mog2Args m;                  // frame / fg / bgimg / fg_bits point at the FIRST frame of the launch
+  size_t frame_stride;         // bytes from one frame to the next (= pixels of the whole clip slab * 3), likewise below
+  size_t fg_stride, bg_stride, bits_stride;  // bits_stride in 64-bit words
+  float alphaT[kMog2ClipMax], alpha1[kMog2ClipMax], prune[kMog2ClipMax];  // per frame (the automatic rate changes with the frame count)
+};
+
+template <bool TILED, int T>
+__global__ __launch_bounds__(kBlock) void mog2_clip_kernel(const Mog2ClipArgs c) {
+  const Mog2Args& a = c.m;
+  size_t blk = blockIdx.x;
+  if (a.xcd_swizzle) {
+    const size_t per = gridDim.x >> 3, main = per << 3;
+    if (blk < main) blk = (blk & 7) * per + (blk >> 3);
+  }
+  const size_t p0 = blk * kBlock + threadIdx.x;
+  if (p0 >= a.npix) return;  // wave-uniform whenever the packing below runs (npix % 64 == 0)
+  const size_t sp = a.state_off + p0;
+  uint32_t pix[T];  // all T inputs of this pixel are requested before the model: they are what the first update waits for
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const uint8_t* f = a.frame + (size_t)t * c.frame_stride + p0 * 3;
+    pix[t] = (uint32_t)f[0] | ((uint32_t)f[1] << 8) | ((uint32_t)f[2] << 16);
+  }
+  uint8_t* const nmp = mog2_nmodes<TILED>(a, sp);
+  const int nm_in = *nmp;
+  Mog2Px s;
+  auto load_mode = [&](int k) {
+    s.w[k] = a.state[mog2_plane_off<TILED>(a, k, sp)];
+    s.var[k] = a.state[mog2_plane_off<TILED>(a, 5 + k, sp)];
+    s.m0[k] = a.state[mog2_plane_off<TILED>(a, 10 + 3 * k, sp)];
+    s.m1[k] = a.state[mog2_plane_off<TILED>(a, 11 + 3 * k, sp)];
+    s.m2[k] = a.state[mog2_plane_off<TILED>(a, 12 + 3 * k, sp)];
+  };
+  load_mode(0);
+  // the same data-dependent loads as the single-frame kernel: sparse >= 2 loads modes below the wave's largest count + 1,
+  // sparse >= 4 below the lane's own count
+  int nload = kMog2K, lane_need = kMog2K;
+  if (a.sparse >= 2) {
+    if (a.sparse >= 4) lane_need = nm_in - 1;
+    int M = 0;
+#pragma unroll
+    for (int n = 1; n <= kMog2K; ++n)
+      if (__any(nm_in >= n)) M = n;
+    nload = min(M + 1, kMog2K);
+  }
+  if (a.stat && (blockIdx.x & a.stat_mask) == 0) {
+    const bool dense_wave = __any(nm_in >= kMog2K - 1);
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+      atomicAdd(a.stat, 1u);
+      if (!dense_wave) atomicAdd(a.stat + 1, 1u);
+    }
+  }
+#pragma unroll
+  for (int k = 1; k < kMog2K; ++k) {
+    if (k < nload && k <= lane_need)
+      load_mode(k);
+    else
+      s.w[k] = 0.f, s.var[k] = 0.f, s.m0[k] = 0.f, s.m1[k] = 0.f, s.m2[k] = 0.f;
+  }
+  float worig[kMog2K];
+#pragma unroll
+  for (int k = 0; k < kMog2K; ++k) worig[k] = s.w[k];
+  unsigned dirty_m = 0;
+  int nm = nm_in;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const float x0 = (float)(pix[t] & 0xffu), x1 = (float)((pix[t] >> 8) & 0xffu), x2 = (float)(pix[t] >> 16);
+    const int raw = mog2_pixel(s, nm, x0, x1, x2, a, dirty_m, c.alphaT[t], c.alpha1[t], c.prune[t]);
+    const int m = thr_bin(raw, a.thr, a.enable_thr);
+    if (a.fg) a.fg[(size_t)t * c.fg_stride + p0] = (uint8_t)m;
+    if (a.packed) store_packed_mask<1>(a.fg_bits + (size_t)t * c.bits_stride, p0, (uint32_t)(m != 0), true);
+    if (a.want_bg) {
+      int b0, b1, b2;
+      mog2_background(s, nm, a.TB, b0, b1, b2);
+      uint8_t* o = a.bgimg + (size_t)t * c.bg_stride + p0 * 3;
+      o[0] = (uint8_t)b0, o[1] = (uint8_t)b1, o[2] = (uint8_t)b2;
+    }
+  }
+  const bool all = !a.sparse, lanewise = a.sparse >= 4;
+#pragma unroll
+  for (int k = 0; k < kMog2K; ++k) {
+    const bool dw = s.w[k] != worig[k], dm = (dirty_m >> k) & 1u;
+    const bool unloaded = lanewise && k > lane_need;  // holds zeros unless a mode was created here: only then there is something to write
+    const bool sw = unloaded ? ((dw || dm) && nm > k) : (all || (lanewise ? dw : (bool)__any(dw)));
+    const bool sm = unloaded ? sw : (all || (lanewise ? dm : (bool)__any(dm)));
+    if (sw) a.state[mog2_plane_off<TILED>(a, k, sp)] = s.w[k];
+    if (sm) {
+      a.state[mog2_plane_off<TILED>(a, 5 + k, sp)] = s.var[k];
+      a.state[mog2_plane_off<TILED>(a, 10 + 3 * k, sp)] = s.m0[k];
+      a.state[mog2_plane_off<TILED>(a, 11 + 3 * k, sp)] = s.m1[k];
+      a.state[mog2_plane_off<TILED>(a, 12 + 3 * k, sp)] = s.m2[k];
+    }
+  }
+  if (all || (lanewise ? nm != nm_in : (bool)__any(nm != nm_in))) *nmp = (uint8_t)nm;
 }
 
 // (re)initialisation of a pixel range: bgmodel = zeros, modesUsed = 0 (BackgroundSubtractorMOG2::initialize)

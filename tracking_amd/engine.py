@@ -124,6 +124,19 @@ class Engine:
             capi.check(l.bgs_process_range_device(self._h, first, count, self._ptr(frames), self._ptr(fg), self._ptr(bg), self._ptr(fg_bits), C.c_void_p(hip_stream), C.byref(flags)))
         return flags.value
 
+    def process_clip_device(self, frames, nframes, fg=None, bg=None, fg_bits=None, hip_stream=None, first=0, count=None):
+        """bgs_process_clip_device: frames [nframes][count][rows][cols][ch] (torch CUDA tensors, like the outputs).  Returns the
+        nframes out_flags words."""
+        import torch
+        if hip_stream is None:
+            hip_stream = torch.cuda.current_stream().cuda_stream
+        flags = (C.c_uint32 * nframes)()
+        if count is None:
+            count = self.n_streams - first
+        capi.check(capi.lib().bgs_process_clip_device(self._h, first, count, nframes, self._ptr(frames), self._ptr(fg), self._ptr(bg), self._ptr(fg_bits),
+                                                      C.c_void_p(hip_stream), flags))
+        return list(flags)
+
     # -- introspection -----------------------------------------------------------
     def get_state(self, plane, shape, dtype, stream=0):
         out = np.empty(shape, dtype)
