@@ -210,7 +210,12 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
   } else {
     SS_LAUNCH(ss_phase_b_kernel, tilesB, block, s, a);
   }
-  hipLaunchKernelGGL(bgs::ss_blink_kernel, dim3(blocks_for(npix)), block, 0, s, a, npix);
+  // byte maps of this launch as vectors when the pixel count and the caller's buffers allow it (the engine's own planes are 256-byte aligned)
+  const bool v16 = npix % 16 == 0 && (off % 16) == 0, v4 = npix % 4 == 0 && (off % 4) == 0 && e->cols % 4 == 0 && (!d_fg || aligned(d_fg, 4));
+  if (v16)
+    hipLaunchKernelGGL(bgs::ss_blink_kernel<16>, dim3(blocks_for(npix / 16)), block, 0, s, a, npix);
+  else
+    hipLaunchKernelGGL(bgs::ss_blink_kernel<1>, dim3(blocks_for(npix)), block, 0, s, a, npix);
   uint8_t *raw = d->u8[SS_RAW] + off, *t1 = d->u8[SS_T1] + off, *t3 = d->u8[SS_T3] + off, *t4 = d->u8[SS_T4] + off;
   uint8_t* lastFG = d->u8[SS_LASTFG] + off;
   // morphologyEx(MORPH_CLOSE) :628  -> t1 = PreFlood
@@ -230,10 +235,16 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
   hipLaunchKernelGGL(bgs::ss_flood_finish_kernel, dim3(count), dim3(1024), 0, s, (const uint64_t*)mbits, rbits, e->rows, W64, fl, batch);
   // erode x3 :632 -> t3
   ss_morph(t1, t3, e->rows, e->cols, count, 0, 7, s);  // erode x3 = one 7x7 box
-  hipLaunchKernelGGL(bgs::ss_combine_kernel, dim3(blocks_for(npix)), block, 0, s, a, (const uint8_t*)t1, (const uint64_t*)rbits, W64, (const uint8_t*)t3, t4, npix);  // :631-634
+  if (v4)  // :631-634
+    hipLaunchKernelGGL(bgs::ss_combine_kernel<4>, dim3(blocks_for(npix / 4)), block, 0, s, a, (const uint8_t*)t1, (const uint64_t*)rbits, W64, (const uint8_t*)t3, t4, npix);
+  else
+    hipLaunchKernelGGL(bgs::ss_combine_kernel<1>, dim3(blocks_for(npix)), block, 0, s, a, (const uint8_t*)t1, (const uint64_t*)rbits, W64, (const uint8_t*)t3, t4, npix);
   ss_morph(t4, lastFG, e->rows, e->cols, count, 3, d->medK, s);  // medianBlur :635 (the input is a {0,255} mask)
   ss_morph(lastFG, t1, e->rows, e->cols, count, 1, 7, s);        // dilate x3 :636 = one 7x7 box
-  hipLaunchKernelGGL(bgs::ss_finish_kernel, dim3(blocks_for(npix)), block, 0, s, a, (const uint8_t*)t1, npix);  // :637-642
+  if (v4)  // :637-642
+    hipLaunchKernelGGL(bgs::ss_finish_kernel<4>, dim3(blocks_for(npix / 4)), block, 0, s, a, (const uint8_t*)t1, npix);
+  else
+    hipLaunchKernelGGL(bgs::ss_finish_kernel<1>, dim3(blocks_for(npix)), block, 0, s, a, (const uint8_t*)t1, npix);
   if (d->lrScaling) {
     const int dsn = (e->rows / 8) * (e->cols / 8);
     SS_LAUNCH(ss_downsample_kernel, dim3(blocks_for(dsn), 1, count), block, s, a);

@@ -764,14 +764,24 @@ __global__ __launch_bounds__(kBlock) void ss_init_lastcolor_kernel(const SsArgs 
 
 // ----------------------------------------------------------------------------------------------- post-processing :624-642
 // blink maps :624-627
+template <int G>  // pixels per lane: 16 (one dwordx4 per map) when the launch allows it, else 1
 __global__ __launch_bounds__(kBlock) void ss_blink_kernel(const SsArgs a, size_t count) {
-  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const size_t i = ((size_t)blockIdx.x * kBlock + threadIdx.x) * G;
   if (i >= count) return;
   const size_t g = (size_t)a.first * a.rows * a.cols + i;
-  const uint8_t raw = a.raw[g], blink = raw ^ a.lastRaw[g];
-  a.blinks[g] = blink | a.lastRawBlink[g];
-  a.lastRawBlink[g] = blink;
-  a.lastRaw[g] = raw;
+  if constexpr (G == 16) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(a.raw + g), last = *reinterpret_cast<const uint4*>(a.lastRaw + g);
+    const uint4 lb = *reinterpret_cast<const uint4*>(a.lastRawBlink + g);
+    const uint4 blink = make_uint4(raw.x ^ last.x, raw.y ^ last.y, raw.z ^ last.z, raw.w ^ last.w);
+    *reinterpret_cast<uint4*>(a.blinks + g) = make_uint4(blink.x | lb.x, blink.y | lb.y, blink.z | lb.z, blink.w | lb.w);
+    *reinterpret_cast<uint4*>(a.lastRawBlink + g) = blink;
+    *reinterpret_cast<uint4*>(a.lastRaw + g) = raw;
+  } else {
+    const uint8_t raw = a.raw[g], blink = raw ^ a.lastRaw[g];
+    a.blinks[g] = blink | a.lastRawBlink[g];
+    a.lastRawBlink[g] = blink;
+    a.lastRaw[g] = raw;
+  }
 }
 
 // Per-stream constants of a freshly constructed model, handed over BY VALUE in the kernel arguments (no host buffer has to
@@ -942,32 +952,62 @@ __global__ __launch_bounds__(kBlock) void ss_flood_paint_kernel(const uint8_t* s
 
 // cur = raw | ~flooded | eroded(pre)  (:631-634): holes = pixels of `pre` equal to the seed value that the fill did not reach... in
 // mask terms: flooded image = 255 where reached or where pre != seed... written out explicitly below.
+template <int G>  // pixels per lane: 4 consecutive pixels of one row (cols % 4 == 0: they share a word of rbits) or 1
 __global__ __launch_bounds__(kBlock) void ss_combine_kernel(const SsArgs a, const uint8_t* pre, const uint64_t* rbits, int W64, const uint8_t* eroded, uint8_t* out, size_t count) {
-  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const size_t i = ((size_t)blockIdx.x * kBlock + threadIdx.x) * G;
   if (i >= count) return;
   const size_t N = (size_t)a.rows * a.cols, g = (size_t)a.first * N + i;
   const size_t img = i / N, p = i % N;
   const int y = (int)(p / a.cols), x = (int)(p % a.cols);
-  const bool reached = (rbits[(img * a.rows + y) * W64 + (x >> 6)] >> (x & 63)) & 1ull;
-  const uint8_t flooded = reached ? 255 : pre[i];  // floodFill paints the reached region with 255, leaves the rest
-  out[i] = a.raw[g] | (uint8_t)~flooded | eroded[i];
+  const uint64_t word = rbits[(img * a.rows + y) * W64 + (x >> 6)] >> (x & 63);
+  if constexpr (G == 4) {
+    const uint32_t nib = (uint32_t)word & 0xfu;
+    const uint32_t reached = ((nib & 1u) * 0xffu) | ((nib & 2u) * (0xff00u >> 1)) | ((nib & 4u) * (0xff0000u >> 2)) | ((nib & 8u) * (0xff000000u >> 3));
+    const uint32_t flooded = reached | *reinterpret_cast<const uint32_t*>(pre + i);  // floodFill paints the reached region with 255, leaves the rest
+    *reinterpret_cast<uint32_t*>(out + i) = *reinterpret_cast<const uint32_t*>(a.raw + g) | ~flooded | *reinterpret_cast<const uint32_t*>(eroded + i);
+  } else {
+    const bool reached = word & 1ull;
+    const uint8_t flooded = reached ? 255 : pre[i];
+    out[i] = a.raw[g] | (uint8_t)~flooded | eroded[i];
+  }
 }
 
 // :637-642: blink mask clean-up against the dilated final mask (old then new), final-segmentation running means, output
+template <int G>  // pixels per lane: 4 (dword per byte map, float4 per mean map) or 1
 __global__ __launch_bounds__(kBlock) void ss_finish_kernel(const SsArgs a, const uint8_t* dilated, size_t count) {
-  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const size_t i = ((size_t)blockIdx.x * kBlock + threadIdx.x) * G;
   if (i >= count) return;
   const size_t g = (size_t)a.first * a.rows * a.cols + i;
-  uint8_t b = a.blinks[g] & a.lastDilInv[g];
-  const uint8_t inv = (uint8_t)~dilated[i];
-  a.lastDilInv[g] = inv;
-  a.blinks[g] = b & inv;
-  const uint8_t m = a.lastFG[g];
-  if (a.fg) a.fg[i] = m;
   // cv::addWeighted(f32, 1-f, u8, (1/255)*f, 0, dst, CV_32F): both operands as float, arithmetic in double
   const double aLT = (double)(1.0f - a.fLT), bLT = __dmul_rn(1.0 / 255, (double)a.fLT), aST = (double)(1.0f - a.fST), bST = __dmul_rn(1.0 / 255, (double)a.fST);
-  a.FinLT[g] = (float)__dadd_rn(__dmul_rn((double)a.FinLT[g], aLT), __dmul_rn((double)(float)m, bLT));
-  a.FinST[g] = (float)__dadd_rn(__dmul_rn((double)a.FinST[g], aST), __dmul_rn((double)(float)m, bST));
+  if constexpr (G == 4) {
+    const uint32_t b = *reinterpret_cast<const uint32_t*>(a.blinks + g) & *reinterpret_cast<const uint32_t*>(a.lastDilInv + g);
+    const uint32_t inv = ~*reinterpret_cast<const uint32_t*>(dilated + i);
+    *reinterpret_cast<uint32_t*>(a.lastDilInv + g) = inv;
+    *reinterpret_cast<uint32_t*>(a.blinks + g) = b & inv;
+    const uint32_t m4 = *reinterpret_cast<const uint32_t*>(a.lastFG + g);
+    if (a.fg) *reinterpret_cast<uint32_t*>(a.fg + i) = m4;
+    float4 lt = *reinterpret_cast<const float4*>(a.FinLT + g), st = *reinterpret_cast<const float4*>(a.FinST + g);
+    float* l = &lt.x;
+    float* t = &st.x;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const double m = (double)(float)((m4 >> (8 * o)) & 0xffu);
+      l[o] = (float)__dadd_rn(__dmul_rn((double)l[o], aLT), __dmul_rn(m, bLT));
+      t[o] = (float)__dadd_rn(__dmul_rn((double)t[o], aST), __dmul_rn(m, bST));
+    }
+    *reinterpret_cast<float4*>(a.FinLT + g) = lt;
+    *reinterpret_cast<float4*>(a.FinST + g) = st;
+  } else {
+    uint8_t b = a.blinks[g] & a.lastDilInv[g];
+    const uint8_t inv = (uint8_t)~dilated[i];
+    a.lastDilInv[g] = inv;
+    a.blinks[g] = b & inv;
+    const uint8_t m = a.lastFG[g];
+    if (a.fg) a.fg[i] = m;
+    a.FinLT[g] = (float)__dadd_rn(__dmul_rn((double)a.FinLT[g], aLT), __dmul_rn((double)(float)m, bLT));
+    a.FinST[g] = (float)__dadd_rn(__dmul_rn((double)a.FinST[g], aST), __dmul_rn((double)(float)m, bST));
+  }
 }
 
 // ----------------------------------------------------------------------------------------------- frame-level block :656-665
