@@ -277,9 +277,13 @@ def main():
     cpu = None
     surv = None
     clip = None
+    probe = None
     if rank == 0:
         nm = eng.get_state("nmodes", (ROWS * COLS,), np.uint8, stream=0)
         live_modes = float(nm.mean())
+        pr = eng.get_state("probe", (18,), np.float32)
+        probe = {"candidates_ms_per_dense_launch": [round(float(v), 3) for v in pr[2:2 + int(pr[0])]], "kept": int(pr[1]),
+                 "note": "model placement probe at allocation (DESIGN.md 6.2): stops once two speed classes have been seen"}
     if rank == 0 and not args.main_only and not rehearse:
         clip = {"note": "supplementary, never `value`: bgs_process_clip_device on the same engine and saturated model - T consecutive frames per launch, model kept in "
                         "registers across them, bit-identical results; for file-fed video or deployments that accept T-1 frame times of latency",
@@ -350,6 +354,7 @@ def main():
                          "timed_region": "the K timed steps, after %d saturation + %d settle + %d warm-up launches: sustained clocks" % (SATURATE, SETTLE, args.warmup),
                          "sustained": leg(sus_ms), "burst_first_20_after_idle": leg(burst_ms)},
             "cpu_baseline": cpu,
+            "placement_probe": probe,
             "single_stream": single,
             "s_surv": surv,
             "clip": clip,

@@ -303,7 +303,9 @@ size_t mog2_state_bytes(const bgs_engine* e) {
 // one.  The model lives as long as the camera stream, so it pays to look: allocate candidates one after the other (the
 // losers stay allocated meanwhile, otherwise hipMalloc would hand the same pages out again), time `run` on each - one dense
 // pass of the kernel that will stream the buffer, on e->stream - and keep the fastest.
-//   * stops at the first candidate within 2 % of `expect_ms` (the fast class, when the caller knows it): usually the 2nd;
+//   * stops as soon as two speed classes have been seen (fastest >= 5 % ahead of the slowest so far): on average after 3-4
+//     candidates; `expect_ms` is only printed by BGS_DEBUG_PROBE - an absolute test cannot tell a fast placement from the clock
+//     burst after an idle period;
 //   * never takes more than the device has to spare: a further candidate is only tried while free memory stays above
 //     max(2 GiB, 1/16 of the device) AFTER it, so co-resident engines are not pushed out of memory;
 //   * skipped below 768 MB (such a model is not HBM-bound: it sits in the 256 MiB Infinity Cache for a good part).
@@ -318,7 +320,7 @@ int probe_allocate(bgs_engine* e, void** out, size_t bytes, double expect_ms, Ru
   const int debug = getenv("BGS_DEBUG_PROBE") ? atoi(getenv("BGS_DEBUG_PROBE")) : 0;
   void* cand[16] = {nullptr};
   int n = 0, best = -1, rc = BGS_OK;
-  float tmin = 1e30f;
+  float tmin = 1e30f, tmax = 0.f;
   auto time_one = [&](void* buf, float* ms_out) -> int {
     int r = BGS_OK;
     for (int i = 0; i < 2 && !r; ++i) r = run(buf);
@@ -350,7 +352,12 @@ int probe_allocate(bgs_engine* e, void** out, size_t bytes, double expect_ms, Ru
       break;
     }
     if (e->probe_ms[n] < tmin) tmin = e->probe_ms[n], best = n;
-    if (expect_ms > 0 && e->probe_ms[n] <= 1.02 * expect_ms && debug < 2) {
+    if (e->probe_ms[n] > tmax) tmax = e->probe_ms[n];
+    // Stop as soon as two speed classes have been SEEN (the fastest candidate >= 5 % ahead of the slowest; the classes are ~10 %
+    // apart, candidates of one class agree within 1-2 %).  No absolute threshold: right after an idle period the part
+    // runs every candidate 5-10 % faster than it sustains (clock burst), which made a slow placement pass an
+    // absolute "fast enough" test - seen on one box in round 2 (2.39 instead of 2.17 ms per launch in the bench that followed).
+    if (tmin <= 0.95f * tmax && debug < 2) {
       ++n;
       break;
     }
@@ -1261,6 +1268,13 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
     if (hipMemcpy(dst, src, nb, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
     return (int64_t)nb;
   };
+  if (!strcmp(plane, "probe")) {  // diagnostics: [0] candidates measured, [1] index kept, [2..] ms per dense launch of each candidate
+    float rec[18] = {(float)e->probe_n, (float)e->probe_pick};
+    for (int i = 0; i < 16; ++i) rec[2 + i] = i < e->probe_n ? e->probe_ms[i] : 0.f;
+    if (cap < sizeof(rec)) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
+    memcpy(dst, rec, sizeof(rec));
+    return (int64_t)sizeof(rec);
+  }
   if (e->algo == BGS_MOG2) {
     // canonical export: "w" [K][n], "var" [K][n], "mu" [K][3][n] floats, "nmodes" [n] bytes — whatever the device layout
     int p0 = -1, np = 0;

@@ -9,7 +9,7 @@
 // HIP streams must be disjoint (flood flags are per stream; the side stream and its two events are shared, which only serialises).
 
 enum { SS_R, SS_V, SS_T, SS_DLAST0, SS_DLAST1, SS_DMINLT, SS_DMINST, SS_RAWLT, SS_RAWST0, SS_RAWST1, SS_FINLT, SS_FINST, SS_NF32 };
-enum { SS_UNSTABLE, SS_BLINKS, SS_LASTFG, SS_LASTRAW, SS_LASTRAWBLINK, SS_LASTDILINV, SS_RAW, SS_T1, SS_T2, SS_T3, SS_T4, SS_NU8 };
+enum { SS_UNSTABLE, SS_BLINKS, SS_LASTFG, SS_LASTRAW, SS_LASTRAWBLINK, SS_LASTDILINV, SS_RAW, SS_NU8 };
 
 // launch the C = 3 or C = 1 instantiation of a SuBSENSE kernel template
 #define SS_LAUNCH(KERNEL, grid, block, stream, ...)                                             \
@@ -20,6 +20,7 @@ enum { SS_UNSTABLE, SS_BLINKS, SS_LASTFG, SS_LASTRAW, SS_LASTRAWBLINK, SS_LASTDI
       hipLaunchKernelGGL((bgs::KERNEL<1>), grid, block, 0, stream, __VA_ARGS__);                \
   } while (0)
 
+constexpr int SS_NBITS = 6;  // raw, closed-tmp / eroded, pre (closed), combined, final mask, dilated
 struct SsDevice {
   void* samples = nullptr;  // records of colour + descriptor (kernel_subsense.h: SsSample, ss_rec)
   int nSpad = 0, pixelMajor = 0;
@@ -33,11 +34,12 @@ struct SsDevice {
   hipStream_t side = nullptr;  // phase B runs here, beside the post-processing chain (both only need phase A)
   hipEvent_t evA = nullptr, evB = nullptr;
   uint64_t *mbits = nullptr, *rbits = nullptr;  // flood fill: bit-packed mask / reached set, [S][rows][W64]
+  uint64_t* bitws = nullptr;                     // SS_NBITS more bit planes of the same shape: the post-processing chain's intermediates
   std::vector<uint8_t> pp;   // per stream: which copy of Dlast / RawST is current
   int use3x3 = 1, lrScaling = 0, medK = 9;
   float capLo0 = 4.f, capHi0 = 512.f;
   void release() {
-    void* p[] = {samples, lut, lastColor, curColor, lastDesc, curDesc, req, dsLT, dsST, sc, flood_flags, mbits, rbits};
+    void* p[] = {samples, lut, lastColor, curColor, lastDesc, curDesc, req, dsLT, dsST, sc, flood_flags, mbits, rbits, bitws};
     for (void* q : p)
       if (q) (void)hipFree(q);
     for (auto& q : f32)
@@ -47,7 +49,7 @@ struct SsDevice {
     if (side) (void)hipStreamDestroy(side), side = nullptr;
     if (evA) (void)hipEventDestroy(evA), evA = nullptr;
     if (evB) (void)hipEventDestroy(evB), evB = nullptr;
-    samples = nullptr, lut = lastColor = curColor = nullptr, lastDesc = req = curDesc = nullptr, dsLT = dsST = nullptr, sc = nullptr, flood_flags = nullptr, mbits = rbits = nullptr;
+    samples = nullptr, lut = lastColor = curColor = nullptr, lastDesc = req = curDesc = nullptr, dsLT = dsST = nullptr, sc = nullptr, flood_flags = nullptr, mbits = rbits = nullptr, bitws = nullptr;
   }
 };
 
@@ -82,6 +84,7 @@ int ss_allocate(bgs_engine* e) {
   const size_t words = (size_t)e->S * e->rows * ((e->cols + 63) / 64);
   DMALLOC(d->mbits, words * 8);
   DMALLOC(d->rbits, words * 8);
+  if (e->algo == BGS_SUBSENSE) DMALLOC(d->bitws, words * 8 * SS_NBITS);
   for (auto& q : d->f32) DMALLOC(q, P * sizeof(float));
   for (auto& q : d->u8) DMALLOC(q, P);
   const size_t ds = (size_t)(e->rows / 8) * (e->cols / 8) * C * e->S + 4;
@@ -101,7 +104,6 @@ void ss_fill_args(const bgs_engine* e, bgs::SsArgs& a, int first, int cur_pp, un
   a.DminLT = d->f32[SS_DMINLT], a.DminST = d->f32[SS_DMINST], a.RawLT = d->f32[SS_RAWLT], a.FinLT = d->f32[SS_FINLT], a.FinST = d->f32[SS_FINST];
   a.unstable = d->u8[SS_UNSTABLE], a.blinks = d->u8[SS_BLINKS], a.lastFG = d->u8[SS_LASTFG], a.lastRaw = d->u8[SS_LASTRAW];
   a.lastRawBlink = d->u8[SS_LASTRAWBLINK], a.lastDilInv = d->u8[SS_LASTDILINV], a.raw = d->u8[SS_RAW];
-  a.t1 = d->u8[SS_T1], a.t2 = d->u8[SS_T2], a.t3 = d->u8[SS_T3];
   a.dsLT = d->dsLT, a.dsST = d->dsST;
   a.rows = e->rows, a.cols = e->cols, a.nS = p.subsense_n_samples, a.nReq = p.subsense_n_required, a.nMinColor = p.subsense_min_color_dist_threshold;
   a.nDescOff = p.subsense_desc_dist_threshold_offset, a.nMov = p.subsense_samples_for_moving_avgs, a.lbspOff = p.lbsp_threshold_offset;
@@ -216,16 +218,28 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
     hipLaunchKernelGGL(bgs::ss_blink_kernel<16>, dim3(blocks_for(npix / 16)), block, 0, s, a, npix);
   else
     hipLaunchKernelGGL(bgs::ss_blink_kernel<1>, dim3(blocks_for(npix)), block, 0, s, a, npix);
-  uint8_t *raw = d->u8[SS_RAW] + off, *t1 = d->u8[SS_T1] + off, *t3 = d->u8[SS_T3] + off, *t4 = d->u8[SS_T4] + off;
+  uint8_t* raw = d->u8[SS_RAW] + off;
   uint8_t* lastFG = d->u8[SS_LASTFG] + off;
-  // morphologyEx(MORPH_CLOSE) :628  -> t1 = PreFlood
-  ss_morph(raw, t3, e->rows, e->cols, count, 1, 3, s);
-  ss_morph(t3, t1, e->rows, e->cols, count, 0, 3, s);
-  // floodFill(PreFlood copy, (0,0), 255) :629-630 on bit-packed rows -> rbits = reached set
+  // :628-636 on bit planes (kernel_subsense.h): a lane owns 64 pixels of a row
   const int W64 = (e->cols + 63) / 64, tilesY = (e->rows + 63) / 64;
-  uint64_t* mbits = d->mbits + (size_t)first * e->rows * W64;
-  uint64_t* rbits = d->rbits + (size_t)first * e->rows * W64;
-  hipLaunchKernelGGL(bgs::ss_flood_pack_kernel, dim3(blocks_for((size_t)e->rows * W64 * bgs::kWave), 1, count), block, 0, s, (const uint8_t*)t1, mbits, rbits, e->rows, e->cols, W64);
+  const size_t wpi = (size_t)e->rows * W64, nwords = wpi * count, plane = wpi * e->S;  // words per image / of this launch / per plane
+  uint64_t* bw = d->bitws + (size_t)first * wpi;
+  uint64_t *b_raw = bw, *b_tmp = bw + plane, *b_pre = bw + 2 * plane, *b_cur = bw + 3 * plane, *b_fg = bw + 4 * plane, *b_dil = bw + 5 * plane;
+  uint64_t* mbits = d->mbits + (size_t)first * wpi;
+  uint64_t* rbits = d->rbits + (size_t)first * wpi;
+  const dim3 wgrid(blocks_for(nwords));
+  auto pack = [&](const uint8_t* src, uint64_t* dst) {
+    if (e->cols % 16 == 0 && aligned(src, 16))
+      hipLaunchKernelGGL(bgs::ss_bits_pack_kernel<16>, dim3(blocks_for(nwords * 4)), block, 0, s, src, dst, e->rows, e->cols, W64, nwords);
+    else
+      hipLaunchKernelGGL(bgs::ss_bits_pack_kernel<1>, dim3(blocks_for(nwords * bgs::kWave)), block, 0, s, src, dst, e->rows, e->cols, W64, nwords);
+  };
+  pack(raw, b_raw);
+  // morphologyEx(MORPH_CLOSE) :628  -> b_pre = PreFlood
+  hipLaunchKernelGGL((bgs::ss_bits_box_kernel<1, 1>), wgrid, block, 0, s, (const uint64_t*)b_raw, b_tmp, e->rows, e->cols, W64, nwords);
+  hipLaunchKernelGGL((bgs::ss_bits_box_kernel<0, 1>), wgrid, block, 0, s, (const uint64_t*)b_tmp, b_pre, e->rows, e->cols, W64, nwords);
+  // floodFill(PreFlood copy, (0,0), 255) :629-630 -> rbits = reached set
+  hipLaunchKernelGGL(bgs::ss_bits_flood_prepare_kernel, wgrid, block, 0, s, (const uint64_t*)b_pre, mbits, rbits, e->rows, e->cols, W64, nwords);
   hipLaunchKernelGGL(bgs::ss_flood_seed_kernel, dim3(count), block, 0, s, (const uint64_t*)mbits, rbits, e->rows, e->cols, W64);
   const dim3 fgrid(blocks_for((size_t)tilesY * W64 * bgs::kWave), 1, count);
   int* fl = d->flood_flags + (size_t)first * bgs::kSsFloodFlags;
@@ -233,18 +247,19 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
   static const int batch = getenv("BGS_SS_FLOOD_BATCH") ? std::max(0, std::min(bgs::kSsFloodBatch, atoi(getenv("BGS_SS_FLOOD_BATCH")))) : bgs::kSsFloodBatch;  // test knob: 0/1 force the finish kernel to do the work
   for (int k = 0; k < batch; ++k) hipLaunchKernelGGL(bgs::ss_flood_kernel, fgrid, block, 0, s, (const uint64_t*)mbits, rbits, e->rows, W64, fl, k);
   hipLaunchKernelGGL(bgs::ss_flood_finish_kernel, dim3(count), dim3(1024), 0, s, (const uint64_t*)mbits, rbits, e->rows, W64, fl, batch);
-  // erode x3 :632 -> t3
-  ss_morph(t1, t3, e->rows, e->cols, count, 0, 7, s);  // erode x3 = one 7x7 box
-  if (v4)  // :631-634
-    hipLaunchKernelGGL(bgs::ss_combine_kernel<4>, dim3(blocks_for(npix / 4)), block, 0, s, a, (const uint8_t*)t1, (const uint64_t*)rbits, W64, (const uint8_t*)t3, t4, npix);
-  else
-    hipLaunchKernelGGL(bgs::ss_combine_kernel<1>, dim3(blocks_for(npix)), block, 0, s, a, (const uint8_t*)t1, (const uint64_t*)rbits, W64, (const uint8_t*)t3, t4, npix);
-  ss_morph(t4, lastFG, e->rows, e->cols, count, 3, d->medK, s);  // medianBlur :635 (the input is a {0,255} mask)
-  ss_morph(lastFG, t1, e->rows, e->cols, count, 1, 7, s);        // dilate x3 :636 = one 7x7 box
+  // erode x3 :632 = one 7x7 box -> b_tmp;  :631-634 -> b_cur
+  hipLaunchKernelGGL((bgs::ss_bits_box_kernel<0, 3>), wgrid, block, 0, s, (const uint64_t*)b_pre, b_tmp, e->rows, e->cols, W64, nwords);
+  hipLaunchKernelGGL(bgs::ss_bits_combine_kernel, wgrid, block, 0, s, (const uint64_t*)b_raw, (const uint64_t*)b_pre, (const uint64_t*)rbits, (const uint64_t*)b_tmp, b_cur, e->cols, W64, nwords);
+  {  // medianBlur :635 of the binary mask: counts in LDS (morph_box_kernel), input straight from the bit plane, output the byte map phase A reads
+    bgs::MorphArgs m{nullptr, lastFG, e->rows, e->cols, 3, d->medK, b_cur, W64};
+    bgs::morph_launch(m, count, s);
+  }
+  pack(lastFG, b_fg);
+  hipLaunchKernelGGL((bgs::ss_bits_box_kernel<1, 3>), wgrid, block, 0, s, (const uint64_t*)b_fg, b_dil, e->rows, e->cols, W64, nwords);  // dilate x3 :636
   if (v4)  // :637-642
-    hipLaunchKernelGGL(bgs::ss_finish_kernel<4>, dim3(blocks_for(npix / 4)), block, 0, s, a, (const uint8_t*)t1, npix);
+    hipLaunchKernelGGL(bgs::ss_finish_kernel<4>, dim3(blocks_for(npix / 4)), block, 0, s, a, (const uint64_t*)b_dil, W64, npix);
   else
-    hipLaunchKernelGGL(bgs::ss_finish_kernel<1>, dim3(blocks_for(npix)), block, 0, s, a, (const uint8_t*)t1, npix);
+    hipLaunchKernelGGL(bgs::ss_finish_kernel<1>, dim3(blocks_for(npix)), block, 0, s, a, (const uint64_t*)b_dil, W64, npix);
   if (d->lrScaling) {
     const int dsn = (e->rows / 8) * (e->cols / 8);
     SS_LAUNCH(ss_downsample_kernel, dim3(blocks_for(dsn), 1, count), block, s, a);

@@ -219,6 +219,8 @@ struct MorphArgs {
   const uint8_t* src;
   uint8_t* dst;
   int rows, cols, op, ksize;  // op 0 erode, 1 dilate (ksize x ksize box = (ksize-1)/2 iterations of 3x3), 2 median(ksize), 3 median(ksize) of a {0,255} mask
+  const uint64_t* src_bits;   // op 3 only: when set, the input is this bit plane ([images][rows][W64], bit i of word w = pixel 64 w + i) instead of src
+  int W64;
 };
 
 constexpr int kMorphTW = 64, kMorphTH = 4, kMorphMaxR = 7;  // median up to 15x15
@@ -246,7 +248,11 @@ __global__ __launch_bounds__(kBlock) void morph_box_kernel(const MorphArgs a) {
     const int y = y0 + ly - R, x = x0 + lx - R;
     uint8_t c;
     if (op == 3) {
-      c = a.src[img + (size_t)min(max(y, 0), a.rows - 1) * a.cols + min(max(x, 0), a.cols - 1)] != 0;
+      const int yc = min(max(y, 0), a.rows - 1), xc = min(max(x, 0), a.cols - 1);
+      if (a.src_bits)
+        c = (a.src_bits[((size_t)blockIdx.z * a.rows + yc) * a.W64 + (xc >> 6)] >> (xc & 63)) & 1ull;
+      else
+        c = a.src[img + (size_t)yc * a.cols + xc] != 0;
     } else {
       const bool in = y >= 0 && y < a.rows && x >= 0 && x < a.cols;
       c = in ? a.src[img + (size_t)y * a.cols + x] : (op == 0 ? 255 : 0);

@@ -6,7 +6,7 @@
 //                         update decisions :508-551, feedback T/v/R :553-576, non-zero-desc count :577-578, last frame :579-582)
 //   ss_phase_b_kernel    the sample writes decided in phase A (self update + neighbour diffusion), applied in raster order
 //   ss_refresh_kernel    refreshModel                             :249-291   (also the model initialisation, :246)
-//   ss_blink_kernel / ss_combine_kernel / ss_finish_kernel / flood kernels   post-processing chain :624-642
+//   ss_blink_kernel / ss_bits_* / flood kernels / ss_finish_kernel   post-processing chain :624-642 (on bit planes)
 //   ss_downsample_kernel + ss_frame_level_kernel                  frame-level block :643-699 (runs on the device: no host sync)
 //   ss_background_kernel getBackgroundImage                       :702-718
 //
@@ -48,7 +48,7 @@ struct SsArgs {
   float *R, *V, *T, *DlastOld, *DlastNew, *DminLT, *DminST, *RawLT, *RawSTOld, *RawSTNew, *FinLT, *FinST;  // [S][N]
   uint8_t *unstable, *blinks, *lastFG, *lastRaw, *lastRawBlink, *lastDilInv, *lastColor;                  // [S][N] ([S][N][3])
   uint16_t* lastDesc;    // [S][N][3]
-  uint8_t *raw, *t1, *t2, *t3;  // [S][N] scratch masks
+  uint8_t* raw;          // [S][N] phase A's raw segmentation
   uint16_t* req;         // [S][N][2]
   uint8_t* lut;          // [S][256]
   SsScalars* sc;         // [S]
@@ -942,6 +942,109 @@ __global__ __launch_bounds__(1024) void ss_flood_finish_kernel(const uint64_t* m
   }
 }
 
+// ---- the post-processing chain on BIT PLANES (:628-636) ------------------------------------------------------------------------
+// Every mask of the chain is binary, so between phase A's byte mask and the byte maps the next frame reads, the chain runs on
+// bit-packed rows ([images][rows][W64] words, bit i of word w = pixel 64 w + i, bits at x >= cols are 0 in every plane): a lane owns
+// one word = 64 pixels, a 3x3 / 7x7 erode or dilate is shifts and ANDs / ORs of 3 words per row, the flood fill already worked
+// this way.  ~2 operations per pixel instead of ~40 LDS-bound ones in the byte kernels (morph_box_kernel, still used by the
+// stand-alone mask operations, LOBSTER and GMG).
+
+// bytes -> bits (non-zero).  G = 16: a lane packs 16 pixels (one dwordx4), four lanes make a word; needs cols % 16 == 0 and
+// 16-byte aligned rows.  G = 1: one wave per word, a ballot (any geometry).
+template <int G>
+__global__ __launch_bounds__(kBlock) void ss_bits_pack_kernel(const uint8_t* src, uint64_t* dst, int rows, int cols, int W64, size_t nwords) {
+  if constexpr (G == 16) {
+    const size_t id = (size_t)blockIdx.x * kBlock + threadIdx.x;  // (word, quarter)
+    const size_t wid = id >> 2;
+    const int q = (int)(id & 3);
+    uint32_t nib = 0;
+    const bool inw = wid < nwords;
+    if (inw) {
+      const size_t row = wid / W64;  // image * rows + y
+      const int x = (int)(wid % W64) * 64 + q * 16;
+      if (x < cols) {
+        const uint4 v = *reinterpret_cast<const uint4*>(src + row * cols + x);
+        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t t = ((((d[k] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d[k]) >> 7) & 0x01010101u;  // bit 0 of each byte: byte != 0
+          nib |= ((t * 0x01020408u) >> 24 & 0xfu) << (4 * k);
+        }
+      }
+    }
+    uint64_t w = (uint64_t)nib << (16 * q);
+#pragma unroll
+    for (int o = 1; o < 4; o <<= 1) {
+      const uint32_t lo = __shfl_xor((uint32_t)w, o, kWave), hi = __shfl_xor((uint32_t)(w >> 32), o, kWave);
+      w |= ((uint64_t)hi << 32) | lo;
+    }
+    if (inw && q == 0) dst[wid] = w;
+  } else {
+    const size_t wid = (size_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (wid >= nwords) return;  // whole wave
+    const size_t row = wid / W64;
+    const int x = (int)(wid % W64) * 64 + (threadIdx.x & (kWave - 1));
+    const unsigned long long b = __ballot(x < cols && src[row * cols + x] != 0);
+    if ((threadIdx.x & (kWave - 1)) == 0) dst[wid] = b;
+  }
+}
+
+// (2R+1) x (2R+1) box erode (OP 0) / dilate (OP 1) = R iterations of the 3x3 operation; cells outside the image never take part.
+template <int OP, int R>
+__global__ __launch_bounds__(kBlock) void ss_bits_box_kernel(const uint64_t* in, uint64_t* out, int rows, int cols, int W64, size_t nwords) {
+  const size_t wid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (wid >= nwords) return;
+  const int w = (int)(wid % W64);
+  const size_t row = wid / W64;
+  const int y = (int)(row % rows);
+  const uint64_t lastmask = (cols & 63) ? ((1ull << (cols & 63)) - 1) : ~0ull;
+  constexpr uint64_t ident = OP == 0 ? ~0ull : 0ull;
+  auto word = [&](size_t r, int ww) -> uint64_t {  // a row's word with everything outside the image replaced by the identity
+    if (ww < 0 || ww >= W64) return ident;
+    uint64_t v = in[r * W64 + ww];
+    if (OP == 0 && ww == W64 - 1) v |= ~lastmask;
+    return v;
+  };
+  uint64_t acc = ident;
+#pragma unroll
+  for (int dy = -R; dy <= R; ++dy) {
+    const int yy = y + dy;
+    if (yy < 0 || yy >= rows) continue;
+    const size_t r = row + dy;
+    const uint64_t c = word(r, w), l = word(r, w - 1), rr = word(r, w + 1);
+    uint64_t h = c;
+#pragma unroll
+    for (int d = 1; d <= R; ++d) {
+      const uint64_t fromleft = (c << d) | (l >> (64 - d)), fromright = (c >> d) | (rr << (64 - d));  // pixels x-d and x+d
+      h = OP == 0 ? (h & fromleft & fromright) : (h | fromleft | fromright);
+    }
+    acc = OP == 0 ? (acc & h) : (acc | h);
+  }
+  out[wid] = (w == W64 - 1) ? (acc & lastmask) : acc;
+}
+
+// flood fill operands from the closed mask: mbits = pixels that have the seed's value (the value at (0,0)), rbits = nothing reached yet
+__global__ __launch_bounds__(kBlock) void ss_bits_flood_prepare_kernel(const uint64_t* pre, uint64_t* mbits, uint64_t* rbits, int rows, int cols, int W64, size_t nwords) {
+  const size_t wid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (wid >= nwords) return;
+  const size_t img = wid / ((size_t)rows * W64);
+  const bool seed = pre[img * rows * W64] & 1ull;
+  const uint64_t lastmask = (cols & 63) ? ((1ull << (cols & 63)) - 1) : ~0ull;
+  const uint64_t v = pre[wid], valid = ((int)(wid % W64) == W64 - 1) ? lastmask : ~0ull;
+  mbits[wid] = (seed ? v : ~v) & valid;
+  rbits[wid] = 0;
+}
+
+// :631-634  cur = raw | ~floodFill(pre) | erode3(pre), floodFill(pre) = reached ? 255 : pre
+__global__ __launch_bounds__(kBlock) void ss_bits_combine_kernel(const uint64_t* raw, const uint64_t* pre, const uint64_t* reached, const uint64_t* eroded, uint64_t* out, int cols, int W64,
+                                                                 size_t nwords) {
+  const size_t wid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (wid >= nwords) return;
+  const uint64_t lastmask = (cols & 63) ? ((1ull << (cols & 63)) - 1) : ~0ull;
+  const uint64_t valid = ((int)(wid % W64) == W64 - 1) ? lastmask : ~0ull;
+  out[wid] = (raw[wid] | ~(reached[wid] | pre[wid]) | eroded[wid]) & valid;
+}
+
 // cv::floodFill(img, Point(0,0), 255) as an image: reached pixels become 255, the rest keep their value
 __global__ __launch_bounds__(kBlock) void ss_flood_paint_kernel(const uint8_t* src, const uint64_t* rbits, uint8_t* dst, int rows, int cols, int W64) {
   const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -950,39 +1053,22 @@ __global__ __launch_bounds__(kBlock) void ss_flood_paint_kernel(const uint8_t* s
   dst[p] = ((rbits[(size_t)y * W64 + (x >> 6)] >> (x & 63)) & 1ull) ? 255 : src[p];
 }
 
-// cur = raw | ~flooded | eroded(pre)  (:631-634): holes = pixels of `pre` equal to the seed value that the fill did not reach... in
-// mask terms: flooded image = 255 where reached or where pre != seed... written out explicitly below.
-template <int G>  // pixels per lane: 4 consecutive pixels of one row (cols % 4 == 0: they share a word of rbits) or 1
-__global__ __launch_bounds__(kBlock) void ss_combine_kernel(const SsArgs a, const uint8_t* pre, const uint64_t* rbits, int W64, const uint8_t* eroded, uint8_t* out, size_t count) {
+// :637-642: blink mask clean-up against the dilated final mask (old then new), final-segmentation running means, output
+// `dilated` is a bit plane ([images][rows][W64]).
+template <int G>  // pixels per lane: 4 (dword per byte map, float4 per mean map; cols % 4 == 0: they share a word of the bit plane) or 1
+__global__ __launch_bounds__(kBlock) void ss_finish_kernel(const SsArgs a, const uint64_t* dilated, int W64, size_t count) {
   const size_t i = ((size_t)blockIdx.x * kBlock + threadIdx.x) * G;
   if (i >= count) return;
   const size_t N = (size_t)a.rows * a.cols, g = (size_t)a.first * N + i;
-  const size_t img = i / N, p = i % N;
-  const int y = (int)(p / a.cols), x = (int)(p % a.cols);
-  const uint64_t word = rbits[(img * a.rows + y) * W64 + (x >> 6)] >> (x & 63);
-  if constexpr (G == 4) {
-    const uint32_t nib = (uint32_t)word & 0xfu;
-    const uint32_t reached = ((nib & 1u) * 0xffu) | ((nib & 2u) * (0xff00u >> 1)) | ((nib & 4u) * (0xff0000u >> 2)) | ((nib & 8u) * (0xff000000u >> 3));
-    const uint32_t flooded = reached | *reinterpret_cast<const uint32_t*>(pre + i);  // floodFill paints the reached region with 255, leaves the rest
-    *reinterpret_cast<uint32_t*>(out + i) = *reinterpret_cast<const uint32_t*>(a.raw + g) | ~flooded | *reinterpret_cast<const uint32_t*>(eroded + i);
-  } else {
-    const bool reached = word & 1ull;
-    const uint8_t flooded = reached ? 255 : pre[i];
-    out[i] = a.raw[g] | (uint8_t)~flooded | eroded[i];
-  }
-}
-
-// :637-642: blink mask clean-up against the dilated final mask (old then new), final-segmentation running means, output
-template <int G>  // pixels per lane: 4 (dword per byte map, float4 per mean map) or 1
-__global__ __launch_bounds__(kBlock) void ss_finish_kernel(const SsArgs a, const uint8_t* dilated, size_t count) {
-  const size_t i = ((size_t)blockIdx.x * kBlock + threadIdx.x) * G;
-  if (i >= count) return;
-  const size_t g = (size_t)a.first * a.rows * a.cols + i;
+  const size_t img = i / N, pp = i % N;
+  const int py = (int)(pp / a.cols), px = (int)(pp % a.cols);
+  const uint64_t dword = dilated[(img * a.rows + py) * W64 + (px >> 6)] >> (px & 63);
   // cv::addWeighted(f32, 1-f, u8, (1/255)*f, 0, dst, CV_32F): both operands as float, arithmetic in double
   const double aLT = (double)(1.0f - a.fLT), bLT = __dmul_rn(1.0 / 255, (double)a.fLT), aST = (double)(1.0f - a.fST), bST = __dmul_rn(1.0 / 255, (double)a.fST);
   if constexpr (G == 4) {
     const uint32_t b = *reinterpret_cast<const uint32_t*>(a.blinks + g) & *reinterpret_cast<const uint32_t*>(a.lastDilInv + g);
-    const uint32_t inv = ~*reinterpret_cast<const uint32_t*>(dilated + i);
+    const uint32_t nib = (uint32_t)dword & 0xfu;
+    const uint32_t inv = ~(((nib & 1u) * 0xffu) | ((nib & 2u) * (0xff00u >> 1)) | ((nib & 4u) * (0xff0000u >> 2)) | ((nib & 8u) * (0xff000000u >> 3)));
     *reinterpret_cast<uint32_t*>(a.lastDilInv + g) = inv;
     *reinterpret_cast<uint32_t*>(a.blinks + g) = b & inv;
     const uint32_t m4 = *reinterpret_cast<const uint32_t*>(a.lastFG + g);
@@ -1000,7 +1086,7 @@ __global__ __launch_bounds__(kBlock) void ss_finish_kernel(const SsArgs a, const
     *reinterpret_cast<float4*>(a.FinST + g) = st;
   } else {
     uint8_t b = a.blinks[g] & a.lastDilInv[g];
-    const uint8_t inv = (uint8_t)~dilated[i];
+    const uint8_t inv = (dword & 1ull) ? 0 : 255;
     a.lastDilInv[g] = inv;
     a.blinks[g] = b & inv;
     const uint8_t m = a.lastFG[g];
