@@ -1,10 +1,3 @@
 set -o pipefail
-for i in 1 2 3; do
-timeout -k 10 600 env BGS_DEBUG_PROBE=1 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --main-only > gpurun_out/bp$i.json 2> gpurun_out/bp$i.err
-grep "placement probe" gpurun_out/bp$i.err
-python - gpurun_out/bp$i.json <<'P'
-import json,sys
-d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['sustained']['frac'], d['placement_probe'])
-P
-done
+timeout -k 10 900 python -m pytest tests -m gpu -x -q -k "subsense or sample_consensus or large_batches or disjoint" 2>&1 | tail -3
+for k in subsense8 subsense pipeline; do timeout -k 10 300 python tools/bench_configs.py --only $k 2>&1 | grep -v amdgpu.ids; done

@@ -73,7 +73,7 @@ int ss_allocate(bgs_engine* e) {
       return fail(BGS_ERR_UNSUPPORTED, "SuBSENSE frame-level analysis: rows and cols must be multiples of 8 (cv::resize INTER_AREA with an integer ratio)");
   }
   const size_t N = e->n, P = N * e->S, nS = (size_t)p.subsense_n_samples, C = (size_t)e->ch;
-  d->pixelMajor = 0, d->nSpad = (int)nS;  // sample-major planes (kernel_subsense.h: layout note)
+  d->pixelMajor = 1, d->nSpad = ((int)nS + bgs::kSsBatch - 1) / bgs::kSsBatch * bgs::kSsBatch;  // pixel-major records in whole batches (kernel_subsense.h: phase A)
   DMALLOC(d->samples, P * (size_t)d->nSpad * (C == 3 ? 16 : 4));
   DMALLOC(d->lastColor, P * C);
   DMALLOC(d->lastDesc, P * C * 2);
@@ -319,7 +319,8 @@ int64_t ss_get_state(bgs_engine* e, int stream, const char* plane, void* dst, si
     if (hipMemcpy(recs.data(), (const uint8_t*)d->samples + off * per * recB, recs.size(), hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
     for (size_t k = 0; k < nS; ++k)
       for (size_t px = 0; px < N; ++px) {  // export: [nS][N][C], whatever the device order
-        const uint8_t* r = recs.data() + (d->pixelMajor ? px * per + k : k * N + px) * recB;
+        const size_t B = bgs::kSsBatch;  // same mapping as ss_rec (kernel_subsense.h)
+        const uint8_t* r = recs.data() + (!d->pixelMajor ? k * N + px : k < B ? k * N + px : B * N + px * (per - B) + (k - B)) * recB;
         const size_t o = k * N + px;
         for (size_t c = 0; c < C; ++c) {
           if (wantColor)

@@ -127,9 +127,17 @@ struct SsSample<1> {
 __device__ __forceinline__ void ss_wait_here(SsSample<3>& s) { asm volatile("" : "+v"(s.v.x), "+v"(s.v.y), "+v"(s.v.z), "+v"(s.v.w)); }
 __device__ __forceinline__ void ss_wait_here(SsSample<1>& s) { asm volatile("" : "+v"(s.v)); }
 
-// record index of sample k of pixel p (0..N) of absolute stream `stream`
+// Record index of sample k of pixel p (0..N) of absolute stream `stream`.
+//   pixelMajor == 0 (LOBSTER): sample-major planes [nS][N].
+//   pixelMajor == 1 (SuBSENSE): per stream, the FIRST batch (samples 0 .. kSsBatch-1) as sample-major planes [kSsBatch][N] - the
+//     samples every pixel tests, and a quiet scene tests nothing else: neighbouring pixels' records share cache lines - followed
+//     by the remaining nSpad - kSsBatch samples PIXEL-major [N][nSpad - kSsBatch]: a pixel that walks on fetches its next four
+//     samples as 64 contiguous bytes (ss_phase_a_kernel).
+constexpr int kSsBatch = 4;
 __device__ __forceinline__ size_t ss_rec(const SsArgs& a, int stream, size_t N, size_t p, int k) {
-  return a.pixelMajor ? ((size_t)stream * N + p) * (size_t)a.nSpad + (size_t)k : ((size_t)stream * (size_t)a.nS + (size_t)k) * N + p;
+  if (!a.pixelMajor) return ((size_t)stream * (size_t)a.nS + (size_t)k) * N + p;
+  const size_t base = (size_t)stream * N * (size_t)a.nSpad;
+  return k < kSsBatch ? base + (size_t)k * N + p : base + (size_t)kSsBatch * N + p * (size_t)(a.nSpad - kSsBatch) + (size_t)(k - kSsBatch);
 }
 
 // ----------------------------------------------------------------------------------------------- phase A
@@ -259,11 +267,17 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
     uint32_t nb[C][8];
     uint32_t curm[C];  // the current colour, channel c alone in byte c of a word (BGR); the gray value (gray)
     uint32_t iy = 0, iz = 0;  // intra descriptors as the records hold them: d0 | d1 << 16, d2
-    size_t rec = 0;  // record of the NEXT sample to request for this lane's pixel
-    SsSample<C> smp{}, nsmp{};
+    // Records (ss_rec): the first batch sample-major, the rest PIXEL-major in whole batches: a lane fetches its pixel's samples four at
+    // a time, from batch 1 on as 64 contiguous bytes (16 for gray) = memory requests that are all payload.  With one 16-byte record per request the
+    // kernel ran at the L1's limit of outstanding misses (rocprofv3: TCP_PENDING_STALL 84 % of the cycles, 94 M line requests of
+    // which a quarter of every 64-byte sector was used, 10.6 GB fetched per launch on 8 x 1080p); the sample ORDER is unchanged.
+    constexpr int B = kSsBatch;
+    size_t rec = 0, rstep = 1, rnext = 0;  // first record and record stride of the batch to request NEXT for this lane's pixel; its batch 1
+    SsSample<C> bt[B], nbt[B];
+#pragma unroll
+    for (int j = 0; j < B; ++j) bt[j] = SsSample<C>{}, nbt[j] = SsSample<C>{};
 #pragma unroll
     for (int c = 0; c < C; ++c) cur[c] = 0, intra[c] = 0, curm[c] = 0;
-    const size_t sbase = (size_t)stream * a.nS * N;  // sample-major planes (ss_rec)
     for (;;) {
       const unsigned long long idle = __ballot(!active);
       const int nidle = __popcll(idle);
@@ -290,44 +304,35 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
 #pragma unroll
             for (int c = 0; c < C; ++c) curm[c] = (uint32_t)cur[c] << (8 * c);
             const size_t p = (size_t)(y0 + ly) * a.cols + (x0 + lx);
-            rec = sbase + p;
-            smp = nsmp = SsSample<C>::load(a.samples, rec);
+            rec = ss_rec(a, stream, N, p, 0), rstep = N, rnext = ss_rec(a, stream, N, p, B);
+#pragma unroll
+            for (int j = 0; j < B; ++j) bt[j] = nbt[j] = SsSample<C>::load(a.samples, rec + j * rstep);
             idx = 0, good = 0, minDesc = maxDesc, minSum = maxColor;
-#ifdef BGS_EXP_NOLOOP  // timing experiments only (never defined in the product build): queue + gather, no sample tests
-            idx = a.nS;
-#endif
             active = true;
           }
         }
       }
       EXP_COUNT(0, 1);  // wave-iterations
       if (active) {
-        if (good < a.nReq && idx < a.nS) {  // :469-497 (BGR) / :334-357 (gray); sample idx+1 is in flight while idx is tested
-#ifndef BGS_EXP_NOLOAD
-          // Unconditional (the last trip re-reads its own record) so that the loaded registers ARE nsmp: under a condition the
-          // compiler merged them with the old value through copies placed right behind the load - with an s_waitcnt vmcnt(0)
-          // in front - and every trip paid the full memory latency (found in the ISA, round 2).
-          rec += (idx + 1 < a.nS) ? N : 0;
-          nsmp = SsSample<C>::load(a.samples, rec);
-#endif
+        if (good < a.nReq && idx < a.nS) {  // :469-497 (BGR) / :334-357 (gray); batch idx/4 + 1 is in flight while batch idx/4 is tested
+          // Unconditional (the last batch re-reads itself) so that the loaded registers ARE nbt: under a condition the compiler
+          // merged them with the old value through copies placed right behind the load - with an s_waitcnt vmcnt(0) in front
+          // - and every trip paid the full memory latency (found in the ISA, round 2).
+          // Most pixels of a quiet scene are done inside their first batch: a lane does not prefetch behind batch 0 (it re-reads
+          // batch 0, an L1 hit) and pays the latency of batch 1 once if it does go on; from batch 1 on the next one is in flight.
+          rec += (idx > 0 && idx + B < a.nS) ? B : 0;
+#pragma unroll
+          for (int j = 0; j < B; ++j) nbt[j] = SsSample<C>::load(a.samples, rec + j * rstep);
+          // Two passes over the batch.  R: the cheap exact rejection tests on all B samples, every lane busy -> candidate bits.
+          // I: the inter-LBSP test (~150 instructions), one candidate per lane and pass in sample order, stopping at the nReq-th
+          // match exactly like the reference's loop (:469).  Interleaved sample by sample, nearly every trip of a wave paid the
+          // inter-LBSP step for the few lanes that needed it (12 % of the samples get that far: 94 % of the trips of 64 lanes);
+          // per batch of four it is paid ~2.3 times instead of 4.  Rejected samples and samples behind the nReq-th match have no
+          // side effects, and min() does not care about order.
+          uint32_t cand = 0;
           if constexpr (C == 1) {
-            const int bcc = smp.color(0);
-            const unsigned bdc = smp.desc(0);
-            const uint32_t cd = (uint32_t)abs(cur[0] - bcc);
-            if (cd <= colorThr) {
-              const uint32_t intraD = (uint32_t)__popc(intra[0] ^ bdc);
-              const unsigned inter = ss_lbsp(nb[0], bcc, lut[bcc]);
-              const uint32_t dd = (intraD + (uint32_t)__popc(inter ^ bdc)) / 2;
-              if (dd <= descThr) {
-                uint32_t sd = (dd / 4) * (255 / 16) + cd;
-                sd = sd < 255 ? sd : 255;
-                if (sd <= colorThr) {
-                  minDesc = minDesc > dd ? dd : minDesc;
-                  minSum = minSum > sd ? sd : minSum;
-                  good++;
-                }
-              }
-            }
+#pragma unroll
+            for (int j = 0; j < B; ++j) cand |= (uint32_t)(idx + j < a.nS && (uint32_t)abs(cur[0] - bt[j].color(0)) <= colorThr) << j;
           } else {
             // The reference walks the channels in order and drops the sample at the first failed test (:474-491); a sample is kept
             // only if every test passes, so the tests may run in any order.  Exact rejections first, from what costs least:
@@ -335,51 +340,83 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
             // per-channel colour test cd <= scColorThr is implied by the one on the bound lbsd = min(255, k + cd): either
             // lbsd = k + cd >= cd, or lbsd = 255 <= scColorThr and cd <= 255.
             const uint32_t totColorThr = colorThr * 3, totDescThr = descThr * 3, scColorThr = totColorThr / 2;
-            const uint32_t sx = smp.v.x, sy = smp.v.y, sz = smp.v.z;
-            uint32_t cd[3], intraD[3], lbdd[3], lbsd[3];
-            cd[0] = __builtin_amdgcn_sad_u8(curm[0], sx & 0x0000ffu, 0u);
-            cd[1] = __builtin_amdgcn_sad_u8(curm[1], sx & 0x00ff00u, 0u);
-            cd[2] = __builtin_amdgcn_sad_u8(curm[2], sx & 0xff0000u, 0u);
-            const uint32_t xy = iy ^ sy;
-            intraD[0] = (uint32_t)__popc(xy & 0xffffu), intraD[1] = (uint32_t)__popc(xy >> 16), intraD[2] = (uint32_t)__popc(iz ^ sz);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              lbdd[c] = intraD[c] >> 1;
-              lbsd[c] = min((lbdd[c] >> 1) * (255 / 16) + cd[c], 255u);
-            }
-            bool ok = max(max(lbsd[0], lbsd[1]), lbsd[2]) <= scColorThr && lbdd[0] + lbdd[1] + lbdd[2] <= totDescThr && lbsd[0] + lbsd[1] + lbsd[2] <= totColorThr;
-#ifdef BGS_EXP_COUNT
-            {
-              const unsigned long long okm = __ballot(ok);
-              if (okm && (unsigned)(__ffsll((long long)okm) - 1) == (threadIdx.x & 63u)) atomicAdd(&g_exp_cnt[2], 1ull), atomicAdd(&g_exp_cnt[3], (unsigned long long)__popcll(okm));
-            }
-#endif
-#ifdef BGS_EXP_NOEXP
-            ok = false;
-#endif
-            if (ok) {  // the inter-LBSP descriptors: only for samples that can still pass
-              uint32_t totDesc = 0, totSum = 0;
+            for (int j = 0; j < B; ++j) {
+              const uint32_t sx = bt[j].v.x, sy = bt[j].v.y, sz = bt[j].v.z;
+              uint32_t cd[3], lbdd[3], lbsd[3];
+              cd[0] = __builtin_amdgcn_sad_u8(curm[0], sx & 0x0000ffu, 0u);
+              cd[1] = __builtin_amdgcn_sad_u8(curm[1], sx & 0x00ff00u, 0u);
+              cd[2] = __builtin_amdgcn_sad_u8(curm[2], sx & 0xff0000u, 0u);
+              const uint32_t xy = iy ^ sy;
+              lbdd[0] = (uint32_t)__popc(xy & 0xffffu) >> 1, lbdd[1] = (uint32_t)__popc(xy >> 16) >> 1, lbdd[2] = (uint32_t)__popc(iz ^ sz) >> 1;
 #pragma unroll
-              for (int c = 0; c < 3; ++c) {
-                const int bcc = smp.color(c);
-                const unsigned inter = ss_lbsp(nb[c], bcc, lut[bcc]);
-                const uint32_t interD = (uint32_t)__popc(inter ^ smp.desc(c));
-                const uint32_t dd = (intraD[c] + interD) / 2;
-                uint32_t sd = (dd / 2) * (255 / 16) + cd[c];
-                sd = sd < 255 ? sd : 255;
-                ok = ok && sd <= scColorThr;
-                totDesc += dd, totSum += sd;
-              }
-              if (ok && !(totDesc > totDescThr || totSum > totColorThr)) {
-                minDesc = minDesc > totDesc ? totDesc : minDesc;
-                minSum = minSum > totSum ? totSum : minSum;
-                good++;
+              for (int c = 0; c < 3; ++c) lbsd[c] = min((lbdd[c] >> 1) * (255 / 16) + cd[c], 255u);
+              const bool ok = max(max(lbsd[0], lbsd[1]), lbsd[2]) <= scColorThr && lbdd[0] + lbdd[1] + lbdd[2] <= totDescThr && lbsd[0] + lbsd[1] + lbsd[2] <= totColorThr;
+              cand |= (uint32_t)(ok && idx + j < a.nS) << j;
+            }
+          }
+          for (;;) {
+            const bool go = cand != 0 && good < a.nReq;
+            if (!__any(go)) break;
+            if (go) {
+              const int j = __ffs((int)cand) - 1;
+              cand &= cand - 1;
+              SsSample<C> smp = bt[0];
+#pragma unroll
+              for (int jj = 1; jj < B; ++jj)
+                if (j == jj) smp = bt[jj];
+              if constexpr (C == 1) {
+                const int bcc = smp.color(0);
+                const unsigned bdc = smp.desc(0);
+                const uint32_t cd = (uint32_t)abs(cur[0] - bcc);
+                const uint32_t intraD = (uint32_t)__popc(intra[0] ^ bdc);
+                const unsigned inter = ss_lbsp(nb[0], bcc, lut[bcc]);
+                const uint32_t dd = (intraD + (uint32_t)__popc(inter ^ bdc)) / 2;
+                if (dd <= descThr) {
+                  uint32_t sd = (dd / 4) * (255 / 16) + cd;
+                  sd = sd < 255 ? sd : 255;
+                  if (sd <= colorThr) {
+                    minDesc = minDesc > dd ? dd : minDesc;
+                    minSum = minSum > sd ? sd : minSum;
+                    good++;
+                  }
+                }
+              } else {
+                const uint32_t totColorThr = colorThr * 3, totDescThr = descThr * 3, scColorThr = totColorThr / 2;
+                uint32_t totDesc = 0, totSum = 0;
+                bool ok = true;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                  const int bcc = smp.color(c);
+                  const uint32_t cd = (uint32_t)abs(cur[c] - bcc);
+                  const uint32_t intraD = (uint32_t)__popc(intra[c] ^ smp.desc(c));
+                  const unsigned inter = ss_lbsp(nb[c], bcc, lut[bcc]);
+                  const uint32_t interD = (uint32_t)__popc(inter ^ smp.desc(c));
+                  const uint32_t dd = (intraD + interD) / 2;
+                  uint32_t sd = (dd / 2) * (255 / 16) + cd;
+                  sd = sd < 255 ? sd : 255;
+                  ok = ok && sd <= scColorThr;
+                  totDesc += dd, totSum += sd;
+                }
+                if (ok && !(totDesc > totDescThr || totSum > totColorThr)) {
+                  minDesc = minDesc > totDesc ? totDesc : minDesc;
+                  minSum = minSum > totSum ? totSum : minSum;
+                  good++;
+                }
               }
             }
           }
-          idx++;
-          ss_wait_here(nsmp);  // the wait for sample idx+1 belongs HERE, behind the tests of sample idx
-          smp = nsmp;
+          idx += B;
+#pragma unroll
+          for (int j = 0; j < B; ++j) {
+            ss_wait_here(nbt[j]);  // the wait for the next batch belongs HERE, behind the tests of this one
+            bt[j] = nbt[j];
+          }
+          if (idx == B && good < a.nReq && idx < a.nS) {  // leaving batch 0 and not done: fetch batch 1 now, from the pixel-major part
+            rec = rnext, rstep = 1;
+#pragma unroll
+            for (int j = 0; j < B; ++j) bt[j] = SsSample<C>::load(a.samples, rec + j);
+          }
         }
         if (!(good < a.nReq && idx < a.nS)) {
           ctx[q][2] = (uint32_t)good | (minDesc << 8) | (minSum << 16);
