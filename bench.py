@@ -120,6 +120,51 @@ def surv_leg(local, S, fg, steps=200, sparse=1):
     return out
 
 
+def pmc_traffic_live(streams, steps, warmup, inp, timeout_s=150):
+    """roofline.traffic measured IN this run: two child passes of this script's timed leg under `rocprofv3 --kernel-trace --pmc`
+    (FETCH_SIZE, then WRITE_SIZE: they do not fit one pass), the last `steps` dispatches of the update kernel averaged, corrected as
+    MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts half of a wide streaming read; both are in KiB).  Children are
+    started as ordinary subprocesses (never an exec from this GPU-holding process), each under a timeout; any failure returns None
+    and the caller falls back to the committed constant."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not on PATH"
+    out = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="bgs_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+               sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--streams", str(streams),
+               "--input", inp, "--main-only", "--sustain", "0", "--settle", "40", "--no-cpu-baseline"]
+        try:
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, 9)  # exactly the process group this call started
+                p.wait()
+                shutil.rmtree(d, ignore_errors=True)
+                return None, "%s pass timed out after %d s" % (ctr, timeout_s)
+            vals = []
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                rows = [r for r in csv.DictReader(open(f)) if "mog2_update" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+                rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+                vals += [float(r["Counter_Value"]) for r in rows]
+            shutil.rmtree(d, ignore_errors=True)
+            if rc != 0 or len(vals) < steps:
+                return None, "%s pass: rc=%s, %d dispatches" % (ctr, rc, len(vals))
+            out[ctr] = sum(vals[-steps:]) / steps
+        except Exception as ex:  # noqa: BLE001 - diagnostics only, the bench line must still be printed
+            shutil.rmtree(d, ignore_errors=True)
+            return None, "%s pass failed: %r" % (ctr, ex)
+    rd, wr = out["FETCH_SIZE"] * 1024 * 2, out["WRITE_SIZE"] * 1024
+    return {"hbm_bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr)}, "measured in this run: two child passes of the timed leg under rocprofv3 --kernel-trace --pmc (FETCH_SIZE*1024*2 + WRITE_SIZE*1024, mean of the last %d dispatches)" % steps
+
+
 def clip_leg(eng, pool, period, S, T, launches=40, warm=10):
     """Supplementary, never `value`: the same engine and saturated model through bgs_process_clip_device, T consecutive frames of
     every stream per launch with the model held in registers (file-fed video, or a live deployment that accepts T-1 frame
@@ -162,6 +207,7 @@ def main():
     ap.add_argument("--sustain", type=int, default=200, help="further launches after the timed K, reported as roofline.sustained")
     ap.add_argument("--series", default="", help="write the per-launch kernel durations (settle, warmup, timed, sustain) to this CSV")
     ap.add_argument("--rehearse", action="store_true", help="N > 1 control flow on one GPU: all ranks on cuda:0, gloo, masks via host (not a benchmark)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 child passes (then the constant of profiles/pmc_traffic.json is reported)")
     ap.add_argument("--px", type=int, default=0, help="MOG2 pixels per lane (tuning; 0 = default = 1)")
     args = ap.parse_args()
 
@@ -320,13 +366,19 @@ def main():
         mpix = total_px / elapsed / 1e6
         algo_bytes = (BYTES_PER_PIXEL + (3 if args.with_bg else 0)) * px_per_step_rank
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic, traffic_source = None, "none"
+        traffic, traffic_source, traffic_detail = None, "none", None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if world == 1 and not args.main_only and not args.no_pmc and not args.with_bg:
+            traffic_detail, why = pmc_traffic_live(S, args.steps, args.warmup, args.input)
+            if traffic_detail:
+                traffic, traffic_source = traffic_detail["hbm_bytes_per_launch"], why
+            else:
+                traffic_source = "live PMC passes unavailable (%s); " % why
+        if traffic is None and os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc)).get("mog2_update_kernel", {})
                 traffic = rec.get("hbm_bytes_per_launch")
-                traffic_source = "NOT measured in this run: constant read from profiles/pmc_traffic.json (%s)" % rec.get("source", "rocprofv3 --pmc passes of the same workload")
+                traffic_source = (traffic_source if traffic_source != "none" else "") + "NOT measured in this run: constant read from profiles/pmc_traffic.json (%s)" % rec.get("source", "rocprofv3 --pmc passes of the same workload")
             except Exception:
                 traffic = None
 
@@ -349,7 +401,7 @@ def main():
             "frames_per_s": round(mpix * 1e6 / (ROWS * COLS), 1),
             "mean_live_modes_stream0": live_modes,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": traffic, "traffic_source": traffic_source, "kernel": k_name, "kernel_avg_ms": round(k_ms, 4), "kernel_launches": k_n,
+                         "traffic": traffic, "traffic_source": traffic_source, "traffic_read_write": traffic_detail, "kernel": k_name, "kernel_avg_ms": round(k_ms, 4), "kernel_launches": k_n,
                          "algorithmic_bytes_per_launch": algo_bytes, "frac_of_achievable_6290": round(achieved / 6290.0, 4),
                          "timed_region": "the K timed steps, after %d saturation + %d settle + %d warm-up launches: sustained clocks" % (SATURATE, SETTLE, args.warmup),
                          "sustained": leg(sus_ms), "burst_first_20_after_idle": leg(burst_ms)},

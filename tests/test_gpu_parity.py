@@ -376,7 +376,8 @@ def test_subsense_ragged_sizes(shape):
     check_subsense_state(eng, orc, shape[0], shape[1])
 
 
-@pytest.mark.parametrize("kw", [dict(subsense_n_samples=20), dict(subsense_n_required=3), dict(subsense_min_color_dist_threshold=15),
+@pytest.mark.parametrize("kw", [dict(subsense_n_samples=20), dict(subsense_n_samples=3), dict(subsense_n_samples=5), dict(subsense_n_samples=63),  # 3 / 5 / 63: not whole batches of four
+                                dict(subsense_n_required=3), dict(subsense_min_color_dist_threshold=15),
                                 dict(subsense_desc_dist_threshold_offset=1), dict(lbsp_rel_threshold=0.2), dict(subsense_samples_for_moving_avgs=20)])
 def test_subsense_param_variants(kw, golden_frames):
     p = _params(capi.SUBSENSE, **kw)

@@ -1,5 +1,10 @@
 set -o pipefail
-bash tools/pmc_kernel.sh lob_s lob_phase_a "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" -- $GRAFT_REPO_ROOT/tools/bench_configs.py --only lobster
-bash tools/pmc_kernel.sh lob_q lob_phase_a "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum" -- $GRAFT_REPO_ROOT/tools/bench_configs.py --only lobster
-bash tools/pmc_kernel.sh lob_f lob_phase_a "FETCH_SIZE" -- $GRAFT_REPO_ROOT/tools/bench_configs.py --only lobster
-bash tools/pmc_kernel.sh lob_t lob_phase_a "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" -- $GRAFT_REPO_ROOT/tools/bench_configs.py --only lobster
+t0=$(date +%s)
+timeout -k 10 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_live.json 2> gpurun_out/bench_live.err; echo "rc=$? wall=$(( $(date +%s) - t0 )) s"
+python - <<'P'
+import json
+d=json.loads(open('gpurun_out/bench_live.json').read().strip().splitlines()[-1])
+r=d['roofline']
+print(d['value'], d['ms_per_step'], r['frac'], r['traffic'], r['traffic_source'], r['traffic_read_write'])
+print(r['algorithmic_bytes_per_launch'], r['traffic']/r['algorithmic_bytes_per_launch'] if r['traffic'] else None)
+P
