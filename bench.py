@@ -133,6 +133,8 @@ def pmc_traffic_live(streams, steps, warmup, inp, timeout_s=150):
     import tempfile
     if not shutil.which("rocprofv3"):
         return None, "rocprofv3 not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process is itself being profiled"
     out = {}
     env = dict(os.environ, TMPDIR="/tmp")
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
