@@ -5,7 +5,7 @@ sparse level, clip length and starting point."""
 import numpy as np
 import pytest
 
-from gpu_helpers import ALGOS, _params, _torch, check_mog2_state, check_state
+from gpu_helpers import ALGOS, _params, _torch, check_mog1_state, check_mog2_state, check_state
 from oracle import pyoracle
 from tools import synth
 from tracking_amd import Engine, capi
@@ -154,6 +154,60 @@ def test_clip_call_of_the_other_classes_is_the_frame_by_frame_path(name):
                 assert (fg[t, s] == 9).all()
     for s in range(S):
         check_state(name, eng, orcs[s], H * W, stream=s)
+
+
+@pytest.mark.parametrize("alpha", [-1.0, 0.0, 0.02])
+@pytest.mark.parametrize("kind", ["sat", "surv"])
+def test_mog1_clip_equals_oracle_frame_by_frame(kind, alpha):
+    """MixtureOfGaussianV1BGS clips (8 + 4 + 2 fused launches, then single frames): masks, packed masks and the whole model against
+    the oracle fed frame by frame; alpha < 0 = the automatic rate 1/min(n, history), a different rate for every frame of a launch;
+    alpha 0 = classify only."""
+    S, T, H, W = 2, 29, 16, 64
+    clips = _clips(kind, S, T, H, W, seed=41)
+    p = _params(capi.MOG1, alpha=alpha)
+    eng = Engine(capi.MOG1, params=p, n_streams=S)
+    eng.set_geometry(H, W, 3)
+    orcs = [pyoracle.Oracle(capi.MOG1, params=p) for _ in range(S)]
+    t0 = 0
+    for n in (14, 1, 8, 6):
+        fg, bits, _, flags = _run_clip(eng, clips, t0, n, want_bg=False)
+        assert all(f == capi.FG_VALID for f in flags)
+        for j in range(n):
+            for s in range(S):
+                ofg, _ = orcs[s].process(clips[s, t0 + j])
+                assert np.array_equal(fg[j, s], ofg), (t0 + j, s, int((fg[j, s] != ofg).sum()))
+                assert np.array_equal(bits[j, s] * 255, np.where(ofg != 0, 255, 0)), (t0 + j, s)
+        t0 += n
+        for s in range(S):
+            assert eng.frames_seen(s) == t0
+            check_mog1_state(eng, orcs[s], H * W, 3, stream=s)
+
+
+def test_mog1_clip_gray_and_fused_equals_unfused_bitwise():
+    torch = _torch()
+    S, T, H, W = 3, 13, 24, 64
+    rng = np.random.default_rng(3)
+    base = rng.integers(0, 256, (S, 1, H, W)).astype(np.int32)
+    clips = np.clip(base + rng.integers(-5, 6, (S, T, H, W)), 0, 255).astype(np.uint8)  # [S][T][H][W] gray
+    res = []
+    for fuse in (1, 0):
+        eng = Engine(capi.MOG1, n_streams=S)
+        eng.set_geometry(H, W, 1)
+        eng.set_option(capi.OPT_CLIP_FUSE, fuse)
+        d_frames = torch.from_numpy(np.ascontiguousarray(clips.transpose(1, 0, 2, 3))).cuda()
+        d_fg = torch.zeros((T, S, H, W), dtype=torch.uint8, device="cuda")
+        eng.process_clip_device(d_frames, T, d_fg)
+        torch.cuda.synchronize()
+        n = H * W
+        planes = [eng.get_state(pl, sh, np.float32, stream=1) for pl, sh in (("sortkey", (5, n)), ("w", (5, n)), ("mu", (5, 1, n)), ("var", (5, 1, n)))]
+        res.append((d_fg.cpu().numpy(), planes))
+    assert np.array_equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1], res[1][1]):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    orc = pyoracle.Oracle(capi.MOG1)
+    for t in range(T):
+        ofg, _ = orc.process(clips[1, t])
+        assert np.array_equal(res[0][0][t, 1], ofg), t
 
 
 def test_clip_argument_errors():

@@ -199,7 +199,7 @@ def run_cc():
         print("connected components 1920x1080 %-12s: %d components, %.3f ms per mask (incl. count read-back) -> %.1f Mpix/s" % (name, n, ms, 1080 * 1920 / ms / 1e3))
 
 
-def run_clip(S=32, rows=1080, cols=1920, kind="sat", steps=24, Ts=(1, 2, 4, 8)):
+def run_clip(S=32, rows=1080, cols=1920, kind="sat", steps=24, Ts=(1, 2, 4, 8), algo=None, dense=201.0, label="MOG2"):
     """bgs_process_clip_device on the bench geometry: T frames of every stream per launch, the model held in registers."""
     dev = torch.device("cuda", 0)
     P = 16  # a pool of 16 time steps; S_sat has period 5, so a clip may start at any multiple of 5... the pool is walked cyclically in whole clips
@@ -209,7 +209,7 @@ def run_clip(S=32, rows=1080, cols=1920, kind="sat", steps=24, Ts=(1, 2, 4, 8)):
         pool[:, s] = gen(P, rows, cols, seed=4321 + s, device=dev)
     px = S * rows * cols
     for T in Ts:
-        e = Engine(capi.MOG2, n_streams=S)
+        e = Engine(algo if algo is not None else capi.MOG2, n_streams=S)
         e.set_geometry(rows, cols, 3)
         bits = torch.empty((T, S, rows * cols // 64), dtype=torch.int64, device=dev)
         for t in range(0, 64, T):  # saturate the mixture (every mode of every pixel live on S_sat)
@@ -223,10 +223,10 @@ def run_clip(S=32, rows=1080, cols=1920, kind="sat", steps=24, Ts=(1, 2, 4, 8)):
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         ms, n, kname = e.kernel_timing()
-        moved = 201.0 / T + 3 + 1 / 8.0
-        print("MOG2 clip T=%d (%s) %dx%d x%d streams: %-18s %.3f ms per launch = %.3f ms per frame step -> %7.1f Gpix/s = %6.0f 1080p frames/s; "
-              "206 B/px/frame algorithmic -> %.2f of 8 TB/s; bytes actually moved (dense model) %.1f B/px/frame -> %.2f TB/s; wall %.1f Gpix/s"
-              % (T, kind, cols, rows, S, kname, ms, ms / T, px * T / ms / 1e6, px * T / ms * 1e3 / (rows * cols), 206.0 * px * T / ms / 1e9 / 8.0, moved,
+        moved = dense / T + 3 + 1 / 8.0
+        print(label + " clip T=%d (%s) %dx%d x%d streams: %-18s %.3f ms per launch = %.3f ms per frame step -> %7.1f Gpix/s = %6.0f 1080p frames/s; "
+              "%d B/px/frame algorithmic -> %.2f of 8 TB/s; bytes actually moved (dense model) %.1f B/px/frame -> %.2f TB/s; wall %.1f Gpix/s"
+              % (T, kind, cols, rows, S, kname, ms, ms / T, px * T / ms / 1e6, px * T / ms * 1e3 / (rows * cols), dense + 5, (dense + 5.0) * px * T / ms / 1e9 / 8.0, moved,
                  moved * px * T / ms / 1e9, px * T * steps / wall / 1e9))
         e.close()
 
@@ -258,6 +258,10 @@ def main():
     if args.only == "clip":
         run_clip(kind="sat")
         run_clip(kind="surv")
+        return
+    if args.only == "clip1":  # MixtureOfGaussianV1BGS clips (16 streams: 320 B/px of model)
+        run_clip(S=16, kind="sat", algo=capi.MOG1, dense=320.0, label="MOG1")
+        run_clip(S=16, kind="surv", algo=capi.MOG1, dense=320.0, label="MOG1")
         return
     if args.only == "lbsp":
         run_lbsp()

@@ -249,6 +249,18 @@ int launch_mog2(bgs_engine* e, bgs::Mog2Args& a, hipStream_t s, bool timed = tru
   return BGS_OK;
 }
 
+void mog1_fill_args(const bgs_engine* e, bgs::Mog1Args& m, double lr) {
+  const bgs_params& p = e->p;
+  const int C = e->ch;
+  const double defaultNoiseSigma = 30 * 0.5;
+  m.alpha = (float)lr, m.T = (float)p.mog1_background_ratio, m.vT = (float)p.mog1_var_threshold;
+  m.w0 = (float)0.05;
+  m.sk0 = C == 3 ? (float)(m.w0 / (defaultNoiseSigma * 2 * std::sqrt(3.))) : (float)(m.w0 / (defaultNoiseSigma * 2));
+  m.var0 = (float)(defaultNoiseSigma * defaultNoiseSigma * 4);
+  m.minVar = (float)(p.mog1_noise_sigma * p.mog1_noise_sigma);
+  m.thr = p.threshold, m.enable_thr = p.enable_threshold, m.packed = m.fg_bits != nullptr, m.xcd_swizzle = e->xcd_swizzle;
+}
+
 void mog2_fill_args(const bgs_engine* e, bgs::Mog2Args& m, double lr) {
   const bgs_params& p = e->p;
   m.state = e->mog2_state, m.nmodes_planar = e->mog2_nmodes, m.plane = e->n * e->S;
@@ -804,14 +816,8 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
       }
       ++nframes;
       lr = (lr >= 0 && nframes > 1) ? lr : 1. / (double)std::min<int64_t>(nframes, p.mog1_history);
-      const double defaultNoiseSigma = 30 * 0.5;
       m.frame = d_frames, m.fg = d_fg, m.fg_bits = d_bits;
-      m.alpha = (float)lr, m.T = (float)p.mog1_background_ratio, m.vT = (float)p.mog1_var_threshold;
-      m.w0 = (float)0.05;
-      m.sk0 = C == 3 ? (float)(m.w0 / (defaultNoiseSigma * 2 * std::sqrt(3.))) : (float)(m.w0 / (defaultNoiseSigma * 2));
-      m.var0 = (float)(defaultNoiseSigma * defaultNoiseSigma * 4);
-      m.minVar = (float)(p.mog1_noise_sigma * p.mog1_noise_sigma);
-      m.thr = p.threshold, m.enable_thr = p.enable_threshold, m.packed = d_bits != nullptr, m.xcd_swizzle = e->xcd_swizzle;
+      mog1_fill_args(e, m, lr);
       {
         Timed tm(e, s, "mog1_update_kernel");
         // one pixel per lane: with write-backs that follow what a pixel changed, pixel-granular stores move fewer bytes and the
@@ -872,7 +878,7 @@ int process_clip(bgs_engine* e, int first, int count, int nframes, const uint8_t
   if (d_bits && npix % 64) return fail(BGS_ERR_UNSUPPORTED, "packed mask needs rows*cols %% 64 == 0");
   const size_t words = npix / 64;
   // lr >= 1 re-initialises the model on every frame (needToInitialize): nothing to keep in registers
-  const bool fuse_ok = e->algo == BGS_MOG2 && e->clip_fuse && p.alpha < 1;
+  const bool fuse_ok = (e->algo == BGS_MOG2 || e->algo == BGS_MOG1) && e->clip_fuse && p.alpha < 1;
   int t = 0;
   while (t < nframes) {
     const int left = nframes - t;
@@ -889,6 +895,37 @@ int process_clip(bgs_engine* e, int first, int count, int nframes, const uint8_t
       for (int i = first; i < first + count; ++i)
         if (e->seen[i] != seen) return fail(BGS_ERR_INVALID, "streams %d and %d are not in lock-step (%lld vs %lld frames)", first, i, (long long)seen, (long long)e->seen[i]);
       HIP_TRY(hipSetDevice(e->device));
+      if (e->algo == BGS_MOG1) {
+        bgs::Mog1ClipArgs c{};
+        c.m.state = e->mog1_state, c.m.state_off = e->n * first, c.m.npix = npix;
+        if (seen == 0) {  // needToInitialize on a stream's first frame
+          if (C == 3)
+            hipLaunchKernelGGL((bgs::mog1_clear_kernel<3>), dim3(blocks_for(npix)), dim3(bgs::kBlock), 0, s, c.m);
+          else
+            hipLaunchKernelGGL((bgs::mog1_clear_kernel<1>), dim3(blocks_for(npix)), dim3(bgs::kBlock), 0, s, c.m);
+        }
+        c.m.frame = fr, c.m.fg = fg, c.m.fg_bits = bits;
+        mog1_fill_args(e, c.m, 0.0);
+        for (int j = 0; j < fuse; ++j) {
+          const int64_t nf = seen + j + 1;
+          c.alpha[j] = (float)((p.alpha >= 0 && nf > 1) ? p.alpha : 1. / (double)std::min<int64_t>(nf, p.mog1_history));
+        }
+        c.frame_stride = npix * C, c.fg_stride = npix, c.bits_stride = words;
+        {
+          Timed tm(e, s, "mog1_clip_kernel");
+          const dim3 grid(blocks_for(npix)), block(bgs::kBlock);
+#define MOG1_CLIP_CASE(CV, TV) \
+  if (C == CV && fuse == TV) hipLaunchKernelGGL((bgs::mog1_clip_kernel<CV, TV>), grid, block, 0, s, c);
+          MOG1_CLIP_CASE(3, 2) MOG1_CLIP_CASE(3, 4) MOG1_CLIP_CASE(3, 8) MOG1_CLIP_CASE(1, 2) MOG1_CLIP_CASE(1, 4) MOG1_CLIP_CASE(1, 8)
+#undef MOG1_CLIP_CASE
+        }
+        HIP_TRY(hipGetLastError());
+        for (int i = first; i < first + count; ++i) e->seen[i] += fuse;
+        if (out_flags)
+          for (int j = 0; j < fuse; ++j) out_flags[t + j] = BGS_FG_VALID;
+        t += fuse;
+        continue;
+      }
       bgs::Mog2ClipArgs c{};
       c.m.state_off = e->n * first, c.m.npix = npix;
       mog2_fill_args(e, c.m, 0.0);

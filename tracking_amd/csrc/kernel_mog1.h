@@ -57,10 +57,10 @@ __device__ __forceinline__ float mog1_varsum(const Mog1Px<C>& s, int k) {
 
 // one pixel, same statement order as process8uC3 so every float rounds identically; returns 0 / 255
 template <int C>
-__device__ __forceinline__ int mog1_pixel(Mog1Px<C>& s, const float (&pix)[C], const Mog1Args& a) {
+__device__ __forceinline__ int mog1_pixel(Mog1Px<C>& s, const float (&pix)[C], const Mog1Args& a, const float alpha) {
   constexpr int K = kMog1K;
   int kHit = -1, kForeground = -1;
-  if (a.alpha > 0) {
+  if (alpha > 0) {
     float wsum = 0;
     bool done = false;
     int k_end = K;  // value of the scan index when the reference's first loop exits
@@ -77,12 +77,12 @@ __device__ __forceinline__ int mog1_pixel(Mog1Px<C>& s, const float (&pix)[C], c
           for (int c = 0; c < C; ++c) diff[c] = pix[c] - s.mu[k][c], d2 += diff[c] * diff[c];
           if (d2 < a.vT * mog1_varsum<C>(s, k)) {
             wsum -= w;
-            const float dw = a.alpha * (1.f - w);
+            const float dw = alpha * (1.f - w);
             s.w[k] = w + dw;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-              s.mu[k][c] = s.mu[k][c] + a.alpha * diff[c];
-              const float v = s.var[k][c] + a.alpha * (diff[c] * diff[c] - s.var[k][c]);
+              s.mu[k][c] = s.mu[k][c] + alpha * diff[c];
+              const float v = s.var[k][c] + alpha * (diff[c] * diff[c] - s.var[k][c]);
               s.var[k][c] = v > a.minVar ? v : a.minVar;
             }
             s.sk[k] = div_rn(w, sqrt_rn(mog1_varsum<C>(s, k)));  // sic: the OLD weight
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void mog1_update_kernel(const Mog1Args a) {
       float pix[C];
 #pragma unroll
       for (int c = 0; c < C; ++c) pix[c] = (float)px[j * C + c];
-      const int m = thr_bin(mog1_pixel<C>(s, pix, a), a.thr, a.enable_thr);
+      const int m = thr_bin(mog1_pixel<C>(s, pix, a, a.alpha), a.thr, a.enable_thr);
       mword |= (uint32_t)m << (8 * j);
       bits |= (uint32_t)(m != 0) << j;
       // write-back is data-dependent (exact): a plane is stored only if one of this lane's pixels changed its bits.  On a
@@ -265,6 +265,84 @@ __global__ __launch_bounds__(kBlock) void mog1_update_kernel(const Mog1Args a) {
     }
   }
   if (a.packed) store_packed_mask<PX>(a.fg_bits, p0, bits, active);
+}
+
+// ---- clip launches (bgs_process_clip_device): T consecutive frames of every stream in one launch, the model of a pixel loaded
+// once, updated T times in registers with the statements of the single-frame kernel, written back once - see kernel_mog2.h.
+// One pixel per lane; the data-dependent loads / stores are the single-frame kernel's: a plane is stored if any frame of the clip
+// changed its bits, a mean / variance slot that was not loaded is written by the pixel that owns a mode there at the end.
+constexpr int kMog1ClipMax = 8;
+struct Mog1ClipArgs {
+  Mog1Args m;                            // frame / fg / fg_bits point at the first frame of the launch
+  size_t frame_stride, fg_stride, bits_stride;  // bytes (bits_stride: 64-bit words) from one frame to the next
+  float alpha[kMog1ClipMax];             // learning rate of each frame (1/n while the history fills)
+};
+
+template <int C, int T>
+__global__ __launch_bounds__(kBlock) void mog1_clip_kernel(const Mog1ClipArgs c) {
+  constexpr int K = kMog1K, R = 2 + 2 * C, NP = K * R;
+  const Mog1Args& a = c.m;
+  size_t blk = blockIdx.x;
+  if (a.xcd_swizzle) {
+    const size_t per = gridDim.x >> 3, main = per << 3;
+    if (blk < main) blk = (blk & 7) * per + (blk >> 3);
+  }
+  const size_t p0 = blk * kBlock + threadIdx.x;
+  if (p0 >= a.npix) return;  // wave-uniform whenever masks are bit-packed (npix % 64 == 0)
+  const size_t sp = a.state_off + p0;
+  uint32_t pixw[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const uint8_t* f = a.frame + (size_t)t * c.frame_stride + p0 * C;
+    if constexpr (C == 3)
+      pixw[t] = (uint32_t)f[0] | ((uint32_t)f[1] << 8) | ((uint32_t)f[2] << 16);
+    else
+      pixw[t] = f[0];
+  }
+  float st[NP];
+  unsigned need = 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) st[k * R] = a.state[mog1_plane_off<C>(k * R, sp)], st[k * R + 1] = a.state[mog1_plane_off<C>(k * R + 1, sp)];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const bool live = st[k * R + 1] >= FLT_EPSILON;
+    need |= (unsigned)live << k;
+#pragma unroll
+    for (int f = 2; f < R; ++f) st[k * R + f] = live ? a.state[mog1_plane_off<C>(k * R + f, sp)] : 0.f;
+  }
+  Mog1Px<C> s;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    s.sk[k] = st[k * R], s.w[k] = st[k * R + 1];
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) s.mu[k][cc] = st[k * R + 2 + cc], s.var[k][cc] = st[k * R + 2 + C + cc];
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    float pix[C];
+#pragma unroll
+    for (int cc = 0; cc < C; ++cc) pix[cc] = (float)((pixw[t] >> (8 * cc)) & 0xffu);
+    const int m = thr_bin(mog1_pixel<C>(s, pix, a, c.alpha[t]), a.thr, a.enable_thr);
+    if (a.fg) a.fg[(size_t)t * c.fg_stride + p0] = (uint8_t)m;
+    if (a.packed) store_packed_mask<1>(a.fg_bits + (size_t)t * c.bits_stride, p0, (uint32_t)(m != 0), true);
+  }
+  auto put = [&](int q, float v) {  // store a plane only if the clip changed its bits
+    if (__float_as_uint(st[q]) != __float_as_uint(v)) a.state[mog1_plane_off<C>(q, sp)] = v;
+  };
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    put(k * R, s.sk[k]), put(k * R + 1, s.w[k]);
+    if ((need >> k) & 1u) {
+#pragma unroll
+      for (int cc = 0; cc < C; ++cc) put(k * R + 2 + cc, s.mu[k][cc]), put(k * R + 2 + C + cc, s.var[k][cc]);
+    } else if (s.w[k] >= FLT_EPSILON) {  // not loaded, now in use: every field, whatever its value
+#pragma unroll
+      for (int cc = 0; cc < C; ++cc) {
+        a.state[mog1_plane_off<C>(k * R + 2 + cc, sp)] = s.mu[k][cc];
+        a.state[mog1_plane_off<C>(k * R + 2 + C + cc, sp)] = s.var[k][cc];
+      }
+    }
+  }
 }
 
 template <int C>
