@@ -187,7 +187,7 @@ int bgs_set_params(bgs_engine* e, const bgs_params* params);
                                    2 also skip loading the planes of modes no pixel of a wave has; 4 the same per lane (4 pixels)
                                    instead of per wave, loads and stores of partial rows; 3 (default) switch between 1 and 4 from a
                                    sparsity sample of the scene */
-#define BGS_OPT_CLIP_FUSE 7     /* 1 (default): bgs_process_clip_device runs 8 / 4 / 2 consecutive MOG2 / MOG1 frames per launch with the
+#define BGS_OPT_CLIP_FUSE 7     /* 1 (default): bgs_process_clip_device runs 8 / 4 / 2 consecutive frames of a mixture model per launch with the
                                    model held in registers; 0: one launch per frame.  Identical results, only speed differs. */
 int bgs_set_option(bgs_engine* e, int option, int64_t value);
 
@@ -231,9 +231,9 @@ int bgs_process_range_device(bgs_engine* e, int first, int count, const void* d_
  *   d_frames  [nframes][count][rows][cols][channels]   frame t of all streams, then frame t+1 ...
  *   d_fg      [nframes][count][rows][cols] or NULL;  d_bg [nframes][count][rows][cols][channels] or NULL
  *   d_fg_bits [nframes][count][rows*cols/64] or NULL;  out_flags: nframes words or NULL
- * MixtureOfGaussianV2BGS and MixtureOfGaussianV1BGS take runs of 8 / 4 / 2 frames through ONE launch that loads each pixel's model
- * once, applies the frames in order in registers and writes the model back once (model traffic per frame / 8, / 4, / 2); every other
- * class runs the same launches as the frame-by-frame calls.
+ * The mixture models (MixtureOfGaussianV2BGS, MixtureOfGaussianV1BGS, DPZivkovicAGMMBGS, DPGrimsonGMMBGS) take runs of 8 / 4 / 2
+ * frames through ONE launch that loads each pixel's model once, applies the frames in order in registers and writes the model back
+ * once (model traffic per frame / 8, / 4, / 2); every other class runs the same launches as the frame-by-frame calls.
  */
 int bgs_process_clip_device(bgs_engine* e, int first, int count, int nframes, const void* d_frames, void* d_fg, void* d_bg,
                             void* d_fg_bits, void* hip_stream, uint32_t* out_flags);

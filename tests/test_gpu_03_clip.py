@@ -5,7 +5,7 @@ sparse level, clip length and starting point."""
 import numpy as np
 import pytest
 
-from gpu_helpers import ALGOS, _params, _torch, check_mog1_state, check_mog2_state, check_state
+from gpu_helpers import ALGOS, _params, _torch, check_dp_state, check_mog1_state, check_mog2_state, check_state
 from oracle import pyoracle
 from tools import synth
 from tracking_amd import Engine, capi
@@ -208,6 +208,34 @@ def test_mog1_clip_gray_and_fused_equals_unfused_bitwise():
     for t in range(T):
         ofg, _ = orc.process(clips[1, t])
         assert np.array_equal(res[0][0][t, 1], ofg), t
+
+
+@pytest.mark.parametrize("name", ["DPZivkovicAGMMBGS", "DPGrimsonGMMBGS"])
+@pytest.mark.parametrize("kw", [dict(), dict(dp_gaussians=5), dict(dp_alpha=0.6, dp_gaussians=4), dict(dp_alpha=0.3, dp_gaussians=2), dict(dp_gaussians=1)])
+def test_dp_gmm_clip_equals_oracle_frame_by_frame(name, kw):
+    """package_bgs/dp GMMs: clips of 8 + 4 + 2 + 1 frames per launch over a scene that keeps jumping (random_frames: 15 % of the
+    pixels jump every frame), so modes are created AND pruned inside a launch (large alpha); masks and the whole model - entries behind
+    the mode count included - against the oracle fed frame by frame."""
+    algo = ALGOS[name]
+    S, T, H, W = 2, 33, 16, 64
+    clips = _clips("random", S, T, H, W, seed=7 + len(name))
+    p = _params(algo, **kw)
+    eng = Engine(algo, params=p, n_streams=S)
+    eng.set_geometry(H, W, 3)
+    orcs = [pyoracle.Oracle(algo, params=p) for _ in range(S)]
+    t0 = 0
+    for n in (15, 8, 1, 9):
+        fg, bits, _, flags = _run_clip(eng, clips, t0, n, want_bg=False)
+        assert all(f == capi.FG_VALID for f in flags)
+        for j in range(n):
+            for s in range(S):
+                ofg, _ = orcs[s].process(clips[s, t0 + j])
+                assert np.array_equal(fg[j, s], ofg), (t0 + j, s, int((fg[j, s] != ofg).sum()))
+                assert np.array_equal(bits[j, s] * 255, np.where(ofg != 0, 255, 0)), (t0 + j, s)
+        t0 += n
+        for s in range(S):
+            assert eng.frames_seen(s) == t0
+            check_dp_state(name, eng, orcs[s], H * W, K=p.dp_gaussians, stream=s)
 
 
 def test_clip_argument_errors():

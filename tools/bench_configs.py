@@ -259,6 +259,11 @@ def main():
         run_clip(kind="sat")
         run_clip(kind="surv")
         return
+    if args.only == "clipdp":  # package_bgs/dp GMMs (K = 3: 60 / 72 B/px of model + the count byte)
+        run_clip(S=16, kind="sat", algo=capi.DP_ZIVKOVIC_AGMM, dense=122.0, label="DPZivkovicAGMM")
+        run_clip(S=16, kind="surv", algo=capi.DP_ZIVKOVIC_AGMM, dense=122.0, label="DPZivkovicAGMM")
+        run_clip(S=16, kind="sat", algo=capi.DP_GRIMSON_GMM, dense=146.0, label="DPGrimsonGMM")
+        return
     if args.only == "clip1":  # MixtureOfGaussianV1BGS clips (16 streams: 320 B/px of model)
         run_clip(S=16, kind="sat", algo=capi.MOG1, dense=320.0, label="MOG1")
         run_clip(S=16, kind="surv", algo=capi.MOG1, dense=320.0, label="MOG1")

@@ -878,7 +878,8 @@ int process_clip(bgs_engine* e, int first, int count, int nframes, const uint8_t
   if (d_bits && npix % 64) return fail(BGS_ERR_UNSUPPORTED, "packed mask needs rows*cols %% 64 == 0");
   const size_t words = npix / 64;
   // lr >= 1 re-initialises the model on every frame (needToInitialize): nothing to keep in registers
-  const bool fuse_ok = (e->algo == BGS_MOG2 || e->algo == BGS_MOG1) && e->clip_fuse && p.alpha < 1;
+  const bool dp_gmm = e->algo == BGS_DP_ZIVKOVIC_AGMM || e->algo == BGS_DP_GRIMSON_GMM;
+  const bool fuse_ok = e->clip_fuse && (dp_gmm || ((e->algo == BGS_MOG2 || e->algo == BGS_MOG1) && p.alpha < 1));
   int t = 0;
   while (t < nframes) {
     const int left = nframes - t;
@@ -895,6 +896,17 @@ int process_clip(bgs_engine* e, int first, int count, int nframes, const uint8_t
       for (int i = first; i < first + count; ++i)
         if (e->seen[i] != seen) return fail(BGS_ERR_INVALID, "streams %d and %d are not in lock-step (%lld vs %lld frames)", first, i, (long long)seen, (long long)e->seen[i]);
       HIP_TRY(hipSetDevice(e->device));
+      if (dp_gmm) {  // package_bgs/dp GMMs: the same kernel with a frame loop (kernel_dp.h)
+        uint32_t fl = 0;
+        int rc = dp_process(e, first, count, seen, fr, fg, bits, s, &fl, fuse);
+        if (rc) return rc;
+        HIP_TRY(hipGetLastError());
+        for (int i = first; i < first + count; ++i) e->seen[i] += fuse;
+        if (out_flags)
+          for (int j = 0; j < fuse; ++j) out_flags[t + j] = fl;
+        t += fuse;
+        continue;
+      }
       if (e->algo == BGS_MOG1) {
         bgs::Mog1ClipArgs c{};
         c.m.state = e->mog1_state, c.m.state_off = e->n * first, c.m.npix = npix;

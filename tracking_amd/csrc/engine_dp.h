@@ -61,9 +61,12 @@ int dp_allocate(bgs_engine* e) {
 }
 
 // one frame (number t, 0-based = the wrappers' frameNumber) for streams [first, first+count)
-int dp_process(bgs_engine* e, int first, int count, int64_t t, const uint8_t* d_frames, uint8_t* d_fg, uint64_t* d_bits, hipStream_t s, uint32_t* flags) {
+// frames > 1 (Zivkovic / Grimson only, from process_clip): that many consecutive frames in one launch, d_* point at the first
+int dp_process(bgs_engine* e, int first, int count, int64_t t, const uint8_t* d_frames, uint8_t* d_fg, uint64_t* d_bits, hipStream_t s, uint32_t* flags,
+               int frames = 1) {
   const bgs_params& p = e->p;
   bgs::DpArgs a{};
+  a.frames = frames, a.frame_stride = e->n * count * 3, a.fg_stride = e->n * count, a.bits_stride = e->n * count / 64;
   a.frame = d_frames, a.state = e->dp_state, a.bstate = e->bgstate, a.fg = d_fg, a.fg_bits = d_bits;
   a.n = e->n, a.npix = e->n * count, a.first = first;
   a.low = p.dp_threshold, a.high = 2 * a.low, a.alpha = p.dp_alpha;  // HighThreshold = 2*LowThreshold, e.g. DPZivkovicAGMMBGS.cpp:58

@@ -31,6 +31,10 @@ struct DpArgs {
   float low, high, alpha;
   int update;            // AdaptiveMedian: frame_num % samplingRate == 1
   int xcd_swizzle;
+  // clip launches of the GMM kernels (bgs_process_clip_device): `frames` consecutive frames per launch, the model in registers in
+  // between; frame / fg / fg_bits point at the first one, the strides lead to the next (bits_stride in 64-bit words).  0 = 1 frame.
+  int frames;
+  size_t frame_stride, fg_stride, bits_stride;
 };
 
 constexpr int kDpTile = 256;
@@ -40,11 +44,11 @@ __device__ __forceinline__ float* dp_plane0(const DpArgs& a, size_t gp, int plan
   return a.state + (g / kDpTile) * (size_t)planes * kDpTile + (g % kDpTile);
 }
 
-__device__ __forceinline__ void dp_store_mask(const DpArgs& a, size_t gp, bool active, int m) {
-  if (active && a.fg) a.fg[gp] = (uint8_t)m;
+__device__ __forceinline__ void dp_store_mask(const DpArgs& a, size_t gp, bool active, int m, int t = 0) {
+  if (active && a.fg) a.fg[(size_t)t * a.fg_stride + gp] = (uint8_t)m;
   if (a.fg_bits) {  // npix % 64 == 0 is checked on the host: a wave is either all active or all idle
     const unsigned long long w = __ballot(active && m != 0);
-    if ((threadIdx.x & (kWave - 1)) == 0 && active) a.fg_bits[gp >> 6] = w;
+    if ((threadIdx.x & (kWave - 1)) == 0 && active) a.fg_bits[(size_t)t * a.bits_stride + (gp >> 6)] = w;
   }
 }
 
@@ -55,17 +59,22 @@ __global__ __launch_bounds__(kBlock) void dp_gmm_kernel(const DpArgs a) {
   constexpr int VAR = 0, MU = 1, WEIGHT = 4, SIG = 5;
   const size_t gp = xcd_block(a.xcd_swizzle) * kBlock + threadIdx.x;
   const bool active = gp < a.npix;
-  int mask = 0;
+  const int T = a.frames > 0 ? a.frames : 1;  // frames of this launch (clip launches: the model stays in registers in between)
+  float* st = nullptr;
+  uint8_t* pn = nullptr;
+  int nModes = 0, nLoaded = 0, nUsed = 0;
+  float g[K][F];
+  uint32_t g0[K][F];
+  uint32_t pw = 0;
   if (active) {
-    float* st = dp_plane0(a, gp, K * F);
-    uint8_t* pn = a.bstate + (size_t)a.first * a.n + gp;
+    st = dp_plane0(a, gp, K * F);
+    pn = a.bstate + (size_t)a.first * a.n + gp;
+    pw = (uint32_t)a.frame[gp * 3] | ((uint32_t)a.frame[gp * 3 + 1] << 8) | ((uint32_t)a.frame[gp * 3 + 2] << 16);
     // Data-dependent traffic (exact): the sources never read a mode at an index >= the pixel's count (they only create one
     // there, writing every field), so only the used modes are loaded; at the end a field is stored if its bits changed, or
     // unconditionally when the slot was not loaded and is now in use.  One lane = one pixel: no neighbour shares the slot.
-    int nModes = *pn;
-    const int nLoaded = nModes;
-    float g[K][F];
-    uint32_t g0[K][F];
+    nModes = *pn;
+    nLoaded = nModes;
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
@@ -73,7 +82,15 @@ __global__ __launch_bounds__(kBlock) void dp_gmm_kernel(const DpArgs a) {
         g[k][f] = k < nLoaded ? st[(k * F + f) * kDpTile] : 0.f;
         g0[k][f] = __float_as_uint(g[k][f]);
       }
-    const float px[3] = {(float)a.frame[gp * 3], (float)a.frame[gp * 3 + 1], (float)a.frame[gp * 3 + 2]};
+  }
+  for (int t = 0; t < T; ++t) {
+  int mask = 0;
+  if (active) {
+    const float px[3] = {(float)(pw & 0xffu), (float)((pw >> 8) & 0xffu), (float)(pw >> 16)};
+    if (t + 1 < T) {  // the next frame's pixel, requested before this frame's arithmetic
+      const uint8_t* nf = a.frame + (size_t)(t + 1) * a.frame_stride + gp * 3;
+      pw = (uint32_t)nf[0] | ((uint32_t)nf[1] << 8) | ((uint32_t)nf[2] << 16);
+    }
     const float m_bg_threshold = 0.75f, m_variance = 36.0f, m_complexity_prior = 0.05f;
     const float Alpha = a.alpha;
     bool bFitsPDF = false, bBackgroundHigh = false;
@@ -240,15 +257,21 @@ __global__ __launch_bounds__(kBlock) void dp_gmm_kernel(const DpArgs a) {
       }
     }
     if constexpr (GRIMSON) grimson_sort(nModes);  // the second qsort runs whether or not a mode was added (:281)
+    mask = bBackgroundHigh ? 0 : 255;
+    nUsed = max(nUsed, nModes);
+  }
+  dp_store_mask(a, gp, active, mask, t);
+  }
+  if (active) {
+    // a slot that was not loaded is written if it was in use at the end of ANY frame of the launch: the source wrote it then, and a
+    // later frame that prunes the mode again leaves those values behind the count
     if (nModes != nLoaded) *pn = (uint8_t)nModes;
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
       for (int f = 0; f < F; ++f)
-        if (k < nLoaded ? __float_as_uint(g[k][f]) != g0[k][f] : k < nModes) st[(k * F + f) * kDpTile] = g[k][f];
-    mask = bBackgroundHigh ? 0 : 255;
+        if (k < nLoaded ? __float_as_uint(g[k][f]) != g0[k][f] : k < nUsed) st[(k * F + f) * kDpTile] = g[k][f];
   }
-  dp_store_mask(a, gp, active, mask);
 }
 
 __global__ __launch_bounds__(kBlock) void dp_wren_kernel(const DpArgs a) {

@@ -317,6 +317,7 @@ __global__ __launch_bounds__(kBlock) void mog1_clip_kernel(const Mog1ClipArgs c)
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) s.mu[k][cc] = st[k * R + 2 + cc], s.var[k][cc] = st[k * R + 2 + C + cc];
   }
+  unsigned everLive = 0;
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     float pix[C];
@@ -325,6 +326,8 @@ __global__ __launch_bounds__(kBlock) void mog1_clip_kernel(const Mog1ClipArgs c)
     const int m = thr_bin(mog1_pixel<C>(s, pix, a, c.alpha[t]), a.thr, a.enable_thr);
     if (a.fg) a.fg[(size_t)t * c.fg_stride + p0] = (uint8_t)m;
     if (a.packed) store_packed_mask<1>(a.fg_bits + (size_t)t * c.bits_stride, p0, (uint32_t)(m != 0), true);
+#pragma unroll
+    for (int k = 0; k < K; ++k) everLive |= (unsigned)(s.w[k] >= FLT_EPSILON) << k;
   }
   auto put = [&](int q, float v) {  // store a plane only if the clip changed its bits
     if (__float_as_uint(st[q]) != __float_as_uint(v)) a.state[mog1_plane_off<C>(q, sp)] = v;
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(kBlock) void mog1_clip_kernel(const Mog1ClipArgs c)
     if ((need >> k) & 1u) {
 #pragma unroll
       for (int cc = 0; cc < C; ++cc) put(k * R + 2 + cc, s.mu[k][cc]), put(k * R + 2 + C + cc, s.var[k][cc]);
-    } else if (s.w[k] >= FLT_EPSILON) {  // not loaded, now in use: every field, whatever its value
+    } else if ((everLive >> k) & 1u) {  // not loaded, in use after some frame of the clip (the reference wrote it then): every field
 #pragma unroll
       for (int cc = 0; cc < C; ++cc) {
         a.state[mog1_plane_off<C>(k * R + 2 + cc, sp)] = s.mu[k][cc];
