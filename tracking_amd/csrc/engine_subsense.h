@@ -73,7 +73,8 @@ int ss_allocate(bgs_engine* e) {
       return fail(BGS_ERR_UNSUPPORTED, "SuBSENSE frame-level analysis: rows and cols must be multiples of 8 (cv::resize INTER_AREA with an integer ratio)");
   }
   const size_t N = e->n, P = N * e->S, nS = (size_t)p.subsense_n_samples, C = (size_t)e->ch;
-  d->pixelMajor = 1, d->nSpad = ((int)nS + bgs::kSsBatch - 1) / bgs::kSsBatch * bgs::kSsBatch;  // pixel-major records in whole batches (kernel_subsense.h: phase A)
+  // records: the first batch of kSsBatch samples sample-major, the rest pixel-major in whole double batches (kernel_subsense.h: ss_rec, phase A)
+  d->pixelMajor = 1, d->nSpad = bgs::kSsBatch + ((int)std::max<size_t>(nS, bgs::kSsBatch) - bgs::kSsBatch + 2 * bgs::kSsBatch - 1) / (2 * bgs::kSsBatch) * (2 * bgs::kSsBatch);
   DMALLOC(d->samples, P * (size_t)d->nSpad * (C == 3 ? 16 : 4));
   DMALLOC(d->lastColor, P * C);
   DMALLOC(d->lastDesc, P * C * 2);

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
     // kernel ran at the L1's limit of outstanding misses (rocprofv3: TCP_PENDING_STALL 84 % of the cycles, 94 M line requests of
     // which a quarter of every 64-byte sector was used, 10.6 GB fetched per launch on 8 x 1080p); the sample ORDER is unchanged.
     constexpr int B = kSsBatch;
-    size_t rec = 0, rstep = 1, rnext = 0;  // first record and record stride of the batch to request NEXT for this lane's pixel; its batch 1
+    size_t rec = 0, rnext = 0;  // first record of the samples this lane holds; the pixel's first pixel-major record
     SsSample<C> bt[B], nbt[B];
 #pragma unroll
     for (int j = 0; j < B; ++j) bt[j] = SsSample<C>{}, nbt[j] = SsSample<C>{};
@@ -304,9 +304,9 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
 #pragma unroll
             for (int c = 0; c < C; ++c) curm[c] = (uint32_t)cur[c] << (8 * c);
             const size_t p = (size_t)(y0 + ly) * a.cols + (x0 + lx);
-            rec = ss_rec(a, stream, N, p, 0), rstep = N, rnext = ss_rec(a, stream, N, p, B);
+            rec = ss_rec(a, stream, N, p, 0), rnext = ss_rec(a, stream, N, p, B);
 #pragma unroll
-            for (int j = 0; j < B; ++j) bt[j] = nbt[j] = SsSample<C>::load(a.samples, rec + j * rstep);
+            for (int j = 0; j < B; ++j) bt[j] = SsSample<C>::load(a.samples, rec + j * N);
             idx = 0, good = 0, minDesc = maxDesc, minSum = maxColor;
             active = true;
           }
@@ -314,46 +314,48 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
       }
       EXP_COUNT(0, 1);  // wave-iterations
       if (active) {
-        if (good < a.nReq && idx < a.nS) {  // :469-497 (BGR) / :334-357 (gray); batch idx/4 + 1 is in flight while batch idx/4 is tested
-          // Unconditional (the last batch re-reads itself) so that the loaded registers ARE nbt: under a condition the compiler
-          // merged them with the old value through copies placed right behind the load - with an s_waitcnt vmcnt(0) in front
-          // - and every trip paid the full memory latency (found in the ISA, round 2).
-          // Most pixels of a quiet scene are done inside their first batch: a lane does not prefetch behind batch 0 (it re-reads
-          // batch 0, an L1 hit) and pays the latency of batch 1 once if it does go on; from batch 1 on the next one is in flight.
-          rec += (idx > 0 && idx + B < a.nS) ? B : 0;
+        if (good < a.nReq && idx < a.nS) {  // :469-497 (BGR) / :334-357 (gray)
+          // One trip = the samples a lane holds: batch 0 (four samples, bt) on a pixel's first trip, then EIGHT at a time (bt + nbt,
+          // 128 contiguous bytes of the pixel-major part).  Two passes.  R: the cheap exact rejection tests on all held samples,
+          // every lane busy -> candidate bits.  I: the inter-LBSP test (~150 instructions), one candidate per lane and pass in
+          // sample order, stopping at the nReq-th match exactly like the reference's loop (:469).  Interleaved sample by sample,
+          // nearly every trip of a wave paid the inter-LBSP step for the few lanes that needed it (12 % of the samples get that
+          // far: 94 % of the trips of 64 lanes); per eight samples it is paid ~3.5 times instead of 8.  Rejected samples and
+          // samples behind the nReq-th match have no side effects, and min() does not care about order.
+          const bool wide = idx > 0;
+          auto reject_bits = [&](const SsSample<C>(&bb)[B], int first) -> uint32_t {
+            uint32_t bits = 0;
+            if constexpr (C == 1) {
 #pragma unroll
-          for (int j = 0; j < B; ++j) nbt[j] = SsSample<C>::load(a.samples, rec + j * rstep);
-          // Two passes over the batch.  R: the cheap exact rejection tests on all B samples, every lane busy -> candidate bits.
-          // I: the inter-LBSP test (~150 instructions), one candidate per lane and pass in sample order, stopping at the nReq-th
-          // match exactly like the reference's loop (:469).  Interleaved sample by sample, nearly every trip of a wave paid the
-          // inter-LBSP step for the few lanes that needed it (12 % of the samples get that far: 94 % of the trips of 64 lanes);
-          // per batch of four it is paid ~2.3 times instead of 4.  Rejected samples and samples behind the nReq-th match have no
-          // side effects, and min() does not care about order.
-          uint32_t cand = 0;
-          if constexpr (C == 1) {
+              for (int j = 0; j < B; ++j) bits |= (uint32_t)(first + j < a.nS && (uint32_t)abs(cur[0] - bb[j].color(0)) <= colorThr) << j;
+            } else {
+              // The reference walks the channels in order and drops the sample at the first failed test (:474-491); a sample is kept
+              // only if every test passes, so the tests may run in any order.  Exact rejections first, from what costs least:
+              // lower bounds with the intra half of the descriptor distance alone (dd >= intraD/2, and sd grows with dd).  The
+              // per-channel colour test cd <= scColorThr is implied by the one on the bound lbsd = min(255, k + cd): either
+              // lbsd = k + cd >= cd, or lbsd = 255 <= scColorThr and cd <= 255.
+              const uint32_t totColorThr = colorThr * 3, totDescThr = descThr * 3, scColorThr = totColorThr / 2;
 #pragma unroll
-            for (int j = 0; j < B; ++j) cand |= (uint32_t)(idx + j < a.nS && (uint32_t)abs(cur[0] - bt[j].color(0)) <= colorThr) << j;
-          } else {
-            // The reference walks the channels in order and drops the sample at the first failed test (:474-491); a sample is kept
-            // only if every test passes, so the tests may run in any order.  Exact rejections first, from what costs least:
-            // lower bounds with the intra half of the descriptor distance alone (dd >= intraD/2, and sd grows with dd).  The
-            // per-channel colour test cd <= scColorThr is implied by the one on the bound lbsd = min(255, k + cd): either
-            // lbsd = k + cd >= cd, or lbsd = 255 <= scColorThr and cd <= 255.
-            const uint32_t totColorThr = colorThr * 3, totDescThr = descThr * 3, scColorThr = totColorThr / 2;
+              for (int j = 0; j < B; ++j) {
+                const uint32_t sx = bb[j].v.x, sy = bb[j].v.y, sz = bb[j].v.z;
+                uint32_t cd[3], lbdd[3], lbsd[3];
+                cd[0] = __builtin_amdgcn_sad_u8(curm[0], sx & 0x0000ffu, 0u);
+                cd[1] = __builtin_amdgcn_sad_u8(curm[1], sx & 0x00ff00u, 0u);
+                cd[2] = __builtin_amdgcn_sad_u8(curm[2], sx & 0xff0000u, 0u);
+                const uint32_t xy = iy ^ sy;
+                lbdd[0] = (uint32_t)__popc(xy & 0xffffu) >> 1, lbdd[1] = (uint32_t)__popc(xy >> 16) >> 1, lbdd[2] = (uint32_t)__popc(iz ^ sz) >> 1;
 #pragma unroll
-            for (int j = 0; j < B; ++j) {
-              const uint32_t sx = bt[j].v.x, sy = bt[j].v.y, sz = bt[j].v.z;
-              uint32_t cd[3], lbdd[3], lbsd[3];
-              cd[0] = __builtin_amdgcn_sad_u8(curm[0], sx & 0x0000ffu, 0u);
-              cd[1] = __builtin_amdgcn_sad_u8(curm[1], sx & 0x00ff00u, 0u);
-              cd[2] = __builtin_amdgcn_sad_u8(curm[2], sx & 0xff0000u, 0u);
-              const uint32_t xy = iy ^ sy;
-              lbdd[0] = (uint32_t)__popc(xy & 0xffffu) >> 1, lbdd[1] = (uint32_t)__popc(xy >> 16) >> 1, lbdd[2] = (uint32_t)__popc(iz ^ sz) >> 1;
-#pragma unroll
-              for (int c = 0; c < 3; ++c) lbsd[c] = min((lbdd[c] >> 1) * (255 / 16) + cd[c], 255u);
-              const bool ok = max(max(lbsd[0], lbsd[1]), lbsd[2]) <= scColorThr && lbdd[0] + lbdd[1] + lbdd[2] <= totDescThr && lbsd[0] + lbsd[1] + lbsd[2] <= totColorThr;
-              cand |= (uint32_t)(ok && idx + j < a.nS) << j;
+                for (int c = 0; c < 3; ++c) lbsd[c] = min((lbdd[c] >> 1) * (255 / 16) + cd[c], 255u);
+                const bool ok = max(max(lbsd[0], lbsd[1]), lbsd[2]) <= scColorThr && lbdd[0] + lbdd[1] + lbdd[2] <= totDescThr && lbsd[0] + lbsd[1] + lbsd[2] <= totColorThr;
+                bits |= (uint32_t)(ok && first + j < a.nS) << j;
+              }
             }
+            return bits;
+          };
+          uint32_t cand = reject_bits(bt, idx);
+          if (__any(wide)) {
+            const uint32_t hi = reject_bits(nbt, idx + B);
+            if (wide) cand |= hi << B;
           }
           for (;;) {
             const bool go = cand != 0 && good < a.nReq;
@@ -365,6 +367,9 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
 #pragma unroll
               for (int jj = 1; jj < B; ++jj)
                 if (j == jj) smp = bt[jj];
+#pragma unroll
+              for (int jj = 0; jj < B; ++jj)
+                if (j == B + jj) smp = nbt[jj];
               if constexpr (C == 1) {
                 const int bcc = smp.color(0);
                 const unsigned bdc = smp.desc(0);
@@ -406,16 +411,11 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
               }
             }
           }
-          idx += B;
+          idx += wide ? 2 * B : B;
+          if (good < a.nReq && idx < a.nS) {  // not done: the next eight samples (the first trip leaves the sample-major part here)
+            rec = wide ? rec + 2 * B : rnext;
 #pragma unroll
-          for (int j = 0; j < B; ++j) {
-            ss_wait_here(nbt[j]);  // the wait for the next batch belongs HERE, behind the tests of this one
-            bt[j] = nbt[j];
-          }
-          if (idx == B && good < a.nReq && idx < a.nS) {  // leaving batch 0 and not done: fetch batch 1 now, from the pixel-major part
-            rec = rnext, rstep = 1;
-#pragma unroll
-            for (int j = 0; j < B; ++j) bt[j] = SsSample<C>::load(a.samples, rec + j);
+            for (int j = 0; j < B; ++j) bt[j] = SsSample<C>::load(a.samples, rec + j), nbt[j] = SsSample<C>::load(a.samples, rec + B + j);
           }
         }
         if (!(good < a.nReq && idx < a.nS)) {
