@@ -691,3 +691,39 @@ def test_disjoint_stream_ranges_in_flight_on_two_hip_streams(algo):
             ofg, _ = orc.process(clips[s, t], want_bg=False)
             assert np.array_equal(got[t, s], ofg), (s, t, int((got[t, s] != ofg).sum()))
     eng.close()
+
+
+def test_engines_release_their_device_memory():
+    """Create -> geometry -> a few frames (host and device path) -> destroy, every class, three times over: the device's free memory
+    returns to where it started (every buffer an engine allocates - models, bit planes, staging, probe candidates - is freed)."""
+    torch = _torch()
+    H, W = 96, 128
+    frames = synth.random_frames(4, H, W, 3, seed=1)
+    d = torch.from_numpy(np.ascontiguousarray(frames)).cuda()
+    algos = list(ALGOS.values()) + [capi.SUBSENSE, capi.LOBSTER]
+
+    def cycle():
+        for algo in algos:
+            e = Engine(algo, n_streams=2)
+            e.set_geometry(H, W, 3)
+            fg = torch.zeros((2, H, W), dtype=torch.uint8, device="cuda")
+            for t in range(3):
+                e.process_batch_device(torch.stack([d[t], d[t + 1]]).contiguous(), fg)
+            e.process_clip_device(torch.stack([torch.stack([d[0], d[1]]), torch.stack([d[2], d[3]])]).contiguous(), 2, None)
+            torch.cuda.synchronize()
+            e.close()
+            h = Engine(algo)
+            h.process(frames[0])
+            h.process(frames[1])
+            h.close()
+
+    cycle()  # first pass: one-time allocations of the runtime itself
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(3):
+        cycle()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), "device memory shrank by %d bytes over three create/destroy cycles" % (free0 - free1)

@@ -4,7 +4,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/trace_ss
 mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT/raw -o t -- python3 $GRAFT_REPO_ROOT/tools/bench_configs.py --only subsense8 > $OUT/run.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/raw -o t -- python3 $GRAFT_REPO_ROOT/tools/bench_configs.py --only ${LEG:-subsense8} > $OUT/run.log 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, sys
 out = sys.argv[1]
