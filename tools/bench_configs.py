@@ -268,6 +268,11 @@ def main():
         run_clip(S=16, kind="sat", algo=capi.MOG1, dense=320.0, label="MOG1")
         run_clip(S=16, kind="surv", algo=capi.MOG1, dense=320.0, label="MOG1")
         return
+    if args.only == "byte32":  # the same byte-stream kernels with 32 x 4K per launch (2.6 GB): how much of the gap to 0.79 is launch size
+        run(capi.WMV, "WeightedMovingVarianceBGS", 2160, 3840, 32, 10, cpu_frames=0, steps=30)
+        run(capi.ABL, "AdaptiveBackgroundLearning", 2160, 3840, 32, 10, borrow=False, cpu_frames=0, steps=30)
+        run(capi.FRAME_DIFF, "FrameDifferenceBGS", 2160, 3840, 32, 7, cpu_frames=0, steps=30)
+        return
     if args.only == "lbsp":
         run_lbsp()
         return

@@ -17,14 +17,15 @@
 //
 // Background samples are RECORDS: colour and LBSP descriptor of one sample of one pixel together in 16 bytes (BGR: b g r 0 |
 // d0 d1 | d2 0 | 0; 4 bytes for gray: c 0 | d), one vector load per sample in the sample-consensus loops, one store per model
-// update.  Order: SAMPLE-MAJOR [nS][N], one plane per sample index (ss_rec; a pixel-major order is kept selectable there).
-// Round 2 measured the alternatives on 8 x 1080p S_surv (profiles/r02_subsense_phase_a_pmc.txt): planar colour / descriptor
-// arrays (six loads per sample): phase A 2.95 ms, whole step 4.60; these records: 2.96 / 4.42 (phase B's scattered writes are one
-// store each); pixel-major [N][nS] with one load per sample: 3.2-3.6 (1024 resident lanes each want their own line kept, the L1
-// holds 256); pixel-major with 64-byte batches into registers: 3.06, line requests halved (TCP_TCC_READ_REQ 178 M -> 95 M per
-// launch) but +45 % memory and more instructions.  The kernel is VALU-bound, none of this is what limits it.
-// Ten f32 maps [N] (+2 second copies), byte maps [N].  The current frame's 5x5 neighbourhood is staged through LDS once per workgroup (phase A: 64x32 pixel tile +
-// halo 2, with an LDS work queue over its pixels; phase B and LOBSTER's phase A: 64x4).
+// update.  Order (ss_rec): LOBSTER sample-major [nS][N]; SuBSENSE the first four samples sample-major, the rest pixel-major in
+// double batches of eight, because its phase A reads a pixel's samples four and then eight at a time.
+// How round 2 got there on 8 x 1080p S_surv (profiles/r02_subsense_phase_a_pmc.txt): planar colour / descriptor
+// arrays (six loads per sample) -> these records (phase B's scattered writes one store each) -> the sample prefetch freed from a
+// misplaced s_waitcnt (2.95 -> 2.56 ms; every earlier layout experiment had been latency-bound on it and said nothing) -> the L1's
+// miss capacity as the limit, hence batches (2.40) -> rejection tests per batch, inter-LBSP per candidate pass (2.17) -> eight
+// samples per trip (1.99): VALU-bound.
+// Ten f32 maps [N] (+2 second copies), byte maps [N].  The current frame's 5x5 neighbourhood is staged through LDS once per
+// workgroup (phase A: 64x32 pixel tile + halo 2, with an LDS work queue over its pixels; phase B: 64x16 targets; LOBSTER's phase A: 64x4).
 //   lob_phase_a_kernel   LOBSTER's operator()                     BackgroundSubtractorLOBSTER.cpp:172-284 (shares phase B, refresh, background)
 #pragma once
 #include "bgs_device.h"
@@ -43,8 +44,8 @@ struct SsScalars {
 
 struct SsArgs {
   const uint8_t* frame;  // [S][N][3]
-  void* samples;         // records (SsSample<C>), see ss_rec(): SuBSENSE pixel-major [S][N][nSpad], LOBSTER sample-major [S][nS][N]
-  int nSpad, pixelMajor; // records per pixel in the pixel-major order (nS rounded up to a whole batch of 4)
+  void* samples;         // records (SsSample<C>), order: ss_rec()
+  int nSpad, pixelMajor; // records held per pixel (nS padded to 4 + whole groups of 8); 1: SuBSENSE's order, 0: sample-major planes
   float *R, *V, *T, *DlastOld, *DlastNew, *DminLT, *DminST, *RawLT, *RawSTOld, *RawSTNew, *FinLT, *FinST;  // [S][N]
   uint8_t *unstable, *blinks, *lastFG, *lastRaw, *lastRawBlink, *lastDilInv, *lastColor;                  // [S][N] ([S][N][3])
   uint16_t* lastDesc;    // [S][N][3]
@@ -131,7 +132,7 @@ __device__ __forceinline__ void ss_wait_here(SsSample<1>& s) { asm volatile("" :
 //   pixelMajor == 0 (LOBSTER): sample-major planes [nS][N].
 //   pixelMajor == 1 (SuBSENSE): per stream, the FIRST batch (samples 0 .. kSsBatch-1) as sample-major planes [kSsBatch][N] - the
 //     samples every pixel tests, and a quiet scene tests nothing else: neighbouring pixels' records share cache lines - followed
-//     by the remaining nSpad - kSsBatch samples PIXEL-major [N][nSpad - kSsBatch]: a pixel that walks on fetches its next four
+//     by the remaining nSpad - kSsBatch samples PIXEL-major [N][nSpad - kSsBatch]: a pixel that walks on fetches its next eight
 //     samples as 64 contiguous bytes (ss_phase_a_kernel).
 constexpr int kSsBatch = 4;
 __device__ __forceinline__ size_t ss_rec(const SsArgs& a, int stream, size_t N, size_t p, int k) {
@@ -251,12 +252,10 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
   __syncthreads();
 
   // ---- stage 2: sample consensus, lanes fed from the queue
-  // rocprofv3 (round 2, 8 x 1080p S_surv): 21 samples are tested per pixel and 2.6 of them get as far as the inter-LBSP step; the
-  // kernel is VALU-bound (VALU active 71 % of the time, 4 700 VALU instructions per pixel, of which ~80 per loop iteration in the
-  // rejection tests) - experiments that only changed the memory side (one load per sample instead of six, pixel-major batches,
-  // deeper prefetch) or only ran the inter-LBSP step less often (parking) left its 2.95 ms where they were.  So the rejection
-  // tests are written for instruction count: the three colour distances with v_sad_u8 on masked words, the three intra
-  // descriptor distances from two XORs, and the per-channel colour test folded into the bound on sd (sd >= cd, see below).
+  // rocprofv3 (round 2, 8 x 1080p S_surv): 21 samples are tested per pixel and 2.6 of them get as far as the inter-LBSP step.  The
+  // rejection tests are written for instruction count - the three colour distances with v_sad_u8 on masked words, the three intra
+  // descriptor distances from two XORs, the per-channel colour test folded into the bound on sd (sd >= cd, see below) - because at
+  // the end of round 2 the kernel is VALU-bound (92 % of the SIMD cycles are vector issue).
   {
     const int lane = threadIdx.x & (kWave - 1);
     bool active = false, qempty = false;
@@ -267,10 +266,10 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
     uint32_t nb[C][8];
     uint32_t curm[C];  // the current colour, channel c alone in byte c of a word (BGR); the gray value (gray)
     uint32_t iy = 0, iz = 0;  // intra descriptors as the records hold them: d0 | d1 << 16, d2
-    // Records (ss_rec): the first batch sample-major, the rest PIXEL-major in whole batches: a lane fetches its pixel's samples four at
-    // a time, from batch 1 on as 64 contiguous bytes (16 for gray) = memory requests that are all payload.  With one 16-byte record per request the
-    // kernel ran at the L1's limit of outstanding misses (rocprofv3: TCP_PENDING_STALL 84 % of the cycles, 94 M line requests of
-    // which a quarter of every 64-byte sector was used, 10.6 GB fetched per launch on 8 x 1080p); the sample ORDER is unchanged.
+    // Records (ss_rec): the first batch sample-major, the rest PIXEL-major: a lane holds four samples on its pixel's first trip and
+    // eight (128 contiguous bytes; 32 for gray) on every later one - memory requests that are all payload.  With one 16-byte record
+    // per request the kernel ran at the L1's limit of outstanding misses (rocprofv3: TCP_PENDING_STALL 84 % of the cycles, 94 M line
+    // requests of which a quarter of every 64-byte sector was used, 10.6 GB fetched per launch on 8 x 1080p); the sample ORDER is unchanged.
     constexpr int B = kSsBatch;
     size_t rec = 0, rnext = 0;  // first record of the samples this lane holds; the pixel's first pixel-major record
     SsSample<C> bt[B], nbt[B];
