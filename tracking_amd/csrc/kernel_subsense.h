@@ -133,7 +133,7 @@ __device__ __forceinline__ void ss_wait_here(SsSample<1>& s) { asm volatile("" :
 //   pixelMajor == 1 (SuBSENSE): per stream, the FIRST batch (samples 0 .. kSsBatch-1) as sample-major planes [kSsBatch][N] - the
 //     samples every pixel tests, and a quiet scene tests nothing else: neighbouring pixels' records share cache lines - followed
 //     by the remaining nSpad - kSsBatch samples PIXEL-major [N][nSpad - kSsBatch]: a pixel that walks on fetches its next eight
-//     samples as 64 contiguous bytes (ss_phase_a_kernel).
+//     samples as 128 contiguous bytes (ss_phase_a_kernel).
 constexpr int kSsBatch = 4;
 __device__ __forceinline__ size_t ss_rec(const SsArgs& a, int stream, size_t N, size_t p, int k) {
   if (!a.pixelMajor) return ((size_t)stream * (size_t)a.nS + (size_t)k) * N + p;
