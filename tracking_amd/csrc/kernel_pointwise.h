@@ -261,6 +261,30 @@ struct SigmaDeltaArgs {
   int vmin, vmax, xcd_swizzle;
 };
 
+// Two bytes per instruction: the byte pairs (0, 2) and (1, 3) of a dword as 16-bit lanes (v_pk_* on CDNA).  One step of the
+// estimator on both lanes; returns 1 in a lane whose channel does NOT vote foreground.  N <= 256 so that N * ot fits 16 bits.
+typedef short sd_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short sd_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t sd_pair(uint32_t im2, uint32_t& m2, uint32_t& v2, uint32_t n2, uint32_t vmin2, uint32_t vmax2) {
+  auto S = [](uint32_t w) { return __builtin_bit_cast(sd_s2, w); };
+  auto U = [](uint32_t w) { return __builtin_bit_cast(sd_u2, w); };
+  auto W = [](auto v) { return __builtin_bit_cast(uint32_t, v); };
+  const sd_s2 one = {1, 1}, mone = {-1, -1};
+  // sdLaMa091.cpp:535-540  Mt += sign(It - Mt)
+  sd_s2 m = S(m2) + __builtin_elementwise_min(__builtin_elementwise_max(S(im2) - S(m2), mone), one);
+  // :559 absVal((int8_t)(Mt - It)): u = (Mt - It) mod 256, |int8(u)| mod 256 = min(u, 256 - u)
+  const sd_u2 u = U(W(m - S(im2)) & 0x00ff00ffu), c256 = {256, 256};
+  const sd_u2 ot = __builtin_elementwise_min(u, (sd_u2)(c256 - u));
+  // :576-581  Vt += sign(N * Ot - Vt) on a uint8 (255 + 1 wraps to 0); N * Ot only matters up to 256
+  const sd_u2 amp = __builtin_elementwise_min((sd_u2)(ot * U(n2)), c256);
+  sd_s2 v = S(v2) + __builtin_elementwise_min(__builtin_elementwise_max(S(W(amp)) - S(v2), mone), one);
+  sd_u2 vu = U(W(v) & 0x00ff00ffu);
+  vu = __builtin_elementwise_max(__builtin_elementwise_min(vu, U(vmax2)), U(vmin2));  // :583
+  m2 = W(m), v2 = W(vu);
+  // :605  foreground vote Ot >= Vt; the complement: bit 15 of (Ot - Vt) as 0 / 1 per lane
+  return (W(S(W(ot)) - S(W(vu))) >> 15) & 0x00010001u;
+}
+
 template <int G>
 __global__ __launch_bounds__(kBlock) void sigmadelta_kernel(const SigmaDeltaArgs a) {
   const size_t p0 = (xcd_block(a.xcd_swizzle) * kBlock + threadIdx.x) * G;
@@ -274,28 +298,55 @@ __global__ __launch_bounds__(kBlock) void sigmadelta_kernel(const SigmaDeltaArgs
     x.load(a.cur + p0 * 3);
     mt.load(a.mt + p0 * 3);
     vt.load(a.vt + p0 * 3);
+    if (G % 4 == 0 && a.N <= 256u) {
+      // 4 pixels = 12 bytes = 3 dwords at a time, two bytes per packed 16-bit instruction (38 instead of 73 instructions per pixel)
+      const uint32_t n2 = a.N * 0x10001u, vmin2 = (uint32_t)a.vmin * 0x10001u, vmax2 = (uint32_t)a.vmax * 0x10001u;
 #pragma unroll
-    for (int j = 0; j < G; ++j) {
-      bool isfg = false;
+      for (int g = 0; g < G / 4; ++g) {
+        uint32_t nf[3];  // per byte: 1 = this channel does not vote foreground
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int i = 3 * j + c;
-        int mv = mt.b.get(i);
-        const int im = x.b.get(i);
-        mv += (mv < im) - (mv > im);                                   // sdLaMa091.cpp:535-540
-        const int d8 = (int)(int8_t)(uint8_t)(mv - im);                // :559 absVal(int8_t): the difference wraps to int8 first
-        const uint32_t ot = (uint32_t)(d8 < 0 ? -d8 : d8) & 0xffu;
-        const uint32_t amp = a.N * ot;                                 // :576
-        uint32_t v = (uint32_t)vt.b.get(i);
-        v = (v + (v < amp) - (v > amp)) & 0xffu;                       // :578-581 on a uint8: 255+1 wraps to 0
-        v = min(v, (uint32_t)a.vmax);                                  // :583 max(min(Vt, Vmax), Vmin) with uint8 operands
-        v = max(v, (uint32_t)a.vmin);
-        isfg = isfg || ot >= v;                                        // :605
-        mt.b.set(i, mv);
-        vt.b.set(i, (int)v);
+        for (int d = 0; d < 3; ++d) {
+          const int i = 3 * g + d;
+          const uint32_t xw = x.b.w[i], mw = mt.b.w[i], vw = vt.b.w[i];
+          uint32_t mlo = mw & 0x00ff00ffu, mhi = (mw >> 8) & 0x00ff00ffu, vlo = vw & 0x00ff00ffu, vhi = (vw >> 8) & 0x00ff00ffu;
+          const uint32_t flo = sd_pair(xw & 0x00ff00ffu, mlo, vlo, n2, vmin2, vmax2);
+          const uint32_t fhi = sd_pair((xw >> 8) & 0x00ff00ffu, mhi, vhi, n2, vmin2, vmax2);
+          mt.b.w[i] = mlo | (mhi << 8), vt.b.w[i] = vlo | (vhi << 8);
+          nf[d] = flo | (fhi << 8);
+        }
+        // pixel j of the group owns bytes 3j .. 3j+2 of the 12: background iff all three of its channels say so
+        const uint32_t s0 = __builtin_amdgcn_sad_u8(nf[0] & 0x00ffffffu, 0u, 0u);
+        const uint32_t s1 = __builtin_amdgcn_sad_u8(nf[0] & 0xff000000u, 0u, __builtin_amdgcn_sad_u8(nf[1] & 0x0000ffffu, 0u, 0u));
+        const uint32_t s2 = __builtin_amdgcn_sad_u8(nf[1] & 0xffff0000u, 0u, __builtin_amdgcn_sad_u8(nf[2] & 0x000000ffu, 0u, 0u));
+        const uint32_t s3 = __builtin_amdgcn_sad_u8(nf[2] & 0xffffff00u, 0u, 0u);
+        const uint32_t f0 = s0 != 3u, f1 = s1 != 3u, f2 = s2 != 3u, f3 = s3 != 3u;
+        m.b.w[g] = (f0 * 0xffu) | (f1 * 0xff00u) | (f2 * 0xff0000u) | (f3 * 0xff000000u);
+        bits |= (f0 | (f1 << 1) | (f2 << 2) | (f3 << 3)) << (4 * g);
       }
-      m.b.set(j, isfg ? 255 : 0);
-      bits |= (uint32_t)isfg << j;
+    } else {
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        bool isfg = false;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int i = 3 * j + c;
+          int mv = mt.b.get(i);
+          const int im = x.b.get(i);
+          mv += (mv < im) - (mv > im);                                   // sdLaMa091.cpp:535-540
+          const int d8 = (int)(int8_t)(uint8_t)(mv - im);                // :559 absVal(int8_t): the difference wraps to int8 first
+          const uint32_t ot = (uint32_t)(d8 < 0 ? -d8 : d8) & 0xffu;
+          const uint32_t amp = a.N * ot;                                 // :576
+          uint32_t v = (uint32_t)vt.b.get(i);
+          v = (v + (v < amp) - (v > amp)) & 0xffu;                       // :578-581 on a uint8: 255+1 wraps to 0
+          v = min(v, (uint32_t)a.vmax);                                  // :583 max(min(Vt, Vmax), Vmin) with uint8 operands
+          v = max(v, (uint32_t)a.vmin);
+          isfg = isfg || ot >= v;                                        // :605
+          mt.b.set(i, mv);
+          vt.b.set(i, (int)v);
+        }
+        m.b.set(j, isfg ? 255 : 0);
+        bits |= (uint32_t)isfg << j;
+      }
     }
     mt.store(a.mt + p0 * 3);
     vt.store(a.vt + p0 * 3);
