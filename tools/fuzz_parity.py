@@ -2,7 +2,8 @@
 parameters inside the ranges the engine accepts, number of streams, and a random mix of entry points (host frames, device
 batches, device ranges, clips).  Every mask, every background the class delivers and - where the helpers know the model - the
 state at the end must match.  Usage: python tools/fuzz_parity.py [seconds] [seed]; prints one line per case, exits 1 on the
-first mismatch with the seed that reproduces it."""
+first mismatch with the seed that reproduces it.  Extra words: "big" = frames of several tiles (33x64 .. 200x320), "v" = print each case
+before it runs."""
 import sys
 import time
 
@@ -18,6 +19,7 @@ from tools import synth  # noqa: E402
 from tracking_amd import Engine, capi  # noqa: E402
 
 VERBOSE = False
+BIG = False
 ALL = dict(ALGOS)
 ALL["SuBSENSEBGS"] = capi.SUBSENSE
 ALL["LOBSTERBGS"] = capi.LOBSTER
@@ -74,8 +76,11 @@ def one_case(rng, case_seed):
     name = rng.choice(sorted(ALL))
     algo = ALL[name]
     small = name in ("SuBSENSEBGS", "LOBSTERBGS", "GMG")
-    H = int(rng.choice([5, 9, 16, 33, 48] if small else [1, 7, 16, 33, 64]))
-    W = int(rng.choice([5, 37, 64, 131] if small else [3, 64, 70, 128, 200]))
+    if BIG:  # several tiles in both directions, ragged edges
+        H, W = int(rng.choice([33, 65, 97, 130, 200])), int(rng.choice([64, 97, 131, 257, 320]))
+    else:
+        H = int(rng.choice([5, 9, 16, 33, 48] if small else [1, 7, 16, 33, 64]))
+        W = int(rng.choice([5, 37, 64, 131] if small else [3, 64, 70, 128, 200]))
     device_ok = True
     S = int(rng.integers(1, 4))
     T = int(rng.integers(4, 22))
@@ -151,8 +156,9 @@ def one_case(rng, case_seed):
 
 
 def main():
-    global VERBOSE
-    VERBOSE = len(sys.argv) > 3
+    global VERBOSE, BIG
+    VERBOSE = "v" in sys.argv[3:]
+    BIG = "big" in sys.argv[3:]
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time()) % 100000
     t0 = time.time()
