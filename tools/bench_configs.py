@@ -74,7 +74,7 @@ def run(algo, name, rows, cols, S, bpp, steps=60, borrow=True, want_bg=False, cp
     e.close()
 
 
-def run_subsense(S, steps=30, kind="surv", algo=None, label="SuBSENSEBGS", warm=6):
+def run_subsense(S, steps=30, kind="surv", algo=None, label="SuBSENSEBGS", warm=6, groups=1):
     """BASELINE configs[3]: SuBSENSE at 1920x1080 (per-frame wall time: ~20 launches incl. the flood-fill host loop)."""
     dev = torch.device("cuda", 0)
     rows, cols, T = 1080, 1920, 8
@@ -84,19 +84,30 @@ def run_subsense(S, steps=30, kind="surv", algo=None, label="SuBSENSEBGS", warm=
     e = Engine(capi.SUBSENSE if algo is None else algo, n_streams=S)
     e.set_geometry(rows, cols, 3)
     fg = torch.empty((S, rows, cols), dtype=torch.uint8, device=dev)
+    # groups > 1: the batch as `groups` stream ranges, each on its own HIP stream (bgs_process_range_device): one range's memory-bound
+    # tail (sample writes, post-processing) then runs beside another range's VALU-bound phase A
+    hs = [torch.cuda.Stream() for _ in range(groups)] if groups > 1 else None
+    per = S // groups
+
+    def step(t):
+        if groups == 1:
+            e.process_batch_device(pool[t % T], fg, None, None)
+        else:
+            for g in range(groups):
+                e.process_batch_device(pool[t % T, g * per:(g + 1) * per], fg[g * per:(g + 1) * per], None, None, hip_stream=hs[g].cuda_stream, first=g * per, count=per)
     for t in range(warm):
-        e.process_batch_device(pool[t % T], fg, None, None)
+        step(t)
     torch.cuda.synchronize()
     e.enable_kernel_timing(True)
     t0 = time.perf_counter()
     for t in range(steps):
-        e.process_batch_device(pool[(warm + t) % T], fg, None, None)
+        step(warm + t)
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / steps
     ms, n, kname = e.kernel_timing()
     px = S * rows * cols
     print("%-34s %dx%d x%d streams: %.3f ms/frame-step wall -> %8.1f Mpix/s (%.1f 1080p frames/s); %s %.3f ms; fg ratio %.3f"
-          % ("%s (%s input%s)" % (label, kind, "" if warm == 6 else ", model aged %d frames" % warm), cols, rows, S, wall * 1e3, px / wall / 1e6, S / wall, kname, ms, float((fg != 0).float().mean())))
+          % ("%s (%s input%s%s)" % (label, kind, "" if warm == 6 else ", model aged %d frames" % warm, "" if groups == 1 else ", %d ranges on %d HIP streams" % (groups, groups)), cols, rows, S, wall * 1e3, px / wall / 1e6, S / wall, kname, ms, float((fg != 0).float().mean())))
     e.close()
 
 
@@ -291,6 +302,12 @@ def main():
         return
     if args.only == "subsense8":
         run_subsense(8)
+        return
+    if args.only == "subsense8x2":  # the 8 streams as two / four ranges on their own HIP streams
+        run_subsense(8)
+        run_subsense(8, groups=2)
+        run_subsense(8, groups=4)
+        run_subsense(8, kind="smooth", groups=2)
         return
     if args.only == "subsense8aged":  # the model after 300 frames: update rates have settled, far fewer sample writes per frame
         run_subsense(8, warm=300)
