@@ -209,6 +209,7 @@ def main():
     ap.add_argument("--sustain", type=int, default=200, help="further launches after the timed K, reported as roofline.sustained")
     ap.add_argument("--series", default="", help="write the per-launch kernel durations (settle, warmup, timed, sustain) to this CSV")
     ap.add_argument("--rehearse", action="store_true", help="N > 1 control flow on one GPU: all ranks on cuda:0, gloo, masks via host (not a benchmark)")
+    ap.add_argument("--rccl-selftest", action="store_true", help="one rank, but through the N > 1 code path: RCCL process group, packed-mask gather every step (to itself), barrier and max-reduce of the time - the collective calls on real hardware where only one GPU is available (not a scaling result)")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 child passes (then the constant of profiles/pmc_traffic.json is reported)")
     ap.add_argument("--px", type=int, default=0, help="MOG2 pixels per lane (tuning; 0 = default = 1)")
     args = ap.parse_args()
@@ -219,7 +220,11 @@ def main():
     # --rehearse: the N > 1 control flow on ONE GPU (every rank on cuda:0, `gloo` instead of RCCL, the packed masks go through a
     # host copy): RCCL refuses two ranks on one device, and this box has one.  Numbers from it are not benchmark results.
     rehearse = args.rehearse and world > 1
-    if world > 1:
+    selftest = args.rccl_selftest and world == 1
+    if selftest:
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "29517")):
+            os.environ.setdefault(k, v)
+    if world > 1 or selftest:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # the process group comes up before this process makes its first GPU call
@@ -249,7 +254,7 @@ def main():
     fg = torch.empty((S, ROWS, COLS), dtype=torch.uint8, device=dev)
     bg = torch.empty((S, ROWS, COLS, CH), dtype=torch.uint8, device=dev) if args.with_bg else None
     words = ROWS * COLS // 64
-    gather = MaskGather(S, words, "cpu" if rehearse else dev) if world > 1 else None
+    gather = MaskGather(S, words, "cpu" if rehearse else dev, always_collective=selftest) if (world > 1 or selftest) else None
     bits_dev = torch.empty((S, words), dtype=torch.int64, device=dev) if rehearse else None
 
     def step(t):
@@ -280,7 +285,7 @@ def main():
     if gather:
         gather.drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or selftest:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -290,10 +295,10 @@ def main():
     if gather:
         gather.drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or selftest:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or selftest:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -304,6 +309,14 @@ def main():
     if gather:
         gather.drain()
     torch.cuda.synchronize()
+    selftest_ok = None
+    if selftest:  # what came through the RCCL gather is what the kernel wrote (an inverted frame: foreground everywhere, so the words are not all zero)
+        bits = gather.next_buffer()
+        eng.process_batch_device(255 - pool[t % period], fg, bg, bits)
+        gather.post()
+        got = gather.collect()
+        torch.cuda.synchronize()
+        selftest_ok = {"gather_equals_kernel_output": bool(torch.equal(got, gather.bufs[gather.last])), "nonzero_words": int(got.ne(0).sum().item()), "words": int(got.numel())}
     _, _, k_name = eng.kernel_timing()
     series = eng.kernel_timing_series()
     eng.enable_kernel_timing(False)
@@ -398,7 +411,7 @@ def main():
             "config": {"workload": "MixtureOfGaussianV2BGS (MOG2 K=5, alpha=0.05, threshold 15) on 1920x1080x3 uint8, %s synthetic input, %d streams per GPU batched in one launch "
                                    "(BASELINE configs[1] geometry x %d = the per-GPU share of configs[4]); frames resident in HBM" % ("S_sat" if args.input == "sat" else "S_surv", S, S),
                        "streams_per_gpu": S, "rows": ROWS, "cols": COLS, "channels": CH, "K": 5, "input": args.input,
-                       "mask_gather": ("REHEARSAL: gloo gather through host copies, all ranks on one GPU - not a benchmark" if rehearse else "RCCL gather of bit-packed masks to rank 0 every step, overlapped") if world > 1 else "none (1 GPU)"},
+                       "mask_gather": ("REHEARSAL: gloo gather through host copies, all ranks on one GPU - not a benchmark" if rehearse else "RCCL gather of bit-packed masks to rank 0 every step, overlapped") if world > 1 else ("RCCL SELF-TEST: one rank, gather / barrier / all-reduce issued anyway (the N > 1 code path on one GPU; not a scaling result)" if selftest else "none (1 GPU)")},
             "streams_1080p30": round(mpix / (ROWS * COLS / 1e6) / 30.0, 1),
             "frames_per_s": round(mpix * 1e6 / (ROWS * COLS), 1),
             "mean_live_modes_stream0": live_modes,
@@ -409,13 +422,14 @@ def main():
                          "sustained": leg(sus_ms), "burst_first_20_after_idle": leg(burst_ms)},
             "cpu_baseline": cpu,
             "placement_probe": probe,
+            "rccl_selftest_gather_matches_kernel_output": selftest_ok,
             "single_stream": single,
             "s_surv": surv,
             "clip": clip,
         }
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
+    if world > 1 or selftest:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -34,7 +34,10 @@ class MaskGather:
     step's update kernel (which writes the other buffer); collect() waits and, on dst, returns the masks of all
     ranks in global stream order as one [total_streams][words] tensor."""
 
-    def __init__(self, streams_local, words, device, dst=0, group=None):
+    def __init__(self, streams_local, words, device, dst=0, group=None, always_collective=False):
+        # always_collective: issue the gather even in a world of one rank (bench.py --rccl-selftest: the RCCL calls of the N > 1 path
+        # on a box with a single GPU)
+        self.always = always_collective and dist.is_initialized()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.dst, self.group = dst, group
@@ -52,7 +55,7 @@ class MaskGather:
         return self.bufs[self.i]
 
     def post(self):
-        if self.world > 1:
+        if self.world > 1 or self.always:
             self.work[self.i] = dist.gather(self.bufs[self.i], self.recv[self.i], dst=self.dst, group=self.group, async_op=True)
         self.last = self.i
         self.i ^= 1
@@ -64,7 +67,7 @@ class MaskGather:
             self.work[j] = None
         if self.rank != self.dst:
             return None
-        return torch.cat(self.recv[j], 0) if self.world > 1 else self.bufs[j]
+        return torch.cat(self.recv[j], 0) if (self.world > 1 or self.always) else self.bufs[j]
 
     def drain(self):
         for j in (0, 1):
