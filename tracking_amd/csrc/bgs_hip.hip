@@ -1788,13 +1788,5 @@ int bgs_ingest_host(int hip_device, const bgs_ingest* c, const uint8_t* src, int
   return rc;
 }
 
-#ifdef BGS_EXP_COUNT
-int bgs_debug_counters(unsigned long long* out8, int reset) {
-  unsigned long long z[8] = {0};
-  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(bgs::g_exp_cnt), sizeof(z)) != hipSuccess) return -1;
-  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(bgs::g_exp_cnt), z, sizeof(z)) != hipSuccess) return -1;
-  return 0;
-}
-#endif
 
 }  // extern "C"

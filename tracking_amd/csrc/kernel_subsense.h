@@ -153,15 +153,6 @@ __device__ __forceinline__ size_t ss_rec(const SsArgs& a, int stream, size_t N, 
 constexpr int kSsATH = 32, kSsAPix = kSsTW * kSsATH, kSsRefill = 16;
 constexpr uint32_t kSsNotInterior = 0xffffffffu;
 
-#ifdef BGS_EXP_COUNT  // counting build (tools/exp_phase_a.sh): never defined in the product build
-__device__ unsigned long long g_exp_cnt[8];
-#define EXP_COUNT(i, v)                                                      \
-  do {                                                                       \
-    if ((threadIdx.x & 63) == 0) atomicAdd(&g_exp_cnt[i], (unsigned long long)(v)); \
-  } while (0)
-#else
-#define EXP_COUNT(i, v)
-#endif
 
 template <int C>
 __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
@@ -282,8 +273,6 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
       const int nidle = __popcll(idle);
       if (qempty && nidle == kWave) break;
       if (!qempty && nidle >= a.refill) {  // wave-uniform
-        EXP_COUNT(4, 1);
-        EXP_COUNT(5, nidle);
         const int leader = __ffsll((long long)idle) - 1;
         unsigned base = 0;
         if (lane == leader) base = atomicAdd(&qhead, (unsigned)nidle);
@@ -311,7 +300,6 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
           }
         }
       }
-      EXP_COUNT(0, 1);  // wave-iterations
       if (active) {
         if (good < a.nReq && idx < a.nS) {  // :469-497 (BGR) / :334-357 (gray)
           // One trip = the samples a lane holds: batch 0 (four samples, bt) on a pixel's first trip, then EIGHT at a time (bt + nbt,
