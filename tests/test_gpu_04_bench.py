@@ -1,0 +1,44 @@
+"""bench.py itself, on a small batch so that it takes seconds: the JSON contract of the line the driver parses, and the N > 1 code
+path's RCCL calls (process group, per-step packed-mask gather, barrier, max-reduce) with the one rank a one-GPU box has."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--streams", "2", "--settle", "4", "--sustain", "4", *extra],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line on stdout"
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    d = _bench("--no-pmc")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["unit"] == "Mpixels/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["kernel_launches"] == 4
+    assert r["achieved"] > 0 and d["value"] > 0 and abs(d["value"] - 2 * 1920 * 1080 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mpixels/s" and "sample" in c
+    assert d["clip"]["T4"]["frames_per_launch"] == 4 and d["clip"]["T8"]["kernel"] == "mog2_clip_kernel"
+
+
+def test_bench_rccl_selftest_gathers_what_the_kernel_wrote():
+    d = _bench("--rccl-selftest", "--main-only")
+    assert d["config"]["mask_gather"].startswith("RCCL SELF-TEST")
+    s = d["rccl_selftest_gather_matches_kernel_output"]
+    assert s["gather_equals_kernel_output"] is True and s["nonzero_words"] > 0 and s["words"] == 2 * 1920 * 1080 // 64
