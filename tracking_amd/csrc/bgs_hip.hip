@@ -71,6 +71,7 @@ struct bgs_engine {
   uint8_t* ring[3] = {nullptr, nullptr, nullptr};
   int nring = 0;
   bool borrow = false;               // device path: history = the caller's previous d_frames, no copies
+  bool borrow_in_clip = false;       // set by process_clip: frames of the clip serve as history, for the range of that call
   const uint8_t* borrowed[2] = {nullptr, nullptr};
   // byte state (SFD background, ABL/ASBL background): [S][n*state_ch]
   uint8_t* bgstate = nullptr;
@@ -625,7 +626,7 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
   a.xcd_swizzle = e->xcd_swizzle >= 2;
 
   const bool whole = (first == 0 && count == e->S);
-  if (e->borrow && !whole && e->nring) return fail(BGS_ERR_INVALID, "borrowed frame history needs whole-batch calls");
+  if (e->borrow && !whole && e->nring && !e->borrow_in_clip) return fail(BGS_ERR_INVALID, "borrowed frame history needs whole-batch calls");
 
   switch (e->algo) {
     case BGS_FRAME_DIFF:
@@ -880,6 +881,31 @@ int process_clip(bgs_engine* e, int first, int count, int nframes, const uint8_t
   // lr >= 1 re-initialises the model on every frame (needToInitialize): nothing to keep in registers
   const bool dp_gmm = e->algo == BGS_DP_ZIVKOVIC_AGMM || e->algo == BGS_DP_GRIMSON_GMM;
   const bool fuse_ok = e->clip_fuse && (dp_gmm || ((e->algo == BGS_MOG2 || e->algo == BGS_MOG1) && p.alpha < 1));
+  // FrameDifference / WeightedMoving*: frame t needs frames t-1 (t-2).  A per-frame call copies its frame into the engine's ring; inside
+  // a clip the earlier frames of the clip ARE that history, so only the last one (two) are copied into the ring, once, at the end.
+  const bool ring_clip = e->nring > 0 && !e->borrow && nframes >= 2;
+  const uint8_t* saved_borrowed[2] = {e->borrowed[0], e->borrowed[1]};
+  const int64_t ring_t0 = e->seen[first];
+  if (ring_clip) {
+    const int R = e->nring;
+    const size_t offb = e->n * (size_t)first * C;
+    e->borrow = true, e->borrow_in_clip = true;
+    e->borrowed[0] = ring_t0 >= 1 ? e->ring[(ring_t0 - 1) % R] + offb : nullptr;
+    e->borrowed[1] = (ring_t0 >= 2 && R == 3) ? e->ring[(ring_t0 - 2) % R] + offb : nullptr;
+  }
+  auto end_ring_clip = [&](int done) -> int {  // `done` frames of the clip went through: leave the ring as per-frame calls would have
+    if (!ring_clip) return BGS_OK;
+    e->borrow = false, e->borrow_in_clip = false;
+    e->borrowed[0] = saved_borrowed[0], e->borrowed[1] = saved_borrowed[1];
+    const int R = e->nring;
+    const size_t offb = e->n * (size_t)first * C;
+    for (int k = 1; k < R; ++k) {
+      const int j = done - k;  // clip frame ring_t0 + j is the k-th last one
+      if (j < 0) break;        // older ones are in the ring already
+      HIP_TRY(hipMemcpyAsync(e->ring[(ring_t0 + j) % R] + offb, d_frames + (size_t)j * npix * C, npix * C, hipMemcpyDeviceToDevice, s));
+    }
+    return BGS_OK;
+  };
   int t = 0;
   while (t < nframes) {
     const int left = nframes - t;
@@ -890,7 +916,10 @@ int process_clip(bgs_engine* e, int first, int count, int nframes, const uint8_t
     uint64_t* bits = d_bits ? d_bits + (size_t)t * words : nullptr;
     if (fuse == 1) {
       int rc = process_range(e, first, count, fr, fg, bg, bits, s, out_flags ? out_flags + t : nullptr);
-      if (rc) return rc;
+      if (rc) {
+        (void)end_ring_clip(t);
+        return rc;
+      }
     } else {
       const int64_t seen = e->seen[first];
       for (int i = first; i < first + count; ++i)
@@ -958,7 +987,7 @@ int process_clip(bgs_engine* e, int first, int count, int nframes, const uint8_t
     }
     t += fuse;
   }
-  return BGS_OK;
+  return end_ring_clip(nframes);
 }
 
 }  // namespace
