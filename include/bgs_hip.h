@@ -233,7 +233,9 @@ int bgs_process_range_device(bgs_engine* e, int first, int count, const void* d_
  *   d_fg_bits [nframes][count][rows*cols/64] or NULL;  out_flags: nframes words or NULL
  * The mixture models (MixtureOfGaussianV2BGS, MixtureOfGaussianV1BGS, DPZivkovicAGMMBGS, DPGrimsonGMMBGS) take runs of 8 / 4 / 2
  * frames through ONE launch that loads each pixel's model once, applies the frames in order in registers and writes the model back
- * once (model traffic per frame / 8, / 4, / 2); every other class runs the same launches as the frame-by-frame calls.
+ * once (model traffic per frame / 8, / 4, / 2); FrameDifference / WeightedMovingMean / WeightedMovingVariance take their frame history
+ * from the clip itself instead of copying every frame into the engine's ring; every other class runs the same launches as the
+ * frame-by-frame calls.
  */
 int bgs_process_clip_device(bgs_engine* e, int first, int count, int nframes, const void* d_frames, void* d_fg, void* d_bg,
                             void* d_fg_bits, void* hip_stream, uint32_t* out_flags);
