@@ -171,6 +171,44 @@ def run_pipeline(S=8, steps=30):
     wall = (time.perf_counter() - t0) / steps
     print("pipeline SuBSENSE -> components  1920x1080 x%d streams: %.3f ms per step = %.1f 1080p frames/s end to end; %.1f boxes and %.0f bytes D2H per step "
           "(full masks would be %d bytes)" % (S, wall * 1e3, S / wall, nbox / steps, nbytes / steps, S * rows * cols))
+    # The same, as a streaming consumer would drive it: nothing waits for step t before step t+1 is enqueued - two sets of output
+    # buffers, the boxes of step t go to pinned memory asynchronously and are read when the event behind that copy has fired, one step late.
+    import ctypes as C
+    max_boxes = 65536
+    lib = capi.lib()
+    wsz = lib.bgs_mask_components_batch_workspace(S, rows, cols)
+    fgs = [torch.empty((S, rows, cols), dtype=torch.uint8, device=dev) for _ in range(2)]
+    boxes = [torch.zeros((max_boxes, 6), dtype=torch.int32, device=dev) for _ in range(2)]
+    offs = [torch.zeros(S + 1, dtype=torch.int32, device=dev) for _ in range(2)]
+    work = [torch.empty(wsz, dtype=torch.uint8, device=dev) for _ in range(2)]
+    hbox = [torch.zeros((4096, 6), dtype=torch.int32).pin_memory() for _ in range(2)]
+    hoff = [torch.zeros(S + 1, dtype=torch.int32).pin_memory() for _ in range(2)]
+    ev = [torch.cuda.Event() for _ in range(2)]
+    stream = torch.cuda.current_stream().cuda_stream
+    nbox = 0
+    e.close()
+    e = Engine(capi.SUBSENSE, n_streams=S)  # a fresh model, the same 6 warm-up frames: comparable with the figure above
+    e.set_geometry(rows, cols, 3)
+    for t in range(6):
+        e.process_batch_device(pool[t % T], fg, None, None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(steps + 1):
+        i = t & 1
+        if t < steps:
+            e.process_batch_device(pool[(6 + t) % T], fgs[i], None, None)
+            capi.check(lib.bgs_mask_components_batch_device(0, C.c_void_p(fgs[i].data_ptr()), S, rows, cols, 8, None, C.c_void_p(boxes[i].data_ptr()), max_boxes,
+                                                            C.c_void_p(offs[i].data_ptr()), C.c_void_p(work[i].data_ptr()), C.c_void_p(stream)))
+            hbox[i].copy_(boxes[i][:4096], non_blocking=True)
+            hoff[i].copy_(offs[i], non_blocking=True)
+            ev[i].record()
+        if t >= 1:
+            j = (t - 1) & 1
+            ev[j].synchronize()
+            nbox += int(hoff[j][-1])
+    wall2 = (time.perf_counter() - t0) / steps
+    print("pipeline, consumer one step behind   1920x1080 x%d streams: %.3f ms per step = %.1f 1080p frames/s end to end; %.1f boxes per step"
+          % (S, wall2 * 1e3, S / wall2, nbox / steps))
     e.close()
 
 
