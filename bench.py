@@ -342,7 +342,7 @@ def main():
     if rank == 0:
         nm = eng.get_state("nmodes", (ROWS * COLS,), np.uint8, stream=0)
         live_modes = float(nm.mean())
-        pr = eng.get_state("probe", (18,), np.float32)
+        pr = eng.get_state("probe", (26,), np.float32)
         probe = {"candidates_ms_per_dense_launch": [round(float(v), 3) for v in pr[2:2 + int(pr[0])]], "kept": int(pr[1]),
                  "note": "model placement probe at allocation (DESIGN.md 6.2): stops once two speed classes have been seen"}
     if rank == 0 and not args.main_only and not rehearse:

@@ -177,7 +177,8 @@ int bgs_set_params(bgs_engine* e, const bgs_params* params);
  *   BGS_OPT_MOG2_TILED     1 (default) = tiled AoSoA model, 0 = planar SoA (A/B measurements); before the geometry is set.
  *   BGS_OPT_XCD_SWIZZLE    XCD-aware workgroup order: 1 (default) = for the kernels that stream a multi-plane model
  *                          (MOG2, MOG1, dp/), 2 = also for the byte-stream kernels (slower there: A/B only), 0 = off.
- *   BGS_OPT_PLACEMENT_PROBE  number of model placements tried at allocation (default 8, <= 1 = off); before the geometry. */
+ *   BGS_OPT_PLACEMENT_PROBE  most model placements tried at allocation (default 20, at most 24, <= 1 = off; the probe stops at the first
+ *                          one that is >= 5 % faster than the slowest seen, typically the 2nd-6th); before the geometry. */
 #define BGS_OPT_BORROW_FRAMES 1
 #define BGS_OPT_MOG2_PIXELS_PER_LANE 2
 #define BGS_OPT_MOG2_TILED 3

@@ -58,6 +58,8 @@ namespace {
 struct SsDevice;  // engine_subsense.h
 }
 
+constexpr int kProbeMax = 24;  // placement probe: most candidates ever held at once
+
 struct bgs_engine {
   bgs_algo algo;
   bgs_params p;
@@ -101,8 +103,8 @@ struct bgs_engine {
   unsigned* h_stat = nullptr;      // pinned copy
   hipEvent_t stat_ev = nullptr;
   bool stat_pending = false;
-  int probe_max = 8;               // placement probe: candidates tried at allocation (<= 1: off)
-  float probe_ms[16] = {0};         // what the probe measured (diagnostics)
+  int probe_max = 20;              // placement probe: candidates tried at most at allocation (<= 1: off); it stops at the first fast one
+  float probe_ms[kProbeMax] = {0};  // what the probe measured (diagnostics)
   int probe_n = 0, probe_pick = -1;
   bool poison = false;             // BGS_DEBUG_POISON: every fresh device buffer is filled with 0xA5 (see dmalloc)
 
@@ -325,13 +327,13 @@ size_t mog2_state_bytes(const bgs_engine* e) {
 // The buffer is handed over with unspecified contents: every model is initialised at its first frame on the launch stream.
 template <class Run>
 int probe_allocate(bgs_engine* e, void** out, size_t bytes, double expect_ms, Run run) {
-  const int tries = std::min(e->probe_max, 16);
+  const int tries = std::min(e->probe_max, kProbeMax);
   if (tries <= 1 || bytes < ((size_t)768 << 20)) return dmalloc(e, out, bytes);
   hipEvent_t ev0, ev1;
   HIP_TRY(hipEventCreate(&ev0));
   HIP_TRY(hipEventCreate(&ev1));
   const int debug = getenv("BGS_DEBUG_PROBE") ? atoi(getenv("BGS_DEBUG_PROBE")) : 0;
-  void* cand[16] = {nullptr};
+  void* cand[kProbeMax] = {nullptr};
   int n = 0, best = -1, rc = BGS_OK;
   float tmin = 1e30f, tmax = 0.f;
   auto time_one = [&](void* buf, float* ms_out) -> int {
@@ -382,7 +384,7 @@ int probe_allocate(bgs_engine* e, void** out, size_t bytes, double expect_ms, Ru
   }
   if (debug >= 2 && !rc) {  // de-confounding passes: the same candidates again, in reverse and then in the original order
     for (int pass = 0; pass < 2; ++pass) {
-      float again[16] = {0};
+      float again[kProbeMax] = {0};
       for (int j = 0; j < n; ++j) {
         const int i = pass == 0 ? n - 1 - j : j;
         (void)time_one(cand[i], &again[i]);
@@ -1347,8 +1349,8 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
     return (int64_t)nb;
   };
   if (!strcmp(plane, "probe")) {  // diagnostics: [0] candidates measured, [1] index kept, [2..] ms per dense launch of each candidate
-    float rec[18] = {(float)e->probe_n, (float)e->probe_pick};
-    for (int i = 0; i < 16; ++i) rec[2 + i] = i < e->probe_n ? e->probe_ms[i] : 0.f;
+    float rec[2 + kProbeMax] = {(float)e->probe_n, (float)e->probe_pick};
+    for (int i = 0; i < kProbeMax; ++i) rec[2 + i] = i < e->probe_n ? e->probe_ms[i] : 0.f;
     if (cap < sizeof(rec)) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
     memcpy(dst, rec, sizeof(rec));
     return (int64_t)sizeof(rec);
