@@ -90,13 +90,11 @@ struct bgs_engine {
   int32_t* gmg_colors = nullptr;  // GMG histograms (kernel_gmg.h)
   float* gmg_weights = nullptr;
   uint8_t* gmg_nfeat = nullptr;
-  // MOG2 model (kernel_mog2.h: tiled AoSoA by default, planar kept for A/B runs)
-  float* mog2_state = nullptr;
-  uint8_t* mog2_nmodes = nullptr;  // planar layout only
-  bool mog2_tiled = true;
-  int mog2_px = 0;                 // pixels per lane, 0 = widest the alignment allows
+  // MOG2 model (kernel_mog2.h: tiles of ranked weights + fixed-slot records + rank->slot meta words)
+  uint8_t* mog2_state = nullptr;
   int xcd_swizzle = 1;             // XCD-aware block order (kernel_mog2.h): 0 off, 1 model kernels (MOG2, MOG1, dp), 2 also the byte-stream kernels
-  int mog2_sparse = 3;             // data-dependent plane skipping (kernel_mog2.h): 0 dense, 1 stores, 2 stores+loads per wave, 4 per lane, 3 = choose 1 or 4 from the scene
+  int mog2_sparse = 3;             // data-dependent traffic (kernel_mog2.h): 0 dense (everything loaded and written), 1 only what changed is written, 2 / 4 a lane also loads only the modes its pixel has, 3 = choose 1 or 4 from the scene
+  int mog2_complete = 1;           // sector-complete stores (kernel_mog2.h); BGS_MOG2_COMPLETE=0 for A/B runs
   bool clip_fuse = true;           // MOG2 clip calls keep the model in registers across frames (option 7; results identical either way)
   int mog2_sparse_now = 1;         // what auto mode currently runs
   unsigned* d_stat = nullptr;      // device: {sampled waves, sparse waves}
@@ -140,10 +138,10 @@ void free_all(bgs_engine* e) {
   if (e->d_raw) (void)hipFree(e->d_raw), e->d_raw = nullptr;
   if (e->d_ingest_ws) (void)hipFree(e->d_ingest_ws), e->d_ingest_ws = nullptr;
   e->last_fg_stream = -1;
-  void* dev[] = {e->dp_state, e->gmg_colors, e->gmg_weights, e->gmg_nfeat, e->bgstate, e->bgstate2, e->mog1_state, e->mog2_state, e->mog2_nmodes, e->d_in, e->d_fg, e->d_bg};
+  void* dev[] = {e->dp_state, e->gmg_colors, e->gmg_weights, e->gmg_nfeat, e->bgstate, e->bgstate2, e->mog1_state, e->mog2_state, e->d_in, e->d_fg, e->d_bg};
   for (void* d : dev)
     if (d) (void)hipFree(d);
-  e->dp_state = nullptr, e->gmg_colors = nullptr, e->gmg_weights = nullptr, e->gmg_nfeat = nullptr, e->bgstate = e->bgstate2 = nullptr, e->mog1_state = nullptr, e->mog2_state = nullptr, e->mog2_nmodes = nullptr, e->d_in = e->d_fg = e->d_bg = nullptr;
+  e->dp_state = nullptr, e->gmg_colors = nullptr, e->gmg_weights = nullptr, e->gmg_nfeat = nullptr, e->bgstate = e->bgstate2 = nullptr, e->mog1_state = nullptr, e->mog2_state = nullptr, e->d_in = e->d_fg = e->d_bg = nullptr;
   void* host[] = {e->h_in, e->h_fg, e->h_bg};
   for (void* h : host)
     if (h) (void)hipHostFree(h);
@@ -229,25 +227,16 @@ int launch_mog2(bgs_engine* e, bgs::Mog2Args& a, hipStream_t s, bool timed = tru
   // shadow test only when it can change the delivered mask: not thresholded, or the threshold separates shadow from foreground
   a.shadow = p.mog2_detect_shadows && (!p.enable_threshold || ((p.mog2_shadow_value > p.threshold) != (255 > p.threshold)));
   a.want_bg = a.bgimg != nullptr, a.packed = a.fg_bits != nullptr;
-  a.xcd_swizzle = e->xcd_swizzle;
+  a.xcd_swizzle = e->xcd_swizzle, a.complete = e->mog2_complete;
   a.sparse = e->mog2_sparse == 3 ? e->mog2_sparse_now : e->mog2_sparse;
   a.stat = (timed && e->mog2_sparse == 3) ? e->d_stat : nullptr;
-  // One pixel per lane by default: measured equal or better than 2 / 4 everywhere once the write-backs follow what changed
-  // (S_sat 30.8 vs 30.6 Gpixel/s, S_surv 81 vs 75), with half the registers.  BGS_OPT_MOG2_PIXELS_PER_LANE = 2 / 4 for A/B runs.
-  int PX = 1;
-  if (e->mog2_px == 4 && !(a.npix % 4 || a.state_off % 4 || !aligned(a.frame, 4) || (a.fg && !aligned(a.fg, 4)) || (a.bgimg && !aligned(a.bgimg, 4)))) PX = 4;
-  if (e->mog2_px == 2 && !(a.npix % 2 || a.state_off % 2 || !aligned(a.frame, 2) || (a.fg && !aligned(a.fg, 2)))) PX = 2;
   if (a.packed && a.npix % 64) return fail(BGS_ERR_UNSUPPORTED, "packed mask needs pixels %% 64 == 0");
   Timed t(e, s, "mog2_update_kernel", timed);
-  const dim3 grid(blocks_for(a.npix / PX)), block(bgs::kBlock);
+  const dim3 grid(blocks_for(a.npix)), block(bgs::kBlock);  // one pixel per lane (66 VGPRs in round 2's 1 / 2 / 4 comparison: equal or better everywhere)
   unsigned every = 1;  // sample about 256 workgroups per launch whatever the grid: enough to decide, few enough atomics not to show
   while (grid.x / every > 256) every <<= 1;
   a.stat_mask = every - 1;
-  const bool tiled = e->mog2_tiled;
-#define MOG2_CASE(PXV, TL) \
-  if (PX == PXV && tiled == TL) hipLaunchKernelGGL((bgs::mog2_update_kernel<PXV, TL>), grid, block, 0, s, a);
-  MOG2_CASE(4, true) MOG2_CASE(2, true) MOG2_CASE(1, true) MOG2_CASE(4, false) MOG2_CASE(2, false) MOG2_CASE(1, false)
-#undef MOG2_CASE
+  hipLaunchKernelGGL(bgs::mog2_update_kernel, grid, block, 0, s, a);
   if (a.stat) mog2_stat_poll(e, s);
   return BGS_OK;
 }
@@ -266,7 +255,7 @@ void mog1_fill_args(const bgs_engine* e, bgs::Mog1Args& m, double lr) {
 
 void mog2_fill_args(const bgs_engine* e, bgs::Mog2Args& m, double lr) {
   const bgs_params& p = e->p;
-  m.state = e->mog2_state, m.nmodes_planar = e->mog2_nmodes, m.plane = e->n * e->S;
+  m.state = e->mog2_state;
   m.alphaT = (float)lr, m.alpha1 = 1.f - m.alphaT, m.prune = (float)(-lr * (double)p.mog2_ct);
   m.Tb = p.mog2_var_threshold, m.TB = p.mog2_background_ratio, m.Tg = p.mog2_var_threshold_gen;
   m.varInit = p.mog2_var_init, m.varMin = p.mog2_var_min, m.varMax = p.mog2_var_max, m.tau = p.mog2_tau;
@@ -274,10 +263,7 @@ void mog2_fill_args(const bgs_engine* e, bgs::Mog2Args& m, double lr) {
 }
 
 void mog2_clear(bgs_engine* e, const bgs::Mog2Args& m, hipStream_t s) {
-  if (e->mog2_tiled)
-    hipLaunchKernelGGL((bgs::mog2_clear_kernel<true>), dim3(blocks_for(m.npix)), dim3(bgs::kBlock), 0, s, m);
-  else
-    hipLaunchKernelGGL((bgs::mog2_clear_kernel<false>), dim3(blocks_for(m.npix)), dim3(bgs::kBlock), 0, s, m);
+  hipLaunchKernelGGL(bgs::mog2_clear_kernel, dim3(blocks_for(m.npix)), dim3(bgs::kBlock), 0, s, m);
 }
 
 // One launch over `fuse` (2, 4 or 8) consecutive frames of streams whose model starts at c.m.state_off (kernel_mog2.h, clip launches)
@@ -286,7 +272,7 @@ int launch_mog2_clip(bgs_engine* e, bgs::Mog2ClipArgs& c, int fuse, hipStream_t 
   bgs::Mog2Args& a = c.m;
   a.shadow = p.mog2_detect_shadows && (!p.enable_threshold || ((p.mog2_shadow_value > p.threshold) != (255 > p.threshold)));
   a.want_bg = a.bgimg != nullptr, a.packed = a.fg_bits != nullptr;
-  a.xcd_swizzle = e->xcd_swizzle;
+  a.xcd_swizzle = e->xcd_swizzle, a.complete = e->mog2_complete;
   a.sparse = e->mog2_sparse == 3 ? e->mog2_sparse_now : e->mog2_sparse;
   a.stat = e->mog2_sparse == 3 ? e->d_stat : nullptr;
   if (a.packed && a.npix % 64) return fail(BGS_ERR_UNSUPPORTED, "packed mask needs pixels %% 64 == 0");
@@ -295,10 +281,9 @@ int launch_mog2_clip(bgs_engine* e, bgs::Mog2ClipArgs& c, int fuse, hipStream_t 
   unsigned every = 1;
   while (grid.x / every > 256) every <<= 1;
   a.stat_mask = every - 1;
-  const bool tiled = e->mog2_tiled;
-#define MOG2_CLIP_CASE(TL, TV) \
-  if (tiled == TL && fuse == TV) hipLaunchKernelGGL((bgs::mog2_clip_kernel<TL, TV>), grid, block, 0, s, c);
-  MOG2_CLIP_CASE(true, 2) MOG2_CLIP_CASE(true, 4) MOG2_CLIP_CASE(true, 8) MOG2_CLIP_CASE(false, 2) MOG2_CLIP_CASE(false, 4) MOG2_CLIP_CASE(false, 8)
+#define MOG2_CLIP_CASE(TV) \
+  if (fuse == TV) hipLaunchKernelGGL((bgs::mog2_clip_kernel<TV>), grid, block, 0, s, c);
+  MOG2_CLIP_CASE(2) MOG2_CLIP_CASE(4) MOG2_CLIP_CASE(8)
 #undef MOG2_CLIP_CASE
   if (a.stat) mog2_stat_poll(e, s);
   return BGS_OK;
@@ -306,8 +291,7 @@ int launch_mog2_clip(bgs_engine* e, bgs::Mog2ClipArgs& c, int fuse, hipStream_t 
 
 size_t mog2_state_bytes(const bgs_engine* e) {
   const size_t P = e->n * e->S;
-  if (e->mog2_tiled) return (P + bgs::kMog2Tile - 1) / bgs::kMog2Tile * bgs::kMog2TileFloats * sizeof(float);
-  return P * bgs::kMog2Planes * sizeof(float);
+  return (P + bgs::kMog2Tile - 1) / bgs::kMog2Tile * bgs::kMog2TileBytes;
 }
 
 // Model allocation with a PLACEMENT PROBE for the big, long-lived models (MOG2, MOG1, dp GMMs).
@@ -411,11 +395,6 @@ int mog2_allocate(bgs_engine* e) {
   HIP_TRY(hipMemsetAsync(e->d_stat, 0, 2 * sizeof(unsigned), e->stream));  // ordered: allocate() drains e->stream before it returns
   HIP_TRY(hipHostMalloc((void**)&e->h_stat, 2 * sizeof(unsigned), hipHostMallocDefault));
   HIP_TRY(hipEventCreateWithFlags(&e->stat_ev, hipEventDisableTiming));
-  if (!e->mog2_tiled) {
-    DMALLOC(e->mog2_state, bytes);
-    DMALLOC(e->mog2_nmodes, P);
-    return BGS_OK;
-  }
   const bool probing = e->probe_max > 1 && bytes >= ((size_t)768 << 20);
   uint8_t* d_frame = nullptr;  // a black frame for the probe launches
   if (probing) {
@@ -424,11 +403,11 @@ int mog2_allocate(bgs_engine* e) {
   }
   const int saved_sparse = e->mog2_sparse;
   e->mog2_sparse = 0;  // probe with the dense traffic pattern: that is what a busy scene produces
-  // a dense launch moves 206 B/pixel; on a good placement this part sustains ~6.15 TB/s
-  const double expect_ms = 206.0 * (double)P / 6.15e12 * 1e3;
-  float* saved_state = e->mog2_state;
+  // a dense launch (sparse 0: everything read and written back) moves 208 B/pixel; on a good placement this part sustains ~6.15 TB/s
+  const double expect_ms = 208.0 * (double)P / 6.15e12 * 1e3;
+  uint8_t* saved_state = e->mog2_state;
   int rc = probe_allocate(e, (void**)&e->mog2_state, bytes, expect_ms, [&](void* cand) -> int {
-    e->mog2_state = (float*)cand;
+    e->mog2_state = (uint8_t*)cand;
     bgs::Mog2Args m{};
     mog2_fill_args(e, m, 0.05);
     m.frame = d_frame, m.state_off = 0, m.npix = P;
@@ -1138,8 +1117,7 @@ int bgs_create(bgs_algo algo, const bgs_params* params, int hip_device, int n_st
   e->seen.assign(n_streams, 0);
   e->counter.assign(n_streams, 0);
   e->flip.assign(n_streams, 0);
-  if (const char* env = getenv("BGS_MOG2_PX")) e->mog2_px = atoi(env);
-  if (const char* env = getenv("BGS_MOG2_LAYOUT")) e->mog2_tiled = strcmp(env, "planar") != 0;
+  if (const char* env = getenv("BGS_MOG2_COMPLETE")) e->mog2_complete = atoi(env) != 0;
   if (const char* env = getenv("BGS_XCD_SWIZZLE")) e->xcd_swizzle = atoi(env);
   if (const char* env = getenv("BGS_MOG2_SPARSE")) e->mog2_sparse = atoi(env);
   if (const char* env = getenv("BGS_PLACEMENT_PROBE")) e->probe_max = atoi(env);
@@ -1202,11 +1180,8 @@ int bgs_set_option(bgs_engine* e, int option, int64_t value) {
   if (!e) return fail(BGS_ERR_INVALID, "engine is NULL");
   switch (option) {
     case 1: e->borrow = value != 0; return BGS_OK;
-    case 2: e->mog2_px = (int)value; return BGS_OK;
-    case 3:
-      if (e->n) return fail(BGS_ERR_INVALID, "the model layout must be chosen before the geometry is set");
-      e->mog2_tiled = value != 0;
-      return BGS_OK;
+    case 2:  // round-2 A/B knobs (pixels per lane, planar layout): accepted and ignored since the slot layout of round 3
+    case 3: return BGS_OK;
     case 4: e->xcd_swizzle = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return BGS_OK;
     case 6: e->mog2_sparse = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 4); return BGS_OK;
     case 7: e->clip_fuse = value != 0; return BGS_OK;
@@ -1337,12 +1312,6 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
   if (hipSetDevice(e->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(BGS_ERR_HIP, "device sync failed");
   const size_t n = e->n, P = n * e->S, off = n * stream;
   const int C = e->ch;
-  auto copy_planes = [&](const float* base, int planes) -> int64_t {
-    if (cap < (size_t)planes * n * 4) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
-    for (int k = 0; k < planes; ++k)
-      if (hipMemcpy((float*)dst + (size_t)k * n, base + (size_t)k * P + off, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
-    return (int64_t)planes * n * 4;
-  };
   auto copy_bytes = [&](const uint8_t* src, size_t nb) -> int64_t {
     if (cap < nb) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
     if (hipMemcpy(dst, src, nb, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
@@ -1363,23 +1332,32 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
     if (!strcmp(plane, "mu")) p0 = 10, np = 15;
     const bool nm = !strcmp(plane, "nmodes");
     if (p0 >= 0 || nm) {
-      if (!e->mog2_tiled) {
-        if (nm) return copy_bytes(e->mog2_nmodes + off, n);
-        return copy_planes(e->mog2_state + (size_t)p0 * P, np);
-      }
+      // device layout (kernel_mog2.h): weights by rank, {var, mean} records in fixed slots, meta = rank -> slot.  Exported in the
+      // reference's array order (rank); entries past a pixel's mode count are zero, as in the reference's zero-initialised bgmodel.
       const size_t need = nm ? n : (size_t)np * n * 4;
       if (cap < need) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
-      const size_t T = bgs::kMog2Tile, TF = bgs::kMog2TileFloats;
+      const size_t T = bgs::kMog2Tile, TB = bgs::kMog2TileBytes;
       const size_t t0 = off / T, t1 = (off + n + T - 1) / T;
-      std::vector<float> tiles((t1 - t0) * TF);
-      if (hipMemcpy(tiles.data(), e->mog2_state + t0 * TF, tiles.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+      std::vector<uint8_t> tiles((t1 - t0) * TB);
+      if (hipMemcpy(tiles.data(), e->mog2_state + t0 * TB, tiles.size(), hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
       for (size_t i = 0; i < n; ++i) {
-        const size_t sp = off + i, tl = sp / T - t0, in = sp % T;
-        const float* tb = tiles.data() + tl * TF;
-        if (nm)
-          ((uint8_t*)dst)[i] = reinterpret_cast<const uint8_t*>(tb + bgs::kMog2Planes * T)[in];
-        else
-          for (int q = 0; q < np; ++q) ((float*)dst)[(size_t)q * n + i] = tb[(p0 + q) * T + in];
+        const size_t sp = off + i, in = sp % T;
+        const uint8_t* tb = tiles.data() + (sp / T - t0) * TB;
+        const float* w = reinterpret_cast<const float*>(tb) + in;
+        const float* rec = reinterpret_cast<const float*>(tb + bgs::kMog2RecOff) + in * 4;
+        const unsigned meta = reinterpret_cast<const uint16_t*>(tb + bgs::kMog2MetaOff)[in];
+        if (nm) {
+          ((uint8_t*)dst)[i] = (uint8_t)bgs::mog2_meta_count(meta);
+          continue;
+        }
+        for (int r = 0; r < bgs::kMog2K; ++r) {
+          const unsigned f = (meta >> (3 * r)) & 7u;
+          const float* rc = f ? rec + (size_t)(f - 1) * T * 4 : nullptr;
+          if (p0 == 0) ((float*)dst)[(size_t)r * n + i] = f ? w[(size_t)r * T] : 0.f;
+          if (p0 == 5) ((float*)dst)[(size_t)r * n + i] = f ? rc[0] : 0.f;
+          if (p0 == 10)
+            for (int c = 0; c < 3; ++c) ((float*)dst)[((size_t)r * 3 + c) * n + i] = f ? rc[1 + c] : 0.f;
+        }
       }
       return (int64_t)need;
     }

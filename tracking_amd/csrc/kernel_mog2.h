@@ -5,69 +5,87 @@
 //           (mog(img, fg, alpha); mog.getBackgroundImage(bg); cv::threshold(fg, 15))
 // Algorithm: Zivkovic adaptive GMM as implemented by OpenCV 2.4 bgfg_gaussmix2.cpp MOG2Invoker.
 //
-// Layout: SoA planes in HBM, P = streams*pixels floats per plane:
-//   w[k][P], var[k][P], mu[k][c][P] (k < K = 5, c < 3), nmodes u8[P].  Modes of a pixel are kept sorted by weight
-//   (descending) exactly like the reference's per-pixel GMM array, so plane k holds every pixel's k-th heaviest mode.
-// Mapping: one lane owns PX consecutive pixels -> every plane access is one PX*4-byte vector load/store per lane
-//   (PX = 4: global_load_dwordx4, 1 KiB per wave instruction), the frame is PX*3 bytes per lane, the mask PX bytes.
-//   The whole per-pixel model (25 floats) lives in VGPRs; K is a compile-time constant so the insertion sort is a
-//   fully unrolled network of predicated swaps.  No LDS: the op is pointwise and HBM-bound
-//   (206 B/pixel/frame algorithmic traffic vs ~400 VALU ops).
+// Model layout, round 3: RANKED WEIGHTS + FIXED SLOTS.
+//   The reference keeps each pixel's K = 5 modes physically sorted by weight: the matched mode bubbles towards the front and
+//   drags every mode it passes - {weight, variance, mean[3]} = 20 bytes each - through the swap.  On a busy scene that makes all
+//   100 bytes of a pixel's model dirty every frame although only ONE mode's variance and mean were recomputed.  Here
+//     * the WEIGHTS stay in rank order (plane r = weight of the r-th heaviest mode; every live weight changes every frame anyway);
+//     * a mode's {variance, mean[3]} is a 16-byte RECORD that lives in a fixed SLOT from the frame the mode is created until it
+//       is replaced (slots are handed out in creation order: a pixel with n modes owns slots 0..n-1);
+//     * a 16-bit META word per pixel maps rank -> slot: bits 3r..3r+2 = slot + 1 of rank r, 0 = rank unused (so a zeroed model is
+//       an empty model, BackgroundSubtractorMOG2::initialize).  modesUsed = number of non-zero fields.
+//   A frame then reads 3 (frame) + 2 (meta) + 20 (weights) + 80 (records) and writes 20 (weights) + 16 (the one record that was
+//   updated or created) + 2 (meta, when the order changed) + 1 (mask) = 144 B/pixel instead of 206.
+//   The arithmetic is the reference's statement for statement: the records are gathered into rank order in registers, the same
+//   predicated bubble runs there (the slot ids travel with it), and only what changed goes back.
+// Tiles: pixels are grouped in tiles of kMog2Tile (256); a tile is 5 weight planes (T floats each), 5 record planes (T float4
+//   each) and T meta words = 102 T contiguous bytes.  One workgroup owns one tile, one lane one pixel: every access is a
+//   coalesced wave instruction (dwordx4 for the records), and with the XCD-aware block order each XCD streams one contiguous
+//   eighth of the model.
+// Stores are SECTOR-COMPLETE (args.complete): HBM moves 32-byte sectors, so a lane also writes back an unchanged value of its own
+//   when another lane of the same sector (2 lanes of a record plane, 8 of a weight plane, 16 of the meta row) has something to
+//   write there - no partially written sector ever reaches the memory controller.
+// No LDS: the op is pointwise and HBM-bound.
 #pragma once
 #include "bgs_device.h"
 
 namespace bgs {
 
 constexpr int kMog2K = 5;
+#ifndef BGS_MOG2_TILE
+#define BGS_MOG2_TILE 256
+#endif
+constexpr int kMog2Tile = BGS_MOG2_TILE;                                          // pixels per tile
+constexpr size_t kMog2TileBytes = (size_t)kMog2Tile * (4 * kMog2K + 16 * kMog2K + 2);  // 102 B per pixel: 26 112 B
+constexpr size_t kMog2RecOff = (size_t)kMog2Tile * 4 * kMog2K;                    // byte offset of record plane 0 inside a tile
+constexpr size_t kMog2MetaOff = kMog2RecOff + (size_t)kMog2Tile * 16 * kMog2K;   // byte offset of the meta row
+static_assert(kMog2Tile % 64 == 0, "a wave never straddles two tiles");
 
 struct Mog2Args {
   const uint8_t* frame;  // [P][3] interleaved BGR
   uint8_t* fg;           // [P] or null
   uint8_t* bgimg;        // [P][3] or null
   uint64_t* fg_bits;     // [P/64] or null
-  float* state;          // model, layout below (updated in place)
-  uint8_t* nmodes_planar;// planar layout only: [plane] bytes
-  size_t plane;          // planar layout only: floats per plane (= streams * pixels of the engine)
+  uint8_t* state;        // model tiles (updated in place)
   size_t state_off;      // first pixel of this launch inside the model
   size_t npix;           // pixels in this launch
   float alphaT, alpha1, prune;
   float Tb, TB, Tg, varInit, varMin, varMax, tau;
   int thr, enable_thr, shadow_val;
   int shadow, want_bg, packed;  // wave-uniform feature switches
-  unsigned* stat;               // null, or 2 counters: sampled waves, sampled waves whose largest nmodes is below K-1 (auto mode)
+  unsigned* stat;               // null, or 2 counters: sampled waves, sampled waves whose largest mode count is below K-1 (auto mode)
   unsigned stat_mask;           // workgroups with (blockIdx.x & stat_mask) == 0 are sampled (~256 per launch)
-  int sparse;                   // 0 dense; 1 skip the stores of planes nothing changed in; 2 also skip the loads of modes no pixel of the wave has;
-                                // 4 the same per lane (4 pixels) instead of per wave: partial rows, traffic follows the live modes
+  int sparse;                   // 0 dense: every weight, record and meta word loaded and written back (placement probe, A/B);
+                                // 1 everything loaded, only what changed written; >= 2 a lane also loads only the modes its pixel has
+  int complete;                 // sector-complete stores (see above)
   int xcd_swizzle;              // workgroups that share an XCD walk one contiguous eighth of the launch
 };
 
-// Model layouts.  25 float "planes" per pixel: w[k] = k, var[k] = 5+k, mu[k][c] = 10+3k+c, plus nmodes (u8).
-//   TILED  (default): AoSoA — pixels are grouped in tiles of 256; a tile is 25 x 256 floats followed by 256 nmodes bytes
-//            (25 856 B, contiguous).  One wave (PX = 4) owns one tile: it streams ONE contiguous 25 KB block in and out,
-//            every access still a coalesced 1 KiB wave instruction.  With the XCD-aware block order each of the 8 XCDs
-//            then reads and writes one sequential stream, which is what HBM likes best (measured: DESIGN.md §6).
-//   PLANAR : 25 planes of P floats + one plane of P bytes (52 concurrent DRAM streams; kept for A/B measurements).
-constexpr int kMog2Planes = 25;
-constexpr int kMog2Tile = 256;                                            // pixels per tile
-constexpr int kMog2TileFloats = kMog2Planes * kMog2Tile + kMog2Tile / 4;  // 6464 floats = 25 856 B
-
-template <bool TILED>
-__device__ __forceinline__ size_t mog2_plane_off(const Mog2Args& a, int p, size_t sp) {
-  if constexpr (TILED)
-    return (sp >> 8) * kMog2TileFloats + p * kMog2Tile + (sp & 255);
-  else
-    return (size_t)p * a.plane + sp;
+struct Mog2Ptr {
+  float* w;        // weight of rank r at w[r * kMog2Tile]
+  float4* rec;     // record of slot s at rec[s * kMog2Tile]: {variance, mean0, mean1, mean2}
+  uint16_t* meta;
+};
+__device__ __forceinline__ Mog2Ptr mog2_ptr(uint8_t* state, size_t sp) {
+  uint8_t* tb = state + (sp / kMog2Tile) * kMog2TileBytes;
+  const size_t in = sp % kMog2Tile;
+  Mog2Ptr p;
+  p.w = reinterpret_cast<float*>(tb) + in;
+  p.rec = reinterpret_cast<float4*>(tb + kMog2RecOff) + in;
+  p.meta = reinterpret_cast<uint16_t*>(tb + kMog2MetaOff) + in;
+  return p;
 }
-template <bool TILED>
-__device__ __forceinline__ uint8_t* mog2_nmodes(const Mog2Args& a, size_t sp) {
-  if constexpr (TILED)
-    return reinterpret_cast<uint8_t*>(a.state + (sp >> 8) * kMog2TileFloats + kMog2Planes * kMog2Tile) + (sp & 255);
-  else
-    return a.nmodes_planar + sp;
+// modesUsed of a meta word: its non-zero 3-bit fields (always a prefix)
+__device__ __host__ __forceinline__ int mog2_meta_count(unsigned meta) {
+  unsigned t = (meta | (meta >> 1) | (meta >> 2)) & 0x1249u;
+  t = (t & 1u) + ((t >> 3) & 1u) + ((t >> 6) & 1u) + ((t >> 9) & 1u) + ((t >> 12) & 1u);
+  return (int)t;
 }
 
+// One pixel's model in rank order, as MOG2Invoker sees it; sl[r] = slot + 1 of the mode at rank r (0: rank unused)
 struct Mog2Px {
   float w[kMog2K], var[kMog2K], m0[kMog2K], m1[kMog2K], m2[kMog2K];
+  int sl[kMog2K];
 };
 
 __device__ __forceinline__ void mog2_swap(Mog2Px& s, int i, int j) {
@@ -77,6 +95,8 @@ __device__ __forceinline__ void mog2_swap(Mog2Px& s, int i, int j) {
   t = s.m0[i], s.m0[i] = s.m0[j], s.m0[j] = t;
   t = s.m1[i], s.m1[i] = s.m1[j], s.m1[j] = t;
   t = s.m2[i], s.m2[i] = s.m2[j], s.m2[j] = t;
+  const int u = s.sl[i];
+  s.sl[i] = s.sl[j], s.sl[j] = u;
 }
 
 // detectShadowGMM of bgfg_gaussmix2.cpp, predicated form of its early returns
@@ -117,6 +137,7 @@ __device__ __forceinline__ bool mog2_shadow(const Mog2Px& s, int nmodes, float x
 // One pixel of MOG2Invoker::operator() — same statement order as the reference so every float rounds identically.
 // Returns the raw mask value (0 background, shadow_val, 255 foreground) before the wrapper's threshold.
 // alphaT / alpha1 / prune are the learning-rate terms of THIS frame (they differ between the frames of a clip launch).
+// `dirty`: bit (slot + 1) is set for the slot whose record this frame recomputed (the matched mode) or created.
 __device__ __forceinline__ int mog2_pixel(Mog2Px& s, int& nmodes_io, float x0, float x1, float x2, const Mog2Args& a, unsigned& dirty,
                                           const float alphaT, const float alpha1, const float prune) {
   bool background = false, fitsPDF = false;
@@ -145,7 +166,7 @@ __device__ __forceinline__ int mog2_pixel(Mog2Px& s, int& nmodes_io, float x0, f
           varnew = varnew > a.varMin ? varnew : a.varMin;
           varnew = varnew < a.varMax ? varnew : a.varMax;
           s.var[mode] = varnew;
-          dirty |= 1u << mode;  // mean / variance of this mode changed
+          dirty |= 1u << s.sl[mode];  // the record of this mode's slot changed
         }
       }
       const bool pruned = weight < -prune;
@@ -158,7 +179,7 @@ __device__ __forceinline__ int mog2_pixel(Mog2Px& s, int& nmodes_io, float x0, f
 #pragma unroll
         for (int i = mode; i > 0; --i) {
           moving = moving && !(weight < s.w[i - 1]);
-          if (moving) mog2_swap(s, i, i - 1), dirty |= 3u << (i - 1);
+          if (moving) mog2_swap(s, i, i - 1);
         }
       }
       totalWeight += pruned ? 0.f : weight;
@@ -170,6 +191,9 @@ __device__ __forceinline__ int mog2_pixel(Mog2Px& s, int& nmodes_io, float x0, f
     if (mode < nmodes) s.w[mode] *= totalWeight;
   nmodes = nNewModes;  // sic: the pruned count is discarded
   if (!fitsPDF) {
+    // the reference overwrites gmm[K-1] when the array is full, else appends: the new mode takes over the slot of the mode it
+    // replaces, or the next free slot (slots are handed out in creation order)
+    const int slot = (nmodes == kMog2K) ? s.sl[kMog2K - 1] : nmodes + 1;
     const int mode = (nmodes == kMog2K) ? kMog2K - 1 : nmodes++;
 #pragma unroll
     for (int k = 0; k < kMog2K; ++k) {
@@ -177,17 +201,18 @@ __device__ __forceinline__ int mog2_pixel(Mog2Px& s, int& nmodes_io, float x0, f
         s.w[k] = (nmodes == 1) ? 1.f : alphaT;
         s.m0[k] = x0, s.m1[k] = x1, s.m2[k] = x2;
         s.var[k] = a.varInit;
-        dirty |= 1u << k;
+        s.sl[k] = slot;
       } else if (nmodes != 1 && k < nmodes - 1) {
         s.w[k] *= alpha1;
       }
     }
+    dirty |= 1u << slot;
     bool moving = true;
 #pragma unroll
     for (int i = kMog2K - 1; i > 0; --i) {
       if (i <= nmodes - 1) {
         moving = moving && !(alphaT < s.w[i - 1]);
-        if (moving) mog2_swap(s, i, i - 1), dirty |= 3u << (i - 1);
+        if (moving) mog2_swap(s, i, i - 1);
       }
     }
   }
@@ -218,186 +243,23 @@ __device__ __forceinline__ void mog2_background(const Mog2Px& s, int nmodes, flo
   b0 = sat_u8(v0 * inv), b1 = sat_u8(v1 * inv), b2 = sat_u8(v2 * inv);
 }
 
-// grid: ceil(npix / PX / kBlock) blocks of kBlock lanes; npix % PX == 0 (the host picks PX = 1 otherwise).
-template <int PX, bool TILED>
-__global__ __launch_bounds__(kBlock) void mog2_update_kernel(const Mog2Args a) {
-  size_t blk = blockIdx.x;
-  if (a.xcd_swizzle) {
-    // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 says which blocks share an XCD and its L2).  Give
-    // each XCD one CONTIGUOUS eighth of the launch instead of every 8th block, so every XCD reads and writes a single
-    // sequential run of the model (measured +16 % on HBM; placement only ever changes speed, never results).
-    const size_t per = gridDim.x >> 3, main = per << 3;
-    if (blk < main) blk = (blk & 7) * per + (blk >> 3);
-  }
-  const size_t g = blk * kBlock + threadIdx.x;
-  const size_t p0 = g * PX;  // first pixel of this lane, launch-relative
-  const bool active = p0 < a.npix;
-  uint32_t bits = 0;
-  if (active) {
-    const size_t sp = a.state_off + p0;  // index inside the model
-    constexpr int FB = (PX * 3 + 3) / 4 * 4;  // frame bytes per lane, rounded up to dwords
-    Bytes<FB> pix;
-    if constexpr (PX == 1) {
-      const uint8_t* f = a.frame + p0 * 3;
-      pix.w[0] = (uint32_t)f[0] | ((uint32_t)f[1] << 8) | ((uint32_t)f[2] << 16);
-    } else if constexpr (PX == 2) {
-      const uint16_t* f = reinterpret_cast<const uint16_t*>(a.frame + p0 * 3);
-      pix.w[0] = (uint32_t)f[0] | ((uint32_t)f[1] << 16);
-      pix.w[1] = f[2];
-    } else {
-      pix = load_bytes<PX * 3>(a.frame + p0 * 3);
-    }
-    uint8_t* const nmp = mog2_nmodes<TILED>(a, sp);
-    uint32_t nmw;
-    if constexpr (PX == 4)
-      nmw = *reinterpret_cast<const uint32_t*>(nmp);
-    else if constexpr (PX == 2)
-      nmw = *reinterpret_cast<const uint16_t*>(nmp);
-    else
-      nmw = *nmp;
-    // Data-dependent traffic (exact).  sparse >= 1: a plane is written back only if some pixel of the wave changed it.
-    // sparse == 2: the algorithm never touches modes at index >= nmodes(pixel) except to create one AT index nmodes, so with
-    // M = the largest nmodes in this wave only modes 0..min(M, K-1) are loaded at all.  That makes the plane loads depend on
-    // the nmodes load (one extra memory round trip per wave): a clear win on sparse scenes (x1.9 on S_surv), a loss of ~8 %
-    // when every mode is live, hence opt-in; mode 0 is requested before M is known so part of the latency overlaps.
-    float st[kMog2Planes][PX];
-    auto load_mode = [&](int k) {
-      load_f<PX>(a.state + mog2_plane_off<TILED>(a, k, sp), st[k]);
-      load_f<PX>(a.state + mog2_plane_off<TILED>(a, 5 + k, sp), st[5 + k]);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) load_f<PX>(a.state + mog2_plane_off<TILED>(a, 10 + 3 * k + c, sp), st[10 + 3 * k + c]);
-    };
-    int nload = kMog2K;
-    load_mode(0);
-    // sparse == 4: the same two rules per LANE (its PX pixels) instead of per wave.  With L = the largest nmodes among the
-    // lane's pixels, the lane loads modes 0..L-1 only and stores a plane only if one of its own pixels changed it.  The one
-    // unloaded slot a pixel can still write is index L (a pixel with nmodes == L creating a mode): the lane's other pixels
-    // keep stale, unread entries there, so that slot is written per pixel (scalar stores), never as a vector.
-    const bool lanewise = a.sparse >= 4;
-    int lane_need = kMog2K;
-    if (a.sparse >= 2) {
-      int lane_max = 0;
-#pragma unroll
-      for (int j = 0; j < PX; ++j) lane_max = max(lane_max, (int)((nmw >> (8 * j)) & 0xffu));
-      if (lanewise) lane_need = lane_max - 1;
-      int M = 0;
-#pragma unroll
-      for (int n = 1; n <= kMog2K; ++n)
-        if (__any(lane_max >= n)) M = n;
-      nload = min(M + 1, kMog2K);
-    }
-    if (a.stat && (blockIdx.x & a.stat_mask) == 0) {  // scene-sparsity sample for the engine's automatic choice between sparse 1 and 4
-      int lane_max = 0;
-#pragma unroll
-      for (int j = 0; j < PX; ++j) lane_max = max(lane_max, (int)((nmw >> (8 * j)) & 0xffu));
-      const bool dense_wave = __any(lane_max >= kMog2K - 1);
-      if ((threadIdx.x & (kWave - 1)) == 0) {
-        atomicAdd(a.stat, 1u);
-        if (!dense_wave) atomicAdd(a.stat + 1, 1u);
-      }
-    }
-#pragma unroll
-    for (int k = 1; k < kMog2K; ++k) {
-      if (k < nload && k <= lane_need) {
-        load_mode(k);
-      } else {
-#pragma unroll
-        for (int j = 0; j < PX; ++j) st[k][j] = 0.f, st[5 + k][j] = 0.f, st[10 + 3 * k][j] = 0.f, st[11 + 3 * k][j] = 0.f, st[12 + 3 * k][j] = 0.f;
-      }
-    }
-
-    uint32_t mask_word = 0, nm_out = 0;
-    unsigned dirty_m = 0, dirty_w = 0;  // per mode: mean/variance changed, weight changed (any of this lane's pixels)
-    Bytes<FB> bgout;
-#pragma unroll
-    for (int i = 0; i < FB / 4; ++i) bgout.w[i] = 0;
-#pragma unroll
-    for (int j = 0; j < PX; ++j) {
-      Mog2Px s;
-#pragma unroll
-      for (int k = 0; k < kMog2K; ++k)
-        s.w[k] = st[k][j], s.var[k] = st[5 + k][j], s.m0[k] = st[10 + 3 * k][j], s.m1[k] = st[11 + 3 * k][j], s.m2[k] = st[12 + 3 * k][j];
-      int nm = (int)((nmw >> (8 * j)) & 0xffu);
-      const float x0 = (float)pix.get(3 * j), x1 = (float)pix.get(3 * j + 1), x2 = (float)pix.get(3 * j + 2);
-      float worig[kMog2K];
-#pragma unroll
-      for (int k = 0; k < kMog2K; ++k) worig[k] = s.w[k];
-      const int raw = mog2_pixel(s, nm, x0, x1, x2, a, dirty_m, a.alphaT, a.alpha1, a.prune);
-#pragma unroll
-      for (int k = 0; k < kMog2K; ++k) dirty_w |= (unsigned)(s.w[k] != worig[k]) << k;
-      const int m = thr_bin(raw, a.thr, a.enable_thr);
-      mask_word |= (uint32_t)m << (8 * j);
-      bits |= (uint32_t)(m != 0) << j;
-      nm_out |= (uint32_t)nm << (8 * j);
-      if (a.want_bg) {
-        int b0, b1, b2;
-        mog2_background(s, nm, a.TB, b0, b1, b2);
-        bgout.set(3 * j, b0), bgout.set(3 * j + 1, b1), bgout.set(3 * j + 2, b2);
-      }
-#pragma unroll
-      for (int k = 0; k < kMog2K; ++k)
-        st[k][j] = s.w[k], st[5 + k][j] = s.var[k], st[10 + 3 * k][j] = s.m0[k], st[11 + 3 * k][j] = s.m1[k], st[12 + 3 * k][j] = s.m2[k];
-    }
-    // a plane is written back only if some pixel of the wave changed it (wave-uniform, so every store stays a full 1 KiB row)
-    const bool all = !a.sparse;
-#pragma unroll
-    for (int k = 0; k < kMog2K; ++k) {
-      const bool dw = (dirty_w >> k) & 1u, dm = (dirty_m >> k) & 1u;
-      if (lanewise && k > lane_need) {  // slot not loaded by this lane: only a pixel that now owns a mode here may write, and only its own element
-        if (dw || dm) {
-#pragma unroll
-          for (int j = 0; j < PX; ++j)
-            if ((int)((nm_out >> (8 * j)) & 0xffu) > k) {
-              a.state[mog2_plane_off<TILED>(a, k, sp) + j] = st[k][j];
-              a.state[mog2_plane_off<TILED>(a, 5 + k, sp) + j] = st[5 + k][j];
-#pragma unroll
-              for (int c = 0; c < 3; ++c) a.state[mog2_plane_off<TILED>(a, 10 + 3 * k + c, sp) + j] = st[10 + 3 * k + c][j];
-            }
-        }
-        continue;
-      }
-      if (all || (lanewise ? dw : (bool)__any(dw))) store_f<PX>(a.state + mog2_plane_off<TILED>(a, k, sp), st[k]);
-      if (all || (lanewise ? dm : (bool)__any(dm))) {
-        store_f<PX>(a.state + mog2_plane_off<TILED>(a, 5 + k, sp), st[5 + k]);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) store_f<PX>(a.state + mog2_plane_off<TILED>(a, 10 + 3 * k + c, sp), st[10 + 3 * k + c]);
-      }
-    }
-    const bool nm_dirty = all || (lanewise ? nm_out != nmw : (bool)__any(nm_out != nmw));
-    if constexpr (PX == 4) {
-      if (nm_dirty) *reinterpret_cast<uint32_t*>(nmp) = nm_out;
-      if (a.fg) *reinterpret_cast<uint32_t*>(a.fg + p0) = mask_word;
-    } else if constexpr (PX == 2) {
-      if (nm_dirty) *reinterpret_cast<uint16_t*>(nmp) = (uint16_t)nm_out;
-      if (a.fg) *reinterpret_cast<uint16_t*>(a.fg + p0) = (uint16_t)mask_word;
-    } else {
-      if (nm_dirty) *nmp = (uint8_t)nm_out;
-      if (a.fg) a.fg[p0] = (uint8_t)mask_word;
-    }
-    if (a.want_bg) {
-      if constexpr (PX == 4) {
-        store_bytes<12>(a.bgimg + p0 * 3, bgout);
-      } else {
-#pragma unroll
-        for (int i = 0; i < PX * 3; ++i) a.bgimg[p0 * 3 + i] = (uint8_t)bgout.get(i);
-      }
-    }
-  }
-  if (a.packed) {
-    // every lane of the wave takes part (inactive tail lanes contribute 0); npix % 64 == 0 is checked by the host
-    store_packed_mask<PX>(a.fg_bits, p0, bits, active);
-  }
+// lane-crossing OR for the sector-complete stores (DPP row operations, no LDS traffic): returns the OR over the lane's aligned
+// group of 2 / 8 / 16 lanes.  quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140;
+// lanes that left the kernel (past npix) read as 0 (bound_ctrl).
+__device__ __forceinline__ void mog2_group_or(unsigned v, unsigned& or2, unsigned& or8, unsigned& or16) {
+  v |= (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);
+  or2 = v;
+  v |= (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);
+  v |= (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true);
+  or8 = v;
+  v |= (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, true);
+  or16 = v;
 }
 
-// ---- clip launches: T consecutive frames of every stream in ONE launch (bgs_process_clip_device) -------------------------
-// The model of a pixel is loaded once, updated T times in registers in frame order with exactly the statements of the
-// single-frame kernel, and written back once: model traffic per frame drops from 201 B/pixel to 201/T, the frame and mask bytes
-// stay (4 B/pixel/frame).  Results are those of T successive single-frame launches, bit for bit: a pixel's update depends on
-// nothing but its own model and its own input.  One pixel per lane; npix % 64 == 0 when masks are bit-packed (then a wave is
-// active or idle as a whole, which the cross-lane packing needs).
-// Slots at index >= nmodes are all-zero in memory ever since mog2_clear (nmodes never shrinks), so the slots a lane does not
-// load are exactly the zeros it holds for them; a mode created in such a slot during the clip is written back like any other
-// changed plane.
+// T consecutive frames of one pixel per lane (T = 1: the per-frame launch; 2 / 4 / 8: clip launches, bgs_process_clip_device).
+// The model of a pixel is loaded once, updated T times in registers in frame order with exactly the statements of the reference,
+// and what changed is written back once: results are those of T successive single-frame launches, bit for bit, because a pixel's
+// update depends on nothing but its own model and its own input.
 constexpr int kMog2ClipMax = 8;
 struct Mog2ClipArgs {
   Mog2Args m;                  // frame / fg / bgimg / fg_bits point at the FIRST frame of the launch
@@ -406,105 +268,138 @@ struct Mog2ClipArgs {
   float alphaT[kMog2ClipMax], alpha1[kMog2ClipMax], prune[kMog2ClipMax];  // per frame (the automatic rate changes with the frame count)
 };
 
-template <bool TILED, int T>
-__global__ __launch_bounds__(kBlock) void mog2_clip_kernel(const Mog2ClipArgs c) {
-  const Mog2Args& a = c.m;
+template <int T>
+__device__ __forceinline__ void mog2_body(const Mog2Args& a, const size_t frame_stride, const size_t fg_stride, const size_t bg_stride, const size_t bits_stride,
+                                          const float* alphaT, const float* alpha1, const float* prune) {
   size_t blk = blockIdx.x;
   if (a.xcd_swizzle) {
+    // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 says which blocks share an XCD and its L2).  Give
+    // each XCD one CONTIGUOUS eighth of the launch instead of every 8th block, so every XCD reads and writes a single
+    // sequential run of the model (measured +16 % on HBM; placement only ever changes speed, never results).
     const size_t per = gridDim.x >> 3, main = per << 3;
     if (blk < main) blk = (blk & 7) * per + (blk >> 3);
   }
-  const size_t p0 = blk * kBlock + threadIdx.x;
-  if (p0 >= a.npix) return;  // wave-uniform whenever the packing below runs (npix % 64 == 0)
-  const size_t sp = a.state_off + p0;
+  const size_t p0 = blk * kBlock + threadIdx.x;  // this lane's pixel, launch-relative
+  if (p0 >= a.npix) return;                      // wave-uniform whenever masks are bit-packed (npix % 64 == 0, checked by the host)
+  const size_t sp = a.state_off + p0;            // index inside the model
   uint32_t pix[T];  // all T inputs of this pixel are requested before the model: they are what the first update waits for
 #pragma unroll
   for (int t = 0; t < T; ++t) {
-    const uint8_t* f = a.frame + (size_t)t * c.frame_stride + p0 * 3;
+    const uint8_t* f = a.frame + (size_t)t * frame_stride + p0 * 3;
     pix[t] = (uint32_t)f[0] | ((uint32_t)f[1] << 8) | ((uint32_t)f[2] << 16);
   }
-  uint8_t* const nmp = mog2_nmodes<TILED>(a, sp);
-  const int nm_in = *nmp;
-  Mog2Px s;
-  auto load_mode = [&](int k) {
-    s.w[k] = a.state[mog2_plane_off<TILED>(a, k, sp)];
-    s.var[k] = a.state[mog2_plane_off<TILED>(a, 5 + k, sp)];
-    s.m0[k] = a.state[mog2_plane_off<TILED>(a, 10 + 3 * k, sp)];
-    s.m1[k] = a.state[mog2_plane_off<TILED>(a, 11 + 3 * k, sp)];
-    s.m2[k] = a.state[mog2_plane_off<TILED>(a, 12 + 3 * k, sp)];
-  };
-  load_mode(0);
-  // the same data-dependent loads as the single-frame kernel: sparse >= 2 loads modes below the wave's largest count + 1,
-  // sparse >= 4 below the lane's own count
-  int nload = kMog2K, lane_need = kMog2K;
-  if (a.sparse >= 2) {
-    if (a.sparse >= 4) lane_need = nm_in - 1;
-    int M = 0;
+  const Mog2Ptr mp = mog2_ptr(a.state, sp);
+  const unsigned meta_in = *mp.meta;
+  // Loads.  sparse < 2: everything, independent of the meta word (all the loads of a lane are in flight at once: what a busy
+  // scene wants).  sparse >= 2: rank 0 / slot 0 at once (every pixel has them after its first frame), the rest only for the modes
+  // this pixel has - those loads wait for the meta word, which pays when most pixels have one or two modes (quiet scenes).
+  float wv[kMog2K];
+  float4 rec[kMog2K];
+  const int nm_in = mog2_meta_count(meta_in);
+  const bool lazy = a.sparse >= 2;
+  wv[0] = mp.w[0];
+  rec[0] = mp.rec[0];
 #pragma unroll
-    for (int n = 1; n <= kMog2K; ++n)
-      if (__any(nm_in >= n)) M = n;
-    nload = min(M + 1, kMog2K);
+  for (int k = 1; k < kMog2K; ++k) {
+    if (!lazy || k < nm_in) {
+      wv[k] = mp.w[(size_t)k * kMog2Tile];
+      rec[k] = mp.rec[(size_t)k * kMog2Tile];
+    } else {
+      wv[k] = 0.f;
+      rec[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
-  if (a.stat && (blockIdx.x & a.stat_mask) == 0) {
+  if (a.stat && (blockIdx.x & a.stat_mask) == 0) {  // scene-sparsity sample for the engine's automatic choice between sparse 1 and 4
     const bool dense_wave = __any(nm_in >= kMog2K - 1);
     if ((threadIdx.x & (kWave - 1)) == 0) {
       atomicAdd(a.stat, 1u);
       if (!dense_wave) atomicAdd(a.stat + 1, 1u);
     }
   }
+  // records into rank order (what the reference's array order is)
+  Mog2Px s;
 #pragma unroll
-  for (int k = 1; k < kMog2K; ++k) {
-    if (k < nload && k <= lane_need)
-      load_mode(k);
-    else
-      s.w[k] = 0.f, s.var[k] = 0.f, s.m0[k] = 0.f, s.m1[k] = 0.f, s.m2[k] = 0.f;
+  for (int r = 0; r < kMog2K; ++r) {
+    const int f = (int)((meta_in >> (3 * r)) & 7u);
+    s.sl[r] = f;
+    s.w[r] = wv[r];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < kMog2K; ++q)
+      if (f == q + 1) v = rec[q];
+    s.var[r] = v.x, s.m0[r] = v.y, s.m1[r] = v.z, s.m2[r] = v.w;
   }
-  float worig[kMog2K];
-#pragma unroll
-  for (int k = 0; k < kMog2K; ++k) worig[k] = s.w[k];
-  unsigned dirty_m = 0;
+  unsigned dirty = 0;
   int nm = nm_in;
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     const float x0 = (float)(pix[t] & 0xffu), x1 = (float)((pix[t] >> 8) & 0xffu), x2 = (float)(pix[t] >> 16);
-    const int raw = mog2_pixel(s, nm, x0, x1, x2, a, dirty_m, c.alphaT[t], c.alpha1[t], c.prune[t]);
+    const int raw = mog2_pixel(s, nm, x0, x1, x2, a, dirty, alphaT[t], alpha1[t], prune[t]);
     const int m = thr_bin(raw, a.thr, a.enable_thr);
-    if (a.fg) a.fg[(size_t)t * c.fg_stride + p0] = (uint8_t)m;
-    if (a.packed) store_packed_mask<1>(a.fg_bits + (size_t)t * c.bits_stride, p0, (uint32_t)(m != 0), true);
+    if (a.fg) a.fg[(size_t)t * fg_stride + p0] = (uint8_t)m;
+    if (a.packed) store_packed_mask<1>(a.fg_bits + (size_t)t * bits_stride, p0, (uint32_t)(m != 0), true);
     if (a.want_bg) {
       int b0, b1, b2;
       mog2_background(s, nm, a.TB, b0, b1, b2);
-      uint8_t* o = a.bgimg + (size_t)t * c.bg_stride + p0 * 3;
+      uint8_t* o = a.bgimg + (size_t)t * bg_stride + p0 * 3;
       o[0] = (uint8_t)b0, o[1] = (uint8_t)b1, o[2] = (uint8_t)b2;
     }
   }
-  const bool all = !a.sparse, lanewise = a.sparse >= 4;
+  // what changed: bits 0..4 weight of rank r, bit 5 the meta word, bits 6..10 the record of slot s
+  unsigned meta_out = 0;
 #pragma unroll
-  for (int k = 0; k < kMog2K; ++k) {
-    const bool dw = s.w[k] != worig[k], dm = (dirty_m >> k) & 1u;
-    const bool unloaded = lanewise && k > lane_need;  // holds zeros unless a mode was created here: only then there is something to write
-    const bool sw = unloaded ? ((dw || dm) && nm > k) : (all || (lanewise ? dw : (bool)__any(dw)));
-    const bool sm = unloaded ? sw : (all || (lanewise ? dm : (bool)__any(dm)));
-    if (sw) a.state[mog2_plane_off<TILED>(a, k, sp)] = s.w[k];
-    if (sm) {
-      a.state[mog2_plane_off<TILED>(a, 5 + k, sp)] = s.var[k];
-      a.state[mog2_plane_off<TILED>(a, 10 + 3 * k, sp)] = s.m0[k];
-      a.state[mog2_plane_off<TILED>(a, 11 + 3 * k, sp)] = s.m1[k];
-      a.state[mog2_plane_off<TILED>(a, 12 + 3 * k, sp)] = s.m2[k];
+  for (int r = 0; r < kMog2K; ++r) meta_out |= (unsigned)s.sl[r] << (3 * r);
+  unsigned d = 0;
+#pragma unroll
+  for (int r = 0; r < kMog2K; ++r) d |= (unsigned)(s.w[r] != wv[r]) << r;
+  d |= (unsigned)(meta_out != meta_in) << 5;
+  d |= (dirty >> 1) << 6;
+  if (a.sparse == 0) {
+    d = 0x7ffu;
+  } else if (a.complete) {
+    // whole 32-byte sectors or nothing: 2 lanes share a sector of a record plane, 8 of a weight plane, 16 of the meta row
+    unsigned d2, d8, d16;
+    mog2_group_or(d, d2, d8, d16);
+    d = (d2 & 0x7c0u) | (d8 & 0x1fu) | (d16 & 0x20u);
+  }
+#pragma unroll
+  for (int r = 0; r < kMog2K; ++r)
+    if ((d >> r) & 1u) mp.w[(size_t)r * kMog2Tile] = s.w[r];
+  if ((d >> 5) & 1u) *mp.meta = (uint16_t)meta_out;
+#pragma unroll
+  for (int q = 0; q < kMog2K; ++q) {
+    if ((d >> (6 + q)) & 1u) {
+      // the record of slot q as it stands now: wherever the bubble left it (a slot this pixel does not own holds nothing anyone reads)
+      float4 v = rec[q];
+#pragma unroll
+      for (int r = 0; r < kMog2K; ++r)
+        if (s.sl[r] == q + 1) v = make_float4(s.var[r], s.m0[r], s.m1[r], s.m2[r]);
+      mp.rec[(size_t)q * kMog2Tile] = v;
     }
   }
-  if (all || (lanewise ? nm != nm_in : (bool)__any(nm != nm_in))) *nmp = (uint8_t)nm;
+}
+
+// grid: ceil(npix / kBlock) blocks of kBlock lanes, one pixel per lane
+__global__ __launch_bounds__(kBlock) void mog2_update_kernel(const Mog2Args a) {
+  mog2_body<1>(a, 0, 0, 0, 0, &a.alphaT, &a.alpha1, &a.prune);
+}
+
+template <int T>
+__global__ __launch_bounds__(kBlock) void mog2_clip_kernel(const Mog2ClipArgs c) {
+  mog2_body<T>(c.m, c.frame_stride, c.fg_stride, c.bg_stride, c.bits_stride, c.alphaT, c.alpha1, c.prune);
 }
 
 // (re)initialisation of a pixel range: bgmodel = zeros, modesUsed = 0 (BackgroundSubtractorMOG2::initialize)
-template <bool TILED>
 __global__ __launch_bounds__(kBlock) void mog2_clear_kernel(const Mog2Args a) {
   const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= a.npix) return;
-  const size_t sp = a.state_off + p;
+  const Mog2Ptr mp = mog2_ptr(a.state, a.state_off + p);
 #pragma unroll
-  for (int q = 0; q < kMog2Planes; ++q) a.state[mog2_plane_off<TILED>(a, q, sp)] = 0.f;
-  *mog2_nmodes<TILED>(a, sp) = 0;
+  for (int k = 0; k < kMog2K; ++k) {
+    mp.w[(size_t)k * kMog2Tile] = 0.f;
+    mp.rec[(size_t)k * kMog2Tile] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  *mp.meta = 0;
 }
 
 }  // namespace bgs
