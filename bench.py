@@ -125,12 +125,16 @@ def surv_leg(local, S, fg, steps=200, sparse=1):
     return out
 
 
+CLIP_PMC_LAUNCHES = 10  # clip launches per T in the counter passes
+
+
 def pmc_traffic_live(streams, steps, warmup, inp, timeout_s=150):
-    """roofline.traffic measured IN this run: two child passes of this script's timed leg under `rocprofv3 --kernel-trace --pmc`
-    (FETCH_SIZE, then WRITE_SIZE: they do not fit one pass), the last `steps` dispatches of the update kernel averaged, corrected as
-    MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts half of a wide streaming read; both are in KiB).  Children are
-    started as ordinary subprocesses (never an exec from this GPU-holding process), each under a timeout; any failure returns None
-    and the caller falls back to the committed constant."""
+    """roofline.traffic (and the clip legs' traffic) measured IN this run: two child passes of this script under `rocprofv3 --kernel-trace
+    --pmc` (FETCH_SIZE, then WRITE_SIZE: they do not fit one pass).  A child runs the timed leg and then CLIP_PMC_LAUNCHES clip launches
+    of 4 and of 8 frames; the last `steps` dispatches of the update kernel and the last CLIP_PMC_LAUNCHES of each clip kernel are averaged and
+    corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts half of a wide streaming read; both are in KiB).
+    Children are ordinary subprocesses (never an exec from this GPU-holding process), each under a timeout; any failure returns None
+    and the caller falls back to the committed constant.  Returns ({kernel key: {hbm_bytes_per_launch, read_bytes, write_bytes}}, note)."""
     import csv
     import glob
     import shutil
@@ -140,13 +144,14 @@ def pmc_traffic_live(streams, steps, warmup, inp, timeout_s=150):
         return None, "rocprofv3 not on PATH"
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None, "this process is itself being profiled"
-    out = {}
+    want = {"update": ("mog2_update", steps), "clip4": ("mog2_clip_kernel<4>", CLIP_PMC_LAUNCHES), "clip8": ("mog2_clip_kernel<8>", CLIP_PMC_LAUNCHES)}
+    out = {k: {} for k in want}
     env = dict(os.environ, TMPDIR="/tmp")
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="bgs_pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
                sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--streams", str(streams),
-               "--input", inp, "--main-only", "--sustain", "0", "--settle", "40", "--no-cpu-baseline"]
+               "--input", inp, "--pmc-child", "--sustain", "0", "--settle", "100", "--no-cpu-baseline"]
         try:
             p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
@@ -156,20 +161,26 @@ def pmc_traffic_live(streams, steps, warmup, inp, timeout_s=150):
                 p.wait()
                 shutil.rmtree(d, ignore_errors=True)
                 return None, "%s pass timed out after %d s" % (ctr, timeout_s)
-            vals = []
+            rows = []
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-                rows = [r for r in csv.DictReader(open(f)) if "mog2_update" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
-                rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-                vals += [float(r["Counter_Value"]) for r in rows]
+                rows += [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == ctr]
             shutil.rmtree(d, ignore_errors=True)
-            if rc != 0 or len(vals) < steps:
-                return None, "%s pass: rc=%s, %d dispatches" % (ctr, rc, len(vals))
-            out[ctr] = sum(vals[-steps:]) / steps
+            rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+            for key, (pat, n) in want.items():
+                vals = [float(r["Counter_Value"]) for r in rows if pat in r["Kernel_Name"]]
+                if key == "update" and (rc != 0 or len(vals) < n):
+                    return None, "%s pass: rc=%s, %d dispatches" % (ctr, rc, len(vals))
+                if len(vals) >= n:
+                    out[key][ctr] = sum(vals[-n:]) / n
         except Exception as ex:  # noqa: BLE001 - diagnostics only, the bench line must still be printed
             shutil.rmtree(d, ignore_errors=True)
             return None, "%s pass failed: %r" % (ctr, ex)
-    rd, wr = out["FETCH_SIZE"] * 1024 * 2, out["WRITE_SIZE"] * 1024
-    return {"hbm_bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr)}, "measured in this run: two child passes of the timed leg under rocprofv3 --kernel-trace --pmc (FETCH_SIZE*1024*2 + WRITE_SIZE*1024, mean of the last %d dispatches)" % steps
+    res = {}
+    for key, v in out.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            rd, wr = v["FETCH_SIZE"] * 1024 * 2, v["WRITE_SIZE"] * 1024
+            res[key] = {"hbm_bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr)}
+    return res, "measured in this run: two child passes under rocprofv3 --kernel-trace --pmc (FETCH_SIZE*1024*2 + WRITE_SIZE*1024, mean of the last %d dispatches of the update kernel / %d of each clip kernel)" % (steps, CLIP_PMC_LAUNCHES)
 
 
 def clip_leg(eng, pool, period, S, T, launches=40, warm=10):
@@ -192,12 +203,13 @@ def clip_leg(eng, pool, period, S, T, launches=40, warm=10):
     ms, n, name = eng.kernel_timing()
     eng.enable_kernel_timing(False)
     px = S * ROWS * COLS * T
-    moved = 201.0 / T + 4.0  # model read + written once per launch, frame 3 B + mask 1 B per frame
+    # per launch and pixel: model read once (2 meta + 20 weights + 80 records) and written back once (20 weights + 16 per record a frame of the
+    # clip updated: min(T, 5) on S_sat + 2 meta); per frame 3 B of input and 1 B of mask
+    model = (102.0 + 20.0 + 16.0 * min(T, 5) + 2.0) / T + 4.0
     return {"frames_per_launch": T, "kernel": name, "launches": int(n), "kernel_avg_ms": round(ms, 4), "ms_per_frame_step": round(ms / T, 4),
             "mpixels_per_s": round(px * launches / wall / 1e6, 1), "frames_per_s": round(px * launches / wall / (ROWS * COLS), 1),
             "streams_1080p30": round(px * launches / wall / (ROWS * COLS) / 30.0, 1),
-            "bytes_moved_per_pixel_frame_dense": round(moved, 1), "hbm_GBps_moved": round(moved * px / (ms * 1e-3) / 1e9, 1),
-            "added_latency_frames": T - 1}
+            "bytes_model_per_pixel_frame": round(model, 1), "added_latency_frames": T - 1}
 
 
 def main():
@@ -210,6 +222,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-bg", action="store_true", help="also produce the background image every frame (+3 B/px)")
     ap.add_argument("--main-only", action="store_true", help="only the timed S_sat leg (used under rocprofv3 so the last K launches are the timed ones)")
+    ap.add_argument("--pmc-child", action="store_true", help="what the counter passes run: the timed leg, then a few clip launches of 4 and 8 frames, nothing else")
+    ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs[2] / configs[3] block")
     ap.add_argument("--settle", type=int, default=340, help="untimed launches after model saturation and before the W warm-up steps: they age the model until the weights have equalised and every frame re-orders the modes (steady-state traffic)")
     ap.add_argument("--sustain", type=int, default=200, help="further launches after the timed K, reported as roofline.sustained")
     ap.add_argument("--series", default="", help="write the per-launch kernel durations (settle, warmup, timed, sustain) to this CSV")
@@ -219,6 +233,8 @@ def main():
     ap.add_argument("--px", type=int, default=0, help="MOG2 pixels per lane (tuning; 0 = default = 1)")
     args = ap.parse_args()
 
+    if args.pmc_child:
+        args.main_only = True
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -294,6 +310,8 @@ def main():
     if world > 1 or selftest:
         dist.barrier()
     torch.cuda.synchronize()
+    if gather:
+        gather.reset_stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(t)
@@ -304,10 +322,12 @@ def main():
     if world > 1 or selftest:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    local_elapsed = elapsed
     if world > 1 or selftest:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    gather_wait_ms = gather.blocked_s / max(1, args.steps) * 1e3 if gather else 0.0  # of the timed region only (reset above)
     # sustained leg (untimed by the contract's clock, reported beside it): SUSTAIN further launches of the same step
     for _ in range(SUSTAIN):
         step(t)
@@ -339,8 +359,21 @@ def main():
                 phase = "settle" if i < SETTLE else "warmup" if i < i0 else "timed" if i < i0 + args.steps else "sustain"
                 f.write("%d,%s,%.4f\n" % (i, phase, v))
 
+    # N > 1 diagnostics (a sub-linear scaling curve must be explainable from the line alone): every rank's own kernel time over the
+    # timed steps, its elapsed time, and the host time per step that MaskGather.next_buffer() spent blocked on an earlier gather
+    per_rank = None
+    if world > 1 or selftest:
+        mine = torch.tensor([k_ms, gather_wait_ms, local_elapsed * 1e3 / max(1, args.steps)], dtype=torch.float64, device="cpu" if rehearse else dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        if rank == 0:
+            per_rank = {"kernel_avg_ms": [round(float(v[0]), 4) for v in allr], "gather_wait_ms_per_step": [round(float(v[1]), 4) for v in allr],
+                        "ms_per_step_local": [round(float(v[2]), 4) for v in allr],
+                        "note": "one entry per rank: mean duration of the update kernel over the timed steps (HIP events), host time per step blocked in MaskGather.next_buffer() "
+                                "waiting for the gather that last used the buffer, and the rank's own wall time per step; `ms_per_step` is the MAX over ranks"}
     live_modes = None
     single = None
+    configs = None
     cpu = None
     surv = None
     clip = None
@@ -351,6 +384,9 @@ def main():
         pr = eng.get_state("probe", (26,), np.float32)
         probe = {"candidates_ms_per_dense_launch": [round(float(v), 3) for v in pr[2:2 + int(pr[0])]], "kept": int(pr[1]),
                  "note": "model placement probe at allocation (DESIGN.md 6.2): stops once two speed classes have been seen"}
+    if rank == 0 and args.pmc_child:
+        for T in (4, 8):
+            clip_leg(eng, pool, period, S, T, launches=CLIP_PMC_LAUNCHES, warm=4)
     if rank == 0 and not args.main_only and not rehearse:
         clip = {"note": "supplementary, never `value`: bgs_process_clip_device on the same engine and saturated model - T consecutive frames per launch, model kept in "
                         "registers across them, bit-identical results; for file-fed video or deployments that accept T-1 frame times of latency",
@@ -378,8 +414,18 @@ def main():
         e1.close()
         if args.input == "sat":
             surv = {"default": surv_leg(local, S, fg, sparse=3), "stores_only": surv_leg(local, S, fg, sparse=1)}
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(pool, args.input)
+        if world == 1 and not args.no_configs:
+            # BASELINE configs[2] (WMV + ABL at 3840x2160) and configs[3] (SuBSENSE / LBSP at 1080p) in the driver-timed line, never `value`
+            from tools import bench_configs
+            eng.close()  # the 6.8 GB MOG2 model is not needed any more (its state was read above)
+            eng = None
+            try:
+                configs = bench_configs.configs_block(device=local, cpu=not args.no_cpu_baseline)
+            except Exception as ex:  # noqa: BLE001 - the headline must still be printed
+                configs = {"error": repr(ex)}
+        if not args.no_cpu_baseline and not rehearse:
+            # N > 1: a shorter sample on rank 0 (the other ranks wait in the final barrier), so the line stays self-contained
+            cpu = cpu_baseline(pool, args.input, budget_s=16.0 if world == 1 else 6.0)
 
     if rank == 0:
         px_per_step_rank = S * ROWS * COLS
@@ -390,9 +436,17 @@ def main():
         traffic, traffic_source, traffic_detail = None, "none", None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if world == 1 and not args.main_only and not args.no_pmc and not args.with_bg:
-            traffic_detail, why = pmc_traffic_live(S, args.steps, args.warmup, args.input)
-            if traffic_detail:
+            pmc_all, why = pmc_traffic_live(S, args.steps, args.warmup, args.input)
+            if pmc_all and "update" in pmc_all:
+                traffic_detail = pmc_all["update"]
                 traffic, traffic_source = traffic_detail["hbm_bytes_per_launch"], why
+                for key, T in (("clip4", 4), ("clip8", 8)):  # the clip legs get their measured traffic too (never a byte model priced as bandwidth)
+                    leg_c = clip and clip.get("T%d" % T)
+                    if leg_c and key in pmc_all:
+                        tb = pmc_all[key]
+                        leg_c["traffic"] = tb
+                        leg_c["traffic_B_per_pixel_frame"] = round(tb["hbm_bytes_per_launch"] / (px_per_step_rank * T), 2)
+                        leg_c["hbm_GBps_measured"] = round(tb["hbm_bytes_per_launch"] / (leg_c["kernel_avg_ms"] * 1e-3) / 1e9, 1)
             else:
                 traffic_source = "live PMC passes unavailable (%s); " % why
         if traffic is None and os.path.exists(pmc):
@@ -432,14 +486,17 @@ def main():
                          "timed_region": "the K timed steps, after %d saturation + %d model-ageing (settle) + %d warm-up launches: steady-state traffic" % (SATURATE, SETTLE, args.warmup),
                          "sustained": leg(sus_ms), "young_model_first_20": leg(burst_ms)},
             "cpu_baseline": cpu,
+            "per_rank": per_rank,
             "placement_probe": probe,
             "rccl_selftest_gather_matches_kernel_output": selftest_ok,
             "single_stream": single,
             "s_surv": surv,
             "clip": clip,
+            "configs": configs,
         }
         print(json.dumps(out), flush=True)
-    eng.close()
+    if eng is not None:
+        eng.close()
     if world > 1 or selftest:
         dist.barrier()
         dist.destroy_process_group()

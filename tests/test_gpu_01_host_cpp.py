@@ -180,6 +180,30 @@ def test_last_mask_blobs_match_oracle_components(golden_frames):
 
 
 @pytest.mark.gpu
+def test_last_mask_blobs_keeps_a_large_blob_behind_more_speckles_than_the_scratch_holds():
+    """1 600 one-pixel components in the top rows (more than the 1 024 boxes the device scratch starts with), then one 30x20 block:
+    with min_w = min_h = 5 and max_boxes = 256 (what HipFGDetector::GetBlobs asks for) the block must come back - the size filter
+    runs after ALL components were kept, not on the first 1 024 in raster order."""
+    from tracking_amd import Engine, capi
+    H, W = 96, 160
+    f0 = np.zeros((H, W, 3), np.uint8)
+    f1 = f0.copy()
+    f1[0:40:2, 0:W:2] = 255
+    f1[60:80, 100:130] = 200
+    eng = Engine(capi.FRAME_DIFF)
+    eng.process(f0)
+    fg, _ = eng.process(f1)
+    assert int((fg != 0).sum()) == 20 * 80 + 20 * 30
+    boxes, _, n = eng.last_mask_blobs(connectivity=8, min_w=5, min_h=5, max_boxes=256)
+    assert n == 1 and boxes[0, :5].tolist() == [100, 60, 30, 20, 600], (n, boxes[:2])
+    boxes, _, n = eng.last_mask_blobs(connectivity=8, min_w=0, min_h=0, max_boxes=4096)  # unfiltered: every speckle and the block
+    assert n == 1601 and boxes[-1, :5].tolist() == [100, 60, 30, 20, 600]
+    boxes, _, n = eng.last_mask_blobs(connectivity=8, min_w=0, min_h=0, max_boxes=8)  # truncated output, true count
+    assert n == 1601 and len(boxes) == 8
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_last_mask_blobs_needs_a_valid_mask(golden_frames):
     from tracking_amd import Engine, capi
     eng = Engine(capi.FRAME_DIFF, n_streams=2)

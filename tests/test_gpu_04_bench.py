@@ -42,3 +42,27 @@ def test_bench_rccl_selftest_gathers_what_the_kernel_wrote():
     assert d["config"]["mask_gather"].startswith("RCCL SELF-TEST")
     s = d["rccl_selftest_gather_matches_kernel_output"]
     assert s["gather_equals_kernel_output"] is True and s["nonzero_words"] > 0 and s["words"] == 2 * 1920 * 1080 // 64
+    pr = d["per_rank"]  # N > 1 diagnostics, present whenever the collective path runs
+    assert len(pr["kernel_avg_ms"]) == 1 and pr["kernel_avg_ms"][0] > 0 and len(pr["gather_wait_ms_per_step"]) == 1 and pr["gather_wait_ms_per_step"][0] >= 0
+
+
+def test_bench_rehearsal_two_ranks_reports_per_rank_diagnostics():
+    """The N > 1 control flow with two ranks on the one GPU of this box (gloo, masks through host copies - not a benchmark): the line
+    must carry what a first scaling run needs to be diagnosed - every rank's kernel time, its wall time per step, and the time
+    MaskGather.next_buffer() blocked on the gather."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--streams", "2", "--settle", "4", "--sustain", "4", "--rehearse", "--main-only"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["mask_gather"].startswith("REHEARSAL")
+    pr = d["per_rank"]
+    for k in ("kernel_avg_ms", "gather_wait_ms_per_step", "ms_per_step_local"):
+        assert len(pr[k]) == 2 and all(v >= 0 for v in pr[k]), k
+    assert all(v > 0 for v in pr["kernel_avg_ms"]) and max(pr["ms_per_step_local"]) <= d["ms_per_step"] * 1.001
+    assert abs(d["value"] - 2 * 2 * 1920 * 1080 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01  # whole-job aggregate over both ranks

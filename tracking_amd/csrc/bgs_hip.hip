@@ -1631,23 +1631,32 @@ int bgs_last_mask_blobs(bgs_engine* e, int stream, int connectivity, int min_w, 
   if (!e->n || e->last_fg_stream != stream)
     return fail(BGS_ERR_STATE, "bgs_last_mask_blobs: the last bgs_process call left no valid mask of stream %d on the device", stream);
   HIP_TRY(hipSetDevice(e->device));
-  // device scratch, grown on demand: [workspace][boxes cap][moments cap][count]; more components than `cap` are counted but not kept
-  const int cap = std::max(max_boxes, 1024);
+  // device scratch, grown on demand: [workspace][boxes cap][moments cap][count].  The component pass keeps the first `cap` components in
+  // raster order and COUNTS all of them; the size filter below runs on the host, so every component has to be kept: when a mask
+  // holds more than the scratch has room for (an unfiltered FrameDifference mask can carry thousands of one-pixel speckles before the
+  // first real blob), the scratch is regrown to the true total and the pass repeated - otherwise late large blobs would be lost.
   const size_t ws = (bgs_mask_components_workspace(e->rows, e->cols) + 15) & ~(size_t)15;
-  if (!e->cc_work || e->cc_cap < cap) {
-    if (e->cc_work) (void)hipFree(e->cc_work), e->cc_work = nullptr;
-    HIP_TRY(hipMalloc(&e->cc_work, ws + (size_t)cap * (sizeof(bgs_box) + sizeof(bgs_moments)) + 16));
-    e->cc_cap = cap;
-  }
-  bgs_box* d_boxes = (bgs_box*)((char*)e->cc_work + ws);
-  bgs_moments* d_mom = (bgs_moments*)(d_boxes + e->cc_cap);
-  int32_t* d_count = (int32_t*)(d_mom + e->cc_cap);
-  int rc = cc_run(e->device, e->d_fg, 1, e->rows, e->cols, connectivity, nullptr, d_boxes, e->cc_cap, d_count, nullptr, e->cc_work, e->stream, d_mom);
-  if (rc) return rc;
+  int cap = std::max(std::max(max_boxes, 1024), e->cc_cap);
   int32_t n = 0;
-  HIP_TRY(hipMemcpyAsync(&n, d_count, sizeof(n), hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  n = std::min(n, e->cc_cap);
+  bgs_box* d_boxes = nullptr;
+  bgs_moments* d_mom = nullptr;
+  for (int pass = 0; pass < 2; ++pass) {
+    if (!e->cc_work || e->cc_cap < cap) {
+      if (e->cc_work) (void)hipFree(e->cc_work), e->cc_work = nullptr, e->cc_cap = 0;
+      HIP_TRY(hipMalloc(&e->cc_work, ws + (size_t)cap * (sizeof(bgs_box) + sizeof(bgs_moments)) + 16));
+      e->cc_cap = cap;
+    }
+    d_boxes = (bgs_box*)((char*)e->cc_work + ws);
+    d_mom = (bgs_moments*)(d_boxes + e->cc_cap);
+    int32_t* d_count = (int32_t*)(d_mom + e->cc_cap);
+    int rc = cc_run(e->device, e->d_fg, 1, e->rows, e->cols, connectivity, nullptr, d_boxes, e->cc_cap, d_count, nullptr, e->cc_work, e->stream, d_mom);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(&n, d_count, sizeof(n), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (n <= e->cc_cap) break;
+    cap = n + n / 8 + 64;  // the true total is known now: one more pass with room for all of them
+  }
+  n = std::min(n, e->cc_cap);  // (cannot bind after the second pass: the mask has not changed)
   std::vector<bgs_box> hb((size_t)n);
   std::vector<bgs_moments> hm((size_t)n);
   if (n) {

@@ -7,6 +7,8 @@ xGMI is point-to-point: a gather to root is 7 independent transfers over 7 disti
 not ring bound), and bit-packing makes it 8x smaller than byte masks (1080p: 259 200 B per stream and frame).
 torch.distributed here is plumbing: backend "nccl" (= RCCL) on GPUs, "gloo" in the CPU tests.
 """
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -46,12 +48,19 @@ class MaskGather:
         self.recv = [[torch.empty(self.shape, dtype=torch.int64, device=device) for _ in range(self.world)] if self.rank == dst else None for _ in range(2)]
         self.work = [None, None]
         self.i = 0
+        self.blocked_s, self.blocked_calls = 0.0, 0  # host time next_buffer() spent waiting for an earlier gather (diagnostics of a scaling run)
+
+    def reset_stats(self):
+        self.blocked_s, self.blocked_calls = 0.0, 0
 
     def next_buffer(self):
         """Buffer the update kernel should write this step (waits for the gather that last used it)."""
         if self.work[self.i] is not None:
+            t0 = time.perf_counter()
             self.work[self.i].wait()
+            self.blocked_s += time.perf_counter() - t0
             self.work[self.i] = None
+        self.blocked_calls += 1
         return self.bufs[self.i]
 
     def post(self):
