@@ -195,6 +195,76 @@ def test_mog2_sparse_levels_are_exact(level, shape):
     check_mog2_state(eng, orc, H * W)
 
 
+def _mog2_summary_invariants(eng, n, stream=0):
+    """kernel_mog2.h: where a pixel's meta word says its summaries are valid, every live mode's 4-byte summary {q0, q1, q2, vb}
+    must cover its record - |mean_c - q_c| <= 2 and var <= 2 vb (vb = 255: unbounded) - or the filter path could rule out a mode the
+    reference would have matched.  Returns the fraction of pixels whose summaries are valid."""
+    nm = eng.get_state("nmodes", (n,), np.uint8, stream=stream).astype(np.int32)
+    valid = eng.get_state("summary_valid", (n,), np.uint8, stream=stream).astype(bool)
+    mu = eng.get_state("mu", (5, 3, n), np.float32, stream=stream)
+    var = eng.get_state("var", (5, n), np.float32, stream=stream)
+    sm = eng.get_state("summary", (5, n), np.uint32, stream=stream)
+    live = (np.arange(5)[:, None] < nm[None, :]) & valid[None, :]
+    for c in range(3):
+        q = ((sm >> (8 * c)) & 0xff).astype(np.float32)
+        assert np.all(np.abs(mu[:, c] - q)[live] <= 2.0), ("mean", c, float(np.abs(mu[:, c] - q)[live].max()))
+    vb = (sm >> 24).astype(np.float32)
+    assert np.all(((vb == 255) | (var <= 2 * vb))[live]), "variance bound"
+    return float(valid.mean())
+
+
+@pytest.mark.parametrize("level", [1, 2, 3, 4])
+def test_mog2_summary_filter_boundary_and_invariants(level):
+    """The record filter of MOG2's filter path (sparse 4; sparse 3 = auto: on a frame this small every workgroup is a sampled one and
+    takes it too) against the oracle where it is most likely to slip: modes spaced 6 .. 34 grey levels apart (per column band), so
+    that for neighbouring pixels the same comparison is ruled out by the summary, or barely not, or needs the record; noise and a slow
+    drift keep the means moving across the summaries' rounding.  Masks, backgrounds every third frame (that launch reads every mode)
+    and the whole model must equal the oracle; wherever a pixel's summaries are marked valid they must cover its records - after
+    per-frame launches, after clip launches (which invalidate them) and after the per-frame launches that rebuild them."""
+    torch = _torch()
+    rng = np.random.default_rng(99 + level)
+    H, W, T = 48, 320, 90
+    spacing = np.repeat(np.array([6, 8, 10, 12, 14, 17, 20, 24, 28, 34]), W // 10)[None, :, None]
+    base = rng.integers(10, 60, (H, W, 3))
+    phase = rng.integers(0, 5, (H, W, 1))
+    frames = np.empty((T, H, W, 3), np.uint8)
+    for t in range(T):
+        lvl = (t + phase) % (3 + (t // 30))  # 3, then 4, then 5 levels in play
+        f = base + spacing * lvl + rng.integers(-3, 4, (H, W, 3)) + t // 12
+        frames[t] = np.clip(f, 0, 255).astype(np.uint8)
+    eng = Engine(capi.MOG2)
+    eng.set_option(capi.OPT_MOG2_SPARSE, level)
+    orc = pyoracle.Oracle(capi.MOG2)
+    for t in range(60):
+        want_bg = t % 3 == 0
+        fg, bg = eng.process(frames[t], want_bg=want_bg)
+        ofg, obg = orc.process(frames[t], want_bg=want_bg)
+        assert np.array_equal(fg, ofg), (level, t, int((fg != ofg).sum()))
+        if want_bg:
+            assert np.array_equal(bg, obg), (level, t)
+    check_mog2_state(eng, orc, H * W)
+    vfrac = _mog2_summary_invariants(eng, H * W)
+    assert vfrac == (1.0 if level >= 3 else 0.0), (level, vfrac)  # frame 59 delivered no background: the filter path ran (levels 3, 4)
+    # the rest of the clip through clip launches (8 + 8 + 8 + 4 + 2 frames): they change records without looking after the summaries
+    dev = torch.from_numpy(frames[60:]).cuda().unsqueeze(1)
+    fgd = torch.empty((30, 1, H, W), dtype=torch.uint8, device="cuda")
+    eng.process_clip_device(dev, 30, fgd)
+    torch.cuda.synchronize()
+    for t in range(60, 90):
+        ofg, _ = orc.process(frames[t], want_bg=False)
+        assert np.array_equal(fgd[t - 60, 0].cpu().numpy(), ofg), (level, t)
+    check_mog2_state(eng, orc, H * W)
+    assert _mog2_summary_invariants(eng, H * W) == 0.0
+    for t in range(5):  # per-frame again: the first launch rebuilds the summaries, the next ones use them
+        fg, _ = eng.process(frames[t], want_bg=False)
+        ofg, _ = orc.process(frames[t], want_bg=False)
+        assert np.array_equal(fg, ofg), (level, "after clip", t)
+        vfrac = _mog2_summary_invariants(eng, H * W)
+        assert vfrac == (1.0 if level >= 3 else 0.0), (level, t, vfrac)
+    check_mog2_state(eng, orc, H * W)
+    eng.close()
+
+
 @pytest.mark.parametrize("algo,S,T", [(capi.SUBSENSE, 8, 3), (capi.MOG1, 16, 4), (capi.DP_GRIMSON_GMM, 32, 3)])
 def test_large_batches_match_single_stream_engines(algo, S, T):
     """Models past 4 GB (SuBSENSE: 8 x 1080p x 50 samples = 7.5 GB; MOG1: 16 x 1080p = 5.3 GB; Grimson: 32 x 1080p = 4.8 GB): the

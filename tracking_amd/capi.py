@@ -126,6 +126,14 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError("libbgs_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` (%s)" % LIB_PATH)
+        # torch ships its own copy of the HIP runtime (same soname, libamdhip64.so.7).  Whichever copy a process loads first serves
+        # both; loaded in the other order - this library first, torch afterwards - torch came up with "No HIP GPUs are available"
+        # on the GPU boxes (round 3, a test run that touched the C ABI before its first torch.cuda call).  So where torch exists
+        # (tests, bench.py) it is imported first; a C++ host never has it and is not affected.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # noqa: BLE001
+            pass
         l = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             if os.environ.get("BGS_LIB_PATH") and os.environ.get("BGS_LIB_PARTIAL_ABI") and not hasattr(l, name):

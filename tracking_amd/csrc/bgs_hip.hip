@@ -96,8 +96,9 @@ struct bgs_engine {
   int mog2_sparse = 3;             // data-dependent traffic (kernel_mog2.h): 0 dense (everything loaded and written), 1 only what changed is written, 2 / 4 a lane also loads only the modes its pixel has, 3 = choose 1 or 4 from the scene
   int mog2_complete = 1;           // sector-complete stores (kernel_mog2.h); BGS_MOG2_COMPLETE=0 for A/B runs
   bool clip_fuse = true;           // MOG2 clip calls keep the model in registers across frames (option 7; results identical either way)
-  int mog2_sparse_now = 1;         // what auto mode currently runs
-  unsigned* d_stat = nullptr;      // device: {sampled waves, sparse waves}
+  int mog2_sparse_now = 2;         // what auto mode currently runs
+  int mog2_sparse_want = 2;        // what the last poll asked for (a switch needs two polls in a row)
+  unsigned* d_stat = nullptr;      // device: {record slots sampled, modes live, records needed after the summaries}
   unsigned* h_stat = nullptr;      // pinned copy
   hipEvent_t stat_ev = nullptr;
   bool stat_pending = false;
@@ -201,22 +202,29 @@ struct Timed {
 };
 
 void mog2_stat_poll(bgs_engine* e, hipStream_t s) {
-  // Automatic sparse level (results are identical either way, only speed differs): skipping the loads of absent modes
-  // makes the plane loads wait for the nmodes load, which pays only when a good part of the waves can skip something.
-  // The kernel samples "largest nmodes in the wave < K-1" on every 64th block; the host reads the two counters back
-  // without ever blocking (event query) and switches with hysteresis.
+  // Automatic choice of how a per-frame launch loads a pixel's model (kernel_mog2.h; results are identical, only speed differs):
+  //   1 eager   everything at once, no dependent loads: right when most pixels have most modes and need them;
+  //   2 count   only the modes a pixel has (one dependent round): quiet scenes, one or two modes per pixel;
+  //   4 filter  summaries first, then only the records they cannot rule out (two dependent rounds, +4 B per mode for the
+  //             summaries): pays when at least half of a pixel's records are ruled out (modes far apart).
+  // About 256 sampled workgroups per launch always take the filter path and count, per pixel, the modes it has and the records
+  // that path loads; the host reads the three counters back without ever blocking (event query) and switches when two polls in
+  // a row ask for the same other mode.
   if (e->stat_pending && hipEventQuery(e->stat_ev) == hipSuccess) {
     e->stat_pending = false;
-    const unsigned total = e->h_stat[0], sparse_waves = e->h_stat[1];
-    if (total >= 64) {
-      const float frac = (float)sparse_waves / (float)total;
-      if (frac > 0.30f) e->mog2_sparse_now = 4;
-      if (frac < 0.15f) e->mog2_sparse_now = 1;
+    const unsigned total = e->h_stat[0], live = e->h_stat[1], need = e->h_stat[2];
+    if (total >= 64 * 5) {
+      const float lf = (float)live / (float)total, nf = (float)need / (float)total;
+      const int want = (nf < 0.5f * lf && lf - nf > 0.1f) ? 4 : lf < 0.7f ? 2 : 1;
+      static const bool debug = getenv("BGS_DEBUG_STAT") != nullptr;
+      if (debug) fprintf(stderr, "[bgs] mog2 auto: %u record slots sampled, %.3f live, %.3f needed after the summaries -> mode %d (now %d)\n", total, lf, nf, want, e->mog2_sparse_now);
+      if (want != e->mog2_sparse_now && want == e->mog2_sparse_want) e->mog2_sparse_now = want;
+      e->mog2_sparse_want = want;
     }
   }
   if (!e->stat_pending) {
-    (void)hipMemcpyAsync(e->h_stat, e->d_stat, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s);
-    (void)hipMemsetAsync(e->d_stat, 0, 2 * sizeof(unsigned), s);
+    (void)hipMemcpyAsync(e->h_stat, e->d_stat, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, s);
+    (void)hipMemsetAsync(e->d_stat, 0, 3 * sizeof(unsigned), s);
     (void)hipEventRecord(e->stat_ev, s);
     e->stat_pending = true;
   }
@@ -229,6 +237,7 @@ int launch_mog2(bgs_engine* e, bgs::Mog2Args& a, hipStream_t s, bool timed = tru
   a.want_bg = a.bgimg != nullptr, a.packed = a.fg_bits != nullptr;
   a.xcd_swizzle = e->xcd_swizzle, a.complete = e->mog2_complete;
   a.sparse = e->mog2_sparse == 3 ? e->mog2_sparse_now : e->mog2_sparse;
+  if (a.sparse >= 4 && (a.shadow || a.want_bg)) a.sparse = 2;  // shadow test and background image read every mode's mean: nothing to rule out
   a.stat = (timed && e->mog2_sparse == 3) ? e->d_stat : nullptr;
   if (a.packed && a.npix % 64) return fail(BGS_ERR_UNSUPPORTED, "packed mask needs pixels %% 64 == 0");
   Timed t(e, s, "mog2_update_kernel", timed);
@@ -273,8 +282,8 @@ int launch_mog2_clip(bgs_engine* e, bgs::Mog2ClipArgs& c, int fuse, hipStream_t 
   a.shadow = p.mog2_detect_shadows && (!p.enable_threshold || ((p.mog2_shadow_value > p.threshold) != (255 > p.threshold)));
   a.want_bg = a.bgimg != nullptr, a.packed = a.fg_bits != nullptr;
   a.xcd_swizzle = e->xcd_swizzle, a.complete = e->mog2_complete;
-  a.sparse = e->mog2_sparse == 3 ? e->mog2_sparse_now : e->mog2_sparse;
-  a.stat = e->mog2_sparse == 3 ? e->d_stat : nullptr;
+  a.sparse = e->mog2_sparse == 0 ? 0 : 1;  // clip launches load every record at once (kernel_mog2.h)
+  a.stat = nullptr;
   if (a.packed && a.npix % 64) return fail(BGS_ERR_UNSUPPORTED, "packed mask needs pixels %% 64 == 0");
   Timed t(e, s, "mog2_clip_kernel");
   const dim3 grid(blocks_for(a.npix)), block(bgs::kBlock);
@@ -285,7 +294,6 @@ int launch_mog2_clip(bgs_engine* e, bgs::Mog2ClipArgs& c, int fuse, hipStream_t 
   if (fuse == TV) hipLaunchKernelGGL((bgs::mog2_clip_kernel<TV>), grid, block, 0, s, c);
   MOG2_CLIP_CASE(2) MOG2_CLIP_CASE(4) MOG2_CLIP_CASE(8)
 #undef MOG2_CLIP_CASE
-  if (a.stat) mog2_stat_poll(e, s);
   return BGS_OK;
 }
 
@@ -391,9 +399,9 @@ int probe_allocate(bgs_engine* e, void** out, size_t bytes, double expect_ms, Ru
 
 int mog2_allocate(bgs_engine* e) {
   const size_t P = e->n * e->S, bytes = mog2_state_bytes(e);
-  HIP_TRY(hipMalloc((void**)&e->d_stat, 2 * sizeof(unsigned)));
-  HIP_TRY(hipMemsetAsync(e->d_stat, 0, 2 * sizeof(unsigned), e->stream));  // ordered: allocate() drains e->stream before it returns
-  HIP_TRY(hipHostMalloc((void**)&e->h_stat, 2 * sizeof(unsigned), hipHostMallocDefault));
+  HIP_TRY(hipMalloc((void**)&e->d_stat, 3 * sizeof(unsigned)));
+  HIP_TRY(hipMemsetAsync(e->d_stat, 0, 3 * sizeof(unsigned), e->stream));  // ordered: allocate() drains e->stream before it returns
+  HIP_TRY(hipHostMalloc((void**)&e->h_stat, 3 * sizeof(unsigned), hipHostMallocDefault));
   HIP_TRY(hipEventCreateWithFlags(&e->stat_ev, hipEventDisableTiming));
   const bool probing = e->probe_max > 1 && bytes >= ((size_t)768 << 20);
   uint8_t* d_frame = nullptr;  // a black frame for the probe launches
@@ -403,8 +411,8 @@ int mog2_allocate(bgs_engine* e) {
   }
   const int saved_sparse = e->mog2_sparse;
   e->mog2_sparse = 0;  // probe with the dense traffic pattern: that is what a busy scene produces
-  // a dense launch (sparse 0: everything read and written back) moves 208 B/pixel; on a good placement this part sustains ~6.15 TB/s
-  const double expect_ms = 208.0 * (double)P / 6.15e12 * 1e3;
+  // a dense launch (sparse 0: everything read and written back) moves 248 B/pixel; on a good placement this part sustains ~6.15 TB/s
+  const double expect_ms = 248.0 * (double)P / 6.15e12 * 1e3;
   uint8_t* saved_state = e->mog2_state;
   int rc = probe_allocate(e, (void**)&e->mog2_state, bytes, expect_ms, [&](void* cand) -> int {
     e->mog2_state = (uint8_t*)cand;
@@ -1330,7 +1338,9 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
     if (!strcmp(plane, "w")) p0 = 0, np = 5;
     if (!strcmp(plane, "var")) p0 = 5, np = 5;
     if (!strcmp(plane, "mu")) p0 = 10, np = 15;
-    const bool nm = !strcmp(plane, "nmodes");
+    if (!strcmp(plane, "summary")) p0 = 100, np = 5;  // uint32 [K][n] by rank: q0 | q1 << 8 | q2 << 16 | vb << 24 (kernel_mog2.h; for the invariant test)
+    const bool nm = !strcmp(plane, "nmodes") || !strcmp(plane, "summary_valid");  // bytes [n]; summary_valid: bit 15 of the meta word
+    const bool want_valid = !strcmp(plane, "summary_valid");
     if (p0 >= 0 || nm) {
       // device layout (kernel_mog2.h): weights by rank, {var, mean} records in fixed slots, meta = rank -> slot.  Exported in the
       // reference's array order (rank); entries past a pixel's mode count are zero, as in the reference's zero-initialised bgmodel.
@@ -1345,14 +1355,16 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
         const uint8_t* tb = tiles.data() + (sp / T - t0) * TB;
         const float* w = reinterpret_cast<const float*>(tb) + in;
         const float* rec = reinterpret_cast<const float*>(tb + bgs::kMog2RecOff) + in * 4;
+        const uint32_t* sum = reinterpret_cast<const uint32_t*>(tb + bgs::kMog2SumOff) + in;
         const unsigned meta = reinterpret_cast<const uint16_t*>(tb + bgs::kMog2MetaOff)[in];
         if (nm) {
-          ((uint8_t*)dst)[i] = (uint8_t)bgs::mog2_meta_count(meta);
+          ((uint8_t*)dst)[i] = want_valid ? (uint8_t)((meta >> 15) & 1u) : (uint8_t)bgs::mog2_meta_count(meta);
           continue;
         }
         for (int r = 0; r < bgs::kMog2K; ++r) {
           const unsigned f = (meta >> (3 * r)) & 7u;
           const float* rc = f ? rec + (size_t)(f - 1) * T * 4 : nullptr;
+          if (p0 == 100) ((uint32_t*)dst)[(size_t)r * n + i] = f ? sum[(size_t)(f - 1) * T] : 0u;
           if (p0 == 0) ((float*)dst)[(size_t)r * n + i] = f ? w[(size_t)r * T] : 0.f;
           if (p0 == 5) ((float*)dst)[(size_t)r * n + i] = f ? rc[0] : 0.f;
           if (p0 == 10)

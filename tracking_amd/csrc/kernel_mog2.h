@@ -18,13 +18,25 @@
 //   updated or created) + 2 (meta, when the order changed) + 1 (mask) = 144 B/pixel instead of 206.
 //   The arithmetic is the reference's statement for statement: the records are gathered into rank order in registers, the same
 //   predicated bubble runs there (the slot ids travel with it), and only what changed goes back.
-// Tiles: pixels are grouped in tiles of kMog2Tile (256); a tile is 5 weight planes (T floats each), 5 record planes (T float4
-//   each) and T meta words = 102 T contiguous bytes.  One workgroup owns one tile, one lane one pixel: every access is a
-//   coalesced wave instruction (dwordx4 for the records), and with the XCD-aware block order each XCD streams one contiguous
+// SUMMARIES - reading fewer records, exactly.  A record is only ever consulted by two comparisons, dist2 < Tb var (background) and
+//   dist2 < Tg var (match).  Each slot also has a 4-byte SUMMARY {q0, q1, q2, vb}: the mean rounded to bytes and a variance bound,
+//   maintained under the invariants |mean_c - q_c| <= 2 and var <= 2 vb (vb = 255: no bound).  From the summary alone
+//   dist2 >= sum_c max(|x_c - q_c| - 2, 0)^2 =: L, so L > max(Tb, Tg) 2 vb (+ margins for float rounding) PROVES both comparisons
+//   false: such a mode is REJECTED without its record, and the frame proceeds exactly as the reference would (a rejected mode's
+//   record is used by nothing else: only its weight decays).  The per-frame launch loads the summaries of a pixel's live slots, then
+//   only the records of the modes that survive: on well-separated modes (the saturating benchmark input) one record of five.
+//   A summary is rewritten when its record changes AND stops satisfying the invariants with some slack (hysteresis: quiet pixels
+//   rewrite it rarely).  Shadow detection and the background image read every mode's mean, so launches that deliver them load all
+//   records; so do clip launches (over 4-8 frames nearly every mode is matched by some frame) - those write fresh summaries.
+//   Reads 3 + 2 + 20 + 20 (summaries) + 16 n (n = surviving modes, 1 on the benchmark input), writes 20 + 16 + 4 + 2 + 1:
+//   104 B/pixel on the benchmark input.
+// Tiles: pixels are grouped in tiles of kMog2Tile (256); a tile is 5 weight planes and 5 summary planes (T dwords each), 5 record
+//   planes (T float4 each) and T meta words = 122 T contiguous bytes.  One workgroup owns one tile, one lane one pixel: every access
+//   is a coalesced wave instruction (dwordx4 for the records), and with the XCD-aware block order each XCD streams one contiguous
 //   eighth of the model.
 // Stores are SECTOR-COMPLETE (args.complete): HBM moves 32-byte sectors, so a lane also writes back an unchanged value of its own
-//   when another lane of the same sector (2 lanes of a record plane, 8 of a weight plane, 16 of the meta row) has something to
-//   write there - no partially written sector ever reaches the memory controller.
+//   when another lane of the same sector (8 lanes of a weight or summary plane, 16 of the meta row, 2 of a record plane when every
+//   lane holds all its records) has something to write there - no partially written sector reaches the memory controller.
 // No LDS: the op is pointwise and HBM-bound.
 #pragma once
 #include "bgs_device.h"
@@ -36,9 +48,10 @@ constexpr int kMog2K = 5;
 #define BGS_MOG2_TILE 256
 #endif
 constexpr int kMog2Tile = BGS_MOG2_TILE;                                          // pixels per tile
-constexpr size_t kMog2TileBytes = (size_t)kMog2Tile * (4 * kMog2K + 16 * kMog2K + 2);  // 102 B per pixel: 26 112 B
-constexpr size_t kMog2RecOff = (size_t)kMog2Tile * 4 * kMog2K;                    // byte offset of record plane 0 inside a tile
-constexpr size_t kMog2MetaOff = kMog2RecOff + (size_t)kMog2Tile * 16 * kMog2K;   // byte offset of the meta row
+constexpr size_t kMog2TileBytes = (size_t)kMog2Tile * (4 * kMog2K + 4 * kMog2K + 16 * kMog2K + 2);  // 122 B per pixel: 31 232 B
+constexpr size_t kMog2SumOff = (size_t)kMog2Tile * 4 * kMog2K;                    // byte offset of summary plane 0 inside a tile
+constexpr size_t kMog2RecOff = kMog2SumOff + (size_t)kMog2Tile * 4 * kMog2K;      // ... of record plane 0
+constexpr size_t kMog2MetaOff = kMog2RecOff + (size_t)kMog2Tile * 16 * kMog2K;   // ... of the meta row
 static_assert(kMog2Tile % 64 == 0, "a wave never straddles two tiles");
 
 struct Mog2Args {
@@ -53,16 +66,18 @@ struct Mog2Args {
   float Tb, TB, Tg, varInit, varMin, varMax, tau;
   int thr, enable_thr, shadow_val;
   int shadow, want_bg, packed;  // wave-uniform feature switches
-  unsigned* stat;               // null, or 2 counters: sampled waves, sampled waves whose largest mode count is below K-1 (auto mode)
+  unsigned* stat;               // null, or 3 counters of the sampled workgroups: record slots (5 per pixel), modes the pixels have, records the filter path loads (auto mode)
   unsigned stat_mask;           // workgroups with (blockIdx.x & stat_mask) == 0 are sampled (~256 per launch)
-  int sparse;                   // 0 dense: every weight, record and meta word loaded and written back (placement probe, A/B);
-                                // 1 everything loaded, only what changed written; >= 2 a lane also loads only the modes its pixel has
+  int sparse;                   // 0 dense: every weight, summary, record and meta word loaded and written back (placement probe, A/B);
+                                // 1 eager: every record loaded (no dependent loads), only what changed written;
+                                // 2 count: a lane loads only the modes its pixel has; 4 filter: their summaries, then only the records that survive them
   int complete;                 // sector-complete stores (see above)
   int xcd_swizzle;              // workgroups that share an XCD walk one contiguous eighth of the launch
 };
 
 struct Mog2Ptr {
   float* w;        // weight of rank r at w[r * kMog2Tile]
+  uint32_t* sum;   // summary of slot s at sum[s * kMog2Tile]: q0 | q1 << 8 | q2 << 16 | vb << 24
   float4* rec;     // record of slot s at rec[s * kMog2Tile]: {variance, mean0, mean1, mean2}
   uint16_t* meta;
 };
@@ -71,6 +86,7 @@ __device__ __forceinline__ Mog2Ptr mog2_ptr(uint8_t* state, size_t sp) {
   const size_t in = sp % kMog2Tile;
   Mog2Ptr p;
   p.w = reinterpret_cast<float*>(tb) + in;
+  p.sum = reinterpret_cast<uint32_t*>(tb + kMog2SumOff) + in;
   p.rec = reinterpret_cast<float4*>(tb + kMog2RecOff) + in;
   p.meta = reinterpret_cast<uint16_t*>(tb + kMog2MetaOff) + in;
   return p;
@@ -80,6 +96,44 @@ __device__ __host__ __forceinline__ int mog2_meta_count(unsigned meta) {
   unsigned t = (meta | (meta >> 1) | (meta >> 2)) & 0x1249u;
   t = (t & 1u) + ((t >> 3) & 1u) + ((t >> 6) & 1u) + ((t >> 9) & 1u) + ((t >> 12) & 1u);
   return (int)t;
+}
+
+// ---- summaries (see the header comment) -------------------------------------------------------------------------------------
+// Invariants of a live slot's summary: |mean_c - q_c| <= kMog2SumTol for every channel, and var <= 2 vb unless vb == 255.
+constexpr float kMog2SumTol = 2.f;
+__device__ __host__ __forceinline__ uint32_t mog2_summary_byte(float m) {
+  float r = m + 0.5f;  // floor(m + 0.5): within 0.5 of m (any tie rule does; NaN and out-of-range means end up clamped - such a mode matches nothing)
+  r = r > 0.f ? r : 0.f;
+  r = r < 255.f ? r : 255.f;
+  return (uint32_t)(int)r;
+}
+__device__ __host__ __forceinline__ uint32_t mog2_summary(float var, float m0, float m1, float m2) {
+  // variance bound with 16 of slack above the current value so that ordinary fluctuation does not outgrow it; unbounded past the byte range
+  uint32_t vb = 255;
+  if (var <= 470.f) vb = (uint32_t)(int)(var * 0.5f + 9.f);
+  return mog2_summary_byte(m0) | (mog2_summary_byte(m1) << 8) | (mog2_summary_byte(m2) << 16) | (vb << 24);
+}
+// may the stored summary be kept for this (changed) record?  the invariants, plus "the variance bound is not uselessly loose"
+__device__ __host__ __forceinline__ bool mog2_summary_ok(uint32_t word, float var, float m0, float m1, float m2) {
+  const float q0 = (float)(word & 0xffu), q1 = (float)((word >> 8) & 0xffu), q2 = (float)((word >> 16) & 0xffu);
+  const uint32_t vb = word >> 24;
+  const float V = 2.f * (float)vb;
+  const float e0 = m0 - q0, e1 = m1 - q1, e2 = m2 - q2;
+  const bool means = (e0 <= kMog2SumTol && e0 >= -kMog2SumTol) && (e1 <= kMog2SumTol && e1 >= -kMog2SumTol) && (e2 <= kMog2SumTol && e2 >= -kMog2SumTol);
+  const bool varok = vb == 255 ? var > 440.f : (var <= V && var + 48.f >= V);
+  return means && varok;
+}
+// does the summary PROVE dist2 >= Tmax * var, i.e. both of the reference's comparisons false for this pixel value?
+// Margins: 0.01 on every channel distance and 1.0 on the threshold swallow the float rounding of either side (values <= 2e5,
+// relative error ~1e-7).  x0..x2 are the integer pixel values.
+__device__ __host__ __forceinline__ bool mog2_reject(uint32_t word, float x0, float x1, float x2, float Tmax) {
+  const float q0 = (float)(word & 0xffu), q1 = (float)((word >> 8) & 0xffu), q2 = (float)((word >> 16) & 0xffu);
+  const uint32_t vb = word >> 24;
+  float e0 = x0 - q0, e1 = x1 - q1, e2 = x2 - q2;
+  e0 = (e0 < 0.f ? -e0 : e0) - (kMog2SumTol + 0.01f), e1 = (e1 < 0.f ? -e1 : e1) - (kMog2SumTol + 0.01f), e2 = (e2 < 0.f ? -e2 : e2) - (kMog2SumTol + 0.01f);
+  e0 = e0 > 0.f ? e0 : 0.f, e1 = e1 > 0.f ? e1 : 0.f, e2 = e2 > 0.f ? e2 : 0.f;
+  const float L = e0 * e0 + e1 * e1 + e2 * e2;
+  return vb != 255 && L > Tmax * (2.f * (float)vb) + 1.f;
 }
 
 // One pixel's model in rank order, as MOG2Invoker sees it; sl[r] = slot + 1 of the mode at rank r (0: rank unused)
@@ -138,8 +192,10 @@ __device__ __forceinline__ bool mog2_shadow(const Mog2Px& s, int nmodes, float x
 // Returns the raw mask value (0 background, shadow_val, 255 foreground) before the wrapper's threshold.
 // alphaT / alpha1 / prune are the learning-rate terms of THIS frame (they differ between the frames of a clip launch).
 // `dirty`: bit (slot + 1) is set for the slot whose record this frame recomputed (the matched mode) or created.
+// `rej`: bit (slot + 1) set = this mode's summary proved that neither comparison can hold for this pixel value (mog2_reject): the
+// comparisons are skipped - their outcome is known - and the record, which may not even be loaded, is not touched.
 __device__ __forceinline__ int mog2_pixel(Mog2Px& s, int& nmodes_io, float x0, float x1, float x2, const Mog2Args& a, unsigned& dirty,
-                                          const float alphaT, const float alpha1, const float prune) {
+                                          const float alphaT, const float alpha1, const float prune, const unsigned rej = 0) {
   bool background = false, fitsPDF = false;
   int nmodes = nmodes_io;
   const int nNewModes = nmodes;
@@ -149,7 +205,7 @@ __device__ __forceinline__ int mog2_pixel(Mog2Px& s, int& nmodes_io, float x0, f
     if (mode < nmodes) {  // nmodes shrinks inside the loop when a mode is pruned (reference quirk)
       float weight = alpha1 * s.w[mode] + prune;
       bool matched = false;
-      if (!fitsPDF) {
+      if (!fitsPDF && !((rej >> s.sl[mode]) & 1u)) {
         const float var = s.var[mode];
         const float d0 = s.m0[mode] - x0, d1 = s.m1[mode] - x1, d2 = s.m2[mode] - x2;
         const float dist2 = d0 * d0 + d1 * d1 + d2 * d2;
@@ -243,6 +299,16 @@ __device__ __forceinline__ void mog2_background(const Mog2Px& s, int nmodes, flo
   b0 = sat_u8(v0 * inv), b1 = sat_u8(v1 * inv), b2 = sat_u8(v2 * inv);
 }
 
+// the record of slot q as it stands now: wherever the bubble left it; `loaded` (what the lane read, or zeros) for a slot the pixel
+// does not own - such a slot holds nothing anyone reads
+__device__ __forceinline__ float4 mog2_slot_now(const Mog2Px& s, float4 loaded, int q) {
+  float4 v = loaded;
+#pragma unroll
+  for (int r = 0; r < kMog2K; ++r)
+    if (s.sl[r] == q + 1) v = make_float4(s.var[r], s.m0[r], s.m1[r], s.m2[r]);
+  return v;
+}
+
 // lane-crossing OR for the sector-complete stores (DPP row operations, no LDS traffic): returns the OR over the lane's aligned
 // group of 2 / 8 / 16 lanes.  quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140;
 // lanes that left the kernel (past npix) read as 0 (bound_ctrl).
@@ -289,31 +355,117 @@ __device__ __forceinline__ void mog2_body(const Mog2Args& a, const size_t frame_
     pix[t] = (uint32_t)f[0] | ((uint32_t)f[1] << 8) | ((uint32_t)f[2] << 16);
   }
   const Mog2Ptr mp = mog2_ptr(a.state, sp);
-  const unsigned meta_in = *mp.meta;
-  // Loads.  sparse < 2: everything, independent of the meta word (all the loads of a lane are in flight at once: what a busy
-  // scene wants).  sparse >= 2: rank 0 / slot 0 at once (every pixel has them after its first frame), the rest only for the modes
-  // this pixel has - those loads wait for the meta word, which pays when most pixels have one or two modes (quiet scenes).
-  float wv[kMog2K];
-  float4 rec[kMog2K];
+  // Four ways to load (wave-uniform choice; results are identical, only the traffic differs):
+  //   dense  (sparse 0)  everything, and everything is written back: the placement probe's traffic pattern, A/B runs;
+  //   eager  (sparse 1, every clip launch): all weights and records at once, nothing waits for the meta word - right when most modes
+  //                      are needed anyway;
+  //   count  (sparse 2)  rank 0 / slot 0 at once, the other modes' weights and records only for the modes this pixel has: one
+  //                      dependent round of loads, far fewer bytes on quiet scenes (one or two modes per pixel);
+  //   filter (sparse 4)  the summaries of the modes the pixel has, then only the records the summaries cannot rule out: two
+  //                      dependent rounds; pays when a pixel's modes lie far apart (the saturating benchmark input: 1 record of 5).
+  // Summaries are only maintained by the filter path.  Bit 15 of the meta word says "this pixel's summaries cover its records";
+  // every other path clears it when it changes a record, and the filter path, finding it clear, loads all the pixel's records,
+  // rebuilds the summaries and sets it.  In auto mode the ~256 sampled workgroups always take the filter path, so the host sees
+  // what each way would load.
+  const unsigned meta_raw = *mp.meta;
+  const unsigned meta_in = meta_raw & 0x7fffu;
+  const bool valid_in = (meta_raw >> 15) & 1u;
   const int nm_in = mog2_meta_count(meta_in);
-  const bool lazy = a.sparse >= 2;
-  wv[0] = mp.w[0];
-  rec[0] = mp.rec[0];
+  const bool sampled = T == 1 && a.stat && (blockIdx.x & a.stat_mask) == 0;
+  const bool dense = a.sparse == 0;
+  const bool filter = T == 1 && !dense && (a.sparse >= 4 || sampled);
+  const bool count = T == 1 && !dense && !filter && a.sparse >= 2;
+  const bool can_reject = !a.shadow && !a.want_bg;  // the shadow test and the background image read every mode's mean
+  float wv[kMog2K];
+  uint32_t sm[kMog2K];
+  float4 rc[kMog2K];      // records in registers: rc[j] is the record of slot kj[j]; the first `cnt` entries are meaningful
+  int kj[kMog2K], cnt = kMog2K;
+  unsigned rej = 0;       // bit (slot + 1): rejected by its summary for THIS frame (filter path)
 #pragma unroll
-  for (int k = 1; k < kMog2K; ++k) {
-    if (!lazy || k < nm_in) {
+  for (int k = 0; k < kMog2K; ++k) kj[k] = k, sm[k] = 0u;
+  // Every load below is UNCONDITIONAL per lane and sits in straight-line code: a lane that does not want plane k repeats a load it
+  // does want (same cache line, no extra HBM traffic) and the value is discarded by a select afterwards.  Loads under a per-lane
+  // `if` - and also loads under a chain of wave-uniform branches - made the compiler merge each result with the "not loaded" value
+  // through register copies right behind the load, with s_waitcnt vmcnt(0) in front of them: the loads then went out one memory
+  // round trip after the other (seen in the ISA of the first two versions of this path, and in round 2 in SuBSENSE's sample
+  // prefetch).  So there is ONE wave-uniform two-way choice per round of loads: the short form when no lane of the wave needs
+  // more, else all five.
+  if (!filter && !count) {
+#pragma unroll
+    for (int k = 0; k < kMog2K; ++k) {
       wv[k] = mp.w[(size_t)k * kMog2Tile];
-      rec[k] = mp.rec[(size_t)k * kMog2Tile];
-    } else {
-      wv[k] = 0.f;
-      rec[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rc[k] = mp.rec[(size_t)k * kMog2Tile];
+      if (dense) sm[k] = mp.sum[(size_t)k * kMog2Tile];
     }
-  }
-  if (a.stat && (blockIdx.x & a.stat_mask) == 0) {  // scene-sparsity sample for the engine's automatic choice between sparse 1 and 4
-    const bool dense_wave = __any(nm_in >= kMog2K - 1);
-    if ((threadIdx.x & (kWave - 1)) == 0) {
-      atomicAdd(a.stat, 1u);
-      if (!dense_wave) atomicAdd(a.stat + 1, 1u);
+  } else if (count) {
+    wv[0] = mp.w[0];
+    rc[0] = mp.rec[0];  // slot 0 exists from a pixel's first frame on
+    int wave_nm = 0;
+#pragma unroll
+    for (int n = 1; n <= kMog2K; ++n)
+      if (__any(nm_in >= n)) wave_nm = n;
+    if (wave_nm <= 2) {
+      const size_t idx = (size_t)(1 < nm_in ? 1 : 0) * kMog2Tile;
+      wv[1] = mp.w[idx], rc[1] = mp.rec[idx];
+#pragma unroll
+      for (int k = 2; k < kMog2K; ++k) wv[k] = 0.f, rc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+      for (int k = 1; k < kMog2K; ++k) {
+        const size_t idx = (size_t)(k < nm_in ? k : 0) * kMog2Tile;
+        wv[k] = mp.w[idx], rc[k] = mp.rec[idx];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kMog2K; ++k) wv[k] = k < nm_in ? wv[k] : 0.f;
+    cnt = nm_in;
+  } else {
+    // all five weights and summaries at once, whatever the pixel has: this path is chosen for scenes where pixels have several modes,
+    // and not waiting for the meta word saves a whole round trip (three dependent rounds of loads measured 1.48 ms, two ... see DESIGN.md 6.1)
+#pragma unroll
+    for (int k = 0; k < kMog2K; ++k) wv[k] = mp.w[(size_t)k * kMog2Tile], sm[k] = mp.sum[(size_t)k * kMog2Tile];
+    const float x0 = (float)(pix[0] & 0xffu), x1 = (float)((pix[0] >> 8) & 0xffu), x2 = (float)(pix[0] >> 16);
+    const float Tmax = a.Tb > a.Tg ? a.Tb : a.Tg;
+    unsigned need = 0;  // bit k: the record of slot k must be read
+#pragma unroll
+    for (int k = 0; k < kMog2K; ++k) {
+      const bool live = k < nm_in;
+      wv[k] = live ? wv[k] : 0.f;
+      sm[k] = live ? sm[k] : 0u;
+      const bool r = live && valid_in && can_reject && mog2_reject(sm[k], x0, x1, x2, Tmax);
+      rej |= (unsigned)r << (k + 1);
+      need |= (unsigned)(live && !r) << k;
+    }
+    // the needed slots, compacted: the j-th load of a lane fetches its j-th needed record (a lane with fewer repeats its first)
+    cnt = __popc(need);
+    const int k_first = need ? __ffs(need) - 1 : 0;
+    unsigned left = need;
+#pragma unroll
+    for (int j = 0; j < kMog2K; ++j) {
+      kj[j] = left ? __ffs(left) - 1 : k_first;
+      left &= left - 1;
+    }
+    if (!__any(cnt > 1)) {
+      rc[0] = mp.rec[(size_t)kj[0] * kMog2Tile];
+#pragma unroll
+      for (int j = 1; j < kMog2K; ++j) rc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+      for (int j = 0; j < kMog2K; ++j) rc[j] = mp.rec[(size_t)kj[j] * kMog2Tile];
+    }
+    if (sampled) {  // per pixel: 5 record slots, the modes it has (what `count` loads), the records the summaries leave (what `filter` loads)
+      unsigned s_live = 0, s_need = 0;  // sums over the wave, from the ballots of the three bits of each count
+#pragma unroll
+      for (int bit = 0; bit < 3; ++bit) {
+        s_live += (unsigned)__popcll(__ballot((nm_in >> bit) & 1)) << bit;
+        s_need += (unsigned)__popcll(__ballot((cnt >> bit) & 1)) << bit;
+      }
+      const unsigned lanes = (unsigned)__popcll(__ballot(1));
+      if ((threadIdx.x & (kWave - 1)) == 0) {
+        atomicAdd(a.stat, lanes * kMog2K);
+        atomicAdd(a.stat + 1, s_live);
+        atomicAdd(a.stat + 2, s_need);
+      }
     }
   }
   // records into rank order (what the reference's array order is)
@@ -325,8 +477,8 @@ __device__ __forceinline__ void mog2_body(const Mog2Args& a, const size_t frame_
     s.w[r] = wv[r];
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int q = 0; q < kMog2K; ++q)
-      if (f == q + 1) v = rec[q];
+    for (int j = 0; j < kMog2K; ++j)
+      if (j < cnt && f == kj[j] + 1) v = rc[j];
     s.var[r] = v.x, s.m0[r] = v.y, s.m1[r] = v.z, s.m2[r] = v.w;
   }
   unsigned dirty = 0;
@@ -334,7 +486,7 @@ __device__ __forceinline__ void mog2_body(const Mog2Args& a, const size_t frame_
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     const float x0 = (float)(pix[t] & 0xffu), x1 = (float)((pix[t] >> 8) & 0xffu), x2 = (float)(pix[t] >> 16);
-    const int raw = mog2_pixel(s, nm, x0, x1, x2, a, dirty, alphaT[t], alpha1[t], prune[t]);
+    const int raw = mog2_pixel(s, nm, x0, x1, x2, a, dirty, alphaT[t], alpha1[t], prune[t], rej);
     const int m = thr_bin(raw, a.thr, a.enable_thr);
     if (a.fg) a.fg[(size_t)t * fg_stride + p0] = (uint8_t)m;
     if (a.packed) store_packed_mask<1>(a.fg_bits + (size_t)t * bits_stride, p0, (uint32_t)(m != 0), true);
@@ -345,22 +497,46 @@ __device__ __forceinline__ void mog2_body(const Mog2Args& a, const size_t frame_
       o[0] = (uint8_t)b0, o[1] = (uint8_t)b1, o[2] = (uint8_t)b2;
     }
   }
-  // what changed: bits 0..4 weight of rank r, bit 5 the meta word, bits 6..10 the record of slot s
-  unsigned meta_out = 0;
-#pragma unroll
-  for (int r = 0; r < kMog2K; ++r) meta_out |= (unsigned)s.sl[r] << (3 * r);
+  // what changed: bits 0..4 weight of rank r, bit 5 the meta word, bits 6..10 the record of slot s, bits 11..15 its summary
   unsigned d = 0;
 #pragma unroll
   for (int r = 0; r < kMog2K; ++r) d |= (unsigned)(s.w[r] != wv[r]) << r;
-  d |= (unsigned)(meta_out != meta_in) << 5;
   d |= (dirty >> 1) << 6;
-  if (a.sparse == 0) {
-    d = 0x7ffu;
+  bool valid_out = valid_in;
+  if (filter) {
+    // summaries: of the records that changed, when the stored one no longer covers the record (hysteresis: quiet pixels rewrite
+    // theirs rarely); of every mode the pixel has when they were not valid on entry (all its records were loaded for that)
+#pragma unroll
+    for (int q = 0; q < kMog2K; ++q) {
+      const bool changed = (dirty >> (q + 1)) & 1u;
+      if (changed || (!valid_in && q < nm)) {
+        const float4 v = mog2_slot_now(s, make_float4(0.f, 0.f, 0.f, 0.f), q);
+        const bool old_known = valid_in && q < nm_in;  // a slot created by this launch has no summary yet
+        if (!(old_known && mog2_summary_ok(sm[q], v.x, v.y, v.z, v.w))) {
+          sm[q] = mog2_summary(v.x, v.y, v.z, v.w);
+          d |= 1u << (11 + q);
+        }
+      }
+    }
+    valid_out = true;
+  } else if (dirty) {
+    valid_out = false;  // a record changed and nobody looked after its summary
+  }
+  unsigned meta_out = valid_out ? 0x8000u : 0u;
+#pragma unroll
+  for (int r = 0; r < kMog2K; ++r) meta_out |= (unsigned)s.sl[r] << (3 * r);
+  d |= (unsigned)(meta_out != meta_raw) << 5;
+  if (dense) {
+    d = 0xffffu;
   } else if (a.complete) {
-    // whole 32-byte sectors or nothing: 2 lanes share a sector of a record plane, 8 of a weight plane, 16 of the meta row
+    // whole 32-byte sectors or nothing: 8 lanes share a sector of a weight or summary plane, 16 one of the meta row, 2 one of a
+    // record plane.  A lane can only complete a sector with a value it holds: summaries on the filter path, records on the eager paths.
     unsigned d2, d8, d16;
     mog2_group_or(d, d2, d8, d16);
-    d = (d2 & 0x7c0u) | (d8 & 0x1fu) | (d16 & 0x20u);
+    unsigned c = (d8 & 0x1fu) | (d16 & 0x20u);
+    if (filter) c |= d8 & 0xf800u;           // the filter path holds every summary of the pixel (live ones loaded or rebuilt, the rest unused)
+    else if (!count) c |= d2 & 0x7c0u;       // the eager paths hold every record
+    d |= c;
   }
 #pragma unroll
   for (int r = 0; r < kMog2K; ++r)
@@ -368,14 +544,8 @@ __device__ __forceinline__ void mog2_body(const Mog2Args& a, const size_t frame_
   if ((d >> 5) & 1u) *mp.meta = (uint16_t)meta_out;
 #pragma unroll
   for (int q = 0; q < kMog2K; ++q) {
-    if ((d >> (6 + q)) & 1u) {
-      // the record of slot q as it stands now: wherever the bubble left it (a slot this pixel does not own holds nothing anyone reads)
-      float4 v = rec[q];
-#pragma unroll
-      for (int r = 0; r < kMog2K; ++r)
-        if (s.sl[r] == q + 1) v = make_float4(s.var[r], s.m0[r], s.m1[r], s.m2[r]);
-      mp.rec[(size_t)q * kMog2Tile] = v;
-    }
+    if ((d >> (11 + q)) & 1u) mp.sum[(size_t)q * kMog2Tile] = sm[q];
+    if ((d >> (6 + q)) & 1u) mp.rec[(size_t)q * kMog2Tile] = mog2_slot_now(s, rc[q], q);  // rc[q] (eager paths: slot q as loaded) only matters for a slot the pixel does not own
   }
 }
 
@@ -397,6 +567,7 @@ __global__ __launch_bounds__(kBlock) void mog2_clear_kernel(const Mog2Args a) {
 #pragma unroll
   for (int k = 0; k < kMog2K; ++k) {
     mp.w[(size_t)k * kMog2Tile] = 0.f;
+    mp.sum[(size_t)k * kMog2Tile] = 0u;
     mp.rec[(size_t)k * kMog2Tile] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   *mp.meta = 0;
