@@ -215,8 +215,7 @@ def _mog2_summary_invariants(eng, n, stream=0):
 
 @pytest.mark.parametrize("level", [1, 2, 3, 4])
 def test_mog2_summary_filter_boundary_and_invariants(level):
-    """The record filter of MOG2's filter path (sparse 4; sparse 3 = auto: on a frame this small every workgroup is a sampled one and
-    takes it too) against the oracle where it is most likely to slip: modes spaced 6 .. 34 grey levels apart (per column band), so
+    """The record filter of MOG2's filter kernel (sparse 4; sparse 3 = auto runs it at least every 16th launch) against the oracle where it is most likely to slip: modes spaced 6 .. 34 grey levels apart (per column band), so
     that for neighbouring pixels the same comparison is ruled out by the summary, or barely not, or needs the record; noise and a slow
     drift keep the means moving across the summaries' rounding.  Masks, backgrounds every third frame (that launch reads every mode)
     and the whole model must equal the oracle; wherever a pixel's summaries are marked valid they must cover its records - after
@@ -244,7 +243,8 @@ def test_mog2_summary_filter_boundary_and_invariants(level):
             assert np.array_equal(bg, obg), (level, t)
     check_mog2_state(eng, orc, H * W)
     vfrac = _mog2_summary_invariants(eng, H * W)
-    assert vfrac == (1.0 if level >= 3 else 0.0), (level, vfrac)  # frame 59 delivered no background: the filter path ran (levels 3, 4)
+    # frame 59 delivered no background: level 4 ran the filter kernel; levels 1 / 2 never do; auto (3) runs whichever kernel it chose
+    assert vfrac == 1.0 if level == 4 else vfrac == 0.0 if level < 3 else vfrac in (0.0, 1.0), (level, vfrac)
     # the rest of the clip through clip launches (8 + 8 + 8 + 4 + 2 frames): they change records without looking after the summaries
     dev = torch.from_numpy(frames[60:]).cuda().unsqueeze(1)
     fgd = torch.empty((30, 1, H, W), dtype=torch.uint8, device="cuda")
@@ -260,7 +260,7 @@ def test_mog2_summary_filter_boundary_and_invariants(level):
         ofg, _ = orc.process(frames[t], want_bg=False)
         assert np.array_equal(fg, ofg), (level, "after clip", t)
         vfrac = _mog2_summary_invariants(eng, H * W)
-        assert vfrac == (1.0 if level >= 3 else 0.0), (level, t, vfrac)
+        assert vfrac == 1.0 if level == 4 else vfrac == 0.0 if level < 3 else vfrac in (0.0, 1.0), (level, t, vfrac)
     check_mog2_state(eng, orc, H * W)
     eng.close()
 

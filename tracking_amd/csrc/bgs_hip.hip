@@ -98,6 +98,7 @@ struct bgs_engine {
   bool clip_fuse = true;           // MOG2 clip calls keep the model in registers across frames (option 7; results identical either way)
   int mog2_sparse_now = 2;         // what auto mode currently runs
   int mog2_sparse_want = 2;        // what the last poll asked for (a switch needs two polls in a row)
+  unsigned mog2_launches = 0;      // auto mode: per-frame launches so far (every 16th one samples)
   unsigned* d_stat = nullptr;      // device: {record slots sampled, modes live, records needed after the summaries}
   unsigned* h_stat = nullptr;      // pinned copy
   hipEvent_t stat_ev = nullptr;
@@ -201,33 +202,35 @@ struct Timed {
   }
 };
 
-void mog2_stat_poll(bgs_engine* e, hipStream_t s) {
-  // Automatic choice of how a per-frame launch loads a pixel's model (kernel_mog2.h; results are identical, only speed differs):
-  //   1 eager   everything at once, no dependent loads: right when most pixels have most modes and need them;
-  //   2 count   only the modes a pixel has (one dependent round): quiet scenes, one or two modes per pixel;
-  //   4 filter  summaries first, then only the records they cannot rule out (two dependent rounds, +4 B per mode for the
-  //             summaries): pays when at least half of a pixel's records are ruled out (modes far apart).
-  // About 256 sampled workgroups per launch always take the filter path and count, per pixel, the modes it has and the records
-  // that path loads; the host reads the three counters back without ever blocking (event query) and switches when two polls in
-  // a row ask for the same other mode.
-  if (e->stat_pending && hipEventQuery(e->stat_ev) == hipSuccess) {
-    e->stat_pending = false;
-    const unsigned total = e->h_stat[0], live = e->h_stat[1], need = e->h_stat[2];
-    if (total >= 64 * 5) {
-      const float lf = (float)live / (float)total, nf = (float)need / (float)total;
-      const int want = (nf < 0.5f * lf && lf - nf > 0.1f) ? 4 : lf < 0.7f ? 2 : 1;
-      static const bool debug = getenv("BGS_DEBUG_STAT") != nullptr;
-      if (debug) fprintf(stderr, "[bgs] mog2 auto: %u record slots sampled, %.3f live, %.3f needed after the summaries -> mode %d (now %d)\n", total, lf, nf, want, e->mog2_sparse_now);
-      if (want != e->mog2_sparse_now && want == e->mog2_sparse_want) e->mog2_sparse_now = want;
-      e->mog2_sparse_want = want;
-    }
-  }
-  if (!e->stat_pending) {
-    (void)hipMemcpyAsync(e->h_stat, e->d_stat, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, s);
-    (void)hipMemsetAsync(e->d_stat, 0, 3 * sizeof(unsigned), s);
-    (void)hipEventRecord(e->stat_ev, s);
-    e->stat_pending = true;
-  }
+// Automatic choice of how a per-frame launch loads a pixel's model (kernel_mog2.h; results are identical, only speed differs):
+//   1 eager   everything at once, no dependent loads: right when most pixels have most modes and need them;
+//   2 count   only the modes a pixel has (one dependent round): quiet scenes, one or two modes per pixel;
+//   4 filter  summaries first, then only the records they cannot rule out (one dependent round, +4 B per mode for the
+//             summaries): pays when at least half of a pixel's records are ruled out (modes far apart).
+// About 256 sampled workgroups of every filter-kernel launch count, per pixel, the modes it has and the records that kernel loads
+// or would load (when another kernel is current, every 16th launch - every 4th of a stream's first 64 - is a filter launch for
+// that purpose).  The host never blocks: the counters come back through a pinned buffer and an event that is queried before
+// every launch; it switches at once on clear evidence, else when two samples in a row ask for the same other mode.
+void mog2_stat_read(bgs_engine* e) {
+  if (!(e->stat_pending && hipEventQuery(e->stat_ev) == hipSuccess)) return;
+  e->stat_pending = false;
+  const unsigned total = e->h_stat[0], live = e->h_stat[1], need = e->h_stat[2];
+  if (total < 64 * 5) return;
+  const float lf = (float)live / (float)total, nf = (float)need / (float)total;
+  const int want = (nf < 0.5f * lf && lf - nf > 0.1f) ? 4 : lf < 0.7f ? 2 : 1;
+  const bool clear = (want == 4 && nf < 0.35f * lf) || (want != 4 && e->mog2_sparse_now == 4 && nf > 0.8f * lf);
+  static const bool debug = getenv("BGS_DEBUG_STAT") != nullptr;
+  if (debug)
+    fprintf(stderr, "[bgs] mog2 auto: %u record slots sampled, %.3f live, %.3f needed after the summaries -> mode %d (now %d)\n", total, lf, nf, want, e->mog2_sparse_now);
+  if (want != e->mog2_sparse_now && (clear || want == e->mog2_sparse_want)) e->mog2_sparse_now = want;
+  e->mog2_sparse_want = want;
+}
+void mog2_stat_post(bgs_engine* e, hipStream_t s) {
+  if (e->stat_pending) return;
+  (void)hipMemcpyAsync(e->h_stat, e->d_stat, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, s);
+  (void)hipMemsetAsync(e->d_stat, 0, 3 * sizeof(unsigned), s);
+  (void)hipEventRecord(e->stat_ev, s);
+  e->stat_pending = true;
 }
 
 int launch_mog2(bgs_engine* e, bgs::Mog2Args& a, hipStream_t s, bool timed = true) {
@@ -236,17 +239,31 @@ int launch_mog2(bgs_engine* e, bgs::Mog2Args& a, hipStream_t s, bool timed = tru
   a.shadow = p.mog2_detect_shadows && (!p.enable_threshold || ((p.mog2_shadow_value > p.threshold) != (255 > p.threshold)));
   a.want_bg = a.bgimg != nullptr, a.packed = a.fg_bits != nullptr;
   a.xcd_swizzle = e->xcd_swizzle, a.complete = e->mog2_complete;
-  a.sparse = e->mog2_sparse == 3 ? e->mog2_sparse_now : e->mog2_sparse;
-  if (a.sparse >= 4 && (a.shadow || a.want_bg)) a.sparse = 2;  // shadow test and background image read every mode's mean: nothing to rule out
-  a.stat = (timed && e->mog2_sparse == 3) ? e->d_stat : nullptr;
+  const bool autom = timed && e->mog2_sparse == 3;
+  if (autom) mog2_stat_read(e);
+  int mode = e->mog2_sparse == 3 ? e->mog2_sparse_now : e->mog2_sparse;
+  if (mode >= 4 && (a.shadow || a.want_bg)) mode = 2;  // shadow test and background image read every mode's mean: nothing to rule out
+  // auto mode: the filter kernel's sampled workgroups count what each way of loading would read; when another kernel is current,
+  // every 16th launch (every 4th of the first 64) goes through the filter kernel anyway so that the choice keeps following the scene
+  if (autom && mode != 4) {
+    const unsigned n = e->mog2_launches++;
+    if ((n & (n < 64 ? 3u : 15u)) == 0) mode = 4;
+  }
+  a.sparse = mode;
+  a.stat = (autom && mode == 4) ? e->d_stat : nullptr;
   if (a.packed && a.npix % 64) return fail(BGS_ERR_UNSUPPORTED, "packed mask needs pixels %% 64 == 0");
   Timed t(e, s, "mog2_update_kernel", timed);
-  const dim3 grid(blocks_for(a.npix)), block(bgs::kBlock);  // one pixel per lane (66 VGPRs in round 2's 1 / 2 / 4 comparison: equal or better everywhere)
+  const dim3 grid(blocks_for(a.npix)), block(bgs::kBlock);  // one pixel per lane (round 2's 1 / 2 / 4 comparison: equal or better everywhere)
   unsigned every = 1;  // sample about 256 workgroups per launch whatever the grid: enough to decide, few enough atomics not to show
   while (grid.x / every > 256) every <<= 1;
   a.stat_mask = every - 1;
-  hipLaunchKernelGGL(bgs::mog2_update_kernel, grid, block, 0, s, a);
-  if (a.stat) mog2_stat_poll(e, s);
+  if (mode >= 4)
+    hipLaunchKernelGGL((bgs::mog2_update_kernel<bgs::kMog2Filter>), grid, block, 0, s, a);
+  else if (mode >= 2)
+    hipLaunchKernelGGL((bgs::mog2_update_kernel<bgs::kMog2Count>), grid, block, 0, s, a);
+  else
+    hipLaunchKernelGGL((bgs::mog2_update_kernel<bgs::kMog2Eager>), grid, block, 0, s, a);
+  if (a.stat) mog2_stat_post(e, s);
   return BGS_OK;
 }
 

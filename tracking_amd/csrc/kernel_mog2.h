@@ -16,8 +16,9 @@
 //       an empty model, BackgroundSubtractorMOG2::initialize).  modesUsed = number of non-zero fields.
 //   A frame then reads 3 (frame) + 2 (meta) + 20 (weights) + 80 (records) and writes 20 (weights) + 16 (the one record that was
 //   updated or created) + 2 (meta, when the order changed) + 1 (mask) = 144 B/pixel instead of 206.
-//   The arithmetic is the reference's statement for statement: the records are gathered into rank order in registers, the same
-//   predicated bubble runs there (the slot ids travel with it), and only what changed goes back.
+//   The arithmetic is the reference's statement for statement.  In registers only the weights and the slot ids are kept in rank order
+//   and take part in the reference's bubble; a mode's record is fetched from where it was loaded when its turn in the scan comes
+//   (a select chain), and the one record a frame recomputes or creates goes back to its slot with a single store.
 // SUMMARIES - reading fewer records, exactly.  A record is only ever consulted by two comparisons, dist2 < Tb var (background) and
 //   dist2 < Tg var (match).  Each slot also has a 4-byte SUMMARY {q0, q1, q2, vb}: the mean rounded to bytes and a variance bound,
 //   maintained under the invariants |mean_c - q_c| <= 2 and var <= 2 vb (vb = 255: no bound).  From the summary alone
@@ -26,8 +27,10 @@
 //   record is used by nothing else: only its weight decays).  The per-frame launch loads the summaries of a pixel's live slots, then
 //   only the records of the modes that survive: on well-separated modes (the saturating benchmark input) one record of five.
 //   A summary is rewritten when its record changes AND stops satisfying the invariants with some slack (hysteresis: quiet pixels
-//   rewrite it rarely).  Shadow detection and the background image read every mode's mean, so launches that deliver them load all
-//   records; so do clip launches (over 4-8 frames nearly every mode is matched by some frame) - those write fresh summaries.
+//   rewrite it rarely).  Only the filter path maintains summaries: bit 15 of the meta word says "this pixel's summaries cover its
+//   records"; every other path clears it when it changes a record, and the filter path, finding it clear, loads all the pixel's
+//   records, rebuilds the summaries and sets it.  Shadow detection and the background image read every mode's mean, so launches that
+//   deliver them take the count path; clip launches the eager one (over 4-8 frames nearly every mode is matched by some frame).
 //   Reads 3 + 2 + 20 + 20 (summaries) + 16 n (n = surviving modes, 1 on the benchmark input), writes 20 + 16 + 4 + 2 + 1:
 //   104 B/pixel on the benchmark input.
 // Tiles: pixels are grouped in tiles of kMog2Tile (256); a tile is 5 weight planes and 5 summary planes (T dwords each), 5 record
@@ -136,47 +139,97 @@ __device__ __host__ __forceinline__ bool mog2_reject(uint32_t word, float x0, fl
   return vb != 255 && L > Tmax * (2.f * (float)vb) + 1.f;
 }
 
-// One pixel's model in rank order, as MOG2Invoker sees it; sl[r] = slot + 1 of the mode at rank r (0: rank unused)
+// One pixel's model in registers.  Weights and slot ids in rank order, as MOG2Invoker sees its array.  The records {var, mean0,
+// mean1, mean2} in one of three orders (template parameter ORD of what follows):
+//   kMog2Compact  rc[j] is the record of slot kj[j] for j < cnt, wherever the loads put it (filter kernel);
+//   kMog2BySlot   rc[j] is the record of slot j (eager and count per-frame kernels): a mode's record is fetched when its turn in
+//                 the scan comes (a select chain), the records themselves never move;
+//   kMog2Ranked   rc[r] is the record of the mode at rank r and takes part in the bubble like the reference's array (clip kernels:
+//                 gathered once per launch, then T frames index it statically).
+enum { kMog2Compact = 0, kMog2BySlot = 1, kMog2Ranked = 2 };
 struct Mog2Px {
-  float w[kMog2K], var[kMog2K], m0[kMog2K], m1[kMog2K], m2[kMog2K];
-  int sl[kMog2K];
+  float w[kMog2K];
+  int sl[kMog2K];  // slot + 1 of the mode at rank r (0: rank unused)
+};
+struct Mog2Recs {
+  float4 rc[kMog2K];
+  int kj[kMog2K], cnt;
 };
 
-__device__ __forceinline__ void mog2_swap(Mog2Px& s, int i, int j) {
-  float t;
-  t = s.w[i], s.w[i] = s.w[j], s.w[j] = t;
-  t = s.var[i], s.var[i] = s.var[j], s.var[j] = t;
-  t = s.m0[i], s.m0[i] = s.m0[j], s.m0[j] = t;
-  t = s.m1[i], s.m1[i] = s.m1[j], s.m1[j] = t;
-  t = s.m2[i], s.m2[i] = s.m2[j], s.m2[j] = t;
+template <int ORD>
+__device__ __forceinline__ void mog2_swap(Mog2Px& s, Mog2Recs& R, int i, int j) {
+  const float t = s.w[i];
+  s.w[i] = s.w[j], s.w[j] = t;
   const int u = s.sl[i];
   s.sl[i] = s.sl[j], s.sl[j] = u;
+  if constexpr (ORD == kMog2Ranked) {
+    const float4 c = R.rc[i];
+    R.rc[i] = R.rc[j], R.rc[j] = c;
+  }
+}
+
+// the record of the mode with slot code `code` (slot + 1).  BYSLOT: rc[j] is slot j (a compare against constants)
+template <bool BYSLOT>
+__device__ __forceinline__ float4 mog2_pick(const Mog2Recs& R, int code) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < kMog2K; ++j) {
+    const bool here = BYSLOT ? (code == j + 1) : (j < R.cnt && code == R.kj[j] + 1);
+    const float4 c = R.rc[j];  // selects of VALUES, component by component: `if (here) v = R.rc[j]` became a select of addresses + a load, and the whole struct went to scratch
+    v.x = here ? c.x : v.x, v.y = here ? c.y : v.y, v.z = here ? c.z : v.z, v.w = here ? c.w : v.w;
+  }
+  return v;
+}
+// the record of the mode at rank `mode` before this frame's update
+template <int ORD>
+__device__ __forceinline__ float4 mog2_rec_at(const Mog2Px& s, const Mog2Recs& R, int mode) {
+  if constexpr (ORD == kMog2Ranked)
+    return R.rc[mode];
+  else
+    return mog2_pick<ORD == kMog2BySlot>(R, s.sl[mode]);
+}
+// ... as it stands after this frame's update: the recomputed / created record is `out`, of slot code `hit`
+template <bool BYSLOT>
+__device__ __forceinline__ float4 mog2_pick_now(const Mog2Recs& R, int code, int hit, float4 out) {
+  const float4 v = mog2_pick<BYSLOT>(R, code);
+  const bool h = code == hit;
+  return make_float4(h ? out.x : v.x, h ? out.y : v.y, h ? out.z : v.z, h ? out.w : v.w);
+}
+
+template <int ORD>
+__device__ __forceinline__ float4 mog2_rec_now(const Mog2Px& s, const Mog2Recs& R, int mode, int hit, float4 out) {
+  if constexpr (ORD == kMog2Ranked)
+    return R.rc[mode];  // kept current
+  else
+    return mog2_pick_now<ORD == kMog2BySlot>(R, s.sl[mode], hit, out);
 }
 
 // detectShadowGMM of bgfg_gaussmix2.cpp, predicated form of its early returns
-__device__ __forceinline__ bool mog2_shadow(const Mog2Px& s, int nmodes, float x0, float x1, float x2, const Mog2Args& a) {
+template <int ORD>
+__device__ __forceinline__ bool mog2_shadow(const Mog2Px& s, const Mog2Recs& R, int hit, float4 out, int nmodes, float x0, float x1, float x2, const Mog2Args& a) {
   bool done = false, result = false;
   float tWeight = 0.f;
 #pragma unroll
   for (int mode = 0; mode < kMog2K; ++mode) {
     if (mode < nmodes && !done) {
+      const float4 v = mog2_rec_now<ORD>(s, R, mode, hit, out);
       float num = 0.0f, den = 0.0f;
-      num += x0 * s.m0[mode];
-      den += s.m0[mode] * s.m0[mode];
-      num += x1 * s.m1[mode];
-      den += s.m1[mode] * s.m1[mode];
-      num += x2 * s.m2[mode];
-      den += s.m2[mode] * s.m2[mode];
+      num += x0 * v.y;
+      den += v.y * v.y;
+      num += x1 * v.z;
+      den += v.z * v.z;
+      num += x2 * v.w;
+      den += v.w * v.w;
       if (den == 0) {
         done = true;
       } else {
         if (num <= den && num >= a.tau * den) {
           const float q = div_rn(num, den);
           float d2a = 0.0f, dD;
-          dD = q * s.m0[mode] - x0, d2a += dD * dD;
-          dD = q * s.m1[mode] - x1, d2a += dD * dD;
-          dD = q * s.m2[mode] - x2, d2a += dD * dD;
-          if (d2a < a.Tb * s.var[mode] * q * q) result = true, done = true;
+          dD = q * v.y - x0, d2a += dD * dD;
+          dD = q * v.z - x1, d2a += dD * dD;
+          dD = q * v.w - x2, d2a += dD * dD;
+          if (d2a < a.Tb * v.x * q * q) result = true, done = true;
         }
         if (!done) {
           tWeight += s.w[mode];
@@ -191,23 +244,27 @@ __device__ __forceinline__ bool mog2_shadow(const Mog2Px& s, int nmodes, float x
 // One pixel of MOG2Invoker::operator() — same statement order as the reference so every float rounds identically.
 // Returns the raw mask value (0 background, shadow_val, 255 foreground) before the wrapper's threshold.
 // alphaT / alpha1 / prune are the learning-rate terms of THIS frame (they differ between the frames of a clip launch).
-// `dirty`: bit (slot + 1) is set for the slot whose record this frame recomputed (the matched mode) or created.
+// Every frame recomputes (the matched mode) or creates exactly one record: `out`, of slot code `hit` (slot + 1).
 // `rej`: bit (slot + 1) set = this mode's summary proved that neither comparison can hold for this pixel value (mog2_reject): the
-// comparisons are skipped - their outcome is known - and the record, which may not even be loaded, is not touched.
-__device__ __forceinline__ int mog2_pixel(Mog2Px& s, int& nmodes_io, float x0, float x1, float x2, const Mog2Args& a, unsigned& dirty,
-                                          const float alphaT, const float alpha1, const float prune, const unsigned rej = 0) {
+// comparisons are skipped - their outcome is known - and the record, which is not even loaded, is not touched.
+template <int ORD>
+__device__ __forceinline__ int mog2_pixel(Mog2Px& s, Mog2Recs& R, int& nmodes_io, float x0, float x1, float x2, const Mog2Args& a, int& hit, float4& out,
+                                          const float alphaT, const float alpha1, const float prune, const unsigned rej) {
   bool background = false, fitsPDF = false;
   int nmodes = nmodes_io;
   const int nNewModes = nmodes;
   float totalWeight = 0.f;
+  hit = 0;
+  out = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int mode = 0; mode < kMog2K; ++mode) {
     if (mode < nmodes) {  // nmodes shrinks inside the loop when a mode is pruned (reference quirk)
       float weight = alpha1 * s.w[mode] + prune;
       bool matched = false;
       if (!fitsPDF && !((rej >> s.sl[mode]) & 1u)) {
-        const float var = s.var[mode];
-        const float d0 = s.m0[mode] - x0, d1 = s.m1[mode] - x1, d2 = s.m2[mode] - x2;
+        const float4 v = mog2_rec_at<ORD>(s, R, mode);
+        const float var = v.x;
+        const float d0 = v.y - x0, d1 = v.z - x1, d2 = v.w - x2;
         const float dist2 = d0 * d0 + d1 * d1 + d2 * d2;
         if (totalWeight < a.TB && dist2 < a.Tb * var) background = true;
         if (dist2 < a.Tg * var) {
@@ -215,14 +272,12 @@ __device__ __forceinline__ int mog2_pixel(Mog2Px& s, int& nmodes_io, float x0, f
           matched = true;
           weight += alphaT;
           const float k = div_rn(alphaT, weight);
-          s.m0[mode] -= k * d0;
-          s.m1[mode] -= k * d1;
-          s.m2[mode] -= k * d2;
           float varnew = var + k * (dist2 - var);
           varnew = varnew > a.varMin ? varnew : a.varMin;
           varnew = varnew < a.varMax ? varnew : a.varMax;
-          s.var[mode] = varnew;
-          dirty |= 1u << s.sl[mode];  // the record of this mode's slot changed
+          out = make_float4(varnew, v.y - k * d0, v.z - k * d1, v.w - k * d2);
+          hit = s.sl[mode];
+          if constexpr (ORD == kMog2Ranked) R.rc[mode] = out;
         }
       }
       const bool pruned = weight < -prune;
@@ -235,7 +290,7 @@ __device__ __forceinline__ int mog2_pixel(Mog2Px& s, int& nmodes_io, float x0, f
 #pragma unroll
         for (int i = mode; i > 0; --i) {
           moving = moving && !(weight < s.w[i - 1]);
-          if (moving) mog2_swap(s, i, i - 1);
+          if (moving) mog2_swap<ORD>(s, R, i, i - 1);
         }
       }
       totalWeight += pruned ? 0.f : weight;
@@ -255,58 +310,50 @@ __device__ __forceinline__ int mog2_pixel(Mog2Px& s, int& nmodes_io, float x0, f
     for (int k = 0; k < kMog2K; ++k) {
       if (k == mode) {
         s.w[k] = (nmodes == 1) ? 1.f : alphaT;
-        s.m0[k] = x0, s.m1[k] = x1, s.m2[k] = x2;
-        s.var[k] = a.varInit;
         s.sl[k] = slot;
+        if constexpr (ORD == kMog2Ranked) R.rc[k] = make_float4(a.varInit, x0, x1, x2);
       } else if (nmodes != 1 && k < nmodes - 1) {
         s.w[k] *= alpha1;
       }
     }
-    dirty |= 1u << slot;
+    out = make_float4(a.varInit, x0, x1, x2);
+    hit = slot;
     bool moving = true;
 #pragma unroll
     for (int i = kMog2K - 1; i > 0; --i) {
       if (i <= nmodes - 1) {
         moving = moving && !(alphaT < s.w[i - 1]);
-        if (moving) mog2_swap(s, i, i - 1);
+        if (moving) mog2_swap<ORD>(s, R, i, i - 1);
       }
     }
   }
   nmodes_io = nmodes;
   if (background) return 0;
   if (a.shadow) {
-    if (mog2_shadow(s, nmodes, x0, x1, x2, a)) return a.shadow_val;
+    if (mog2_shadow<ORD>(s, R, hit, out, nmodes, x0, x1, x2, a)) return a.shadow_val;
   }
   return 255;
 }
 
 // cv::BackgroundSubtractorMOG2::getBackgroundImage, one pixel, from the registers that already hold the model
-__device__ __forceinline__ void mog2_background(const Mog2Px& s, int nmodes, float TB, int& b0, int& b1, int& b2) {
+template <int ORD>
+__device__ __forceinline__ void mog2_background(const Mog2Px& s, const Mog2Recs& R, int hit, float4 out, int nmodes, float TB, int& b0, int& b1, int& b2) {
   float v0 = 0.f, v1 = 0.f, v2 = 0.f, totalWeight = 0.f;
   bool stop = false;
 #pragma unroll
   for (int g = 0; g < kMog2K; ++g) {
     if (g < nmodes && !stop) {
+      const float4 v = mog2_rec_now<ORD>(s, R, g, hit, out);
       const float w = s.w[g];
-      v0 += w * s.m0[g];
-      v1 += w * s.m1[g];
-      v2 += w * s.m2[g];
+      v0 += w * v.y;
+      v1 += w * v.z;
+      v2 += w * v.w;
       totalWeight += w;
       if (totalWeight > TB) stop = true;
     }
   }
   const float inv = div_rn(1.f, totalWeight);
   b0 = sat_u8(v0 * inv), b1 = sat_u8(v1 * inv), b2 = sat_u8(v2 * inv);
-}
-
-// the record of slot q as it stands now: wherever the bubble left it; `loaded` (what the lane read, or zeros) for a slot the pixel
-// does not own - such a slot holds nothing anyone reads
-__device__ __forceinline__ float4 mog2_slot_now(const Mog2Px& s, float4 loaded, int q) {
-  float4 v = loaded;
-#pragma unroll
-  for (int r = 0; r < kMog2K; ++r)
-    if (s.sl[r] == q + 1) v = make_float4(s.var[r], s.m0[r], s.m1[r], s.m2[r]);
-  return v;
 }
 
 // lane-crossing OR for the sector-complete stores (DPP row operations, no LDS traffic): returns the OR over the lane's aligned
@@ -334,9 +381,21 @@ struct Mog2ClipArgs {
   float alphaT[kMog2ClipMax], alpha1[kMog2ClipMax], prune[kMog2ClipMax];  // per frame (the automatic rate changes with the frame count)
 };
 
-template <int T>
+// How a launch loads a pixel's model (one kernel instance each; results are identical, only the traffic differs):
+//   EAGER   all weights and records at once, nothing waits for the meta word - right when most modes are needed anyway; every clip
+//           launch.  With args.sparse == 0 also "dense": everything is written back too (the placement probe's traffic, A/B runs);
+//   COUNT   rank 0 / slot 0 at once, the other modes' weights and records only for the modes the pixel has: one dependent round of
+//           loads, far fewer bytes on quiet scenes (one or two modes per pixel);
+//   FILTER  all weights and summaries at once, then only the records the summaries cannot rule out: one dependent round; pays when
+//           a pixel's modes lie far apart (the saturating benchmark input: 1 record of 5).  Its sampled workgroups also count what
+//           each way would load, for the engine's automatic choice.
+enum { kMog2Eager = 1, kMog2Count = 2, kMog2Filter = 4 };
+
+template <int MODE, int T>
 __device__ __forceinline__ void mog2_body(const Mog2Args& a, const size_t frame_stride, const size_t fg_stride, const size_t bg_stride, const size_t bits_stride,
                                           const float* alphaT, const float* alpha1, const float* prune) {
+  static_assert(T == 1 || MODE == kMog2Eager, "clip launches load eagerly");
+  constexpr int ORD = MODE == kMog2Filter ? kMog2Compact : T > 1 ? kMog2Ranked : kMog2BySlot;
   size_t blk = blockIdx.x;
   if (a.xcd_swizzle) {
     // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 says which blocks share an XCD and its L2).  Give
@@ -355,34 +414,19 @@ __device__ __forceinline__ void mog2_body(const Mog2Args& a, const size_t frame_
     pix[t] = (uint32_t)f[0] | ((uint32_t)f[1] << 8) | ((uint32_t)f[2] << 16);
   }
   const Mog2Ptr mp = mog2_ptr(a.state, sp);
-  // Four ways to load (wave-uniform choice; results are identical, only the traffic differs):
-  //   dense  (sparse 0)  everything, and everything is written back: the placement probe's traffic pattern, A/B runs;
-  //   eager  (sparse 1, every clip launch): all weights and records at once, nothing waits for the meta word - right when most modes
-  //                      are needed anyway;
-  //   count  (sparse 2)  rank 0 / slot 0 at once, the other modes' weights and records only for the modes this pixel has: one
-  //                      dependent round of loads, far fewer bytes on quiet scenes (one or two modes per pixel);
-  //   filter (sparse 4)  the summaries of the modes the pixel has, then only the records the summaries cannot rule out: two
-  //                      dependent rounds; pays when a pixel's modes lie far apart (the saturating benchmark input: 1 record of 5).
-  // Summaries are only maintained by the filter path.  Bit 15 of the meta word says "this pixel's summaries cover its records";
-  // every other path clears it when it changes a record, and the filter path, finding it clear, loads all the pixel's records,
-  // rebuilds the summaries and sets it.  In auto mode the ~256 sampled workgroups always take the filter path, so the host sees
-  // what each way would load.
   const unsigned meta_raw = *mp.meta;
   const unsigned meta_in = meta_raw & 0x7fffu;
   const bool valid_in = (meta_raw >> 15) & 1u;
   const int nm_in = mog2_meta_count(meta_in);
-  const bool sampled = T == 1 && a.stat && (blockIdx.x & a.stat_mask) == 0;
-  const bool dense = a.sparse == 0;
-  const bool filter = T == 1 && !dense && (a.sparse >= 4 || sampled);
-  const bool count = T == 1 && !dense && !filter && a.sparse >= 2;
+  const bool dense = MODE == kMog2Eager && a.sparse == 0;
   const bool can_reject = !a.shadow && !a.want_bg;  // the shadow test and the background image read every mode's mean
   float wv[kMog2K];
   uint32_t sm[kMog2K];
-  float4 rc[kMog2K];      // records in registers: rc[j] is the record of slot kj[j]; the first `cnt` entries are meaningful
-  int kj[kMog2K], cnt = kMog2K;
-  unsigned rej = 0;       // bit (slot + 1): rejected by its summary for THIS frame (filter path)
+  Mog2Recs R;
+  R.cnt = kMog2K;
+  unsigned rej = 0;  // bit (slot + 1): rejected by its summary for THIS frame (filter path)
 #pragma unroll
-  for (int k = 0; k < kMog2K; ++k) kj[k] = k, sm[k] = 0u;
+  for (int k = 0; k < kMog2K; ++k) R.kj[k] = k, sm[k] = 0u;
   // Every load below is UNCONDITIONAL per lane and sits in straight-line code: a lane that does not want plane k repeats a load it
   // does want (same cache line, no extra HBM traffic) and the value is discarded by a select afterwards.  Loads under a per-lane
   // `if` - and also loads under a chain of wave-uniform branches - made the compiler merge each result with the "not loaded" value
@@ -390,38 +434,38 @@ __device__ __forceinline__ void mog2_body(const Mog2Args& a, const size_t frame_
   // round trip after the other (seen in the ISA of the first two versions of this path, and in round 2 in SuBSENSE's sample
   // prefetch).  So there is ONE wave-uniform two-way choice per round of loads: the short form when no lane of the wave needs
   // more, else all five.
-  if (!filter && !count) {
+  if constexpr (MODE == kMog2Eager) {
 #pragma unroll
     for (int k = 0; k < kMog2K; ++k) {
       wv[k] = mp.w[(size_t)k * kMog2Tile];
-      rc[k] = mp.rec[(size_t)k * kMog2Tile];
+      R.rc[k] = mp.rec[(size_t)k * kMog2Tile];
       if (dense) sm[k] = mp.sum[(size_t)k * kMog2Tile];
     }
-  } else if (count) {
+  } else if constexpr (MODE == kMog2Count) {
     wv[0] = mp.w[0];
-    rc[0] = mp.rec[0];  // slot 0 exists from a pixel's first frame on
+    R.rc[0] = mp.rec[0];  // slot 0 exists from a pixel's first frame on
     int wave_nm = 0;
 #pragma unroll
     for (int n = 1; n <= kMog2K; ++n)
       if (__any(nm_in >= n)) wave_nm = n;
     if (wave_nm <= 2) {
       const size_t idx = (size_t)(1 < nm_in ? 1 : 0) * kMog2Tile;
-      wv[1] = mp.w[idx], rc[1] = mp.rec[idx];
+      wv[1] = mp.w[idx], R.rc[1] = mp.rec[idx];
 #pragma unroll
-      for (int k = 2; k < kMog2K; ++k) wv[k] = 0.f, rc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 2; k < kMog2K; ++k) wv[k] = 0.f, R.rc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
 #pragma unroll
       for (int k = 1; k < kMog2K; ++k) {
         const size_t idx = (size_t)(k < nm_in ? k : 0) * kMog2Tile;
-        wv[k] = mp.w[idx], rc[k] = mp.rec[idx];
+        wv[k] = mp.w[idx], R.rc[k] = mp.rec[idx];
       }
     }
 #pragma unroll
     for (int k = 0; k < kMog2K; ++k) wv[k] = k < nm_in ? wv[k] : 0.f;
-    cnt = nm_in;
+    R.cnt = nm_in;
   } else {
     // all five weights and summaries at once, whatever the pixel has: this path is chosen for scenes where pixels have several modes,
-    // and not waiting for the meta word saves a whole round trip (three dependent rounds of loads measured 1.48 ms, two ... see DESIGN.md 6.1)
+    // and not waiting for the meta word saves a whole round trip
 #pragma unroll
     for (int k = 0; k < kMog2K; ++k) wv[k] = mp.w[(size_t)k * kMog2Tile], sm[k] = mp.sum[(size_t)k * kMog2Tile];
     const float x0 = (float)(pix[0] & 0xffu), x1 = (float)((pix[0] >> 8) & 0xffu), x2 = (float)(pix[0] >> 16);
@@ -437,28 +481,41 @@ __device__ __forceinline__ void mog2_body(const Mog2Args& a, const size_t frame_
       need |= (unsigned)(live && !r) << k;
     }
     // the needed slots, compacted: the j-th load of a lane fetches its j-th needed record (a lane with fewer repeats its first)
-    cnt = __popc(need);
+    R.cnt = __popc(need);
     const int k_first = need ? __ffs(need) - 1 : 0;
     unsigned left = need;
 #pragma unroll
     for (int j = 0; j < kMog2K; ++j) {
-      kj[j] = left ? __ffs(left) - 1 : k_first;
+      R.kj[j] = left ? __ffs(left) - 1 : k_first;
       left &= left - 1;
     }
-    if (!__any(cnt > 1)) {
-      rc[0] = mp.rec[(size_t)kj[0] * kMog2Tile];
+    if (!__any(R.cnt > 1)) {
+      R.rc[0] = mp.rec[(size_t)R.kj[0] * kMog2Tile];
 #pragma unroll
-      for (int j = 1; j < kMog2K; ++j) rc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 1; j < kMog2K; ++j) R.rc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
 #pragma unroll
-      for (int j = 0; j < kMog2K; ++j) rc[j] = mp.rec[(size_t)kj[j] * kMog2Tile];
+      for (int j = 0; j < kMog2K; ++j) R.rc[j] = mp.rec[(size_t)R.kj[j] * kMog2Tile];
     }
-    if (sampled) {  // per pixel: 5 record slots, the modes it has (what `count` loads), the records the summaries leave (what `filter` loads)
-      unsigned s_live = 0, s_need = 0;  // sums over the wave, from the ballots of the three bits of each count
+    if (a.stat && (blockIdx.x & a.stat_mask) == 0) {
+      // per pixel: 5 record slots, the modes it has (what COUNT loads), the records the summaries leave (what FILTER loads);
+      // sums over the wave from the ballots of the three bits of each count
+      // (a pixel whose summaries were not valid had all its records loaded: what fresh summaries would have left is counted instead,
+      // so that a single filter launch in the middle of another kernel's run can tell whether filtering would pay)
+      int would = R.cnt;
+      if (!valid_in && can_reject) {
+        would = 0;
+#pragma unroll
+        for (int j = 0; j < kMog2K; ++j) {
+          const float4 c = R.rc[j];
+          if (j < R.cnt && !mog2_reject(mog2_summary(c.x, c.y, c.z, c.w), x0, x1, x2, Tmax)) ++would;
+        }
+      }
+      unsigned s_live = 0, s_need = 0;
 #pragma unroll
       for (int bit = 0; bit < 3; ++bit) {
         s_live += (unsigned)__popcll(__ballot((nm_in >> bit) & 1)) << bit;
-        s_need += (unsigned)__popcll(__ballot((cnt >> bit) & 1)) << bit;
+        s_need += (unsigned)__popcll(__ballot((would >> bit) & 1)) << bit;
       }
       const unsigned lanes = (unsigned)__popcll(__ballot(1));
       if ((threadIdx.x & (kWave - 1)) == 0) {
@@ -468,49 +525,48 @@ __device__ __forceinline__ void mog2_body(const Mog2Args& a, const size_t frame_
       }
     }
   }
-  // records into rank order (what the reference's array order is)
   Mog2Px s;
 #pragma unroll
-  for (int r = 0; r < kMog2K; ++r) {
-    const int f = (int)((meta_in >> (3 * r)) & 7u);
-    s.sl[r] = f;
-    s.w[r] = wv[r];
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = 0; r < kMog2K; ++r) s.sl[r] = (int)((meta_in >> (3 * r)) & 7u), s.w[r] = wv[r];
+  if constexpr (ORD == kMog2Ranked) {  // clip launches: the records into rank order, once
+    Mog2Recs Q;
 #pragma unroll
-    for (int j = 0; j < kMog2K; ++j)
-      if (j < cnt && f == kj[j] + 1) v = rc[j];
-    s.var[r] = v.x, s.m0[r] = v.y, s.m1[r] = v.z, s.m2[r] = v.w;
+    for (int r = 0; r < kMog2K; ++r) Q.rc[r] = mog2_pick<true>(R, s.sl[r]);
+#pragma unroll
+    for (int r = 0; r < kMog2K; ++r) R.rc[r] = Q.rc[r];
   }
-  unsigned dirty = 0;
-  int nm = nm_in;
+  unsigned dirty = 0;  // bit (slot + 1): the record changed
+  int nm = nm_in, hit = 0;
+  float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     const float x0 = (float)(pix[t] & 0xffu), x1 = (float)((pix[t] >> 8) & 0xffu), x2 = (float)(pix[t] >> 16);
-    const int raw = mog2_pixel(s, nm, x0, x1, x2, a, dirty, alphaT[t], alpha1[t], prune[t], rej);
+    const int raw = mog2_pixel<ORD>(s, R, nm, x0, x1, x2, a, hit, out, alphaT[t], alpha1[t], prune[t], rej);
     const int m = thr_bin(raw, a.thr, a.enable_thr);
     if (a.fg) a.fg[(size_t)t * fg_stride + p0] = (uint8_t)m;
     if (a.packed) store_packed_mask<1>(a.fg_bits + (size_t)t * bits_stride, p0, (uint32_t)(m != 0), true);
     if (a.want_bg) {
       int b0, b1, b2;
-      mog2_background(s, nm, a.TB, b0, b1, b2);
+      mog2_background<ORD>(s, R, hit, out, nm, a.TB, b0, b1, b2);
       uint8_t* o = a.bgimg + (size_t)t * bg_stride + p0 * 3;
       o[0] = (uint8_t)b0, o[1] = (uint8_t)b1, o[2] = (uint8_t)b2;
     }
+    dirty |= 1u << hit;
   }
   // what changed: bits 0..4 weight of rank r, bit 5 the meta word, bits 6..10 the record of slot s, bits 11..15 its summary
   unsigned d = 0;
 #pragma unroll
   for (int r = 0; r < kMog2K; ++r) d |= (unsigned)(s.w[r] != wv[r]) << r;
   d |= (dirty >> 1) << 6;
-  bool valid_out = valid_in;
-  if (filter) {
-    // summaries: of the records that changed, when the stored one no longer covers the record (hysteresis: quiet pixels rewrite
-    // theirs rarely); of every mode the pixel has when they were not valid on entry (all its records were loaded for that)
+  bool valid_out = false;  // every launch changes a record of every pixel; only the filter path looks after the summaries
+  if constexpr (MODE == kMog2Filter) {
+    // summaries: of the record that changed, when the stored one no longer covers it (hysteresis: quiet pixels rewrite theirs rarely);
+    // of every mode the pixel has when they were not valid on entry (all its records were loaded for that)
 #pragma unroll
     for (int q = 0; q < kMog2K; ++q) {
-      const bool changed = (dirty >> (q + 1)) & 1u;
+      const bool changed = hit == q + 1;
       if (changed || (!valid_in && q < nm)) {
-        const float4 v = mog2_slot_now(s, make_float4(0.f, 0.f, 0.f, 0.f), q);
+        const float4 v = mog2_pick_now<false>(R, q + 1, hit, out);
         const bool old_known = valid_in && q < nm_in;  // a slot created by this launch has no summary yet
         if (!(old_known && mog2_summary_ok(sm[q], v.x, v.y, v.z, v.w))) {
           sm[q] = mog2_summary(v.x, v.y, v.z, v.w);
@@ -519,8 +575,6 @@ __device__ __forceinline__ void mog2_body(const Mog2Args& a, const size_t frame_
       }
     }
     valid_out = true;
-  } else if (dirty) {
-    valid_out = false;  // a record changed and nobody looked after its summary
   }
   unsigned meta_out = valid_out ? 0x8000u : 0u;
 #pragma unroll
@@ -530,33 +584,60 @@ __device__ __forceinline__ void mog2_body(const Mog2Args& a, const size_t frame_
     d = 0xffffu;
   } else if (a.complete) {
     // whole 32-byte sectors or nothing: 8 lanes share a sector of a weight or summary plane, 16 one of the meta row, 2 one of a
-    // record plane.  A lane can only complete a sector with a value it holds: summaries on the filter path, records on the eager paths.
+    // record plane.  A lane can only complete a sector with a value it holds: summaries on the filter path, records on the eager path.
     unsigned d2, d8, d16;
     mog2_group_or(d, d2, d8, d16);
     unsigned c = (d8 & 0x1fu) | (d16 & 0x20u);
-    if (filter) c |= d8 & 0xf800u;           // the filter path holds every summary of the pixel (live ones loaded or rebuilt, the rest unused)
-    else if (!count) c |= d2 & 0x7c0u;       // the eager paths hold every record
+    if constexpr (MODE == kMog2Filter) c |= d8 & 0xf800u;  // it holds every summary of the pixel (live ones loaded or rebuilt, the rest unused)
+    if constexpr (MODE == kMog2Eager) c |= d2 & 0x7c0u;    // it holds every record
     d |= c;
   }
 #pragma unroll
   for (int r = 0; r < kMog2K; ++r)
     if ((d >> r) & 1u) mp.w[(size_t)r * kMog2Tile] = s.w[r];
   if ((d >> 5) & 1u) *mp.meta = (uint16_t)meta_out;
+  if constexpr (MODE == kMog2Eager) {
+    // slot q as it stands: per-frame launch = as loaded, with this frame's record patched in; clip = wherever the bubble left it
+    // (a slot the pixel does not own holds nothing anyone reads: zeros)
 #pragma unroll
-  for (int q = 0; q < kMog2K; ++q) {
-    if ((d >> (11 + q)) & 1u) mp.sum[(size_t)q * kMog2Tile] = sm[q];
-    if ((d >> (6 + q)) & 1u) mp.rec[(size_t)q * kMog2Tile] = mog2_slot_now(s, rc[q], q);  // rc[q] (eager paths: slot q as loaded) only matters for a slot the pixel does not own
+    for (int q = 0; q < kMog2K; ++q) {
+      if ((d >> (11 + q)) & 1u) mp.sum[(size_t)q * kMog2Tile] = sm[q];  // dense only
+      if ((d >> (6 + q)) & 1u) {
+        float4 v;
+        if constexpr (T == 1) {
+          const bool h = hit == q + 1;
+          v = make_float4(h ? out.x : R.rc[q].x, h ? out.y : R.rc[q].y, h ? out.z : R.rc[q].z, h ? out.w : R.rc[q].w);
+        } else {
+          v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int r = 0; r < kMog2K; ++r) {
+            const bool h = s.sl[r] == q + 1;
+            v.x = h ? R.rc[r].x : v.x, v.y = h ? R.rc[r].y : v.y, v.z = h ? R.rc[r].z : v.z, v.w = h ? R.rc[r].w : v.w;
+          }
+        }
+        mp.rec[(size_t)q * kMog2Tile] = v;
+      }
+    }
+  } else {
+    // exactly one record per pixel and frame, at the slot it belongs to: one store with a per-lane address
+    mp.rec[(size_t)(hit - 1) * kMog2Tile] = out;
+    if constexpr (MODE == kMog2Filter) {
+#pragma unroll
+      for (int q = 0; q < kMog2K; ++q)
+        if ((d >> (11 + q)) & 1u) mp.sum[(size_t)q * kMog2Tile] = sm[q];
+    }
   }
 }
 
 // grid: ceil(npix / kBlock) blocks of kBlock lanes, one pixel per lane
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void mog2_update_kernel(const Mog2Args a) {
-  mog2_body<1>(a, 0, 0, 0, 0, &a.alphaT, &a.alpha1, &a.prune);
+  mog2_body<MODE, 1>(a, 0, 0, 0, 0, &a.alphaT, &a.alpha1, &a.prune);
 }
 
 template <int T>
 __global__ __launch_bounds__(kBlock) void mog2_clip_kernel(const Mog2ClipArgs c) {
-  mog2_body<T>(c.m, c.frame_stride, c.fg_stride, c.bg_stride, c.bits_stride, c.alphaT, c.alpha1, c.prune);
+  mog2_body<kMog2Eager, T>(c.m, c.frame_stride, c.fg_stride, c.bg_stride, c.bits_stride, c.alphaT, c.alpha1, c.prune);
 }
 
 // (re)initialisation of a pixel range: bgmodel = zeros, modesUsed = 0 (BackgroundSubtractorMOG2::initialize)
