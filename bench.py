@@ -27,8 +27,9 @@ SURVEY_BYTES_PER_PIXEL = 206  # SURVEY.md §8(d), the reference's formulation (m
 # What THIS formulation must move per pixel and frame on the all-modes-live, well-separated input S_sat (kernel_mog2.h:
 # weights by rank, {var, mean} records in fixed slots, a 16-bit rank->slot word, 4-byte summaries that rule modes out without their record):
 #   read  3 frame + 2 meta + 5*4 weights + 5*4 summaries + 16 (the ONE record the summaries cannot rule out) = 61
-#   write 5*4 weights + 16 (that record, updated) + 4 (its summary, when it no longer covers the record) + 2 meta (the order changes every frame) + 1 mask = 43
-BYTES_PER_PIXEL = 104
+#   write 5*4 weights + 16 (that record, updated) + 2 meta (the order changes every frame) + 1 mask = 39
+#   (+ 4 when the record's summary no longer covers it and is rewritten: rare by construction, the PMC counters show 38.8 B written)
+BYTES_PER_PIXEL = 100
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured achievable)
 
 
@@ -478,7 +479,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": traffic, "traffic_source": traffic_source, "traffic_read_write": traffic_detail, "kernel": k_name, "kernel_avg_ms": round(k_ms, 4), "kernel_launches": k_n,
                          "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_pixel": BYTES_PER_PIXEL + (3 if args.with_bg else 0),
-                         "bytes_per_pixel_derivation": "r 3 frame + 2 meta + 20 weights + 20 summaries + 16 one record; w 20 weights + 16 one record + 4 its summary + 2 meta + 1 mask (DESIGN.md 6.1)",
+                         "bytes_per_pixel_derivation": "r 3 frame + 2 meta + 20 weights + 20 summaries + 16 the one record the summaries cannot rule out; w 20 weights + 16 that record + 2 meta + 1 mask (+4 when its summary is rewritten: rare) (DESIGN.md 6.1)",
                          "frac_of_achievable_6290": round(achieved / 6290.0, 4),
                          "vs_survey_206B": {"note": "the same kernel time priced at SURVEY.md 8(d)'s 206 B/pixel (the reference's sorted-array formulation): an EQUIVALENT rate, comparable with rounds 1-2, not bytes moved - it may exceed the peak",
                                             "equivalent_GBps": round(SURVEY_BYTES_PER_PIXEL * px_per_step_rank / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else 0.0,

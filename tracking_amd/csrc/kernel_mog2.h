@@ -135,8 +135,9 @@ __device__ __host__ __forceinline__ bool mog2_reject(uint32_t word, float x0, fl
   float e0 = x0 - q0, e1 = x1 - q1, e2 = x2 - q2;
   e0 = (e0 < 0.f ? -e0 : e0) - (kMog2SumTol + 0.01f), e1 = (e1 < 0.f ? -e1 : e1) - (kMog2SumTol + 0.01f), e2 = (e2 < 0.f ? -e2 : e2) - (kMog2SumTol + 0.01f);
   e0 = e0 > 0.f ? e0 : 0.f, e1 = e1 > 0.f ? e1 : 0.f, e2 = e2 > 0.f ? e2 : 0.f;
-  const float L = e0 * e0 + e1 * e1 + e2 * e2;
-  return vb != 255 && L > Tmax * (2.f * (float)vb) + 1.f;
+  // (this bound is this file's own, not the reference's arithmetic: fused multiply-adds are fine here, the margins cover any rounding)
+  const float L = __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0));
+  return vb != 255 && L > __builtin_fmaf(2.f * Tmax, (float)vb, 1.f);
 }
 
 // One pixel's model in registers.  Weights and slot ids in rank order, as MOG2Invoker sees its array.  The records {var, mean0,
@@ -560,15 +561,19 @@ __device__ __forceinline__ void mog2_body(const Mog2Args& a, const size_t frame_
   d |= (dirty >> 1) << 6;
   bool valid_out = false;  // every launch changes a record of every pixel; only the filter path looks after the summaries
   if constexpr (MODE == kMog2Filter) {
-    // summaries: of the record that changed, when the stored one no longer covers it (hysteresis: quiet pixels rewrite theirs rarely);
-    // of every mode the pixel has when they were not valid on entry (all its records were loaded for that)
+    // Summaries.  The common case costs a select and a few compares: the one record that changed is `out`; its stored summary is
+    // kept while it still covers the record (hysteresis: quiet pixels rewrite theirs rarely).  Rewrites and rebuilds (a pixel whose
+    // summaries were not valid on entry had all its records loaded for this) take the slot loop - skipped by the whole wave otherwise.
+    uint32_t old = 0;
 #pragma unroll
-    for (int q = 0; q < kMog2K; ++q) {
-      const bool changed = hit == q + 1;
-      if (changed || (!valid_in && q < nm)) {
-        const float4 v = mog2_pick_now<false>(R, q + 1, hit, out);
-        const bool old_known = valid_in && q < nm_in;  // a slot created by this launch has no summary yet
-        if (!(old_known && mog2_summary_ok(sm[q], v.x, v.y, v.z, v.w))) {
+    for (int q = 0; q < kMog2K; ++q) old = hit == q + 1 ? sm[q] : old;
+    const bool keep = valid_in && hit <= nm_in && mog2_summary_ok(old, out.x, out.y, out.z, out.w);  // (a slot created by this launch has no summary yet)
+    if (__any(!keep)) {
+#pragma unroll
+      for (int q = 0; q < kMog2K; ++q) {
+        const bool changed = hit == q + 1;
+        if ((changed && !keep) || (!valid_in && q < nm)) {
+          const float4 v = mog2_pick_now<false>(R, q + 1, hit, out);
           sm[q] = mog2_summary(v.x, v.y, v.z, v.w);
           d |= 1u << (11 + q);
         }
