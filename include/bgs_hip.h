@@ -173,8 +173,8 @@ int bgs_set_params(bgs_engine* e, const bgs_params* params);
  *                          1 = use the caller's previous d_frames buffers as history instead of copying each frame
  *                          into the engine's ring; the buffers handed to the previous one (FD) or two (WMM/WMV)
  *                          whole-batch calls must then stay valid and unchanged.  Default 0 (private copy).
- *   BGS_OPT_MOG2_PIXELS_PER_LANE  1, 2 or 4 (tuning knob; 0 = default = 1).
- *   BGS_OPT_MOG2_TILED     1 (default) = tiled AoSoA model, 0 = planar SoA (A/B measurements); before the geometry is set.
+ *   BGS_OPT_MOG2_PIXELS_PER_LANE, BGS_OPT_MOG2_TILED  round-2 A/B knobs of the sorted-array MOG2 kernel; accepted and ignored since
+ *                          round 3 (one pixel per lane, one model layout: ranked weights + fixed-slot records + summaries).
  *   BGS_OPT_XCD_SWIZZLE    XCD-aware workgroup order: 1 (default) = for the kernels that stream a multi-plane model
  *                          (MOG2, MOG1, dp/), 2 = also for the byte-stream kernels (slower there: A/B only), 0 = off.
  *   BGS_OPT_PLACEMENT_PROBE  most model placements tried at allocation (default 20, at most 24, <= 1 = off; the probe stops at the first
@@ -184,10 +184,10 @@ int bgs_set_params(bgs_engine* e, const bgs_params* params);
 #define BGS_OPT_MOG2_TILED 3
 #define BGS_OPT_XCD_SWIZZLE 4
 #define BGS_OPT_PLACEMENT_PROBE 5
-#define BGS_OPT_MOG2_SPARSE 6   /* exact traffic reduction: 0 dense; 1 planes nothing changed in are not written back;
-                                   2 also skip loading the planes of modes no pixel of a wave has; 4 the same per lane (4 pixels)
-                                   instead of per wave, loads and stores of partial rows; 3 (default) switch between 1 and 4 from a
-                                   sparsity sample of the scene */
+#define BGS_OPT_MOG2_SPARSE 6   /* which MOG2 per-frame kernel runs (identical results, different traffic): 0 dense (everything read and
+                                   written back: A/B, placement probe); 1 eager (every record read, only what changed written); 2 count
+                                   (only the modes a pixel has are read); 4 filter (4-byte summaries first, then only the records they
+                                   cannot rule out); 3 (default) automatic, from what sampled workgroups count */
 #define BGS_OPT_CLIP_FUSE 7     /* 1 (default): bgs_process_clip_device runs 8 / 4 / 2 consecutive frames of a mixture model per launch with the
                                    model held in registers; 0: one launch per frame.  Identical results, only speed differs. */
 int bgs_set_option(bgs_engine* e, int option, int64_t value);
@@ -215,7 +215,13 @@ int bgs_process(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols
  *   d_fg      [n_streams][rows][cols] uint8 or NULL
  *   d_bg      [n_streams][rows][cols][channels] uint8 or NULL
  *   d_fg_bits [n_streams][ceil(rows*cols/64)] uint64, bit i of word j = pixel 64j+i foreground, or NULL
- * All streams must be in lock-step (same number of frames seen).
+ * The streams need NOT be in lock-step: cameras join, drop frames and are reset independently (the reference creates and deletes
+ * one IBGS object per stream whenever it likes, FrameProcessor.cpp:35-155, :342-482).  Streams whose next frame needs the same
+ * kernel arguments share a launch - for the mixture models that is "first frame or not" plus the learning rate, i.e. every
+ * stream past its first frame under the wrappers' fixed alpha; for the history classes the warm-up level; for SuBSENSE / LOBSTER
+ * the frame index itself - so a batch fed by whole-batch calls is ONE launch, and a straggler costs one more.
+ * out_flags: what holds for every stream of the call; per stream see bgs_stream_flags.
+ * (BGS_OPT_BORROW_FRAMES still needs lock-step: the borrowed history is one buffer for the whole batch.)
  */
 int bgs_process_batch_device(bgs_engine* e, const void* d_frames, void* d_fg, void* d_bg, void* d_fg_bits,
                              void* hip_stream, uint32_t* out_flags);
@@ -249,8 +255,18 @@ int bgs_process_clip_device(bgs_engine* e, int first, int count, int nframes, co
  */
 int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, size_t cap);
 
-/* Number of frames stream `stream` has consumed so far. */
+/* Number of frames stream `stream` has consumed so far (since bgs_create or its last bgs_reset_stream). */
 int64_t bgs_frames_seen(const bgs_engine* e, int stream);
+
+/* One camera of the batch starts over - what `delete bgs; bgs = new <Class>;` is for one stream in the reference
+ * (FrameProcessor.cpp:342-482 / :35-155, ustc_src/ustc_bgs.cpp:75-77): its frame count returns to 0 and its NEXT frame, on the
+ * HIP stream of that call and in order with everything queued before it, re-initialises its model and restarts its warm-up
+ * exactly like a first frame.  No launch happens here; the other streams are not touched. */
+int bgs_reset_stream(bgs_engine* e, int stream);
+
+/* out_flags (BGS_FG_VALID / BGS_BG_VALID) of the stream's last frame: in a call over streams of different ages the call's own
+ * out_flags word only holds what is true of all of them. */
+int bgs_stream_flags(const bgs_engine* e, int stream, uint32_t* out_flags);
 
 /* Average duration in ms of the dominant kernel of this engine since the last reset, measured
  * with HIP events on the launch stream when timing is enabled (bench.py's roofline leg). */

@@ -250,8 +250,8 @@ def test_clip_argument_errors():
     with pytest.raises(capi.BgsError):
         eng.process_clip_device(d, 2, first=1, count=2)
     eng.process_clip_device(d[:, :1], 2, first=0, count=1)
-    with pytest.raises(capi.BgsError):  # stream 0 is two frames ahead of stream 1 now
-        eng.process_clip_device(d, 2)
+    eng.process_clip_device(d, 2)  # stream 0 is two frames ahead of stream 1 now: allowed since round 3 (one pass per run of equal age)
+    assert eng.frames_seen(0) == 4 and eng.frames_seen(1) == 2
 
 
 def test_mog2_clip_full_size_1080p_sampled_parity():

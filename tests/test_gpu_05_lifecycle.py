@@ -1,0 +1,130 @@
+"""Independent per-camera lifetime inside one batched engine (one IBGS object per stream, created and deleted whenever the
+caller likes - FrameProcessor.cpp:35-155, :342-482; ustc_src/ustc_bgs.cpp:75-77): streams of one engine join at different frames, skip
+frames, are reset mid-run, and every one of them must equal ITS OWN oracle instance at every frame - through the per-frame device
+path (one call over streams of different ages) and through clip calls."""
+import numpy as np
+import pytest
+
+from gpu_helpers import ALGOS, _torch, check_lobster_state, check_state, check_subsense_state
+from oracle import pyoracle
+from tools import synth
+from tracking_amd import Engine, capi
+
+pytestmark = pytest.mark.gpu
+
+NAMES = sorted(ALGOS) + ["SuBSENSEBGS", "LOBSTERBGS"]
+ALL = dict(ALGOS, SuBSENSEBGS=capi.SUBSENSE, LOBSTERBGS=capi.LOBSTER)
+
+
+def _compare(name, algo, eng, orcs, s, frame, d_fg, d_bg, H, W, tag):
+    ofg, obg = orcs[s].process(frame)
+    fl = eng.stream_flags(s)
+    assert bool(fl & capi.FG_VALID) == (ofg is not None), (name, tag, s, fl)
+    assert bool(fl & capi.BG_VALID) == (obg is not None), (name, tag, s, fl)
+    if ofg is not None:
+        got = d_fg.cpu().numpy()
+        assert np.array_equal(got, ofg), (name, tag, s, int((got != ofg).sum()))
+    else:
+        assert bool((d_fg == 9).all()), (name, tag, s, "a warm-up frame must leave the output untouched")
+    if obg is not None:
+        assert np.array_equal(d_bg.cpu().numpy().reshape(obg.shape), obg), (name, tag, s)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_streams_join_skip_and_reset_independently(name):
+    torch = _torch()
+    algo = ALL[name]
+    S, T, H, W = 4, 14, 32, 64
+    clips = np.stack([synth.random_frames(T, H, W, 3, seed=500 + s) for s in range(S)])  # [S][T][H][W][3]
+    eng = Engine(algo, n_streams=S)
+    eng.set_geometry(H, W, 3)
+    orcs = [pyoracle.Oracle(algo) for _ in range(S)]
+    fed = [0] * S                     # frames each stream has been given so far (its own clock)
+    seen = [0] * S                    # ... since its last reset
+    join = [0, 2, 3, 5]               # step at which a camera comes up
+    skip = {(2, 7), (0, 9)}           # (stream, step): this camera drops this step's frame
+    reset_at = {8: 1, 11: 3}          # step -> stream whose IBGS object is deleted and created again
+    bg_c = 1 if algo == capi.ASBL else 3
+    for step in range(T):
+        if step in reset_at:
+            r = reset_at[step]
+            eng.reset_stream(r)
+            orcs[r].close()
+            orcs[r] = pyoracle.Oracle(algo)
+            seen[r] = 0
+            assert eng.frames_seen(r) == 0
+        active = [s for s in range(S) if join[s] <= step and (s, step) not in skip]
+        # contiguous groups of active streams go through ONE call each, whatever their ages
+        groups, cur = [], []
+        for s in range(S):
+            if s in active:
+                cur.append(s)
+            elif cur:
+                groups.append(cur)
+                cur = []
+        if cur:
+            groups.append(cur)
+        for g in groups:
+            frames = np.stack([clips[s, fed[s]] for s in g])
+            d_frames = torch.from_numpy(frames).cuda()
+            d_fg = torch.full((len(g), H, W), 9, dtype=torch.uint8, device="cuda")
+            d_bg = torch.full((len(g), H, W, bg_c), 9, dtype=torch.uint8, device="cuda")
+            eng.process_batch_device(d_frames, d_fg, d_bg, None, first=g[0], count=len(g))
+            torch.cuda.synchronize()
+            for k, s in enumerate(g):
+                _compare(name, algo, eng, orcs, s, clips[s, fed[s]], d_fg[k], d_bg[k], H, W, ("step", step))
+                fed[s] += 1
+                seen[s] += 1
+                assert eng.frames_seen(s) == seen[s]
+    for s in range(S):
+        if name == "SuBSENSEBGS":
+            check_subsense_state(eng, orcs[s], H, W, stream=s)
+        elif name == "LOBSTERBGS":
+            check_lobster_state(eng, orcs[s], H, W, stream=s)
+        else:
+            check_state(name, eng, orcs[s], H * W, stream=s)
+    eng.close()
+    for o in orcs:
+        o.close()
+
+
+@pytest.mark.parametrize("name", ["MixtureOfGaussianV2BGS", "MixtureOfGaussianV1BGS", "DPZivkovicAGMMBGS", "FrameDifferenceBGS", "WeightedMovingVarianceBGS", "AdaptiveBackgroundLearning"])
+def test_clip_call_over_streams_of_different_ages(name):
+    """bgs_process_clip_device over a range whose streams have seen 0, 3, 3 and 1 frames: each stream's masks over the clip equal its
+    own oracle's; then one more per-frame call over all four (ages 6, 9, 9, 7)."""
+    torch = _torch()
+    algo = ALL[name]
+    S, H, W, NC = 4, 32, 64, 6
+    ages = [0, 3, 3, 1]
+    clips = np.stack([synth.random_frames(12, H, W, 3, seed=900 + s) for s in range(S)])
+    eng = Engine(algo, n_streams=S)
+    eng.set_geometry(H, W, 3)
+    orcs = [pyoracle.Oracle(algo) for _ in range(S)]
+    for s in range(S):  # bring every stream to its age with single-stream calls
+        for t in range(ages[s]):
+            d = torch.from_numpy(np.ascontiguousarray(clips[s, t])).cuda().unsqueeze(0)
+            eng.process_batch_device(d, None, None, None, first=s, count=1)
+            orcs[s].process(clips[s, t])
+    slab = np.stack([np.stack([clips[s, ages[s] + t] for s in range(S)]) for t in range(NC)])  # [NC][S][H][W][3]
+    d_slab = torch.from_numpy(slab).cuda()
+    d_fg = torch.full((NC, S, H, W), 9, dtype=torch.uint8, device="cuda")
+    eng.process_clip_device(d_slab, NC, d_fg)
+    torch.cuda.synchronize()
+    fg = d_fg.cpu().numpy()
+    for s in range(S):
+        for t in range(NC):
+            ofg, _ = orcs[s].process(clips[s, ages[s] + t], want_bg=False)
+            if ofg is not None:
+                assert np.array_equal(fg[t, s], ofg), (name, s, t)
+            else:
+                assert (fg[t, s] == 9).all(), (name, s, t)
+        assert eng.frames_seen(s) == ages[s] + NC
+    frames = np.stack([clips[s, ages[s] + NC] for s in range(S)])
+    d_fg1 = torch.full((S, H, W), 9, dtype=torch.uint8, device="cuda")
+    eng.process_batch_device(torch.from_numpy(frames).cuda(), d_fg1, None, None)
+    torch.cuda.synchronize()
+    for s in range(S):
+        ofg, _ = orcs[s].process(frames[s], want_bg=False)
+        assert np.array_equal(d_fg1[s].cpu().numpy(), ofg), (name, s, "after clip")
+        check_state(name, eng, orcs[s], H * W, stream=s)
+    eng.close()

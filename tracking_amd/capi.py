@@ -114,6 +114,8 @@ SYMBOLS = [
     ("bgs_ingest_device", C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, _P, _P, _P]),
     ("bgs_set_ingest", C.c_int, [_P, _P]),
     ("bgs_ingest_host", C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_size_t, _P, C.c_size_t]),
+    ("bgs_reset_stream", C.c_int, [_P, C.c_int]),
+    ("bgs_stream_flags", C.c_int, [_P, C.c_int, C.POINTER(C.c_uint32)]),
     ("bgs_last_mask_blobs", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_int32)]),
 ]
 

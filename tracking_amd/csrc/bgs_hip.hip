@@ -68,6 +68,8 @@ struct bgs_engine {
   int rows = 0, cols = 0, ch = 0;
   size_t n = 0;  // pixels per stream; 0 until the geometry is known
   std::vector<int64_t> seen, counter;
+  std::vector<int64_t> rpos;         // frame history ring: where a stream's NEXT frame goes (ring[rpos % nring]); survives bgs_reset_stream, so that streams fed in the same calls keep sharing launches
+  std::vector<uint32_t> last_flags;  // out_flags of each stream's last frame (bgs_stream_flags)
 
   // frame history ring (FD: 2 slots, WMM/WMV: 3): frame t of stream s lives in ring[t % nring] + s*n*ch
   uint8_t* ring[3] = {nullptr, nullptr, nullptr};
@@ -607,16 +609,74 @@ int pick_group(const bgs::FrameArgs& a, int C, int cap = 16) {
   return G;
 }
 
-// One frame for streams [first, first+count), device pointers, asynchronous on s.
+// What one launch can cover: streams whose next frame needs the same kernel arguments share a RUN.  Cameras come and go
+// independently (the reference creates and deletes one IBGS object per stream whenever it likes: FrameProcessor.cpp:35-155,
+// :342-482; ustc_src/ustc_bgs.cpp:75-77), so the streams of a batch may have seen different numbers of frames; what a launch
+// depends on is far less than the age - e.g. for MOG2 only "first frame?" and the learning rate, which with the wrapper's fixed
+// alpha is the same from a stream's second frame on.  Streams in lock-step (the benchmark, any batch fed by whole-batch calls) are
+// one run = one launch, exactly as before.
+uint64_t launch_key(const bgs_engine* e, int i) {
+  const bgs_params& p = e->p;
+  const int64_t t = e->seen[i];
+  auto lr_key = [&](double alpha, int64_t cap, int64_t mult) -> uint64_t {  // MOG1 / MOG2: needToInitialize + the learning rate of frame t
+    if (t == 0 || alpha >= 1) return 1;
+    if (alpha >= 0) return 2;
+    return 3 + (uint64_t)std::min<int64_t>(mult * (t + 1), cap);
+  };
+  switch (e->algo) {
+    case BGS_FRAME_DIFF:
+    case BGS_WMM:
+    case BGS_WMV: return (uint64_t)(e->rpos[i] % e->nring) | (uint64_t)std::min<int64_t>(t, e->nring - 1) << 8;  // ring slot + warm-up level
+    case BGS_STATIC_FRAME_DIFF:
+    case BGS_SIGMA_DELTA:
+    case BGS_DP_ZIVKOVIC_AGMM:
+    case BGS_DP_GRIMSON_GMM:
+    case BGS_DP_WREN_GA:
+    case BGS_DP_MEAN: return t == 0;
+    case BGS_ABL: return (uint64_t)(t == 0) | (uint64_t)(((p.limit > 0 && p.limit < e->counter[i]) || p.limit == -1) ? 2 : 0) | (uint64_t)(p.limit > 0 ? std::min<int64_t>(e->counter[i], (int64_t)p.limit + 1) : 0) << 2;
+    case BGS_GMG: return (uint64_t)(t == 0) | (uint64_t)(t >= p.gmg_init_frames) << 1 | (uint64_t)(t == (int64_t)p.gmg_init_frames - 1) << 2;
+    case BGS_ASBL: return (uint64_t)(t == 0) | (uint64_t)e->flip[i] << 1 | (uint64_t)((p.learning_frames > 0 && e->counter[i] <= p.learning_frames) ? 4 : 0);
+    case BGS_DP_ADAPTIVE_MEDIAN: return (uint64_t)(t == 0) | (uint64_t)((t % p.dp_sampling_rate) == 1) << 1;
+    case BGS_MOG1: return lr_key(p.alpha, p.mog1_history, 1);
+    case BGS_MOG2: return lr_key(p.alpha, p.mog2_history, 2);
+    default: return (uint64_t)t | (uint64_t)(e->ss ? e->ss->pp[i] & 1 : 0) << 62;  // SuBSENSE / LOBSTER: the frame index itself goes into the kernels (counter-based random draws); + which half of the ping-pong maps is current
+  }
+}
+
+int process_run(bgs_engine* e, int first, int count, const uint8_t* d_frames, uint8_t* d_fg, uint8_t* d_bg, uint64_t* d_bits, hipStream_t s, uint32_t* out_flags);
+
+// One frame for streams [first, first+count), device pointers, asynchronous on s: one launch per run of streams (see launch_key).
 int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, uint8_t* d_fg, uint8_t* d_bg, uint64_t* d_bits, hipStream_t s,
                   uint32_t* out_flags) {
   if (out_flags) *out_flags = 0;
   if (!e->n) return fail(BGS_ERR_INVALID, "geometry not set: call bgs_set_geometry or bgs_process first");
   if (first < 0 || count <= 0 || first + count > e->S) return fail(BGS_ERR_INVALID, "stream range [%d,%d) outside 0..%d", first, first + count, e->S);
   if (!d_frames) return fail(BGS_ERR_INVALID, "d_frames is NULL");
+  if (d_bits && e->n % 64) return fail(BGS_ERR_UNSUPPORTED, "packed mask needs rows*cols %% 64 == 0");
+  uint32_t all = ~0u;
+  const size_t C = (size_t)e->ch, bgC = e->algo == BGS_ASBL ? 1 : C;
+  for (int a = first; a < first + count;) {
+    int b = a + 1;
+    const uint64_t key = launch_key(e, a);
+    while (b < first + count && launch_key(e, b) == key) ++b;
+    if (e->borrow && (a != first || b != first + count) && e->nring && !e->borrow_in_clip)
+      return fail(BGS_ERR_INVALID, "borrowed frame history needs streams in lock-step (streams %d and %d are not)", a, b);
+    const size_t o = (size_t)(a - first) * e->n;
+    uint32_t fl = 0;
+    int rc = process_run(e, a, b - a, d_frames + o * C, d_fg ? d_fg + o : nullptr, d_bg ? d_bg + o * bgC : nullptr, d_bits ? d_bits + o / 64 : nullptr, s, &fl);
+    if (rc) return rc;
+    all &= fl;
+    a = b;
+  }
+  if (out_flags) *out_flags = all;  // what holds for every stream of the range; per stream: bgs_stream_flags
+  return BGS_OK;
+}
+
+// One frame for a run of streams that share every kernel argument.
+int process_run(bgs_engine* e, int first, int count, const uint8_t* d_frames, uint8_t* d_fg, uint8_t* d_bg, uint64_t* d_bits, hipStream_t s,
+                uint32_t* out_flags) {
+  if (out_flags) *out_flags = 0;
   const int64_t t = e->seen[first];
-  for (int i = first; i < first + count; ++i)
-    if (e->seen[i] != t) return fail(BGS_ERR_INVALID, "streams %d and %d are not in lock-step (%lld vs %lld frames)", first, i, (long long)t, (long long)e->seen[i]);
   HIP_TRY(hipSetDevice(e->device));
   const bgs_params& p = e->p;
   const int C = e->ch;
@@ -639,15 +699,16 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
     case BGS_WMM:
     case BGS_WMV: {
       const int R = e->nring, warm = R - 1;
+      const int64_t rp = e->rpos[first];  // the same for every stream of the run (launch_key)
       const uint8_t *cur = d_frames, *h1 = nullptr, *h2 = nullptr;
       if (e->borrow) {
         h1 = e->borrowed[0], h2 = e->borrowed[1];
       } else {
-        uint8_t* slot = e->ring[t % R] + off * C;
+        uint8_t* slot = e->ring[rp % R] + off * C;
         if (cur != slot) HIP_TRY(hipMemcpyAsync(slot, cur, fb, hipMemcpyDeviceToDevice, s));  // keep a private copy as history
         cur = slot;
-        if (t >= 1) h1 = e->ring[(t - 1) % R] + off * C;
-        if (t >= 2 && R == 3) h2 = e->ring[(t - 2) % R] + off * C;
+        if (t >= 1) h1 = e->ring[(rp + R - 1) % R] + off * C;
+        if (t >= 2 && R == 3) h2 = e->ring[(rp + R - 2) % R] + off * C;
       }
       if (t >= warm) {
         a.cur = cur, a.p1 = h1, a.p2 = h2;
@@ -837,7 +898,8 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
         if (C == 1 && px2) hipLaunchKernelGGL((bgs::mog1_update_kernel<1, 2>), grid, block, 0, s, m);
         if (C == 1 && !px2) hipLaunchKernelGGL((bgs::mog1_update_kernel<1, 1>), grid, block, 0, s, m);
       }
-      for (int i = first; i < first + count; ++i) e->seen[i] = nframes - 1;
+      if (nframes == 1)  // re-initialisation restarts the count (the streams of a run may otherwise have different ages: launch_key)
+        for (int i = first; i < first + count; ++i) e->seen[i] = 0;
       flags = BGS_FG_VALID;  // BackgroundSubtractorMOG has no getBackgroundImage (MixtureOfGaussianV1BGS.cpp:53)
       break;
     }
@@ -858,14 +920,15 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
       m.frame = d_frames, m.fg = d_fg, m.bgimg = d_bg, m.fg_bits = d_bits;
       int rc = launch_mog2(e, m, s);
       if (rc) return rc;
-      for (int i = first; i < first + count; ++i) e->seen[i] = nframes - 1;  // re-initialisation restarts the count
+      if (nframes == 1)  // re-initialisation restarts the count (the streams of a run may otherwise have different ages: launch_key)
+        for (int i = first; i < first + count; ++i) e->seen[i] = 0;
       flags = BGS_FG_VALID | BGS_BG_VALID;
       break;
     }
     default: return fail(BGS_ERR_UNSUPPORTED, "algorithm %d is not implemented in this build", (int)e->algo);
   }
   HIP_TRY(hipGetLastError());
-  for (int i = first; i < first + count; ++i) e->seen[i]++;
+  for (int i = first; i < first + count; ++i) e->seen[i]++, e->rpos[i]++, e->last_flags[i] = flags;
   if (out_flags) *out_flags = flags;
   return BGS_OK;
 }
@@ -874,16 +937,41 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
 // bgs_process_clip_device: `nframes` consecutive frames of streams [first, first+count).  Every algorithm: frame by frame
 // through process_range (the same launches as nframes range calls).  MOG2: runs of 8 / 4 / 2 frames go through ONE launch
 // that keeps the model in registers (kernel_mog2.h); what is left over takes the single-frame kernel.
+int process_clip_run(bgs_engine* e, int first, int count, int slab_count, int nframes, const uint8_t* d_frames, uint8_t* d_fg, uint8_t* d_bg, uint64_t* d_bits,
+                     hipStream_t s, uint32_t* out_flags);
+
+// The streams of a clip call may have different ages too: one pass per run of streams with the same age and launch arguments
+// (launch_key); the frames of a run sit inside the caller's [nframes][count] slab, so a run keeps the slab's strides.
 int process_clip(bgs_engine* e, int first, int count, int nframes, const uint8_t* d_frames, uint8_t* d_fg, uint8_t* d_bg, uint64_t* d_bits, hipStream_t s,
                  uint32_t* out_flags) {
   if (nframes < 1) return fail(BGS_ERR_INVALID, "nframes must be >= 1");
   if (!e->n) return fail(BGS_ERR_INVALID, "geometry not set: call bgs_set_geometry or bgs_process first");
   if (first < 0 || count <= 0 || first + count > e->S) return fail(BGS_ERR_INVALID, "stream range [%d,%d) outside 0..%d", first, first + count, e->S);
   if (!d_frames) return fail(BGS_ERR_INVALID, "d_frames is NULL");
+  if (d_bits && e->n % 64) return fail(BGS_ERR_UNSUPPORTED, "packed mask needs rows*cols %% 64 == 0");
+  const size_t C = (size_t)e->ch, bgC = e->algo == BGS_ASBL ? 1 : C;
+  std::vector<uint32_t> fl((size_t)nframes), all((size_t)nframes, ~0u);
+  for (int a = first; a < first + count;) {
+    int b = a + 1;
+    while (b < first + count && e->seen[b] == e->seen[a] && launch_key(e, b) == launch_key(e, a)) ++b;
+    const size_t o = (size_t)(a - first) * e->n;
+    int rc = process_clip_run(e, a, b - a, count, nframes, d_frames + o * C, d_fg ? d_fg + o : nullptr, d_bg ? d_bg + o * bgC : nullptr, d_bits ? d_bits + o / 64 : nullptr, s, fl.data());
+    if (rc) return rc;
+    for (int t = 0; t < nframes; ++t) all[t] &= fl[t];
+    a = b;
+  }
+  if (out_flags)
+    for (int t = 0; t < nframes; ++t) out_flags[t] = all[t];
+  return BGS_OK;
+}
+
+// `count` streams of one age starting at `first`, inside a slab of `slab_count` streams per frame
+int process_clip_run(bgs_engine* e, int first, int count, int slab_count, int nframes, const uint8_t* d_frames, uint8_t* d_fg, uint8_t* d_bg, uint64_t* d_bits,
+                     hipStream_t s, uint32_t* out_flags) {
   const bgs_params& p = e->p;
   const size_t npix = e->n * count, C = (size_t)e->ch;
-  if (d_bits && npix % 64) return fail(BGS_ERR_UNSUPPORTED, "packed mask needs rows*cols %% 64 == 0");
-  const size_t words = npix / 64;
+  const size_t slab = e->n * slab_count;  // pixels from one frame of the clip to the next
+  const size_t words = slab / 64;
   // lr >= 1 re-initialises the model on every frame (needToInitialize): nothing to keep in registers
   const bool dp_gmm = e->algo == BGS_DP_ZIVKOVIC_AGMM || e->algo == BGS_DP_GRIMSON_GMM;
   const bool fuse_ok = e->clip_fuse && (dp_gmm || ((e->algo == BGS_MOG2 || e->algo == BGS_MOG1) && p.alpha < 1));
@@ -891,13 +979,13 @@ int process_clip(bgs_engine* e, int first, int count, int nframes, const uint8_t
   // a clip the earlier frames of the clip ARE that history, so only the last one (two) are copied into the ring, once, at the end.
   const bool ring_clip = e->nring > 0 && !e->borrow && nframes >= 2;
   const uint8_t* saved_borrowed[2] = {e->borrowed[0], e->borrowed[1]};
-  const int64_t ring_t0 = e->seen[first];
+  const int64_t ring_t0 = e->seen[first], ring_p0 = e->rpos[first];
   if (ring_clip) {
     const int R = e->nring;
     const size_t offb = e->n * (size_t)first * C;
     e->borrow = true, e->borrow_in_clip = true;
-    e->borrowed[0] = ring_t0 >= 1 ? e->ring[(ring_t0 - 1) % R] + offb : nullptr;
-    e->borrowed[1] = (ring_t0 >= 2 && R == 3) ? e->ring[(ring_t0 - 2) % R] + offb : nullptr;
+    e->borrowed[0] = ring_t0 >= 1 ? e->ring[(ring_p0 + R - 1) % R] + offb : nullptr;
+    e->borrowed[1] = (ring_t0 >= 2 && R == 3) ? e->ring[(ring_p0 + R - 2) % R] + offb : nullptr;
   }
   auto end_ring_clip = [&](int done) -> int {  // `done` frames of the clip went through: leave the ring as per-frame calls would have
     if (!ring_clip) return BGS_OK;
@@ -906,9 +994,9 @@ int process_clip(bgs_engine* e, int first, int count, int nframes, const uint8_t
     const int R = e->nring;
     const size_t offb = e->n * (size_t)first * C;
     for (int k = 1; k < R; ++k) {
-      const int j = done - k;  // clip frame ring_t0 + j is the k-th last one
+      const int j = done - k;  // clip frame j is the k-th last one
       if (j < 0) break;        // older ones are in the ring already
-      HIP_TRY(hipMemcpyAsync(e->ring[(ring_t0 + j) % R] + offb, d_frames + (size_t)j * npix * C, npix * C, hipMemcpyDeviceToDevice, s));
+      HIP_TRY(hipMemcpyAsync(e->ring[(ring_p0 + j) % R] + offb, d_frames + (size_t)j * slab * C, npix * C, hipMemcpyDeviceToDevice, s));
     }
     return BGS_OK;
   };
@@ -916,9 +1004,9 @@ int process_clip(bgs_engine* e, int first, int count, int nframes, const uint8_t
   while (t < nframes) {
     const int left = nframes - t;
     const int fuse = !fuse_ok ? 1 : left >= 8 ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1;
-    const uint8_t* fr = d_frames + (size_t)t * npix * C;
-    uint8_t* fg = d_fg ? d_fg + (size_t)t * npix : nullptr;
-    uint8_t* bg = d_bg ? d_bg + (size_t)t * npix * C : nullptr;
+    const uint8_t* fr = d_frames + (size_t)t * slab * C;
+    uint8_t* fg = d_fg ? d_fg + (size_t)t * slab : nullptr;
+    uint8_t* bg = d_bg ? d_bg + (size_t)t * slab * (e->algo == BGS_ASBL ? 1 : C) : nullptr;
     uint64_t* bits = d_bits ? d_bits + (size_t)t * words : nullptr;
     if (fuse == 1) {
       int rc = process_range(e, first, count, fr, fg, bg, bits, s, out_flags ? out_flags + t : nullptr);
@@ -933,10 +1021,10 @@ int process_clip(bgs_engine* e, int first, int count, int nframes, const uint8_t
       HIP_TRY(hipSetDevice(e->device));
       if (dp_gmm) {  // package_bgs/dp GMMs: the same kernel with a frame loop (kernel_dp.h)
         uint32_t fl = 0;
-        int rc = dp_process(e, first, count, seen, fr, fg, bits, s, &fl, fuse);
+        int rc = dp_process(e, first, count, seen, fr, fg, bits, s, &fl, fuse, slab);
         if (rc) return rc;
         HIP_TRY(hipGetLastError());
-        for (int i = first; i < first + count; ++i) e->seen[i] += fuse;
+        for (int i = first; i < first + count; ++i) e->seen[i] += fuse, e->rpos[i] += fuse, e->last_flags[i] = fl;
         if (out_flags)
           for (int j = 0; j < fuse; ++j) out_flags[t + j] = fl;
         t += fuse;
@@ -957,7 +1045,7 @@ int process_clip(bgs_engine* e, int first, int count, int nframes, const uint8_t
           const int64_t nf = seen + j + 1;
           c.alpha[j] = (float)((p.alpha >= 0 && nf > 1) ? p.alpha : 1. / (double)std::min<int64_t>(nf, p.mog1_history));
         }
-        c.frame_stride = npix * C, c.fg_stride = npix, c.bits_stride = words;
+        c.frame_stride = slab * C, c.fg_stride = slab, c.bits_stride = words;
         {
           Timed tm(e, s, "mog1_clip_kernel");
           const dim3 grid(blocks_for(npix)), block(bgs::kBlock);
@@ -967,7 +1055,7 @@ int process_clip(bgs_engine* e, int first, int count, int nframes, const uint8_t
 #undef MOG1_CLIP_CASE
         }
         HIP_TRY(hipGetLastError());
-        for (int i = first; i < first + count; ++i) e->seen[i] += fuse;
+        for (int i = first; i < first + count; ++i) e->seen[i] += fuse, e->rpos[i] += fuse, e->last_flags[i] = BGS_FG_VALID;
         if (out_flags)
           for (int j = 0; j < fuse; ++j) out_flags[t + j] = BGS_FG_VALID;
         t += fuse;
@@ -983,11 +1071,11 @@ int process_clip(bgs_engine* e, int first, int count, int nframes, const uint8_t
         c.alphaT[j] = (float)lr, c.alpha1[j] = 1.f - c.alphaT[j], c.prune[j] = (float)(-lr * (double)p.mog2_ct);
       }
       c.m.frame = fr, c.m.fg = fg, c.m.bgimg = bg, c.m.fg_bits = bits;
-      c.frame_stride = npix * 3, c.fg_stride = npix, c.bg_stride = npix * 3, c.bits_stride = words;
+      c.frame_stride = slab * 3, c.fg_stride = slab, c.bg_stride = slab * 3, c.bits_stride = words;
       int rc = launch_mog2_clip(e, c, fuse, s);
       if (rc) return rc;
       HIP_TRY(hipGetLastError());
-      for (int i = first; i < first + count; ++i) e->seen[i] += fuse;
+      for (int i = first; i < first + count; ++i) e->seen[i] += fuse, e->rpos[i] += fuse, e->last_flags[i] = BGS_FG_VALID | BGS_BG_VALID;
       if (out_flags)
         for (int j = 0; j < fuse; ++j) out_flags[t + j] = BGS_FG_VALID | BGS_BG_VALID;
     }
@@ -1140,6 +1228,8 @@ int bgs_create(bgs_algo algo, const bgs_params* params, int hip_device, int n_st
   e->device = hip_device;
   e->S = n_streams;
   e->seen.assign(n_streams, 0);
+  e->rpos.assign(n_streams, 0);
+  e->last_flags.assign(n_streams, 0);
   e->counter.assign(n_streams, 0);
   e->flip.assign(n_streams, 0);
   if (const char* env = getenv("BGS_MOG2_COMPLETE")) e->mog2_complete = atoi(env) != 0;
@@ -1264,7 +1354,7 @@ int bgs_process(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols
   const size_t rb = (size_t)cols * channels, fb = e->n * channels;
   // history-keeping algorithms receive the upload straight in their ring slot (zero-copy history)
   uint8_t* dst = e->d_in;
-  if (e->nring) dst = e->ring[e->seen[stream] % e->nring] + (size_t)stream * fb;
+  if (e->nring) dst = e->ring[e->rpos[stream] % e->nring] + (size_t)stream * fb;
   if (ingest_on_device) {
     // resize / equalizeHist / GaussianBlur: the raw frame goes up as it is, the preparation runs between the upload and the model kernel
     const size_t raw_rb = (size_t)raw_cols * channels, raw_bytes = raw_rb * raw_rows;
@@ -1447,14 +1537,35 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
   if (!strcmp(plane, "bg") && e->algo == BGS_ASBL) return copy_bytes((e->flip[stream] ? e->bgstate2 : e->bgstate) + off, n);
   if (!strcmp(plane, "bg") && e->bgstate) return copy_bytes(e->bgstate + off * e->state_ch, n * e->state_ch);
   const int64_t t = e->seen[stream];
-  if (!strcmp(plane, "prev1") && e->nring && t >= 1) return copy_bytes(e->ring[(t - 1) % e->nring] + off * C, n * C);
-  if (!strcmp(plane, "prev2") && e->nring == 3 && t >= 2) return copy_bytes(e->ring[(t - 2) % e->nring] + off * C, n * C);
+  const int64_t rp = e->rpos[stream];
+  if (!strcmp(plane, "prev1") && e->nring && t >= 1) return copy_bytes(e->ring[(rp + e->nring - 1) % e->nring] + off * C, n * C);
+  if (!strcmp(plane, "prev2") && e->nring == 3 && t >= 2) return copy_bytes(e->ring[(rp + e->nring - 2) % e->nring] + off * C, n * C);
   return fail(BGS_ERR_STATE, "unknown state plane '%s' for algorithm %d", plane, (int)e->algo);
 }
 
 int64_t bgs_frames_seen(const bgs_engine* e, int stream) {
   if (!e || stream < 0 || stream >= e->S) return BGS_ERR_INVALID;
   return e->seen[stream];
+}
+
+// One camera starts over: what deleting its IBGS object and creating a new one does in the reference (FrameProcessor.cpp:342-482 then
+// :35-155; ustc_src/ustc_bgs.cpp:75-77).  Nothing is launched here: the stream's frame count goes back to 0, so its next frame - on
+// whatever HIP stream that call uses, in order with everything before it - re-initialises its model exactly like a first frame
+// (mog2_clear, ss_init_streams, the warm-up of the history classes ...).  The other streams of the batch are not touched and keep
+// sharing launches with each other; the reset stream re-joins them as soon as its launch arguments equal theirs again (launch_key).
+int bgs_reset_stream(bgs_engine* e, int stream) {
+  if (!e) return fail(BGS_ERR_INVALID, "engine is NULL");
+  if (stream < 0 || stream >= e->S) return fail(BGS_ERR_INVALID, "stream %d outside 0..%d", stream, e->S - 1);
+  e->seen[stream] = 0, e->counter[stream] = 0, e->last_flags[stream] = 0;
+  if (e->last_fg_stream == stream) e->last_fg_stream = -1;
+  return BGS_OK;
+}
+
+int bgs_stream_flags(const bgs_engine* e, int stream, uint32_t* out_flags) {
+  if (!e || !out_flags) return fail(BGS_ERR_INVALID, "NULL argument");
+  if (stream < 0 || stream >= e->S) return fail(BGS_ERR_INVALID, "stream %d outside 0..%d", stream, e->S - 1);
+  *out_flags = e->last_flags[stream];
+  return BGS_OK;
 }
 
 int bgs_enable_kernel_timing(bgs_engine* e, int on) {

@@ -62,11 +62,13 @@ int dp_allocate(bgs_engine* e) {
 
 // one frame (number t, 0-based = the wrappers' frameNumber) for streams [first, first+count)
 // frames > 1 (Zivkovic / Grimson only, from process_clip): that many consecutive frames in one launch, d_* point at the first
+// slab: pixels from one frame of a clip to the next (0: the run is the whole slab)
 int dp_process(bgs_engine* e, int first, int count, int64_t t, const uint8_t* d_frames, uint8_t* d_fg, uint64_t* d_bits, hipStream_t s, uint32_t* flags,
-               int frames = 1) {
+               int frames = 1, size_t slab = 0) {
   const bgs_params& p = e->p;
   bgs::DpArgs a{};
-  a.frames = frames, a.frame_stride = e->n * count * 3, a.fg_stride = e->n * count, a.bits_stride = e->n * count / 64;
+  if (!slab) slab = e->n * count;
+  a.frames = frames, a.frame_stride = slab * 3, a.fg_stride = slab, a.bits_stride = slab / 64;
   a.frame = d_frames, a.state = e->dp_state, a.bstate = e->bgstate, a.fg = d_fg, a.fg_bits = d_bits;
   a.n = e->n, a.npix = e->n * count, a.first = first;
   a.low = p.dp_threshold, a.high = 2 * a.low, a.alpha = p.dp_alpha;  // HighThreshold = 2*LowThreshold, e.g. DPZivkovicAGMMBGS.cpp:58

@@ -148,6 +148,15 @@ class Engine:
     def frames_seen(self, stream=0):
         return capi.lib().bgs_frames_seen(self._h, stream)
 
+    def reset_stream(self, stream):
+        """bgs_reset_stream: the stream's next frame is a first frame again (model re-initialised on that call's HIP stream)."""
+        capi.check(capi.lib().bgs_reset_stream(self._h, stream))
+
+    def stream_flags(self, stream):
+        f = C.c_uint32(0)
+        capi.check(capi.lib().bgs_stream_flags(self._h, stream, C.byref(f)))
+        return f.value
+
     def enable_kernel_timing(self, on=True):
         capi.check(capi.lib().bgs_enable_kernel_timing(self._h, 1 if on else 0))
 
