@@ -61,6 +61,8 @@ def lib():
         l.orc_equalize_hist_u8.argtypes = [_P, C.c_size_t]
         l.orc_equalize_hist_u8.restype = None
         l.orc_gaussian7_kernel.argtypes = [_P]
+        l.orc_resize_area_u8.argtypes = [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int]
+        l.orc_resize_area_u8.restype = None
         l.orc_gaussian_blur7_u8.argtypes = [_P, _P, C.c_int, C.c_int, C.c_int]
         l.orc_gaussian_blur7_u8.restype = None
         _lib = l
@@ -174,6 +176,15 @@ def dilate3x3(img, iterations=1):
     img = np.ascontiguousarray(img)
     out = np.empty_like(img)
     lib().orc_dilate3x3(_ptr(img), _ptr(out), img.shape[0], img.shape[1], iterations)
+    return out
+
+
+def resize_area(img, drows, dcols):
+    """cv::resize(img, (dcols, drows), INTER_AREA), general path (oracle/subsense_oracle.c area_value)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    out = np.empty((drows, dcols) if img.ndim == 2 else (drows, dcols, ch), np.uint8)
+    lib().orc_resize_area_u8(_ptr(img), img.shape[0], img.shape[1], ch, _ptr(out), drows, dcols)
     return out
 
 

@@ -15,8 +15,12 @@
  *   What is identical to the reference for a given (model, frame): thresholds, LBSP intra/inter descriptors, the
  *   sample-consensus test and its early exit, all feedback formulas, the post-processing chain, the frame-level block.
  *   (3) OpenCV primitives (morphology, floodFill, medianBlur, addWeighted, INTER_AREA resize, accumulateWeighted) follow
- *       SURVEY.md App. A; the frame-level down-sampling is restated for sizes that are multiples of 8 only
- *       (cv::resize INTER_AREA with an exact integer ratio).
+ *       SURVEY.md App. A.  The frame-level down-sampling (cv::resize ... INTER_AREA to width/8 x height/8, :153, :656) takes
+ *       OpenCV's integer-ratio path (resizeAreaFast_: sum * (1/64) in float, saturate_cast) when rows and cols are multiples of 8
+ *       and the general one otherwise (resizeArea_<uchar, float> with computeResizeAreaTab's fractional cell weights: per source
+ *       row buf += S * alpha over the cells of a destination column in table order, then sum = beta * buf for the first source
+ *       row of a destination row and sum += beta * buf for the others, saturate_cast at the end) - recalled from OpenCV 2.4
+ *       imgwarp.cpp like everything else that is OpenCV's; area_span() below is that table for one destination index.
  */
 #include <math.h>
 #include <stdlib.h>
@@ -26,6 +30,61 @@
 #include "subsense_oracle.h"
 
 /* ------------------------------------------------------------------------------------------------ shared contract */
+
+static inline uint8_t sat_u8_f(float v); /* cv::saturate_cast<uchar>(float), below */
+
+/* computeResizeAreaTab (OpenCV 2.4 imgwarp.cpp) for ONE destination index d of an axis with ssize source and dsize destination
+ * cells, scale = ssize / dsize > 1: a left partial cell (index l, weight al; l = -1: none), the whole cells [s1, s2) with weight af
+ * each, a right partial cell (index r, weight ar; r = -1: none) - in that order, which is the order resizeArea_ accumulates in. */
+typedef struct { int l, s1, s2, r; float al, af, ar; } area_span_t;
+static area_span_t area_span(int ssize, int dsize, int d) {
+  const double scale = (double)ssize / dsize;
+  const double fsx1 = d * scale, fsx2 = fsx1 + scale;
+  const double cell = scale < ssize - fsx1 ? scale : ssize - fsx1;
+  int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+  if (sx2 > ssize - 1) sx2 = ssize - 1;
+  if (sx1 > sx2) sx1 = sx2;
+  area_span_t a;
+  a.l = a.r = -1, a.al = a.ar = 0.f, a.s1 = sx1, a.s2 = sx2, a.af = (float)(1.0 / cell);
+  if (sx1 - fsx1 > 1e-3) a.l = sx1 - 1, a.al = (float)((sx1 - fsx1) / cell);
+  if (fsx2 - sx2 > 1e-3) {
+    double w = fsx2 - sx2;
+    if (w > 1.) w = 1.;
+    if (w > cell) w = cell;
+    a.r = sx2, a.ar = (float)(w / cell);
+  }
+  return a;
+}
+/* one source row's contribution to destination column x (channel c): resizeArea_'s buf[dx] */
+static float area_row(const uint8_t* row, int C, int c, area_span_t ax) {
+  float buf = 0.f;
+  if (ax.l >= 0) buf += row[(size_t)ax.l * C + c] * ax.al;
+  for (int sx = ax.s1; sx < ax.s2; ++sx) buf += row[(size_t)sx * C + c] * ax.af;
+  if (ax.r >= 0) buf += row[(size_t)ax.r * C + c] * ax.ar;
+  return buf;
+}
+/* cv::resize(img, dsw x dsh, INTER_AREA), general (non-integer ratio) path, one destination value */
+static float area_value(const uint8_t* img, int rows, int cols, int C, int dsh, int dsw, int y, int x, int c) {
+  const area_span_t ax = area_span(cols, dsw, x), ay = area_span(rows, dsh, y);
+  float sum = 0.f;
+  int first = 1;
+  if (ay.l >= 0) sum = ay.al * area_row(img + (size_t)ay.l * cols * C, C, c, ax), first = 0;
+  for (int sy = ay.s1; sy < ay.s2; ++sy) {
+    const float b = ay.af * area_row(img + (size_t)sy * cols * C, C, c, ax);
+    sum = first ? b : sum + b, first = 0;
+  }
+  if (ay.r >= 0) {
+    const float b = ay.ar * area_row(img + (size_t)ay.r * cols * C, C, c, ax);
+    sum = first ? b : sum + b;
+  }
+  return sum;
+}
+/* cv::resize(src, dcols x drows, INTER_AREA) for a down-scaling ratio that is not an integer on both axes (exported for the tests) */
+void orc_resize_area_u8(const uint8_t* src, int srows, int scols, int ch, uint8_t* dst, int drows, int dcols) {
+  for (int y = 0; y < drows; ++y)
+    for (int x = 0; x < dcols; ++x)
+      for (int c = 0; c < ch; ++c) dst[((size_t)y * dcols + x) * ch + c] = (uint8_t)sat_u8_f(area_value(src, srows, scols, ch, drows, dcols, y, x, c));
+}
 
 uint32_t ss_rand(uint32_t frame, uint32_t pixel, uint32_t draw) {
   uint32_t x = frame * 0x9E3779B1u;
@@ -183,10 +242,6 @@ int ss_create(const bgs_params* p, const uint8_t* img, int rows, int cols, int C
   } else {
     s->lrScaling = 0, s->autoReset = 0, s->use3x3 = 1, s->medK = 9;
     s->capLo = 4.0f, s->capHi = 512.0f;
-  }
-  if (s->lrScaling && (rows % 8 || cols % 8)) {
-    free(s);
-    return BGS_ERR_UNSUPPORTED; /* INTER_AREA with a fractional ratio is not restated */
   }
   s->T = fmap(n, s->capLo), s->R = fmap(n, 1.0f), s->V = fmap(n, 10.0f);
   s->Dlast[0] = fmap(n, 0), s->Dlast[1] = fmap(n, 0), s->DminLT = fmap(n, 0), s->DminST = fmap(n, 0);
@@ -473,10 +528,15 @@ int ss_process(ss_state* s, const uint8_t* img, uint8_t* fg /* [n] */, uint8_t* 
       for (int x = 0; x < s->dsw; ++x) {
         float d[3] = {0, 0, 0};
         for (int c = 0; c < C; ++c) {
-          int sum = 0;
-          for (int yy = 0; yy < 8; ++yy)
-            for (int xx = 0; xx < 8; ++xx) sum += img[((size_t)(y * 8 + yy) * s->cols + (x * 8 + xx)) * C + c];
-          const float v = (float)sat_u8_f((float)sum * (1.f / 64)); /* INTER_AREA, integer ratio */
+          float v;
+          if (s->rows % 8 == 0 && s->cols % 8 == 0) { /* INTER_AREA, integer ratio on both axes: resizeAreaFast_ */
+            int sum = 0;
+            for (int yy = 0; yy < 8; ++yy)
+              for (int xx = 0; xx < 8; ++xx) sum += img[((size_t)(y * 8 + yy) * s->cols + (x * 8 + xx)) * C + c];
+            v = (float)sat_u8_f((float)sum * (1.f / 64));
+          } else {
+            v = (float)sat_u8_f(area_value(img, s->rows, s->cols, C, s->dsh, s->dsw, y, x, c)); /* resizeArea_ */
+          }
           float* lt = s->dsLT + ((size_t)y * s->dsw + x) * C + c;
           float* st = s->dsST + ((size_t)y * s->dsw + x) * C + c;
           *lt = v * fLT + *lt * (1 - fLT); /* accumulateWeighted: src*a + dst*(1-a) */

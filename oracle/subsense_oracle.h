@@ -16,6 +16,8 @@ void ss_destroy(ss_state* s);
 /* LOBSTERBGS (same state type, fewer planes) */
 int lob_create(const bgs_params* p, const uint8_t* first_frame, int rows, int cols, int channels, ss_state** out);
 int lob_process(ss_state* s, const uint8_t* img, uint8_t* fg, uint8_t* bg);
+/* cv::resize(..., INTER_AREA), general (fractional ratio) path: what SuBSENSE's frame-level block uses on sizes that are not multiples of 8 */
+void orc_resize_area_u8(const uint8_t* src, int srows, int scols, int ch, uint8_t* dst, int drows, int dcols);
 #ifdef __cplusplus
 }
 #endif

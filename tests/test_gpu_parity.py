@@ -420,9 +420,31 @@ def test_subsense_grayscale_qvga_scene_cut():
     check_subsense_state(eng, orc, 240, 320, C=1)
 
 
-def test_subsense_rejects_unsupported_inputs():
-    with pytest.raises(capi.BgsError):
-        Engine(capi.SUBSENSE).process(np.zeros((243, 325, 3), np.uint8))  # >= QVGA and not a multiple of 8
+@pytest.mark.parametrize("shape,ch", [((243, 325), 3), ((250, 333), 1)])
+def test_subsense_sizes_that_are_not_multiples_of_8(shape, ch):
+    """>= QVGA and not a multiple of 8 (the reference takes any size: BackgroundSubtractorSuBSENSE.cpp:153 down-samples to
+    width/8 x height/8 with cv::resize INTER_AREA, whose general path has fractional cell weights): learning-rate scaling + auto model
+    reset enabled; a scene cut triggers refreshModel(0.1).  The whole model must equal the oracle, frame-level scalars included."""
+    H, W = shape
+    a = synth.numpy_frames("surv", 30, H, W, seed=21) // 6
+    b = 255 - synth.numpy_frames("surv", 10, H, W, seed=99) // 6
+    frames = np.concatenate([a, b])
+    if ch == 1:
+        frames = np.ascontiguousarray(frames[..., 1])
+    eng, orc, _ = run_pair(capi.SUBSENSE, frames)
+    check_subsense_state(eng, orc, H, W, C=ch)
+    sc = eng.get_state("scalars", (7,), np.float64)
+    if ch == 3:  # (the 1-channel measure is |ST - LT| / 2, :664: this cut stays below its threshold - the scalars still equal the oracle's)
+        assert sc[2] > 0, "the scene cut should have started a model-reset cooldown"
+
+
+def test_subsense_854x480_not_a_multiple_of_8():
+    """854 x 480 (the verdict's example; 854 = 8 * 106 + 6): 5x5 diffusion, median 13, the fractional down-sampling on the x axis only."""
+    a = synth.numpy_frames("surv", 7, 480, 854, seed=3) // 5
+    b = 255 - synth.numpy_frames("surv", 3, 480, 854, seed=4) // 5
+    frames = np.concatenate([a, b])
+    eng, orc, _ = run_pair(capi.SUBSENSE, frames)
+    check_subsense_state(eng, orc, 480, 854)
 
 
 @pytest.mark.parametrize("shape", [(64, 64), (37, 53), (1, 1), (3, 200), (130, 257), (200, 70), (300, 520)])

@@ -504,3 +504,32 @@ def test_cpu_code_is_clean_under_asan_and_ubsan():
     r = subprocess.run(["bash", os.path.join(root, "tools", "sanitize_cpu.sh")], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "oracle under ASan+UBSan: OK" in r.stdout and "host mirror under ASan+UBSan: OK" in r.stdout
+
+
+@pytest.mark.parametrize("shape", [(243, 325), (480, 854), (250, 333), (241, 320)])
+def test_resize_area_general_path_vs_exact_area_average(shape):
+    """cv::resize(INTER_AREA) to (w/8, h/8) for sizes that are not multiples of 8 (SuBSENSE's frame-level block,
+    BackgroundSubtractorSuBSENSE.cpp:153, :656): the restated float accumulation (recalled from OpenCV 2.4 resizeArea_, unpinned) must
+    stay within one grey level of the exact area-weighted mean computed in float64 (the weights of a destination cell sum to 1; the
+    last cell of an axis is the clipped one)."""
+    rng = np.random.default_rng(shape[0])
+    H, W = shape
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    dh, dw = H // 8, W // 8
+    got = pyoracle.resize_area(img, dh, dw).astype(np.float64)
+
+    def weights(ssize, dsize):
+        scale = ssize / dsize
+        M = np.zeros((dsize, ssize))
+        for d in range(dsize):
+            a, b = d * scale, min((d + 1) * scale, ssize)
+            for sx in range(int(np.floor(a)), min(int(np.ceil(b)), ssize)):
+                M[d, sx] = max(0.0, min(b, sx + 1) - max(a, sx))
+            M[d] /= M[d].sum()
+        return M
+    My, Mx = weights(H, dh), weights(W, dw)
+    exact = np.einsum("yh,hwc,xw->yxc", My, img.astype(np.float64), Mx)
+    assert np.abs(got - exact).max() <= 1.0, float(np.abs(got - exact).max())
+    assert np.abs(got - np.rint(exact)).mean() < 0.02  # nearly always THE rounded mean
+    g1 = pyoracle.resize_area(img[:, :, 1].copy(), dh, dw)
+    assert np.array_equal(g1, got[:, :, 1].astype(np.uint8))  # the 1-channel path is the same arithmetic

@@ -69,8 +69,6 @@ int ss_allocate(bgs_engine* e) {
     k = std::min(k, 14);
     d->medK = (k % 2) ? k : k - 1;
     d->capLo0 = 2.f, d->capHi0 = 256.f;
-    if (e->rows % 8 || e->cols % 8)
-      return fail(BGS_ERR_UNSUPPORTED, "SuBSENSE frame-level analysis: rows and cols must be multiples of 8 (cv::resize INTER_AREA with an integer ratio)");
   }
   const size_t N = e->n, P = N * e->S, nS = (size_t)p.subsense_n_samples, C = (size_t)e->ch;
   // records: the first batch of kSsBatch samples sample-major, the rest pixel-major in whole double batches (kernel_subsense.h: ss_rec, phase A)

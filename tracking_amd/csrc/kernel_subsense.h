@@ -1121,6 +1121,56 @@ __global__ __launch_bounds__(kBlock) void ss_finish_kernel(const SsArgs a, const
 }
 
 // ----------------------------------------------------------------------------------------------- frame-level block :656-665
+// cv::resize(..., width/8 x height/8, INTER_AREA) (:153, :656) for sizes that are NOT multiples of 8: OpenCV's general path
+// (resizeArea_<uchar, float> over computeResizeAreaTab's fractional cell weights; recalled, unpinned - oracle/subsense_oracle.c
+// area_span() is the same function).  One destination index of one axis: a left partial cell, whole cells [s1, s2), a right partial.
+struct SsAreaSpan {
+  int l, s1, s2, r;
+  float al, af, ar;
+};
+__device__ __forceinline__ SsAreaSpan ss_area_span(int ssize, int dsize, int d) {
+  const double scale = (double)ssize / dsize;
+  const double fsx1 = d * scale, fsx2 = fsx1 + scale;
+  const double cell = scale < ssize - fsx1 ? scale : ssize - fsx1;
+  int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+  sx2 = min(sx2, ssize - 1);
+  sx1 = min(sx1, sx2);
+  SsAreaSpan a;
+  a.l = a.r = -1, a.al = a.ar = 0.f, a.s1 = sx1, a.s2 = sx2, a.af = (float)(1.0 / cell);
+  if (sx1 - fsx1 > 1e-3) a.l = sx1 - 1, a.al = (float)((sx1 - fsx1) / cell);
+  if (fsx2 - sx2 > 1e-3) {
+    double w = fsx2 - sx2;
+    w = w > 1. ? 1. : w;
+    w = w > cell ? cell : w;
+    a.r = sx2, a.ar = (float)(w / cell);
+  }
+  return a;
+}
+template <int C>
+__device__ __forceinline__ float ss_area_row(const uint8_t* row, int c, const SsAreaSpan& ax) {
+  float buf = 0.f;
+  if (ax.l >= 0) buf += row[(size_t)ax.l * C + c] * ax.al;
+  for (int sx = ax.s1; sx < ax.s2; ++sx) buf += row[(size_t)sx * C + c] * ax.af;
+  if (ax.r >= 0) buf += row[(size_t)ax.r * C + c] * ax.ar;
+  return buf;
+}
+template <int C>
+__device__ __forceinline__ float ss_area_value(const uint8_t* img, int rows, int cols, int dsh, int dsw, int y, int x, int c) {
+  const SsAreaSpan ax = ss_area_span(cols, dsw, x), ay = ss_area_span(rows, dsh, y);
+  float sum = 0.f;
+  bool first = true;
+  if (ay.l >= 0) sum = ay.al * ss_area_row<C>(img + (size_t)ay.l * cols * C, c, ax), first = false;
+  for (int sy = ay.s1; sy < ay.s2; ++sy) {
+    const float b = ay.af * ss_area_row<C>(img + (size_t)sy * cols * C, c, ax);
+    sum = first ? b : sum + b, first = false;
+  }
+  if (ay.r >= 0) {
+    const float b = ay.ar * ss_area_row<C>(img + (size_t)ay.r * cols * C, c, ax);
+    sum = first ? b : sum + b;
+  }
+  return sum;
+}
+
 template <int C>
 __global__ __launch_bounds__(kBlock) void ss_downsample_kernel(const SsArgs a) {
   const int stream = a.first + blockIdx.z;
@@ -1133,10 +1183,15 @@ __global__ __launch_bounds__(kBlock) void ss_downsample_kernel(const SsArgs a) {
     float d[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      int sum = 0;
-      for (int yy = 0; yy < 8; ++yy)
-        for (int xx = 0; xx < 8; ++xx) sum += img[((size_t)(y * 8 + yy) * a.cols + (x * 8 + xx)) * C + c];
-      const float v = (float)sat_u8((float)sum * (1.f / 64));  // cv::resize INTER_AREA, integer ratio
+      float v;
+      if (a.rows % 8 == 0 && a.cols % 8 == 0) {  // cv::resize INTER_AREA, integer ratio on both axes (resizeAreaFast_)
+        int sum = 0;
+        for (int yy = 0; yy < 8; ++yy)
+          for (int xx = 0; xx < 8; ++xx) sum += img[((size_t)(y * 8 + yy) * a.cols + (x * 8 + xx)) * C + c];
+        v = (float)sat_u8((float)sum * (1.f / 64));
+      } else {
+        v = (float)sat_u8(ss_area_value<C>(img, a.rows, a.cols, dsh, dsw, y, x, c));
+      }
       float* lt = a.dsLT + ((size_t)stream * dsw * dsh + idx) * C + c;
       float* st = a.dsST + ((size_t)stream * dsw * dsh + idx) * C + c;
       const float nlt = v * a.fLT + *lt * (1 - a.fLT), nst = v * a.fST + *st * (1 - a.fST);  // cv::accumulateWeighted
