@@ -258,6 +258,36 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
 /* Number of frames stream `stream` has consumed so far (since bgs_create or its last bgs_reset_stream). */
 int64_t bgs_frames_seen(const bgs_engine* e, int stream);
 
+/*
+ * GROUPS - several classes on the same frames.  FrameProcessor::process hands ONE pre-processed frame to every enabled IBGS, one
+ * call after the other (FrameProcessor.cpp:169-340); BASELINE configs[2] is WeightedMovingVarianceBGS + AdaptiveBackgroundLearning
+ * on the same 3840x2160 frames.  A group takes `n_algos` classes; the byte-stream ones among them - FrameDifference,
+ * StaticFrameDifference, WeightedMovingMean, WeightedMovingVariance, AdaptiveBackgroundLearning, SigmaDelta, one instance each -
+ * run as ONE kernel over one read of the frame and one shared history ring (17 B/pixel for configs[2] instead of 10 + 10; 26
+ * instead of 47 for the five history / state classes together), every other class as a member engine fed the same device frame.
+ * Masks, backgrounds, warm-up conventions and model states are those of n separate engines, bit for bit.
+ *   params      NULL, or n_algos pointers (NULL entries = reference defaults)
+ *   d_fg, d_bg  arrays of n_algos device pointers (entries may be NULL), each laid out as for bgs_process_batch_device
+ *   out_flags   n_algos words (BGS_FG_VALID / BGS_BG_VALID per class)
+ * The streams of a group advance in lock-step (whole-batch calls).  bgs_group_process is the host-buffer call for single-stream
+ * groups - one upload of the frame for all classes - with per-class output pointers and row steps (NULL steps = packed rows).
+ */
+typedef struct bgs_group bgs_group;
+int bgs_group_create(const bgs_algo* algos, const bgs_params* const* params, int n_algos, int hip_device, int n_streams, bgs_group** out);
+void bgs_group_destroy(bgs_group* g);
+int bgs_group_size(const bgs_group* g);
+int bgs_group_is_fused(const bgs_group* g, int index); /* 1: class `index` runs inside the fused kernel; 0: member engine */
+int bgs_group_set_params(bgs_group* g, int index, const bgs_params* params);
+int bgs_group_set_option(bgs_group* g, int option, int64_t value); /* BGS_OPT_BORROW_FRAMES: the shared history too */
+int bgs_group_set_geometry(bgs_group* g, int rows, int cols, int channels);
+int bgs_group_process_batch_device(bgs_group* g, const void* d_frames, void* const* d_fg, void* const* d_bg, void* hip_stream, uint32_t* out_flags);
+int bgs_group_process(bgs_group* g, const uint8_t* in, int rows, int cols, int channels, size_t in_step, uint8_t* const* fg, const size_t* fg_step,
+                      uint8_t* const* bg, const size_t* bg_step, uint32_t* out_flags);
+int64_t bgs_group_get_state(bgs_group* g, int index, int stream, const char* plane, void* dst, size_t cap);
+int64_t bgs_group_frames_seen(const bgs_group* g);
+int bgs_group_enable_kernel_timing(bgs_group* g, int on);
+int bgs_group_kernel_timing(bgs_group* g, double* avg_ms, int64_t* launches); /* the fused launches, HIP events on the launch stream */
+
 /* One camera of the batch starts over - what `delete bgs; bgs = new <Class>;` is for one stream in the reference
  * (FrameProcessor.cpp:342-482 / :35-155, ustc_src/ustc_bgs.cpp:75-77): its frame count returns to 0 and its NEXT frame, on the
  * HIP stream of that call and in order with everything queued before it, re-initialises its model and restarts its warm-up

@@ -114,6 +114,19 @@ SYMBOLS = [
     ("bgs_ingest_device", C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, _P, _P, _P]),
     ("bgs_set_ingest", C.c_int, [_P, _P]),
     ("bgs_ingest_host", C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_size_t, _P, C.c_size_t]),
+    ("bgs_group_create", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("bgs_group_destroy", None, [_P]),
+    ("bgs_group_size", C.c_int, [_P]),
+    ("bgs_group_is_fused", C.c_int, [_P, C.c_int]),
+    ("bgs_group_set_params", C.c_int, [_P, C.c_int, _P]),
+    ("bgs_group_set_option", C.c_int, [_P, C.c_int, C.c_int64]),
+    ("bgs_group_set_geometry", C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    ("bgs_group_process_batch_device", C.c_int, [_P, _P, _P, _P, _P, C.POINTER(C.c_uint32)]),
+    ("bgs_group_process", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_size_t, _P, _P, _P, _P, C.POINTER(C.c_uint32)]),
+    ("bgs_group_get_state", C.c_int64, [_P, C.c_int, C.c_int, C.c_char_p, _P, C.c_size_t]),
+    ("bgs_group_frames_seen", C.c_int64, [_P]),
+    ("bgs_group_enable_kernel_timing", C.c_int, [_P, C.c_int]),
+    ("bgs_group_kernel_timing", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     ("bgs_reset_stream", C.c_int, [_P, C.c_int]),
     ("bgs_stream_flags", C.c_int, [_P, C.c_int, C.POINTER(C.c_uint32)]),
     ("bgs_last_mask_blobs", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_int32)]),

@@ -1948,3 +1948,5 @@ int bgs_ingest_host(int hip_device, const bgs_ingest* c, const uint8_t* src, int
 
 
 }  // extern "C"
+
+#include "engine_group.h"

@@ -52,9 +52,9 @@ struct PxGroup {
   }
 };
 
-// gray (3ch) + threshold of a per-channel u8 difference image, G pixels; returns the mask bytes and the bit nibble
+// gray (3ch) + threshold of a per-channel u8 difference image, G pixels: the mask bytes to `fg`, the bits to `fg_bits`
 template <int G, int C>
-__device__ __forceinline__ void gray_thr_store(const PxGroup<G, C>& d, const FrameArgs& a, size_t p0, bool active, bool packed) {
+__device__ __forceinline__ void gray_thr_store_to(const PxGroup<G, C>& d, int thr, int enable_thr, uint8_t* fg, uint64_t* fg_bits, size_t p0, bool active) {
   PxGroup<G, 1> m;
 #pragma unroll
   for (int i = 0; i < PxGroup<G, 1>::NB / 4; ++i) m.b.w[i] = 0;
@@ -62,14 +62,25 @@ __device__ __forceinline__ void gray_thr_store(const PxGroup<G, C>& d, const Fra
 #pragma unroll
   for (int j = 0; j < G; ++j) {
     const int g = (C == 3) ? gray_bgr(d.b.get(3 * j), d.b.get(3 * j + 1), d.b.get(3 * j + 2)) : d.b.get(j);
-    const int v = thr_bin(g, a.thr, a.enable_thr);
+    const int v = thr_bin(g, thr, enable_thr);
     m.b.set(j, v);
     bits |= (uint32_t)(v != 0) << j;
   }
-  if (active && a.fg) m.store(a.fg + p0);
-  if (packed) {
-    if constexpr (64 % G == 0) store_packed_mask<G>(a.fg_bits, p0, active ? bits : 0u, active);
+  if (active && fg) m.store(fg + p0);
+  if (fg_bits) {
+    if constexpr (64 % G == 0) store_packed_mask<G>(fg_bits, p0, active ? bits : 0u, active);
   }
+}
+template <int G, int C>
+__device__ __forceinline__ void gray_thr_store(const PxGroup<G, C>& d, const FrameArgs& a, size_t p0, bool active, bool packed) {
+  gray_thr_store_to<G, C>(d, a.thr, a.enable_thr, a.fg, packed ? a.fg_bits : nullptr, p0, active);
+}
+
+// cv::absdiff 8U (FrameDifferenceBGS.cpp:45, StaticFrameDifferenceBGS.cpp:42)
+template <int G, int C>
+__device__ __forceinline__ void absdiff_body(const PxGroup<G, C>& x, const PxGroup<G, C>& y, PxGroup<G, C>& d) {
+#pragma unroll
+  for (int i = 0; i < G * C; ++i) d.b.set(i, abs(x.b.get(i) - y.b.get(i)));
 }
 
 template <int G, int C>
@@ -81,8 +92,7 @@ __global__ __launch_bounds__(kBlock) void framediff_kernel(const FrameArgs a) {
     PxGroup<G, C> x, y;
     x.load(a.cur + p0 * C);
     y.load(a.p1 + p0 * C);
-#pragma unroll
-    for (int i = 0; i < G * C; ++i) d.b.set(i, abs(x.b.get(i) - y.b.get(i)));  // cv::absdiff 8U
+    absdiff_body<G, C>(x, y, d);
   }
   gray_thr_store<G, C>(d, a, p0, active, a.fg_bits != nullptr);
 }
@@ -113,6 +123,22 @@ __device__ __forceinline__ float mean3(float i0, float i1, float i2, double w0, 
   }
 }
 
+// WeightedMovingMeanBGS.cpp:52-84: the background bytes `bgq` and the per-channel |I - bg| bytes `d` of G pixels
+template <int G, int C>
+__device__ __forceinline__ void wmm_body(const PxGroup<G, C>& x, const PxGroup<G, C>& y, const PxGroup<G, C>& z, int enable_weight, PxGroup<G, C>& d, PxGroup<G, C>& bgq) {
+#pragma unroll
+  for (int i = 0; i < PxGroup<G, C>::NB / 4; ++i) bgq.b.w[i] = 0;
+#pragma unroll
+  for (int i = 0; i < G * C; ++i) {
+    const int xi = x.b.get(i);
+    const float i0 = to_unit(xi), i1 = to_unit(y.b.get(i)), i2 = to_unit(z.b.get(i));
+    const float bgf = enable_weight ? mean3<false>(i0, i1, i2, 0.5, 0.3, 0.2) : mean3<true>(i0, i1, i2, 0, 0, 0);
+    const int b8 = sat_u8(bgf * 255.f);
+    bgq.b.set(i, b8);
+    d.b.set(i, abs(xi - b8));
+  }
+}
+
 template <int G, int C>
 __global__ __launch_bounds__(kBlock) void wmm_kernel(const FrameArgs a) {
   const size_t p0 = (xcd_block(a.xcd_swizzle) * kBlock + threadIdx.x) * G;
@@ -123,17 +149,7 @@ __global__ __launch_bounds__(kBlock) void wmm_kernel(const FrameArgs a) {
     x.load(a.cur + p0 * C);
     y.load(a.p1 + p0 * C);
     z.load(a.p2 + p0 * C);
-#pragma unroll
-    for (int i = 0; i < PxGroup<G, C>::NB / 4; ++i) bgq.b.w[i] = 0;
-#pragma unroll
-    for (int i = 0; i < G * C; ++i) {
-      const int xi = x.b.get(i);
-      const float i0 = to_unit(xi), i1 = to_unit(y.b.get(i)), i2 = to_unit(z.b.get(i));
-      const float bgf = a.enable_weight ? mean3<false>(i0, i1, i2, 0.5, 0.3, 0.2) : mean3<true>(i0, i1, i2, 0, 0, 0);
-      const int b8 = sat_u8(bgf * 255.f);
-      bgq.b.set(i, b8);
-      d.b.set(i, abs(xi - b8));
-    }
+    wmm_body<G, C>(x, y, z, a.enable_weight, d, bgq);
     if (a.bg) bgq.store(a.bg + p0 * C);
   }
   gray_thr_store<G, C>(d, a, p0, active, a.fg_bits != nullptr);
@@ -152,6 +168,37 @@ __device__ __forceinline__ float wvar(float x, float mean, double w) {
 // every channel of a pixel has range(b0,b1,b2) < 2*thr, every channel byte is <= thr, hence gray <= thr and the thresholded
 // mask is 0 - no float work needed.  Only pixels with real temporal change take the full path (which stays bit-exact).
 template <int G, int C>
+__device__ __forceinline__ void wmv_body(const PxGroup<G, C>& x, const PxGroup<G, C>& y, const PxGroup<G, C>& z, int enable_weight, int enable_thr, int thr, PxGroup<G, C>& d) {
+  const double w0 = enable_weight ? 0.5 : 0.3, w1 = 0.3, w2 = enable_weight ? 0.2 : 0.3;  // :68-70 (unweighted = 0.3 x3, sic)
+  const bool shortcut = enable_weight && enable_thr && thr >= 1;
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    bool quiet = shortcut;
+    if (shortcut) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const int b0 = x.b.get(j * C + c), b1 = y.b.get(j * C + c), b2 = z.b.get(j * C + c);
+        quiet = quiet && (max(b0, max(b1, b2)) - min(b0, min(b1, b2)) < 2 * thr);
+      }
+    }
+    if (quiet) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) d.b.set(j * C + c, 0);  // any value <= thr gives the same mask
+    } else {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const int i = j * C + c;
+        const float i0 = to_unit(x.b.get(i)), i1 = to_unit(y.b.get(i)), i2 = to_unit(z.b.get(i));
+        const float m = mean3<false>(i0, i1, i2, w0, w1, w2);
+        const float v = (wvar(i0, m, w0) + wvar(i1, m, w1)) + wvar(i2, m, w2);  // :83
+        const float sd = sqrt_rn(v);                                            // :95
+        d.b.set(i, sat_u8(sd * 255.f));                                         // :99
+      }
+    }
+  }
+}
+
+template <int G, int C>
 __global__ __launch_bounds__(kBlock) void wmv_kernel(const FrameArgs a) {
   const size_t p0 = (xcd_block(a.xcd_swizzle) * kBlock + threadIdx.x) * G;
   const bool active = p0 < a.npix;
@@ -161,33 +208,7 @@ __global__ __launch_bounds__(kBlock) void wmv_kernel(const FrameArgs a) {
     x.load(a.cur + p0 * C);
     y.load(a.p1 + p0 * C);
     z.load(a.p2 + p0 * C);
-    const double w0 = a.enable_weight ? 0.5 : 0.3, w1 = 0.3, w2 = a.enable_weight ? 0.2 : 0.3;  // :68-70 (unweighted = 0.3 x3, sic)
-    const bool shortcut = a.enable_weight && a.enable_thr && a.thr >= 1;
-#pragma unroll
-    for (int j = 0; j < G; ++j) {
-      bool quiet = shortcut;
-      if (shortcut) {
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-          const int b0 = x.b.get(j * C + c), b1 = y.b.get(j * C + c), b2 = z.b.get(j * C + c);
-          quiet = quiet && (max(b0, max(b1, b2)) - min(b0, min(b1, b2)) < 2 * a.thr);
-        }
-      }
-      if (quiet) {
-#pragma unroll
-        for (int c = 0; c < C; ++c) d.b.set(j * C + c, 0);  // any value <= thr gives the same mask
-      } else {
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-          const int i = j * C + c;
-          const float i0 = to_unit(x.b.get(i)), i1 = to_unit(y.b.get(i)), i2 = to_unit(z.b.get(i));
-          const float m = mean3<false>(i0, i1, i2, w0, w1, w2);
-          const float v = (wvar(i0, m, w0) + wvar(i1, m, w1)) + wvar(i2, m, w2);  // :83
-          const float sd = sqrt_rn(v);                                            // :95
-          d.b.set(i, sat_u8(sd * 255.f));                                         // :99
-        }
-      }
-    }
+    wmv_body<G, C>(x, y, z, a.enable_weight, a.enable_thr, a.thr, d);
   }
   gray_thr_store<G, C>(d, a, p0, active, a.fg_bits != nullptr);
 }
@@ -210,16 +231,33 @@ __global__ __launch_bounds__(kBlock) void abl_lut_kernel(uint8_t* lut, double al
   lut[b * 256 + x] = (uint8_t)sat_u8(add_weighted(to_unit(x), alpha, to_unit(b), beta) * 255.f);
 }
 
+// the 64 KB table into LDS (row stride 260), all lanes of the workgroup; the caller synchronises
+__device__ __forceinline__ void abl_load_lut(uint8_t* T, const uint8_t* __restrict__ lut, int nthreads) {
+  const uint4* src = reinterpret_cast<const uint4*>(lut);
+  for (int i = threadIdx.x; i < 256 * 16; i += nthreads) {  // 16 x 16-byte pieces per row; 260 = 65 dwords keeps dword alignment
+    const uint4 v = src[i];
+    uint32_t* dst = reinterpret_cast<uint32_t*>(T + (i >> 4) * kAblLutStride + (i & 15) * 16);
+    dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
+  }
+}
+// AdaptiveBackgroundLearning.cpp:43-65 for G pixels: d = |I - B| per channel; with UPDATE the background bytes become the table's
+template <int G, int C, bool UPDATE>
+__device__ __forceinline__ void abl_body(const PxGroup<G, C>& x, PxGroup<G, C>& bgq, const uint8_t* T, PxGroup<G, C>& d) {
+#pragma unroll
+  for (int i = 0; i < G * C; ++i) {
+    const int xi = x.b.get(i), bi = bgq.b.get(i);
+    if constexpr (UPDATE) bgq.b.set(i, T[bi * kAblLutStride + xi]);  // :54-58
+    // :50, :64-65: saturate(|i/255 - b/255| * 255) in float == |i - b| for all 65 536 byte pairs (checked exhaustively,
+    // CPU test test_unit_absdiff_is_integer_absdiff), so the float round trip is skipped
+    d.b.set(i, abs(xi - bi));
+  }
+}
+
 template <int G, int C, bool UPDATE>
 __global__ __launch_bounds__(kAblBlock) void abl_kernel(const FrameArgs a, const uint8_t* __restrict__ lut) {
   __shared__ uint8_t T[UPDATE ? 256 * kAblLutStride : 16];
   if constexpr (UPDATE) {
-    const uint4* src = reinterpret_cast<const uint4*>(lut);
-    for (int i = threadIdx.x; i < 256 * 16; i += kAblBlock) {  // 16 x 16-byte pieces per row; 260 = 65 dwords keeps dword alignment
-      const uint4 v = src[i];
-      uint32_t* dst = reinterpret_cast<uint32_t*>(T + (i >> 4) * kAblLutStride + (i & 15) * 16);
-      dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
-    }
+    abl_load_lut(T, lut, kAblBlock);
     __syncthreads();
   }
   const size_t per_tile = (size_t)kAblBlock * G;
@@ -233,14 +271,7 @@ __global__ __launch_bounds__(kAblBlock) void abl_kernel(const FrameArgs a, const
       PxGroup<G, C> x, bgq;
       x.load(a.cur + p0 * C);
       bgq.load(a.p1 + p0 * C);
-#pragma unroll
-      for (int i = 0; i < G * C; ++i) {
-        const int xi = x.b.get(i), bi = bgq.b.get(i);
-        if constexpr (UPDATE) bgq.b.set(i, T[bi * kAblLutStride + xi]);  // :54-58
-        // :50, :64-65: saturate(|i/255 - b/255| * 255) in float == |i - b| for all 65 536 byte pairs (checked exhaustively,
-        // CPU test test_unit_absdiff_is_integer_absdiff), so the float round trip is skipped
-        d.b.set(i, abs(xi - bi));
-      }
+      abl_body<G, C, UPDATE>(x, bgq, T, d);
       if constexpr (UPDATE) bgq.store(a.state_out + p0 * C);
       if (a.bg) bgq.store(a.bg + p0 * C);
     }
@@ -285,6 +316,61 @@ __device__ __forceinline__ uint32_t sd_pair(uint32_t im2, uint32_t& m2, uint32_t
   return (W(S(W(ot)) - S(W(vu))) >> 15) & 0x00010001u;
 }
 
+// one sdLaMa091 step for G pixels (BGR): Mt and Vt updated in place, the mask bytes in `m`, one bit per pixel in `bits`
+template <int G>
+__device__ __forceinline__ void sd_body(const PxGroup<G, 3>& x, PxGroup<G, 3>& mt, PxGroup<G, 3>& vt, uint32_t N, int vmin, int vmax, PxGroup<G, 1>& m, uint32_t& bits) {
+  if (G % 4 == 0 && N <= 256u) {
+    // 4 pixels = 12 bytes = 3 dwords at a time, two bytes per packed 16-bit instruction (38 instead of 73 instructions per pixel)
+    const uint32_t n2 = N * 0x10001u, vmin2 = (uint32_t)vmin * 0x10001u, vmax2 = (uint32_t)vmax * 0x10001u;
+#pragma unroll
+    for (int g = 0; g < G / 4; ++g) {
+      uint32_t nf[3];  // per byte: 1 = this channel does not vote foreground
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const int i = 3 * g + d;
+        const uint32_t xw = x.b.w[i], mw = mt.b.w[i], vw = vt.b.w[i];
+        uint32_t mlo = mw & 0x00ff00ffu, mhi = (mw >> 8) & 0x00ff00ffu, vlo = vw & 0x00ff00ffu, vhi = (vw >> 8) & 0x00ff00ffu;
+        const uint32_t flo = sd_pair(xw & 0x00ff00ffu, mlo, vlo, n2, vmin2, vmax2);
+        const uint32_t fhi = sd_pair((xw >> 8) & 0x00ff00ffu, mhi, vhi, n2, vmin2, vmax2);
+        mt.b.w[i] = mlo | (mhi << 8), vt.b.w[i] = vlo | (vhi << 8);
+        nf[d] = flo | (fhi << 8);
+      }
+      // pixel j of the group owns bytes 3j .. 3j+2 of the 12: background iff all three of its channels say so
+      const uint32_t s0 = __builtin_amdgcn_sad_u8(nf[0] & 0x00ffffffu, 0u, 0u);
+      const uint32_t s1 = __builtin_amdgcn_sad_u8(nf[0] & 0xff000000u, 0u, __builtin_amdgcn_sad_u8(nf[1] & 0x0000ffffu, 0u, 0u));
+      const uint32_t s2 = __builtin_amdgcn_sad_u8(nf[1] & 0xffff0000u, 0u, __builtin_amdgcn_sad_u8(nf[2] & 0x000000ffu, 0u, 0u));
+      const uint32_t s3 = __builtin_amdgcn_sad_u8(nf[2] & 0xffffff00u, 0u, 0u);
+      const uint32_t f0 = s0 != 3u, f1 = s1 != 3u, f2 = s2 != 3u, f3 = s3 != 3u;
+      m.b.w[g] = (f0 * 0xffu) | (f1 * 0xff00u) | (f2 * 0xff0000u) | (f3 * 0xff000000u);
+      bits |= (f0 | (f1 << 1) | (f2 << 2) | (f3 << 3)) << (4 * g);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      bool isfg = false;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int i = 3 * j + c;
+        int mv = mt.b.get(i);
+        const int im = x.b.get(i);
+        mv += (mv < im) - (mv > im);                                   // sdLaMa091.cpp:535-540
+        const int d8 = (int)(int8_t)(uint8_t)(mv - im);                // :559 absVal(int8_t): the difference wraps to int8 first
+        const uint32_t ot = (uint32_t)(d8 < 0 ? -d8 : d8) & 0xffu;
+        const uint32_t amp = N * ot;                                 // :576
+        uint32_t v = (uint32_t)vt.b.get(i);
+        v = (v + (v < amp) - (v > amp)) & 0xffu;                       // :578-581 on a uint8: 255+1 wraps to 0
+        v = min(v, (uint32_t)vmax);                                  // :583 max(min(Vt, Vmax), Vmin) with uint8 operands
+        v = max(v, (uint32_t)vmin);
+        isfg = isfg || ot >= v;                                        // :605
+        mt.b.set(i, mv);
+        vt.b.set(i, (int)v);
+      }
+      m.b.set(j, isfg ? 255 : 0);
+      bits |= (uint32_t)isfg << j;
+    }
+  }
+}
+
 template <int G>
 __global__ __launch_bounds__(kBlock) void sigmadelta_kernel(const SigmaDeltaArgs a) {
   const size_t p0 = (xcd_block(a.xcd_swizzle) * kBlock + threadIdx.x) * G;
@@ -298,56 +384,7 @@ __global__ __launch_bounds__(kBlock) void sigmadelta_kernel(const SigmaDeltaArgs
     x.load(a.cur + p0 * 3);
     mt.load(a.mt + p0 * 3);
     vt.load(a.vt + p0 * 3);
-    if (G % 4 == 0 && a.N <= 256u) {
-      // 4 pixels = 12 bytes = 3 dwords at a time, two bytes per packed 16-bit instruction (38 instead of 73 instructions per pixel)
-      const uint32_t n2 = a.N * 0x10001u, vmin2 = (uint32_t)a.vmin * 0x10001u, vmax2 = (uint32_t)a.vmax * 0x10001u;
-#pragma unroll
-      for (int g = 0; g < G / 4; ++g) {
-        uint32_t nf[3];  // per byte: 1 = this channel does not vote foreground
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          const int i = 3 * g + d;
-          const uint32_t xw = x.b.w[i], mw = mt.b.w[i], vw = vt.b.w[i];
-          uint32_t mlo = mw & 0x00ff00ffu, mhi = (mw >> 8) & 0x00ff00ffu, vlo = vw & 0x00ff00ffu, vhi = (vw >> 8) & 0x00ff00ffu;
-          const uint32_t flo = sd_pair(xw & 0x00ff00ffu, mlo, vlo, n2, vmin2, vmax2);
-          const uint32_t fhi = sd_pair((xw >> 8) & 0x00ff00ffu, mhi, vhi, n2, vmin2, vmax2);
-          mt.b.w[i] = mlo | (mhi << 8), vt.b.w[i] = vlo | (vhi << 8);
-          nf[d] = flo | (fhi << 8);
-        }
-        // pixel j of the group owns bytes 3j .. 3j+2 of the 12: background iff all three of its channels say so
-        const uint32_t s0 = __builtin_amdgcn_sad_u8(nf[0] & 0x00ffffffu, 0u, 0u);
-        const uint32_t s1 = __builtin_amdgcn_sad_u8(nf[0] & 0xff000000u, 0u, __builtin_amdgcn_sad_u8(nf[1] & 0x0000ffffu, 0u, 0u));
-        const uint32_t s2 = __builtin_amdgcn_sad_u8(nf[1] & 0xffff0000u, 0u, __builtin_amdgcn_sad_u8(nf[2] & 0x000000ffu, 0u, 0u));
-        const uint32_t s3 = __builtin_amdgcn_sad_u8(nf[2] & 0xffffff00u, 0u, 0u);
-        const uint32_t f0 = s0 != 3u, f1 = s1 != 3u, f2 = s2 != 3u, f3 = s3 != 3u;
-        m.b.w[g] = (f0 * 0xffu) | (f1 * 0xff00u) | (f2 * 0xff0000u) | (f3 * 0xff000000u);
-        bits |= (f0 | (f1 << 1) | (f2 << 2) | (f3 << 3)) << (4 * g);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < G; ++j) {
-        bool isfg = false;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const int i = 3 * j + c;
-          int mv = mt.b.get(i);
-          const int im = x.b.get(i);
-          mv += (mv < im) - (mv > im);                                   // sdLaMa091.cpp:535-540
-          const int d8 = (int)(int8_t)(uint8_t)(mv - im);                // :559 absVal(int8_t): the difference wraps to int8 first
-          const uint32_t ot = (uint32_t)(d8 < 0 ? -d8 : d8) & 0xffu;
-          const uint32_t amp = a.N * ot;                                 // :576
-          uint32_t v = (uint32_t)vt.b.get(i);
-          v = (v + (v < amp) - (v > amp)) & 0xffu;                       // :578-581 on a uint8: 255+1 wraps to 0
-          v = min(v, (uint32_t)a.vmax);                                  // :583 max(min(Vt, Vmax), Vmin) with uint8 operands
-          v = max(v, (uint32_t)a.vmin);
-          isfg = isfg || ot >= v;                                        // :605
-          mt.b.set(i, mv);
-          vt.b.set(i, (int)v);
-        }
-        m.b.set(j, isfg ? 255 : 0);
-        bits |= (uint32_t)isfg << j;
-      }
-    }
+    sd_body<G>(x, mt, vt, a.N, a.vmin, a.vmax, m, bits);
     mt.store(a.mt + p0 * 3);
     vt.store(a.vt + p0 * 3);
     if (a.fg) m.store(a.fg + p0);

@@ -1122,8 +1122,8 @@ __global__ __launch_bounds__(kBlock) void ss_finish_kernel(const SsArgs a, const
 
 // ----------------------------------------------------------------------------------------------- frame-level block :656-665
 // cv::resize(..., width/8 x height/8, INTER_AREA) (:153, :656) for sizes that are NOT multiples of 8: OpenCV's general path
-// (resizeArea_<uchar, float> over computeResizeAreaTab's fractional cell weights; recalled, unpinned - oracle/subsense_oracle.c
-// area_span() is the same function).  One destination index of one axis: a left partial cell, whole cells [s1, s2), a right partial.
+// (resizeArea_<uchar, float> over computeResizeAreaTab's fractional cell weights; recalled from OpenCV 2.4 imgwarp.cpp, unpinned -
+// the tests' CPU restatement states the same function).  One destination index of one axis: a left partial cell, whole cells [s1, s2), a right partial.
 struct SsAreaSpan {
   int l, s1, s2, r;
   float al, af, ar;

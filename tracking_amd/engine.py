@@ -304,3 +304,96 @@ def ingest_host(cfg, frame, device=0):
     capi.check(capi.lib().bgs_ingest_host(device, C.byref(cfg), frame.ctypes.data_as(C.c_void_p), rows, cols, ch, frame.strides[0],
                                           out.ctypes.data_as(C.c_void_p), out.strides[0]))
     return out
+
+
+class Group:
+    """bgs_group: several classes on the same frames (include/bgs_hip.h, GROUPS) - the byte-stream classes among them as one fused
+    kernel, the rest as member engines.  Binding only: no arithmetic here."""
+
+    def __init__(self, algos, params=None, device=0, n_streams=1):
+        self.algos = list(algos)
+        self.n_streams = n_streams
+        n = len(self.algos)
+        self._params = [(p if p is not None else capi.default_params(a)) for a, p in zip(self.algos, params or [None] * n)]
+        arr = (C.c_int * n)(*self.algos)
+        pp = (C.c_void_p * n)(*[C.cast(C.byref(p), C.c_void_p) for p in self._params])
+        self._h = C.c_void_p()
+        capi.check(capi.lib().bgs_group_create(arr, pp, n, device, n_streams, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            capi.lib().bgs_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def is_fused(self, index):
+        return capi.lib().bgs_group_is_fused(self._h, index) == 1
+
+    def set_params(self, index, params):
+        capi.check(capi.lib().bgs_group_set_params(self._h, index, C.byref(params)))
+        self._params[index] = params
+
+    def set_option(self, option, value):
+        capi.check(capi.lib().bgs_group_set_option(self._h, option, int(value)))
+
+    def set_geometry(self, rows, cols, channels):
+        capi.check(capi.lib().bgs_group_set_geometry(self._h, rows, cols, channels))
+
+    def process(self, frame, want_bg=True):
+        """bgs_group_process (single-stream groups): returns [(mask or None, background or None)] per class, None where the
+        reference leaves the output untouched."""
+        assert frame.dtype == np.uint8
+        rows, cols = frame.shape[:2]
+        ch = 1 if frame.ndim == 2 else frame.shape[2]
+        frame = np.ascontiguousarray(frame)
+        n = len(self.algos)
+        fgs = [np.empty((rows, cols), np.uint8) for _ in range(n)]
+        bgs_ = [np.empty((rows, cols, 1 if a == capi.ASBL else ch), np.uint8) if want_bg else None for a in self.algos]
+        pf = (C.c_void_p * n)(*[f.ctypes.data for f in fgs])
+        pb = (C.c_void_p * n)(*[(b.ctypes.data if b is not None else None) for b in bgs_])
+        flags = (C.c_uint32 * n)()
+        capi.check(capi.lib().bgs_group_process(self._h, frame.ctypes.data_as(C.c_void_p), rows, cols, ch, frame.strides[0], pf, None, pb, None, flags))
+        out = []
+        for i in range(n):
+            f = flags[i]
+            b = bgs_[i]
+            if b is not None and b.shape[2] == 1:
+                b = b[:, :, 0]
+            out.append((fgs[i] if f & capi.FG_VALID else None, b if (b is not None and f & capi.BG_VALID) else None))
+        return out
+
+    def process_batch_device(self, frames, fgs=None, bgs_=None, hip_stream=None):
+        """bgs_group_process_batch_device: frames [n_streams][rows][cols][ch] (torch CUDA tensor), fgs / bgs_: lists of tensors or None
+        per class.  Asynchronous on hip_stream (default: torch's current stream).  Returns the per-class out_flags."""
+        import torch
+        if hip_stream is None:
+            hip_stream = torch.cuda.current_stream().cuda_stream
+        n = len(self.algos)
+        pf = (C.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in (fgs or [None] * n)])
+        pb = (C.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in (bgs_ or [None] * n)])
+        flags = (C.c_uint32 * n)()
+        capi.check(capi.lib().bgs_group_process_batch_device(self._h, C.c_void_p(frames.data_ptr()), pf, pb, C.c_void_p(hip_stream), flags))
+        return list(flags)
+
+    def get_state(self, index, plane, shape, dtype, stream=0):
+        out = np.empty(shape, dtype)
+        n = capi.lib().bgs_group_get_state(self._h, index, stream, plane.encode(), out.ctypes.data_as(C.c_void_p), out.nbytes)
+        capi.check(n)
+        assert n == out.nbytes, (n, out.nbytes)
+        return out
+
+    def frames_seen(self):
+        return capi.lib().bgs_group_frames_seen(self._h)
+
+    def enable_kernel_timing(self, on=True):
+        capi.check(capi.lib().bgs_group_enable_kernel_timing(self._h, 1 if on else 0))
+
+    def kernel_timing(self):
+        ms, n = C.c_double(0), C.c_int64(0)
+        capi.check(capi.lib().bgs_group_kernel_timing(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
