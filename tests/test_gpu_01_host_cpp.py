@@ -82,6 +82,7 @@ def test_demo_masks_equal_oracle_for_every_class(demo, tmp_path, golden_frames):
     r = run_demo(demo, str(tmp_path), frames)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("MixtureOfGaussianV2BGS\ttime(sec):") == len(frames)  # tic/toc line format of FrameProcessor.cpp:493
+    assert "FrameProcessor: 6 byte-stream classes share one launch per frame" in r.stdout  # FD, SFD, WMM, WMV, ABL, SigmaDelta as one bgs_group
     n, rows, cols = frames.shape[:3]
     for c in CLASSES:
         got = np.fromfile(str(tmp_path / ("out.%s.raw" % c)), np.uint8).reshape(n, rows, cols)
@@ -97,6 +98,13 @@ def test_demo_masks_equal_oracle_for_every_class(demo, tmp_path, golden_frames):
                 assert (got[t] == 7).all(), (c, t)  # output left untouched (still empty) -> demo writes the 0x07 marker
             else:
                 assert np.array_equal(got[t], fg), (c, t)
+    # the same run with every class on its own engine (BGS_HOST_NO_GROUP=1): identical files
+    raw = {c: (tmp_path / ("out.%s.raw" % c)).read_bytes() for c in CLASSES}
+    r2 = subprocess.run([demo, str(tmp_path / "frames.raw"), str(rows), str(cols), str(n), str(tmp_path / "out")], cwd=str(tmp_path), capture_output=True, text=True,
+                        env=dict(os.environ, BGS_HOST_NO_GROUP="1"))
+    assert r2.returncode == 0 and "share one launch" not in r2.stdout
+    for c in CLASSES:
+        assert (tmp_path / ("out.%s.raw" % c)).read_bytes() == raw[c], c
 
 
 @pytest.mark.gpu

@@ -318,11 +318,10 @@ def configs_block(device=0, S=8, steps=40, cpu=True):
     wmv.set_option(capi.OPT_BORROW_FRAMES, 1)  # the caller's previous frames ARE the history: the algorithmic 10 B/px (the default copies each frame into a private ring)
     fg1 = torch.empty((S, rows, cols), dtype=torch.uint8, device=dev)
     fg2 = torch.empty((S, rows, cols), dtype=torch.uint8, device=dev)
-    bg2 = torch.empty((S, rows, cols, 3), dtype=torch.uint8, device=dev)
 
-    def step23(t):
+    def step23(t):  # (the background image of ABL IS its uint8 state - SURVEY.md 8a a5 counts it once; no separate copy is asked for)
         wmv.process_batch_device(pool[t % T], fg1, None, None)
-        abl.process_batch_device(pool[t % T], fg2, bg2, None)
+        abl.process_batch_device(pool[t % T], fg2, None, None)
     for t in range(10):
         step23(t)
     torch.cuda.synchronize()
@@ -343,7 +342,28 @@ def configs_block(device=0, S=8, steps=40, cpu=True):
         c2["wmv"]["cpu_baseline"] = _cpu_leg(capi.WMV, sample, 3, "WeightedMovingVarianceBGS, 1 thread")
         c2["abl"]["cpu_baseline"] = _cpu_leg(capi.ABL, sample, 3, "AdaptiveBackgroundLearning, 1 thread")
     wmv.close(), abl.close()
-    del pool, fg1, fg2, bg2
+    # the same two classes as ONE fused launch (bgs_group, kernel_fanout.h): one read of the frame and of the shared history
+    from tracking_amd.engine import Group
+    grp = Group([capi.WMV, capi.ABL], device=device, n_streams=S)
+    grp.set_geometry(rows, cols, 3)
+    grp.set_option(capi.OPT_BORROW_FRAMES, 1)
+    for t in range(10):
+        grp.process_batch_device(pool[t % T], [fg1, fg2], None)
+    torch.cuda.synchronize()
+    grp.enable_kernel_timing(True)
+    t0 = time.perf_counter()
+    for t in range(steps):
+        grp.process_batch_device(pool[(10 + t) % T], [fg1, fg2], None)
+    torch.cuda.synchronize()
+    wall_g = (time.perf_counter() - t0) / steps * 1e3
+    ms_g, _ = grp.kernel_timing()
+    # r 3 x 3 (frame, t-1, t-2) + 3 (ABL background) ; w 3 (ABL background) + 1 + 1 (masks) = 17 B/pixel instead of 10 + 10
+    c2["fused_group"] = dict(_leg(ms_g, px, 17), kernel="fan_kernel", ms_per_step_wall=round(wall_g, 4), frames_4k_per_s=round(S / (wall_g * 1e-3), 1),
+                             speedup_vs_both_kernels=round((ms_w + ms_a) / ms_g, 3) if ms_g > 0 else None,
+                             note="bgs_group of the two classes (kernel_fanout.h): ONE launch per step over one read of the frame and of the shared history - "
+                                  "17 B/pixel moved (3 frames + ABL state in and out + 2 masks) instead of 10 + 10; outputs bit-identical to the two engines")
+    grp.close()
+    del pool, fg1, fg2
     out["configs2_wmv_abl_4k"] = c2
     # ---- configs[3]: SuBSENSE (LBSP descriptor path) at 1920x1080: whole frame step, young and aged model; lbsp_kernel alone
     rows, cols, T = 1080, 1920, 8

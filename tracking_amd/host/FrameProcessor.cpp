@@ -1,6 +1,7 @@
 // FrameProcessor.cpp — see FrameProcessor.h.  Statement order follows FrameProcessor.cpp of the reference.
 #include "FrameProcessor.h"
 
+#include <cstdlib>
 #include <iomanip>
 
 namespace bgs_hip {
@@ -47,6 +48,40 @@ void FrameProcessor::init() {  // FrameProcessor.cpp:35-155
   if (enableSuBSENSEBGS) ssbgs = new SuBSENSEBGS;
   if (enableLOBSTERBGS) lobgs = new LOBSTERBGS;
   if (enableAdaptiveSelectiveBackgroundLearning) adaptiveSelectiveBackgroundLearning = new AdaptiveSelectiveBackgroundLearning;
+  // Every enabled class gets the same pre-processed frame (:169-340).  The byte-stream classes among them run as ONE fused launch
+  // over one upload and one read of that frame (bgs_group) when at least two are enabled; the reference's call shape - one
+  // process(name, bgs, img_prep, img_xxx) per class, in its order - stays, each call then just delivers its class's share.
+  // BGS_HOST_NO_GROUP=1 keeps every class on its own engine (A/B).
+  HipBGSBase* cand[] = {frameDifference, staticFrameDifference, weightedMovingMean, weightedMovingVariance, adaptiveBackgroundLearning, sdbgs};
+  for (HipBGSBase* c : cand)
+    if (c) grouped_.push_back(c);
+  const char* no_group = std::getenv("BGS_HOST_NO_GROUP");
+  if (grouped_.size() < 2 || (no_group && no_group[0] == '1')) {
+    grouped_.clear();
+  } else {
+    std::vector<bgs_algo> algos;
+    for (HipBGSBase* c : grouped_) algos.push_back(c->algo());
+    int rc = bgs_group_create(algos.data(), nullptr, (int)algos.size(), 0, 1, &group_);
+    if (rc) throw Exception(rc, std::string("FrameProcessor: ") + bgs_last_error());
+    for (size_t i = 0; i < grouped_.size(); ++i) grouped_[i]->attachGroup(group_, (int)i);
+    std::cout << "FrameProcessor: " << grouped_.size() << " byte-stream classes share one launch per frame" << std::endl;
+  }
+}
+
+void FrameProcessor::runGroup(const Image& img_input) {
+  if (!group_ || img_input.empty()) return;
+  const size_t n = grouped_.size();
+  std::vector<uint8_t*> fg(n), bg(n);
+  std::vector<size_t> fgs(n), bgs(n);
+  std::vector<uint32_t> flags(n, 0);
+  for (size_t i = 0; i < n; ++i) {
+    grouped_[i]->groupPrepare(img_input);
+    grouped_[i]->groupBuffers(&fg[i], &fgs[i], &bg[i], &bgs[i]);
+  }
+  int rc = bgs_group_process(group_, img_input.data, img_input.rows, img_input.cols, img_input.channels(), img_input.step, fg.data(), fgs.data(), bg.data(), bgs.data(),
+                             flags.data());
+  if (rc) throw Exception(rc, std::string("FrameProcessor: ") + bgs_last_error());
+  for (size_t i = 0; i < n; ++i) grouped_[i]->groupDone(flags[i]);
 }
 
 void FrameProcessor::process(std::string name, IBGS* bgs, const Image& img_input, Image& img_bgs) {  // :157-167
@@ -60,6 +95,7 @@ void FrameProcessor::process(const Image& img_input) {  // :169-340
   frameNumber++;
   if (enablePreProcessor) preProcessor->process(img_input, img_prep);  // :173-174
   // with enablePreProcessor = 0 img_prep stays empty and every class returns at `if(img_input.empty()) return;`
+  runGroup(img_prep);
   if (enableFrameDifferenceBGS) process("FrameDifferenceBGS", frameDifference, img_prep, img_framediff);
   if (enableStaticFrameDifferenceBGS) process("StaticFrameDifferenceBGS", staticFrameDifference, img_prep, img_staticfdiff);
   if (enableWeightedMovingMeanBGS) process("WeightedMovingMeanBGS", weightedMovingMean, img_prep, img_wmovmean);
@@ -100,6 +136,8 @@ void FrameProcessor::finish() {  // :342-482 (reverse order of init)
   delete staticFrameDifference, staticFrameDifference = nullptr;
   delete frameDifference, frameDifference = nullptr;
   delete preProcessor, preProcessor = nullptr;  // :480-481
+  if (group_) bgs_group_destroy(group_), group_ = nullptr;
+  grouped_.clear();
 }
 
 void FrameProcessor::tic(std::string value) {  // :484-488

@@ -38,6 +38,7 @@ class FrameProcessor : public IFrameProcessor {
   Image img_prep, img_framediff, img_staticfdiff, img_wmovmean, img_movvar, img_mog1, img_mog2, img_bkgl_fgmask, img_asbl;
   Image img_gmg, img_adpmed, img_grigmm, img_zivgmm, img_tmpmean, img_wrenga, img_sdbgs, img_ssbgs, img_lobgs;  // FrameProcessor.h:120-236
   double lastDuration() const { return duration; }
+  int groupedClasses() const { return (int)grouped_.size(); }  // how many classes share the fused launch (0: none)
 
  private:
   bool firstTime;
@@ -83,6 +84,11 @@ class FrameProcessor : public IFrameProcessor {
   bool enableLOBSTERBGS;
   AdaptiveSelectiveBackgroundLearning* adaptiveSelectiveBackgroundLearning;  // not in the reference's FrameProcessor (Demo.cpp / USTC_BGS type 7 only)
   bool enableAdaptiveSelectiveBackgroundLearning;
+
+  // the enabled byte-stream classes share ONE launch per frame (bgs_group) when there are at least two of them
+  bgs_group* group_ = nullptr;
+  std::vector<HipBGSBase*> grouped_;
+  void runGroup(const Image& img_input);
 
   void process(std::string name, IBGS* bgs, const Image& img_input, Image& img_bgs);
   void tic(std::string value);

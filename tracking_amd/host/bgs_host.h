@@ -168,6 +168,12 @@ class HipBGSBase : public IBGS {
   }
   void process(const Image& img_input, Image& img_output, Image& img_bgmodel) override {
     if (img_input.empty()) return;  // first line of every reference process()
+    if (group_) {  // this frame already went through the group's one fused launch (FrameProcessor::process): hand the results over
+      if (!group_ready_) throw Exception(BGS_ERR_STATE, std::string(name_) + ": grouped with other classes - FrameProcessor::process runs the group first");
+      group_ready_ = false;
+      deliver(group_flags_, img_output, img_bgmodel);
+      return;
+    }
     loadConfig();
     if (firstTime) saveConfig();
     if (!engine_) {
@@ -184,13 +190,24 @@ class HipBGSBase : public IBGS {
     int rc = bgs_process(engine_, 0, img_input.data, img_input.rows, img_input.cols, img_input.channels(), img_input.step, fg_.data, fg_.step, bg_.data,
                          bg_.step, &flags);
     if (rc) throw Exception(rc, std::string(name_) + ": " + bgs_last_error());
-    if (flags & BGS_FG_VALID) fg_.copyTo(img_output);  // img_foreground.copyTo(img_output)
-    if (flags & BGS_BG_VALID)
-      bg_.copyTo(img_bgmodel);  // img_background.copyTo(img_bgmodel)
-    else if (clears_bg_)
-      img_bgmodel = Image();    // MixtureOfGaussianV1BGS.cpp:68: copyTo of an empty Mat releases the destination
-    firstTime = false;
+    deliver(flags, img_output, img_bgmodel);
   }
+  // ---- several classes on one frame (bgs_group, include/bgs_hip.h): FrameProcessor attaches the byte-stream classes it enables to
+  // one group; per frame it calls groupPrepare() on each (the per-frame XML reload + parameter hand-over every process() starts
+  // with), runs the group's single launch into the buffers groupBuffers() names, and the class's own process() call then only
+  // delivers what that launch produced - same outputs, same conventions, one read of the frame.
+  bgs_algo algo() const { return algo_; }
+  void attachGroup(bgs_group* g, int index) { group_ = g, group_index_ = index; }
+  void groupPrepare(const Image& img_input) {
+    loadConfig();
+    if (firstTime) saveConfig();
+    int rc = bgs_group_set_params(group_, group_index_, &params_);
+    if (rc) throw Exception(rc, std::string(name_) + ": " + bgs_last_error());
+    fg_.create(img_input.rows, img_input.cols, 1);
+    bg_.create(img_input.rows, img_input.cols, img_input.channels());
+  }
+  void groupBuffers(uint8_t** fg, size_t* fg_step, uint8_t** bg, size_t* bg_step) { *fg = fg_.data, *fg_step = fg_.step, *bg = bg_.data, *bg_step = bg_.step; }
+  void groupDone(uint32_t flags) { group_flags_ = flags, group_ready_ = true; }
   // which HIP device the lazily created engine uses (default 0); the reference has no such notion
   void setDevice(int d) { device_ = d; }
   // N2 blob hand-off: connected components of the mask the last process() call produced, found on the device copy of that
@@ -229,6 +246,18 @@ class HipBGSBase : public IBGS {
   int device_ = 0;
   bgs_engine* engine_ = nullptr;
   Image fg_, bg_;
+  bgs_group* group_ = nullptr;  // not owned
+  int group_index_ = -1;
+  bool group_ready_ = false;
+  uint32_t group_flags_ = 0;
+  void deliver(uint32_t flags, Image& img_output, Image& img_bgmodel) {
+    if (flags & BGS_FG_VALID) fg_.copyTo(img_output);  // img_foreground.copyTo(img_output)
+    if (flags & BGS_BG_VALID)
+      bg_.copyTo(img_bgmodel);  // img_background.copyTo(img_bgmodel)
+    else if (clears_bg_)
+      img_bgmodel = Image();    // MixtureOfGaussianV1BGS.cpp:68: copyTo of an empty Mat releases the destination
+    firstTime = false;
+  }
 };
 
 #define BGS_HIP_BANNER_DTOR(Class) \
