@@ -74,8 +74,8 @@ int ss_allocate(bgs_engine* e) {
   // records: the first batch of kSsBatch samples sample-major, the rest pixel-major in whole double batches (kernel_subsense.h: ss_rec, phase A)
   d->pixelMajor = 1, d->nSpad = bgs::kSsBatch + ((int)std::max<size_t>(nS, bgs::kSsBatch) - bgs::kSsBatch + 2 * bgs::kSsBatch - 1) / (2 * bgs::kSsBatch) * (2 * bgs::kSsBatch);
   DMALLOC(d->samples, P * (size_t)d->nSpad * (C == 3 ? 16 : 4));
-  DMALLOC(d->lastColor, P * C);
-  DMALLOC(d->lastDesc, P * C * 2);
+  DMALLOC(d->lastColor, P * C + 8);      // + 8: ss_refresh_one reads a pixel's 3 bytes / 3 words with one 4- / 8-byte load
+  DMALLOC(d->lastDesc, P * C * 2 + 8);
   DMALLOC(d->req, P * 2 * 2);
   DMALLOC(d->lut, (size_t)e->S * 256);
   DMALLOC(d->sc, (size_t)e->S * sizeof(bgs::SsScalars));
@@ -130,6 +130,20 @@ void ss_initial_lut(const bgs_params& p, int channels, uint8_t lut[256]) {
   }
 }
 
+// refreshModel (kernel_subsense.h): the full refresh of SuBSENSE's record layout takes the 16 pixels x 16 columns form
+int ss_launch_refresh(bgs_engine* e, const bgs::SsArgs& a, size_t N, int count, int mode, hipStream_t s) {
+  const bool fast = mode == 0 && a.pixelMajor && a.nS > bgs::kSsBatch;
+  const dim3 grid(fast ? (unsigned)((N + 15) / 16) : blocks_for(N), 1, count), block(bgs::kBlock);
+  if (e->ch == 3) {
+    if (fast) hipLaunchKernelGGL((bgs::ss_refresh_kernel<3, true>), grid, block, 0, s, a, mode);
+    else hipLaunchKernelGGL((bgs::ss_refresh_kernel<3, false>), grid, block, 0, s, a, mode);
+  } else {
+    if (fast) hipLaunchKernelGGL((bgs::ss_refresh_kernel<1, true>), grid, block, 0, s, a, mode);
+    else hipLaunchKernelGGL((bgs::ss_refresh_kernel<1, false>), grid, block, 0, s, a, mode);
+  }
+  return BGS_OK;
+}
+
 int ss_init_streams(bgs_engine* e, int first, int count, const uint8_t* d_frames, hipStream_t s) {
   SsDevice* d = e->ss;
   const size_t N = e->n, off = N * first, npix = N * count, C = (size_t)e->ch;
@@ -170,7 +184,7 @@ int ss_init_streams(bgs_engine* e, int first, int count, const uint8_t* d_frames
   ss_fill_args(e, a, first, 0, 0);
   a.frame = d_frames;
   SS_LAUNCH(ss_init_lastcolor_kernel, dim3(blocks_for(N), 1, count), dim3(bgs::kBlock), s, a);
-  SS_LAUNCH(ss_refresh_kernel, dim3(blocks_for(N), 1, count), dim3(bgs::kBlock), s, a, 0);  // refreshModel(1.0f) (:246)
+  ss_launch_refresh(e, a, N, count, 0, s);  // refreshModel(1.0f) (:246)
   HIP_TRY(hipGetLastError());
   return BGS_OK;
 }
@@ -266,7 +280,7 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
   }
   hipLaunchKernelGGL(bgs::ss_frame_level_kernel, dim3(count), dim3(256), 0, s, a);
   if (overlap) HIP_TRY(hipStreamWaitEvent(s, d->evB, 0));  // the refresh below and the next frame need phase B's writes
-  SS_LAUNCH(ss_refresh_kernel, dim3(blocks_for(N), 1, count), block, s, a, 1);  // refreshModel(0.1f) if asked (:680)
+  ss_launch_refresh(e, a, N, count, 1, s);  // refreshModel(0.1f) if asked (:680)
   if (d_bg) SS_LAUNCH(ss_background_kernel, dim3(blocks_for(N * e->ch), 1, count), block, s, a);
   HIP_TRY(hipGetLastError());
   for (int i = first; i < first + count; ++i) d->pp[i] = (uint8_t)(cur ^ 1);
@@ -361,8 +375,8 @@ int lob_allocate(bgs_engine* e) {
   const size_t N = e->n, P = N * e->S, nS = (size_t)p.subsense_n_samples, C = (size_t)e->ch;
   d->pixelMajor = 0, d->nSpad = (int)nS;  // LOBSTER: sample-major (kernel_subsense.h)
   DMALLOC(d->samples, P * nS * (C == 3 ? 16 : 4));
-  DMALLOC(d->lastColor, P * C);
-  DMALLOC(d->lastDesc, P * C * 2);
+  DMALLOC(d->lastColor, P * C + 8);      // + 8: ss_refresh_one reads a pixel's 3 bytes / 3 words with one 4- / 8-byte load
+  DMALLOC(d->lastDesc, P * C * 2 + 8);
   DMALLOC(d->curColor, P * C);
   DMALLOC(d->curDesc, P * C * 2);
   DMALLOC(d->req, P * 2 * 2);
@@ -413,7 +427,7 @@ int lob_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, ui
     lob_fill_args(e, a0, first, 0);
     a0.frame = d_frames;
     SS_LAUNCH(ss_init_lastcolor_kernel, dim3(blocks_for(N), 1, count), block, s, a0);
-    SS_LAUNCH(ss_refresh_kernel, dim3(blocks_for(N), 1, count), block, s, a0, 0);  // refreshModel(1.0f), :120
+    ss_launch_refresh(e, a0, N, count, 0, s);  // refreshModel(1.0f), :120
   }
   bgs::SsArgs a{};
   lob_fill_args(e, a, first, (unsigned)(t + 1));

@@ -734,42 +734,86 @@ __global__ __launch_bounds__(kBlock) void ss_phase_b_kernel(const SsArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------------- refreshModel :249-291
-// mode 0: unconditional full refresh (initialisation, frac = 1); mode 1: 10 % refresh if the frame-level block asked for it
-template <int C>
-__global__ __launch_bounds__(kBlock) void ss_refresh_kernel(const SsArgs a, int mode) {
-  const int stream = a.first + blockIdx.z;
-  const size_t N = (size_t)a.rows * a.cols, sN = (size_t)stream * N;
-  if (mode == 1 && !a.sc[stream].doRefresh) return;
-  const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (p >= N) return;
-  if (mode == 1) a.T[sN + p] = 1.0f;  // m_oUpdateRateFrame = cv::Scalar(1.0f), every pixel (:682)
-  const int x = (int)(p % a.cols), y = (int)(p / a.cols);
-  if (!(x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2)) return;
-  if (a.lastFG[sN + p]) return;  // bForceFGUpdate = false
-  const int nRefresh = mode == 1 ? (int)(0.1f * a.nS) : a.nS;
-  const uint32_t fr = a.frameIndex;
-  const int start = mode == 1 ? (int)(ss_rand(fr, 0xFFFFFFFFu, 0) % (uint32_t)a.nS) : 0;
-  for (int m = 0; m < nRefresh; ++m) {
-    int r = 1 + (int)(ss_rand(fr, (uint32_t)p, 16u + (uint32_t)m) % 512u), xs, ys = 0;  // RandUtils.h:28-48
+// getRandSamplePosition's scan of the 7x7 pattern (RandUtils.h:28-48) is a pure function of r = 1 + rand % 512: tabulated at
+// compile time, entry r - 1 = (x_sample << 4) | y_sample.
+struct SsPosTab {
+  uint8_t v[512];
+};
+constexpr SsPosTab ss_make_pos_tab() {
+  constexpr int P[7][7] = {{2, 4, 6, 7, 6, 4, 2},     {4, 8, 12, 14, 12, 8, 4},  {6, 12, 21, 25, 21, 12, 6}, {7, 14, 25, 28, 25, 14, 7},
+                           {6, 12, 21, 25, 21, 12, 6}, {4, 8, 12, 14, 12, 8, 4}, {2, 4, 6, 7, 6, 4, 2}};  // = kSsPattern
+  SsPosTab t{};
+  for (int e = 0; e < 512; ++e) {
+    int r = 1 + e, xs = 0, ys = 0;
     bool stop = false;
     for (xs = 0; xs < 7 && !stop; ++xs)
       for (ys = 0; ys < 7; ++ys) {
-        r -= kSsPattern[ys][xs];
+        r -= P[ys][xs];
         if (r <= 0) {
           stop = true;
           break;
         }
       }
     if (stop) --xs;  // the goto leaves x_sample un-incremented
-    xs = min(max(xs + x - 3, 2), a.cols - 3), ys = min(max(ys + y - 3, 2), a.rows - 3);
-    const size_t j = sN + (size_t)ys * a.cols + xs;
-    if (!a.lastFG[j]) {
-      int col[C];
-      unsigned dsc[C];
+    t.v[e] = (uint8_t)((xs << 4) | ys);
+  }
+  return t;
+}
+__device__ __constant__ const SsPosTab kSsPosTab = ss_make_pos_tab();
+
+// one refreshed sample: slot (start + m) % nS of pixel p takes the colour / descriptor of a random 7x7 neighbour (if that one is background)
+template <int C>
+__device__ __forceinline__ void ss_refresh_one(const SsArgs& a, int stream, size_t N, size_t sN, uint32_t p, int x, int y, int m, int start) {
+  const int t = kSsPosTab.v[ss_rand(a.frameIndex, p, 16u + (uint32_t)m) % 512u];
+  const int xs = min(max((t >> 4) + x - 3, 2), a.cols - 3), ys = min(max((t & 15) + y - 3, 2), a.rows - 3);
+  const size_t j = sN + (size_t)ys * a.cols + xs;
+  if (!a.lastFG[j]) {
+    int col[C];
+    unsigned dsc[C];
+    if constexpr (C == 3) {
+      // the neighbour's 3 colour bytes and 3 descriptor words as ONE 4-byte and ONE 8-byte load (global loads need no alignment on
+      // this hardware; the engine allocates 8 spare bytes behind both maps): 3 instead of 7 scattered loads per sample
+      typedef uint32_t __attribute__((aligned(1))) u32u;
+      typedef uint64_t __attribute__((aligned(2))) u64u;
+      const uint32_t cw = *reinterpret_cast<const u32u*>(a.lastColor + j * 3);
+      const uint64_t dw = *reinterpret_cast<const u64u*>(a.lastDesc + j * 3);
+      col[0] = (int)(cw & 0xffu), col[1] = (int)((cw >> 8) & 0xffu), col[2] = (int)((cw >> 16) & 0xffu);
+      dsc[0] = (unsigned)(dw & 0xffffu), dsc[1] = (unsigned)((dw >> 16) & 0xffffu), dsc[2] = (unsigned)((dw >> 32) & 0xffffu);
+    } else {
 #pragma unroll
       for (int c = 0; c < C; ++c) col[c] = a.lastColor[j * C + c], dsc[c] = a.lastDesc[j * C + c];
-      SsSample<C>::make(col, dsc).store(a.samples, ss_rec(a, stream, N, p, (start + m) % a.nS));
     }
+    int slot = start + m;
+    slot = slot >= a.nS ? slot - a.nS : slot;
+    SsSample<C>::make(col, dsc).store(a.samples, ss_rec(a, stream, N, p, slot));
+  }
+}
+
+// mode 0: unconditional full refresh (initialisation, frac = 1); mode 1: 10 % refresh if the frame-level block asked for it.
+// Full refresh of SuBSENSE's layout (FAST): a workgroup owns 16 pixels, lane (pixel q, column s) of the 16 x 16 writes plane s of the
+// sample-major first batch (s < 4) and the pixel-major records 4 + s, 4 + s + 16, ...: every store instruction of a wave is four
+// runs of 256 contiguous bytes (round 2: one lane walked a pixel's 50 samples serially, each store 768 bytes from its neighbour's,
+// each sample through a <= 49-step scan of the pattern: 26 ms for 8 x 1080p, 0.06 of what the 13 GB it writes need).
+// Otherwise (10 % refresh: 5 samples; LOBSTER's sample-major planes): one lane per pixel.
+template <int C, bool FAST>
+__global__ __launch_bounds__(kBlock) void ss_refresh_kernel(const SsArgs a, int mode) {
+  const int stream = a.first + blockIdx.z;
+  const size_t N = (size_t)a.rows * a.cols, sN = (size_t)stream * N;
+  if (mode == 1 && !a.sc[stream].doRefresh) return;
+  const uint32_t p = FAST ? blockIdx.x * 16u + (threadIdx.x >> 4) : blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+  if (p >= N) return;
+  if (mode == 1) a.T[sN + p] = 1.0f;  // m_oUpdateRateFrame = cv::Scalar(1.0f), every pixel (:682)
+  const int x = (int)(p % (uint32_t)a.cols), y = (int)(p / (uint32_t)a.cols);
+  if (!(x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2)) return;
+  if (a.lastFG[sN + p]) return;  // bForceFGUpdate = false
+  if constexpr (FAST) {
+    const int s = threadIdx.x & 15;
+    if (s < kSsBatch) ss_refresh_one<C>(a, stream, N, sN, p, x, y, s, 0);
+    for (int m = kSsBatch + s; m < a.nS; m += 16) ss_refresh_one<C>(a, stream, N, sN, p, x, y, m, 0);
+  } else {
+    const int nRefresh = mode == 1 ? (int)(0.1f * a.nS) : a.nS;
+    const int start = mode == 1 ? (int)(ss_rand(a.frameIndex, 0xFFFFFFFFu, 0) % (uint32_t)a.nS) : 0;
+    for (int m = 0; m < nRefresh; ++m) ss_refresh_one<C>(a, stream, N, sN, p, x, y, m, start);
   }
 }
 
