@@ -92,6 +92,36 @@ def cpu_baseline(pool, kind, budget_s=16.0):
     }
 
 
+def host_leg(local, pool, frames_n=120):
+    """The drop-in call today's IBGS::process callers make - bgs_process, host buffers, one 1080p stream, synchronous - through the
+    ctypes binding: staged (default: every image goes through the engine's pinned buffers) and with BGS_OPT_HOST_REGISTER (the caller's
+    frame and mask buffers stay allocated, as OpenCV's capture loop keeps them: page-locked once, DMA'd in place).  PCIe-inclusive,
+    never `value`."""
+    from tracking_amd import Engine, capi
+    clip = pool[:, 0].cpu().numpy()  # [period][H][W][3]
+    period = clip.shape[0]
+    out = {"note": "bgs_process (host buffers, 1 x 1920x1080x3 stream, mask only, synchronous) through the ctypes binding; PCIe-inclusive; never `value`"}
+    for label, reg in (("staged", 0), ("registered_buffers", 3)):
+        e = Engine(capi.MOG2, device=local)
+        e.set_option(capi.OPT_HOST_REGISTER, reg)
+        frame = np.empty_like(clip[0])  # ONE frame buffer, refilled per frame: what cvQueryFrame's image is
+        fg = np.empty((ROWS, COLS), np.uint8)
+        for t in range(20):
+            frame[...] = clip[t % period]
+            e.process_into(frame, fg)
+        fill = 0.0
+        t0 = time.perf_counter()
+        for t in range(frames_n):
+            f0 = time.perf_counter()
+            frame[...] = clip[t % period]  # stands for the decoder writing the next frame; not part of the call
+            fill += time.perf_counter() - f0
+            e.process_into(frame, fg)
+        dt = time.perf_counter() - t0 - fill
+        out[label] = {"ms_per_frame": round(dt / frames_n * 1e3, 4), "frames_per_s": round(frames_n / dt, 1), "mpixels_per_s": round(frames_n * ROWS * COLS / dt / 1e6, 1)}
+        e.close()
+    return out
+
+
 def surv_leg(local, S, fg, steps=200, sparse=1):
     """Same engine on S_surv (static background + sensor noise + moving boxes, SURVEY.md §8d headline-streams input): the
     kernel skips model planes no pixel of a wave uses or changed, so throughput rises with scene sparsity.  Reported beside
@@ -374,6 +404,7 @@ def main():
                                 "waiting for the gather that last used the buffer, and the rank's own wall time per step; `ms_per_step` is the MAX over ranks"}
     live_modes = None
     single = None
+    host = None
     configs = None
     cpu = None
     surv = None
@@ -415,6 +446,8 @@ def main():
         e1.close()
         if args.input == "sat":
             surv = {"default": surv_leg(local, S, fg, sparse=3), "stores_only": surv_leg(local, S, fg, sparse=1)}
+        if world == 1:
+            host = host_leg(local, pool)
         if world == 1 and not args.no_configs:
             # BASELINE configs[2] (WMV + ABL at 3840x2160) and configs[3] (SuBSENSE / LBSP at 1080p) in the driver-timed line, never `value`
             from tools import bench_configs
@@ -491,6 +524,7 @@ def main():
             "placement_probe": probe,
             "rccl_selftest_gather_matches_kernel_output": selftest_ok,
             "single_stream": single,
+            "host_path": host,
             "s_surv": surv,
             "clip": clip,
             "configs": configs,

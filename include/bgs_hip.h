@@ -190,6 +190,13 @@ int bgs_set_params(bgs_engine* e, const bgs_params* params);
                                    cannot rule out); 3 (default) automatic, from what sampled workgroups count */
 #define BGS_OPT_CLIP_FUSE 7     /* 1 (default): bgs_process_clip_device runs 8 / 4 / 2 consecutive frames of a mixture model per launch with the
                                    model held in registers; 0: one launch per frame.  Identical results, only speed differs. */
+#define BGS_OPT_HOST_REGISTER 8 /* bgs_process (host buffers): bit 0 input frame, bit 1 mask, bit 2 background image.  A buffer passed in an
+                                   enabled role that comes back with the same address and size as in the previous call is page-locked once
+                                   (hipHostRegister) and from then on read / written by the DMA engine in place - no staging copy by the
+                                   CPU (OpenCV's capture loop hands IBGS::process the same frame buffer every frame, VideoCapture.cpp:158-218).
+                                   Contract: such a buffer stays allocated until a different one is passed in that role or the engine is
+                                   destroyed (the engine cannot see a buffer being freed and another mapped at the same address).
+                                   Default 0: every image is staged through the engine's own pinned buffers.  Rows must be contiguous. */
 int bgs_set_option(bgs_engine* e, int option, int64_t value);
 
 /* Fix rows x cols x channels up front and allocate the model (device path). */

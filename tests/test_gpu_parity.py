@@ -762,3 +762,33 @@ def test_engines_release_their_device_memory():
     torch.cuda.empty_cache()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < (8 << 20), "device memory shrank by %d bytes over three create/destroy cycles" % (free0 - free1)
+
+
+@pytest.mark.parametrize("name", ["MixtureOfGaussianV2BGS", "FrameDifferenceBGS", "AdaptiveBackgroundLearning"])
+def test_host_path_with_registered_caller_buffers(name, golden_frames):
+    """BGS_OPT_HOST_REGISTER: the caller keeps ONE frame buffer, ONE mask and ONE background image allocated (what OpenCV's capture loop
+    and a cv::Mat member are); from the second call on they are page-locked and read / written by the DMA engine in place.  Same
+    results as the staged path; switching buffers mid-run drops the registration and takes up the new one."""
+    algo = ALGOS[name]
+    eng, orc = Engine(algo), pyoracle.Oracle(algo)
+    eng.set_option(capi.OPT_HOST_REGISTER, 7)
+    H, W = golden_frames.shape[1:3]
+    bufs = [(np.empty((H, W, 3), np.uint8), np.full((H, W), 9, np.uint8), np.full((H, W, 3), 9, np.uint8)) for _ in range(2)]
+    for t, f in enumerate(golden_frames[:16]):
+        frame, fg, bg = bufs[0 if t < 9 else 1]  # second set of buffers from frame 9 on
+        frame[...] = f
+        fg[...] = 9
+        flags = eng.process_into(frame, fg, bg)
+        ofg, obg = orc.process(f)
+        assert bool(flags & capi.FG_VALID) == (ofg is not None) and bool(flags & capi.BG_VALID) == (obg is not None), (name, t)
+        if ofg is not None:
+            assert np.array_equal(fg, ofg), (name, t)
+        else:
+            assert (fg == 9).all(), (name, t)
+        if obg is not None:
+            assert np.array_equal(bg, obg), (name, t)
+    eng.set_option(capi.OPT_HOST_REGISTER, 0)  # back to staging: unregisters
+    fg2, _ = eng.process(golden_frames[16])
+    ofg, _ = orc.process(golden_frames[16])
+    assert np.array_equal(fg2, ofg)
+    eng.close()

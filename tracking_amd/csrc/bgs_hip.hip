@@ -115,6 +115,13 @@ struct bgs_engine {
   uint8_t *d_in = nullptr, *d_fg = nullptr, *d_bg = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t band_ev[8] = {nullptr};  // bgs_process: one event per output band
+  // bgs_process: caller buffers that came back unchanged call after call are page-locked once and DMA'd directly (host_pin)
+  struct HostPin {
+    const void* ptr = nullptr;   // what the previous call passed for this role
+    size_t bytes = 0;
+    bool pinned = false, refused = false;
+  } pin[3];                       // 0 input, 1 mask, 2 background
+  int host_register = 0;          // BGS_OPT_HOST_REGISTER: roles that may be page-locked in place (bit 0 input, 1 mask, 2 background); 0 = always stage
   bool ingest_on = false;             // bgs_set_ingest: bgs_process takes raw frames
   bgs_ingest ingest{};
   int raw_rows = 0, raw_cols = 0;     // geometry of the raw frames (fixed by the first one)
@@ -158,6 +165,10 @@ void free_all(bgs_engine* e) {
   if (e->stat_ev) (void)hipEventDestroy(e->stat_ev), e->stat_ev = nullptr;
   for (auto& ev : e->band_ev)
     if (ev) (void)hipEventDestroy(ev), ev = nullptr;
+  for (auto& hp : e->pin) {
+    if (hp.pinned) (void)hipHostUnregister(const_cast<void*>(hp.ptr));
+    hp = bgs_engine::HostPin();
+  }
 }
 
 int check_params(bgs_algo algo, const bgs_params& p) {
@@ -555,6 +566,34 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
   // launch - which may come on ANOTHER stream (device path) that nothing else orders against this one.
   HIP_TRY(hipStreamSynchronize(e->stream));
   return BGS_OK;
+}
+
+// OpenCV's capture loop hands IBGS::process the SAME frame buffer every frame (VideoCapture.cpp:158-218: cvQueryFrame's image,
+// wrapped by cv::Mat img_input(frame)), and a caller that keeps its mask / background images allocated does the same on the way
+// out.  A buffer that comes back with the same address and size as in the previous call is page-locked (hipHostRegister, once)
+// and from then on the DMA engine reads / writes it directly: no staging copy by the CPU.  A different buffer in that role drops
+// the registration; bgs_destroy drops them all.  Only contiguous images qualify (row step = row bytes).
+// OPT-IN per role (BGS_OPT_HOST_REGISTER): the engine cannot see a buffer being freed and another one mapped at the same address,
+// so the caller promises that a buffer it passes in an enabled role stays allocated until it passes a different one or destroys
+// the engine.
+bool host_pin(bgs_engine* e, int role, const void* ptr, size_t bytes) {
+  if (!((e->host_register >> role) & 1) || !ptr || !bytes) return false;
+  bgs_engine::HostPin& hp = e->pin[role];
+  if (hp.ptr == ptr && hp.bytes == bytes) {
+    if (hp.pinned) return true;
+    if (hp.refused) return false;
+    if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) return hp.pinned = true;
+    (void)hipGetLastError();  // not registrable (e.g. already registered by the caller, read-only mapping): keep staging
+    hp.refused = true;
+    return false;
+  }
+  if (hp.pinned) {
+    (void)hipStreamSynchronize(e->stream);
+    (void)hipHostUnregister(const_cast<void*>(hp.ptr));
+  }
+  hp = bgs_engine::HostPin();
+  hp.ptr = ptr, hp.bytes = bytes;  // a candidate: registered when it comes back
+  return false;
 }
 
 int ensure_staging(bgs_engine* e) {
@@ -1238,6 +1277,7 @@ int bgs_create(bgs_algo algo, const bgs_params* params, int hip_device, int n_st
   if (const char* env = getenv("BGS_PLACEMENT_PROBE")) e->probe_max = atoi(env);
   if (const char* env = getenv("BGS_CLIP_FUSE")) e->clip_fuse = atoi(env) != 0;
   if (const char* env = getenv("BGS_DEBUG_POISON")) e->poison = atoi(env) != 0;
+  if (const char* env = getenv("BGS_HOST_REGISTER")) e->host_register = atoi(env) & 7;
   *out = e;
   return BGS_OK;
 }
@@ -1300,6 +1340,12 @@ int bgs_set_option(bgs_engine* e, int option, int64_t value) {
     case 4: e->xcd_swizzle = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return BGS_OK;
     case 6: e->mog2_sparse = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 4); return BGS_OK;
     case 7: e->clip_fuse = value != 0; return BGS_OK;
+    case 8:
+      if (hipSetDevice(e->device) == hipSuccess && e->stream) (void)hipStreamSynchronize(e->stream);
+      for (int r = 0; r < 3; ++r)
+        if (!((value >> r) & 1) && e->pin[r].pinned) (void)hipHostUnregister(const_cast<void*>(e->pin[r].ptr)), e->pin[r] = bgs_engine::HostPin();
+      e->host_register = (int)(value & 7);
+      return BGS_OK;
     case 5:
       if (e->n) return fail(BGS_ERR_INVALID, "the placement probe runs when the geometry is set");
       e->probe_max = (int)value;
@@ -1376,15 +1422,19 @@ int bgs_process(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols
     // staging is pipelined: while the DMA engine moves band k, the CPU copies band k+1 of the caller's (pageable, possibly
     // strided) image into the pinned buffer.  Flip (rows reversed) and ROI (a window of the raw frame) cost nothing extra: they
     // only change which source row and column each staged row starts at.
-    const int bands = rows >= 64 ? 8 : 1;
-    for (int b = 0; b < bands; ++b) {
-      const int y0 = (int)((int64_t)rows * b / bands), y1 = (int)((int64_t)rows * (b + 1) / bands);
-      for (int y = y0; y < y1; ++y) {
-        size_t sy = (size_t)y, sx = 0;
-        if (ingest) sy = (size_t)(e->ingest.flip ? pl.rh - 1 - (y + pl.y0) : y + pl.y0), sx = (size_t)pl.x0 * channels;
-        std::memcpy(e->h_in + (size_t)y * rb, in + sy * in_step + sx, rb);
+    if (!ingest && in_step == rb && host_pin(e, 0, in, fb)) {
+      HIP_TRY(hipMemcpyAsync(dst, in, fb, hipMemcpyHostToDevice, e->stream));  // straight from the caller's page-locked frame buffer
+    } else {
+      const int bands = rows >= 64 ? 8 : 1;
+      for (int b = 0; b < bands; ++b) {
+        const int y0 = (int)((int64_t)rows * b / bands), y1 = (int)((int64_t)rows * (b + 1) / bands);
+        for (int y = y0; y < y1; ++y) {
+          size_t sy = (size_t)y, sx = 0;
+          if (ingest) sy = (size_t)(e->ingest.flip ? pl.rh - 1 - (y + pl.y0) : y + pl.y0), sx = (size_t)pl.x0 * channels;
+          std::memcpy(e->h_in + (size_t)y * rb, in + sy * in_step + sx, rb);
+        }
+        HIP_TRY(hipMemcpyAsync(dst + (size_t)y0 * rb, e->h_in + (size_t)y0 * rb, (size_t)(y1 - y0) * rb, hipMemcpyHostToDevice, e->stream));
       }
-      HIP_TRY(hipMemcpyAsync(dst + (size_t)y0 * rb, e->h_in + (size_t)y0 * rb, (size_t)(y1 - y0) * rb, hipMemcpyHostToDevice, e->stream));
     }
   }
   uint32_t flags = 0;
@@ -1398,7 +1448,19 @@ int bgs_process(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols
   const int bg_ch = e->algo == BGS_ASBL ? 1 : channels;
   // the way back is pipelined the same way when there is a background image to return (6 MB at 1080p): band k is copied out to
   // the caller's image while band k+1 is still on the bus; a mask alone (2 MB) is not worth the events
-  const bool out_fg = fg && (flags & BGS_FG_VALID), out_bg = bg && (flags & BGS_BG_VALID);
+  bool out_fg = fg && (flags & BGS_FG_VALID), out_bg = bg && (flags & BGS_BG_VALID);
+  // outputs the caller keeps allocated (same buffer as last call, contiguous rows) are written by the DMA engine directly
+  const bool fg_direct = out_fg && fg_step == (size_t)cols && host_pin(e, 1, fg, e->n);
+  const bool bg_direct = out_bg && bg_step == (size_t)cols * bg_ch && host_pin(e, 2, bg, e->n * bg_ch);
+  if (fg_direct) HIP_TRY(hipMemcpyAsync(fg, e->d_fg, e->n, hipMemcpyDeviceToHost, e->stream));
+  if (bg_direct) HIP_TRY(hipMemcpyAsync(bg, e->d_bg, e->n * bg_ch, hipMemcpyDeviceToHost, e->stream));
+  if (fg_direct) out_fg = false;
+  if (bg_direct) out_bg = false;
+  if (!out_fg && !out_bg) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (out_flags) *out_flags = flags;
+    return BGS_OK;
+  }
   const int obands = out_bg ? (rows >= 64 ? 8 : 1) : 1;
   for (int b = 0; b < obands; ++b) {
     const int y0 = (int)((int64_t)rows * b / obands), y1 = (int)((int64_t)rows * (b + 1) / obands);

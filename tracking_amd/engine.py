@@ -86,6 +86,16 @@ class Engine:
             bg = bg[:, :, 0]
         return (fg if f & capi.FG_VALID else None), (bg if (bg is not None and f & capi.BG_VALID) else None)
 
+    def process_into(self, frame, fg, bg=None, stream=0):
+        """bgs_process into caller-owned arrays (contiguous): what a caller that keeps its images allocated does; with
+        OPT_HOST_REGISTER the same buffers are page-locked once and DMA'd in place.  Returns the out_flags."""
+        rows, cols = frame.shape[:2]
+        ch = 1 if frame.ndim == 2 else frame.shape[2]
+        flags = C.c_uint32(0)
+        capi.check(capi.lib().bgs_process(self._h, stream, frame.ctypes.data_as(C.c_void_p), rows, cols, ch, frame.strides[0], fg.ctypes.data_as(C.c_void_p), fg.strides[0],
+                                          bg.ctypes.data_as(C.c_void_p) if bg is not None else None, bg.strides[0] if bg is not None else 0, C.byref(flags)))
+        return flags.value
+
     def process_mask_only_on_device(self, frame, stream=0):
         """bgs_process with fg = bg = NULL: the mask stays on the device (for last_mask_blobs).  Returns the out_flags."""
         rows, cols = frame.shape[:2]

@@ -179,6 +179,10 @@ class HipBGSBase : public IBGS {
     if (!engine_) {
       int rc = bgs_create(algo_, &params_, device_, 1, &engine_);
       if (rc) throw Exception(rc, std::string(name_) + ": " + bgs_last_error());
+      // fg_ / bg_ below are this object's own images: they live as long as the engine and keep their storage while the frame size
+      // stays, so the DMA engine may write them in place (bit 1 mask, bit 2 background).  The caller's input is staged: this class
+      // cannot know how long img_input's buffer lives.
+      (void)bgs_set_option(engine_, BGS_OPT_HOST_REGISTER, 6);
     } else {
       int rc = bgs_set_params(engine_, &params_);
       if (rc) throw Exception(rc, std::string(name_) + ": " + bgs_last_error());
