@@ -380,6 +380,9 @@ def main():
     i0 = SETTLE + args.warmup
     timed_ms = series[i0:i0 + args.steps]
     k_ms, k_n = (float(timed_ms.mean()), int(timed_ms.size)) if timed_ms.size else (0.0, 0)
+    # the library keeps at most 16384 per-launch timings: a very long run gets its kernel figures from a truncated slice (`value` is
+    # wall-clock and unaffected); say so instead of silently averaging fewer launches
+    timing_truncated = bool(timed_ms.size < args.steps)
     sus_ms = series[i0 + args.steps:]
     burst_ms = series[:20]
     if rank == 0 and args.series:
@@ -510,7 +513,7 @@ def main():
             "frames_per_s": round(mpix * 1e6 / (ROWS * COLS), 1),
             "mean_live_modes_stream0": live_modes,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": traffic, "traffic_source": traffic_source, "traffic_read_write": traffic_detail, "kernel": k_name, "kernel_avg_ms": round(k_ms, 4), "kernel_launches": k_n,
+                         "traffic": traffic, "traffic_source": traffic_source, "traffic_read_write": traffic_detail, "kernel": k_name, "kernel_avg_ms": round(k_ms, 4), "kernel_launches": k_n, "kernel_timing_truncated": timing_truncated,
                          "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_pixel": BYTES_PER_PIXEL + (3 if args.with_bg else 0),
                          "bytes_per_pixel_derivation": "r 3 frame + 2 meta + 20 weights + 20 summaries + 16 the one record the summaries cannot rule out; w 20 weights + 16 that record + 2 meta + 1 mask (+4 when its summary is rewritten: rare) (DESIGN.md 6.1)",
                          "frac_of_achievable_6290": round(achieved / 6290.0, 4),

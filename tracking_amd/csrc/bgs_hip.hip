@@ -17,6 +17,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <atomic>
 #include <vector>
 
 #include "kernel_gmg.h"
@@ -109,6 +110,10 @@ struct bgs_engine {
   float probe_ms[kProbeMax] = {0};  // what the probe measured (diagnostics)
   int probe_n = 0, probe_pick = -1;
   bool poison = false;             // BGS_DEBUG_POISON: every fresh device buffer is filled with 0xA5 (see dmalloc)
+  // BGS_MODEL_VMM_CHUNK_MB (experiment): the MOG2 model built from fixed-size physical chunks with the virtual memory API
+  std::vector<hipMemGenericAllocationHandle_t> vmm_handles;
+  void* vmm_base = nullptr;
+  size_t vmm_bytes = 0, vmm_chunk = 0;
 
   // host staging (bgs_process)
   uint8_t *h_in = nullptr, *h_fg = nullptr, *h_bg = nullptr;
@@ -139,6 +144,7 @@ struct bgs_engine {
 namespace {
 
 void ss_free(bgs_engine* e);  // engine_subsense.h
+void vmm_free(bgs_engine* e);  // below (placement experiment)
 
 void free_all(bgs_engine* e) {
   for (auto& r : e->ring)
@@ -149,6 +155,10 @@ void free_all(bgs_engine* e) {
   if (e->d_raw) (void)hipFree(e->d_raw), e->d_raw = nullptr;
   if (e->d_ingest_ws) (void)hipFree(e->d_ingest_ws), e->d_ingest_ws = nullptr;
   e->last_fg_stream = -1;
+  if (e->vmm_base) {  // the MOG2 model came from vmm_allocate
+    if (e->mog2_state == e->vmm_base) e->mog2_state = nullptr;
+    vmm_free(e);
+  }
   void* dev[] = {e->dp_state, e->gmg_colors, e->gmg_weights, e->gmg_nfeat, e->bgstate, e->bgstate2, e->mog1_state, e->mog2_state, e->d_in, e->d_fg, e->d_bg};
   for (void* d : dev)
     if (d) (void)hipFree(d);
@@ -427,8 +437,55 @@ int probe_allocate(bgs_engine* e, void** out, size_t bytes, double expect_ms, Ru
   return BGS_OK;
 }
 
+// Placement experiment: reserve one virtual range and back it with separately created physical chunks of `chunk` bytes each
+// (hipMemCreate / hipMemMap), instead of whatever one hipMalloc hands out.  Returns BGS_ERR_HIP if the API refuses.
+int vmm_allocate(bgs_engine* e, void** out, size_t bytes, size_t chunk) {
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = e->device;
+  size_t gran = 0;
+  HIP_TRY(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+  if (!gran) gran = 2u << 20;
+  chunk = (chunk + gran - 1) / gran * gran;
+  const size_t total = (bytes + chunk - 1) / chunk * chunk;
+  void* base = nullptr;
+  HIP_TRY(hipMemAddressReserve(&base, total, 0, nullptr, 0));
+  e->vmm_base = base, e->vmm_bytes = total, e->vmm_chunk = chunk;
+  for (size_t off = 0; off < total; off += chunk) {
+    hipMemGenericAllocationHandle_t h;
+    HIP_TRY(hipMemCreate(&h, chunk, &prop, 0));
+    e->vmm_handles.push_back(h);
+    HIP_TRY(hipMemMap((char*)base + off, chunk, 0, h, 0));
+  }
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  HIP_TRY(hipMemSetAccess(base, total, &acc, 1));
+  if (e->poison) HIP_TRY(hipMemsetAsync(base, 0xA5, total, e->stream));
+  *out = base;
+  return BGS_OK;
+}
+void vmm_free(bgs_engine* e) {
+  if (!e->vmm_base) return;
+  (void)hipMemUnmap(e->vmm_base, e->vmm_bytes);
+  for (auto& h : e->vmm_handles) (void)hipMemRelease(h);
+  (void)hipMemAddressFree(e->vmm_base, e->vmm_bytes);
+  e->vmm_handles.clear(), e->vmm_base = nullptr, e->vmm_bytes = 0;
+}
+
 int mog2_allocate(bgs_engine* e) {
   const size_t P = e->n * e->S, bytes = mog2_state_bytes(e);
+  if (const char* env = getenv("BGS_MODEL_VMM_CHUNK_MB")) {
+    const size_t mb = (size_t)atoll(env);
+    if (mb > 0) {
+      HIP_TRY(hipMalloc((void**)&e->d_stat, 3 * sizeof(unsigned)));
+      HIP_TRY(hipMemsetAsync(e->d_stat, 0, 3 * sizeof(unsigned), e->stream));
+      HIP_TRY(hipHostMalloc((void**)&e->h_stat, 3 * sizeof(unsigned), hipHostMallocDefault));
+      HIP_TRY(hipEventCreateWithFlags(&e->stat_ev, hipEventDisableTiming));
+      return vmm_allocate(e, (void**)&e->mog2_state, bytes, mb << 20);
+    }
+  }
   HIP_TRY(hipMalloc((void**)&e->d_stat, 3 * sizeof(unsigned)));
   HIP_TRY(hipMemsetAsync(e->d_stat, 0, 3 * sizeof(unsigned), e->stream));  // ordered: allocate() drains e->stream before it returns
   HIP_TRY(hipHostMalloc((void**)&e->h_stat, 3 * sizeof(unsigned), hipHostMallocDefault));
@@ -786,8 +843,14 @@ int process_run(bgs_engine* e, int first, int count, const uint8_t* d_frames, ui
           const dim3 block(bgs::kAblBlock);
 #define ABL_CASE(GV, CV, UV)                                                                                                               \
   if (G == GV && C == CV && (a.update != 0) == UV) {                                                                                       \
-    static int per_cu = 0;                                                                                                                 \
-    if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bgs::abl_kernel<GV, CV, UV>, bgs::kAblBlock, 0) != hipSuccess || per_cu < 1)) per_cu = 1; \
+    /* resident workgroups per CU of this instantiation: a property of the code object (the library is gfx950-only), cached per   \
+       process; atomic because engines may be driven from several host threads */                                                  \
+    static std::atomic<int> per_cu_cache{0};                                                                                               \
+    int per_cu = per_cu_cache.load(std::memory_order_relaxed);                                                                             \
+    if (!per_cu) {                                                                                                                         \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bgs::abl_kernel<GV, CV, UV>, bgs::kAblBlock, 0) != hipSuccess || per_cu < 1) per_cu = 1; \
+      per_cu_cache.store(per_cu, std::memory_order_relaxed);                                                                               \
+    }                                                                                                                                      \
     const dim3 grid((unsigned)std::min<size_t>(ntiles, (size_t)per_cu * e->n_cu));                                                        \
     hipLaunchKernelGGL((bgs::abl_kernel<GV, CV, UV>), grid, block, 0, s, a, (const uint8_t*)e->abl_lut);                                   \
   }

@@ -224,6 +224,9 @@ __global__ __launch_bounds__(kBlock) void wmv_kernel(const FrameArgs a) {
 //   * per byte: one ds_read_u8 + ~8 integer instructions (the mask side |i - b| -> gray -> threshold was integer already).
 constexpr int kAblLutStride = 260;
 constexpr int kAblBlock = 1024;
+// 256 rows x 260 bytes = 66 560 B of static LDS: fine on gfx950 (160 KB per CU, the only target of this library - csrc/Makefile), above the
+// 64 KiB a workgroup may have on earlier CDNA parts, where this kernel would need a 256-byte row stride
+static_assert(256 * kAblLutStride <= 160 * 1024 / 2, "two resident workgroups per CU must fit the LDS of gfx950");
 
 // lut[b * 256 + x] = the background byte AdaptiveBackgroundLearning.cpp:54-58 produces from input byte x and background byte b
 __global__ __launch_bounds__(kBlock) void abl_lut_kernel(uint8_t* lut, double alpha, double beta) {
