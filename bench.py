@@ -416,9 +416,10 @@ def main():
     if rank == 0:
         nm = eng.get_state("nmodes", (ROWS * COLS,), np.uint8, stream=0)
         live_modes = float(nm.mean())
-        pr = eng.get_state("probe", (26,), np.float32)
-        probe = {"candidates_ms_per_dense_launch": [round(float(v), 3) for v in pr[2:2 + int(pr[0])]], "kept": int(pr[1]),
-                 "note": "model placement probe at allocation (DESIGN.md 6.2): stops once two speed classes have been seen"}
+        pr = eng.get_state("placement", (2,), np.float32)
+        probe = {"chunk_MiB": int(pr[0]), "chunks": int(pr[1]),
+                 "note": "the model is one virtual range backed by separately created physical chunks (hipMemCreate / hipMemMap): deterministic placement in the fast class "
+                         "(DESIGN.md 6.2; rounds 1-2 probed whole-model candidates instead); chunk_MiB 0 = one plain hipMalloc"}
     if rank == 0 and args.pmc_child:
         for T in (4, 8):
             clip_leg(eng, pool, period, S, T, launches=CLIP_PMC_LAUNCHES, warm=4)
@@ -524,7 +525,7 @@ def main():
                          "sustained": leg(sus_ms), "young_model_first_20": leg(burst_ms)},
             "cpu_baseline": cpu,
             "per_rank": per_rank,
-            "placement_probe": probe,
+            "model_placement": probe,
             "rccl_selftest_gather_matches_kernel_output": selftest_ok,
             "single_stream": single,
             "host_path": host,

@@ -177,8 +177,12 @@ int bgs_set_params(bgs_engine* e, const bgs_params* params);
  *                          round 3 (one pixel per lane, one model layout: ranked weights + fixed-slot records + summaries).
  *   BGS_OPT_XCD_SWIZZLE    XCD-aware workgroup order: 1 (default) = for the kernels that stream a multi-plane model
  *                          (MOG2, MOG1, dp/), 2 = also for the byte-stream kernels (slower there: A/B only), 0 = off.
- *   BGS_OPT_PLACEMENT_PROBE  most model placements tried at allocation (default 20, at most 24, <= 1 = off; the probe stops at the first
- *                          one that is >= 5 % faster than the slowest seen, typically the 2nd-6th); before the geometry. */
+ *   BGS_OPT_PLACEMENT_PROBE  rounds 1-2 looked for a fast physical placement of a multi-GB model by trial; accepted and ignored since
+ *                          round 3, which places models deterministically (BGS_OPT_MODEL_CHUNK_MB).
+ *   BGS_OPT_MODEL_CHUNK_MB multi-GB models (MOG2, MOG1, dp/) are ONE virtual range backed by separately created physical chunks of this
+ *                          many MiB (default 256; any size from 2 MiB to 1 GiB lands in the fast placement class on MI355X, 15 of 15
+ *                          processes, where one big hipMalloc is fast or 8-10 % slower by luck); 0 = one plain allocation; before the
+ *                          geometry is set. */
 #define BGS_OPT_BORROW_FRAMES 1
 #define BGS_OPT_MOG2_PIXELS_PER_LANE 2
 #define BGS_OPT_MOG2_TILED 3
@@ -190,6 +194,7 @@ int bgs_set_params(bgs_engine* e, const bgs_params* params);
                                    cannot rule out); 3 (default) automatic, from what sampled workgroups count */
 #define BGS_OPT_CLIP_FUSE 7     /* 1 (default): bgs_process_clip_device runs 8 / 4 / 2 consecutive frames of a mixture model per launch with the
                                    model held in registers; 0: one launch per frame.  Identical results, only speed differs. */
+#define BGS_OPT_MODEL_CHUNK_MB 9
 #define BGS_OPT_HOST_REGISTER 8 /* bgs_process (host buffers): bit 0 input frame, bit 1 mask, bit 2 background image.  A buffer passed in an
                                    enabled role that comes back with the same address and size as in the previous call is page-locked once
                                    (hipHostRegister) and from then on read / written by the DMA engine in place - no staging copy by the

@@ -15,7 +15,7 @@ FRAME_DIFF, STATIC_FRAME_DIFF, WMM, WMV, ABL, ASBL, MOG2, MOG1, GMG, SUBSENSE, L
 DP_ZIVKOVIC_AGMM, DP_GRIMSON_GMM, DP_WREN_GA, DP_MEAN, DP_ADAPTIVE_MEDIAN = range(12, 17)
 LOBSTER = 17
 FG_VALID, BG_VALID = 1, 2
-OPT_BORROW_FRAMES, OPT_MOG2_PIXELS_PER_LANE, OPT_MOG2_TILED, OPT_XCD_SWIZZLE, OPT_PLACEMENT_PROBE, OPT_MOG2_SPARSE, OPT_CLIP_FUSE, OPT_HOST_REGISTER = 1, 2, 3, 4, 5, 6, 7, 8
+OPT_BORROW_FRAMES, OPT_MOG2_PIXELS_PER_LANE, OPT_MOG2_TILED, OPT_XCD_SWIZZLE, OPT_PLACEMENT_PROBE, OPT_MOG2_SPARSE, OPT_CLIP_FUSE, OPT_HOST_REGISTER, OPT_MODEL_CHUNK_MB = 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_GEOMETRY, ERR_HIP, ERR_NOMEM, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
 

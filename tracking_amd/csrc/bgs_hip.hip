@@ -59,7 +59,6 @@ namespace {
 struct SsDevice;  // engine_subsense.h
 }
 
-constexpr int kProbeMax = 24;  // placement probe: most candidates ever held at once
 
 struct bgs_engine {
   bgs_algo algo;
@@ -106,11 +105,9 @@ struct bgs_engine {
   unsigned* h_stat = nullptr;      // pinned copy
   hipEvent_t stat_ev = nullptr;
   bool stat_pending = false;
-  int probe_max = 20;              // placement probe: candidates tried at most at allocation (<= 1: off); it stops at the first fast one
-  float probe_ms[kProbeMax] = {0};  // what the probe measured (diagnostics)
-  int probe_n = 0, probe_pick = -1;
+  int model_chunk_mb = 256;        // big models are built from physical chunks of this size (model_allocate); 0: one plain hipMalloc
   bool poison = false;             // BGS_DEBUG_POISON: every fresh device buffer is filled with 0xA5 (see dmalloc)
-  // BGS_MODEL_VMM_CHUNK_MB (experiment): the MOG2 model built from fixed-size physical chunks with the virtual memory API
+  // a model built from fixed-size physical chunks with the virtual memory API (model_allocate)
   std::vector<hipMemGenericAllocationHandle_t> vmm_handles;
   void* vmm_base = nullptr;
   size_t vmm_bytes = 0, vmm_chunk = 0;
@@ -155,8 +152,10 @@ void free_all(bgs_engine* e) {
   if (e->d_raw) (void)hipFree(e->d_raw), e->d_raw = nullptr;
   if (e->d_ingest_ws) (void)hipFree(e->d_ingest_ws), e->d_ingest_ws = nullptr;
   e->last_fg_stream = -1;
-  if (e->vmm_base) {  // the MOG2 model came from vmm_allocate
-    if (e->mog2_state == e->vmm_base) e->mog2_state = nullptr;
+  if (e->vmm_base) {  // a model built by model_allocate from physical chunks: not hipFree's to release
+    if ((void*)e->mog2_state == e->vmm_base) e->mog2_state = nullptr;
+    if ((void*)e->mog1_state == e->vmm_base) e->mog1_state = nullptr;
+    if ((void*)e->dp_state == e->vmm_base) e->dp_state = nullptr;
     vmm_free(e);
   }
   void* dev[] = {e->dp_state, e->gmg_colors, e->gmg_weights, e->gmg_nfeat, e->bgstate, e->bgstate2, e->mog1_state, e->mog2_state, e->d_in, e->d_fg, e->d_bg};
@@ -342,103 +341,15 @@ size_t mog2_state_bytes(const bgs_engine* e) {
   return (P + bgs::kMog2Tile - 1) / bgs::kMog2Tile * bgs::kMog2TileBytes;
 }
 
-// Model allocation with a PLACEMENT PROBE for the big, long-lived models (MOG2, MOG1, dp GMMs).
-// Measured on MI355X (profiles/r02_placement_probe.txt): the same kernel on the same layout streams a multi-GB
-// model at one of 2-3 speeds (32 x 1080p MOG2: 2.185 / 2.40 / 2.43 ms per dense launch) depending only on which physical VRAM
-// hipMalloc handed out.  The speed belongs to the ALLOCATION: re-timing the same candidates in reverse and again in forward
-// order gives the same numbers per candidate (BGS_DEBUG_PROBE=2), and the first candidate measured is usually not the fast
-// one.  The model lives as long as the camera stream, so it pays to look: allocate candidates one after the other (the
-// losers stay allocated meanwhile, otherwise hipMalloc would hand the same pages out again), time `run` on each - one dense
-// pass of the kernel that will stream the buffer, on e->stream - and keep the fastest.
-//   * stops as soon as two speed classes have been seen (fastest >= 5 % ahead of the slowest so far): on average after 3-4
-//     candidates; `expect_ms` is only printed by BGS_DEBUG_PROBE - an absolute test cannot tell a fast placement from the clock
-//     burst after an idle period;
-//   * never takes more than the device has to spare: a further candidate is only tried while free memory stays above
-//     max(2 GiB, 1/16 of the device) AFTER it, so co-resident engines are not pushed out of memory;
-//   * skipped below 768 MB (such a model is not HBM-bound: it sits in the 256 MiB Infinity Cache for a good part).
-// The buffer is handed over with unspecified contents: every model is initialised at its first frame on the launch stream.
-template <class Run>
-int probe_allocate(bgs_engine* e, void** out, size_t bytes, double expect_ms, Run run) {
-  const int tries = std::min(e->probe_max, kProbeMax);
-  if (tries <= 1 || bytes < ((size_t)768 << 20)) return dmalloc(e, out, bytes);
-  hipEvent_t ev0, ev1;
-  HIP_TRY(hipEventCreate(&ev0));
-  HIP_TRY(hipEventCreate(&ev1));
-  const int debug = getenv("BGS_DEBUG_PROBE") ? atoi(getenv("BGS_DEBUG_PROBE")) : 0;
-  void* cand[kProbeMax] = {nullptr};
-  int n = 0, best = -1, rc = BGS_OK;
-  float tmin = 1e30f, tmax = 0.f;
-  auto time_one = [&](void* buf, float* ms_out) -> int {
-    int r = BGS_OK;
-    for (int i = 0; i < 2 && !r; ++i) r = run(buf);
-    (void)hipEventRecord(ev0, e->stream);
-    for (int i = 0; i < 4 && !r; ++i) r = run(buf);
-    (void)hipEventRecord(ev1, e->stream);
-    if (r) return r;
-    if (hipEventSynchronize(ev1) != hipSuccess) return fail(BGS_ERR_HIP, "placement probe failed: %s", hipGetErrorString(hipGetLastError()));
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, ev0, ev1);
-    *ms_out = ms / 4;
-    return BGS_OK;
-  };
-  for (; n < tries; ++n) {
-    if (n > 0) {
-      size_t free_b = 0, total_b = 0;
-      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) break;
-      if (free_b < bytes + std::max((size_t)2 << 30, total_b / 16)) break;  // leave the device room to breathe
-    }
-    if (hipMalloc(&cand[n], bytes) != hipSuccess) {
-      (void)hipGetLastError();
-      cand[n] = nullptr;
-      break;  // out of memory: settle for what we have
-    }
-    (void)hipMemsetAsync(cand[n], 0, bytes, e->stream);
-    rc = time_one(cand[n], &e->probe_ms[n]);
-    if (rc) {
-      ++n;
-      break;
-    }
-    if (e->probe_ms[n] < tmin) tmin = e->probe_ms[n], best = n;
-    if (e->probe_ms[n] > tmax) tmax = e->probe_ms[n];
-    // Stop as soon as two speed classes have been SEEN (the fastest candidate >= 5 % ahead of the slowest; the classes are ~10 %
-    // apart, candidates of one class agree within 1-2 %).  No absolute threshold: right after an idle period the part
-    // runs every candidate 5-10 % faster than it sustains (clock burst), which made a slow placement pass an
-    // absolute "fast enough" test - seen on one box in round 2 (2.39 instead of 2.17 ms per launch in the bench that followed).
-    if (tmin <= 0.95f * tmax && debug < 2) {
-      ++n;
-      break;
-    }
-  }
-  if (debug) {
-    fprintf(stderr, "[bgs] placement probe (%zu MB, expected %.3f): %d candidates, ms per dense launch:", bytes >> 20, expect_ms, n);
-    for (int i = 0; i < n; ++i) fprintf(stderr, " %.3f%s", e->probe_ms[i], i == best ? "*" : "");
-    fprintf(stderr, "\n");
-  }
-  if (debug >= 2 && !rc) {  // de-confounding passes: the same candidates again, in reverse and then in the original order
-    for (int pass = 0; pass < 2; ++pass) {
-      float again[kProbeMax] = {0};
-      for (int j = 0; j < n; ++j) {
-        const int i = pass == 0 ? n - 1 - j : j;
-        (void)time_one(cand[i], &again[i]);
-      }
-      fprintf(stderr, "[bgs] placement probe re-time (%s order), ms by candidate:", pass == 0 ? "reverse" : "forward");
-      for (int i = 0; i < n; ++i) fprintf(stderr, " %.3f", again[i]);
-      fprintf(stderr, "\n");
-    }
-  }
-  e->probe_n = n, e->probe_pick = best;
-  for (int i = 0; i < n; ++i)
-    if (cand[i] && (i != best || rc)) (void)hipFree(cand[i]);
-  (void)hipEventDestroy(ev0), (void)hipEventDestroy(ev1);
-  if (rc) return rc;
-  if (best < 0) return fail(BGS_ERR_NOMEM, "out of device memory for the model (%zu bytes)", bytes);
-  if (e->poison) HIP_TRY(hipMemsetAsync(cand[best], 0xA5, bytes, e->stream));
-  *out = cand[best];
-  return BGS_OK;
-}
-
-// Placement experiment: reserve one virtual range and back it with separately created physical chunks of `chunk` bytes each
-// (hipMemCreate / hipMemMap), instead of whatever one hipMalloc hands out.  Returns BGS_ERR_HIP if the API refuses.
+// Model allocation for the big, long-lived models (MOG2, MOG1, dp): DETERMINISTIC PLACEMENT.
+// Measured on MI355X in rounds 1-3 (profiles/r02_placement_probe.txt, profiles/r03_placement.txt): the same kernel on
+// the same layout streams a multi-GB model at one of 2-3 speeds, 8-10 % apart, depending only on which physical VRAM one big
+// hipMalloc handed out.  Rounds 1-2 looked for a fast placement by trial (up to 20 candidates of the whole model allocated and
+// timed).  Round 3 found the construction that needs no luck: ONE virtual range backed by separately created physical chunks of at
+// most 1 GiB (hipMemCreate / hipMemMap) - 15 of 15 fresh processes landed in the fast class for chunk sizes 2 MiB .. 1 GiB
+// (1.103-1.110 ms per 32 x 1080p MOG2 launch), 3 of 3 in the slow class with 4 GiB chunks (1.21 ms), while plain hipMalloc gave
+// 1.11 1.11 1.12 1.19 1.21 1.21.  So: chunks of 256 MiB (BGS_MODEL_CHUNK_MB; 0 = one plain hipMalloc), no probe, no transient memory.
+// one virtual range backed by separately created physical chunks of `chunk` bytes each
 int vmm_allocate(bgs_engine* e, void** out, size_t bytes, size_t chunk) {
   hipMemAllocationProp prop = {};
   prop.type = hipMemAllocationTypePinned;
@@ -474,45 +385,25 @@ void vmm_free(bgs_engine* e) {
   e->vmm_handles.clear(), e->vmm_base = nullptr, e->vmm_bytes = 0;
 }
 
-int mog2_allocate(bgs_engine* e) {
-  const size_t P = e->n * e->S, bytes = mog2_state_bytes(e);
-  if (const char* env = getenv("BGS_MODEL_VMM_CHUNK_MB")) {
-    const size_t mb = (size_t)atoll(env);
-    if (mb > 0) {
-      HIP_TRY(hipMalloc((void**)&e->d_stat, 3 * sizeof(unsigned)));
-      HIP_TRY(hipMemsetAsync(e->d_stat, 0, 3 * sizeof(unsigned), e->stream));
-      HIP_TRY(hipHostMalloc((void**)&e->h_stat, 3 * sizeof(unsigned), hipHostMallocDefault));
-      HIP_TRY(hipEventCreateWithFlags(&e->stat_ev, hipEventDisableTiming));
-      return vmm_allocate(e, (void**)&e->mog2_state, bytes, mb << 20);
-    }
+// A model of `bytes`: chunked (see above) from 768 MB up - smaller ones sit in the 256 MiB Infinity Cache for a good part and are
+// not HBM-bound - else, or when the virtual memory API refuses, one hipMalloc.  An engine has at most one such model.
+int model_allocate(bgs_engine* e, void** out, size_t bytes) {
+  if (e->model_chunk_mb > 0 && bytes >= ((size_t)768 << 20) && !e->vmm_base) {
+    if (vmm_allocate(e, out, bytes, (size_t)e->model_chunk_mb << 20) == BGS_OK) return BGS_OK;
+    (void)hipGetLastError();
+    vmm_free(e);  // whatever part of it came to be
+    *out = nullptr;
   }
+  return dmalloc(e, out, bytes);
+}
+
+int mog2_allocate(bgs_engine* e) {
+  const size_t bytes = mog2_state_bytes(e);
   HIP_TRY(hipMalloc((void**)&e->d_stat, 3 * sizeof(unsigned)));
   HIP_TRY(hipMemsetAsync(e->d_stat, 0, 3 * sizeof(unsigned), e->stream));  // ordered: allocate() drains e->stream before it returns
   HIP_TRY(hipHostMalloc((void**)&e->h_stat, 3 * sizeof(unsigned), hipHostMallocDefault));
   HIP_TRY(hipEventCreateWithFlags(&e->stat_ev, hipEventDisableTiming));
-  const bool probing = e->probe_max > 1 && bytes >= ((size_t)768 << 20);
-  uint8_t* d_frame = nullptr;  // a black frame for the probe launches
-  if (probing) {
-    HIP_TRY(hipMalloc((void**)&d_frame, P * 3));
-    HIP_TRY(hipMemsetAsync(d_frame, 0, P * 3, e->stream));
-  }
-  const int saved_sparse = e->mog2_sparse;
-  e->mog2_sparse = 0;  // probe with the dense traffic pattern: that is what a busy scene produces
-  // a dense launch (sparse 0: everything read and written back) moves 248 B/pixel; on a good placement this part sustains ~6.15 TB/s
-  const double expect_ms = 248.0 * (double)P / 6.15e12 * 1e3;
-  uint8_t* saved_state = e->mog2_state;
-  int rc = probe_allocate(e, (void**)&e->mog2_state, bytes, expect_ms, [&](void* cand) -> int {
-    e->mog2_state = (uint8_t*)cand;
-    bgs::Mog2Args m{};
-    mog2_fill_args(e, m, 0.05);
-    m.frame = d_frame, m.state_off = 0, m.npix = P;
-    const int r = launch_mog2(e, m, e->stream, false);
-    e->mog2_state = saved_state;
-    return r;
-  });
-  e->mog2_sparse = saved_sparse;
-  if (d_frame) (void)hipFree(d_frame);
-  return rc;
+  return model_allocate(e, (void**)&e->mog2_state, bytes);
 }
 
 #include "engine_subsense.h"
@@ -581,26 +472,7 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
     const size_t planes = ch == 3 ? bgs::mog1_planes<3>() : bgs::mog1_planes<1>();
     const size_t tiles = (P + bgs::kMog1Tile - 1) / bgs::kMog1Tile;
     const size_t bytes = tiles * planes * bgs::kMog1Tile * sizeof(float);
-    uint8_t* d_zero = nullptr;  // a black frame for the probe launches
-    const bool probing = e->probe_max > 1 && bytes >= ((size_t)768 << 20);
-    if (probing) {
-      HIP_TRY(hipMalloc((void**)&d_zero, P * ch));
-      HIP_TRY(hipMemsetAsync(d_zero, 0, P * ch, e->stream));
-    }
-    int rc = probe_allocate(e, (void**)&e->mog1_state, bytes, 0.0, [&](void* cand) -> int {
-      bgs::Mog1Args m{};
-      m.state = (float*)cand, m.state_off = 0, m.npix = P, m.frame = d_zero, m.fg = nullptr, m.fg_bits = nullptr;
-      m.alpha = 0.05f, m.T = 0.7f, m.vT = 6.25f, m.w0 = 0.05f, m.sk0 = 0.001f, m.var0 = 900.f, m.minVar = 225.f;
-      m.thr = 15, m.enable_thr = 1, m.packed = 0, m.xcd_swizzle = e->xcd_swizzle;
-      const bool px2 = false;  // the production launch is one pixel per lane
-      const dim3 grid(blocks_for(px2 ? P / 2 : P)), block(bgs::kBlock);
-      if (ch == 3 && px2) hipLaunchKernelGGL((bgs::mog1_update_kernel<3, 2>), grid, block, 0, e->stream, m);
-      if (ch == 3 && !px2) hipLaunchKernelGGL((bgs::mog1_update_kernel<3, 1>), grid, block, 0, e->stream, m);
-      if (ch == 1 && px2) hipLaunchKernelGGL((bgs::mog1_update_kernel<1, 2>), grid, block, 0, e->stream, m);
-      if (ch == 1 && !px2) hipLaunchKernelGGL((bgs::mog1_update_kernel<1, 1>), grid, block, 0, e->stream, m);
-      return hipGetLastError() == hipSuccess ? BGS_OK : fail(BGS_ERR_HIP, "probe launch failed");
-    });
-    if (d_zero) (void)hipFree(d_zero);
+    int rc = model_allocate(e, (void**)&e->mog1_state, bytes);
     if (rc) return rc;
   }
   if (e->algo == BGS_MOG2) {
@@ -1337,7 +1209,7 @@ int bgs_create(bgs_algo algo, const bgs_params* params, int hip_device, int n_st
   if (const char* env = getenv("BGS_MOG2_COMPLETE")) e->mog2_complete = atoi(env) != 0;
   if (const char* env = getenv("BGS_XCD_SWIZZLE")) e->xcd_swizzle = atoi(env);
   if (const char* env = getenv("BGS_MOG2_SPARSE")) e->mog2_sparse = atoi(env);
-  if (const char* env = getenv("BGS_PLACEMENT_PROBE")) e->probe_max = atoi(env);
+  if (const char* env = getenv("BGS_MODEL_CHUNK_MB")) e->model_chunk_mb = atoi(env);
   if (const char* env = getenv("BGS_CLIP_FUSE")) e->clip_fuse = atoi(env) != 0;
   if (const char* env = getenv("BGS_DEBUG_POISON")) e->poison = atoi(env) != 0;
   if (const char* env = getenv("BGS_HOST_REGISTER")) e->host_register = atoi(env) & 7;
@@ -1409,9 +1281,10 @@ int bgs_set_option(bgs_engine* e, int option, int64_t value) {
         if (!((value >> r) & 1) && e->pin[r].pinned) (void)hipHostUnregister(const_cast<void*>(e->pin[r].ptr)), e->pin[r] = bgs_engine::HostPin();
       e->host_register = (int)(value & 7);
       return BGS_OK;
-    case 5:
-      if (e->n) return fail(BGS_ERR_INVALID, "the placement probe runs when the geometry is set");
-      e->probe_max = (int)value;
+    case 5: return BGS_OK;  // BGS_OPT_PLACEMENT_PROBE of rounds 1-2: accepted and ignored (placement is deterministic since round 3: model_allocate)
+    case 9:
+      if (e->n) return fail(BGS_ERR_INVALID, "the model is allocated when the geometry is set");
+      e->model_chunk_mb = (int)std::max<int64_t>(value, 0);
       return BGS_OK;
     default: return fail(BGS_ERR_INVALID, "unknown option %d", option);
   }
@@ -1557,9 +1430,8 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
     if (hipMemcpy(dst, src, nb, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
     return (int64_t)nb;
   };
-  if (!strcmp(plane, "probe")) {  // diagnostics: [0] candidates measured, [1] index kept, [2..] ms per dense launch of each candidate
-    float rec[2 + kProbeMax] = {(float)e->probe_n, (float)e->probe_pick};
-    for (int i = 0; i < kProbeMax; ++i) rec[2 + i] = i < e->probe_n ? e->probe_ms[i] : 0.f;
+  if (!strcmp(plane, "placement")) {  // diagnostics: [0] chunk size in MiB of the chunked model (0: one plain allocation), [1] number of chunks
+    float rec[2] = {e->vmm_base ? (float)(e->vmm_chunk >> 20) : 0.f, (float)e->vmm_handles.size()};
     if (cap < sizeof(rec)) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
     memcpy(dst, rec, sizeof(rec));
     return (int64_t)sizeof(rec);

@@ -32,27 +32,7 @@ int dp_allocate(bgs_engine* e) {
   if (planes) {
     const size_t tiles = (P + bgs::kDpTile - 1) / bgs::kDpTile, bytes = tiles * planes * bgs::kDpTile * sizeof(float);
     if (!e->stream) HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    uint8_t* d_zero = nullptr;  // a black frame for the probe launches (probe_allocate, bgs_hip.hip)
-    const bool probing = e->probe_max > 1 && bytes >= ((size_t)768 << 20);
-    if (probing) {
-      HIP_TRY(hipMalloc((void**)&d_zero, P * 3));
-      HIP_TRY(hipMemsetAsync(d_zero, 0, P * 3, e->stream));
-      if (e->bgstate) HIP_TRY(hipMemsetAsync(e->bgstate, 0, P * e->state_ch, e->stream));  // the probe kernels read the mode counts
-    }
-    int rc = probe_allocate(e, (void**)&e->dp_state, bytes, 0.0, [&](void* cand) -> int {
-      bgs::DpArgs a{};
-      a.frame = d_zero, a.state = (float*)cand, a.bstate = e->bgstate, a.fg = nullptr, a.fg_bits = nullptr;
-      a.n = e->n, a.npix = P, a.first = 0, a.low = 25.f, a.high = 50.f, a.alpha = 0.01f, a.update = 0, a.xcd_swizzle = e->xcd_swizzle;
-      const unsigned blocks = blocks_for(P);
-      switch (e->algo) {
-        case BGS_DP_ZIVKOVIC_AGMM: dp_launch_gmm<false>(e->p.dp_gaussians, blocks, e->stream, a); break;
-        case BGS_DP_GRIMSON_GMM: dp_launch_gmm<true>(e->p.dp_gaussians, blocks, e->stream, a); break;
-        case BGS_DP_WREN_GA: hipLaunchKernelGGL(bgs::dp_wren_kernel, dim3(blocks), dim3(bgs::kBlock), 0, e->stream, a); break;
-        default: hipLaunchKernelGGL(bgs::dp_mean_kernel, dim3(blocks), dim3(bgs::kBlock), 0, e->stream, a); break;
-      }
-      return hipGetLastError() == hipSuccess ? BGS_OK : fail(BGS_ERR_HIP, "probe launch failed");
-    });
-    if (d_zero) (void)hipFree(d_zero);
+    int rc = model_allocate(e, (void**)&e->dp_state, bytes);  // chunked placement for multi-GB models (bgs_hip.hip)
     if (rc) return rc;
   }
   // Nothing is initialised here: InitModel runs in dp_process at a stream's first frame, on the launch stream (an
