@@ -119,6 +119,29 @@ def host_leg(local, pool, frames_n=120):
         dt = time.perf_counter() - t0 - fill
         out[label] = {"ms_per_frame": round(dt / frames_n * 1e3, 4), "frames_per_s": round(frames_n / dt, 1), "mpixels_per_s": round(frames_n * ROWS * COLS / dt / 1e6, 1)}
         e.close()
+    # several cameras: bgs_submit / bgs_wait - every camera's frame queued on its own lane before any is collected
+    cams = 8
+    for label, reg in (("submit_wait_8_cameras_staged", 0), ("submit_wait_8_cameras_registered_buffers", 3)):
+        e = Engine(capi.MOG2, device=local, n_streams=cams)
+        e.set_option(capi.OPT_HOST_REGISTER, reg)
+        frames = [np.ascontiguousarray(clip[(3 * c) % period]) for c in range(cams)]
+        fgs = [np.empty((ROWS, COLS), np.uint8) for _ in range(cams)]
+        for t in range(12):
+            for c in range(cams):
+                e.submit(frames[c], fgs[c], None, stream=c)
+            for c in range(cams):
+                e.wait(stream=c)
+        rounds = max(8, frames_n // cams)
+        t0 = time.perf_counter()
+        for t in range(rounds):
+            for c in range(cams):
+                e.submit(frames[c], fgs[c], None, stream=c)
+            for c in range(cams):
+                e.wait(stream=c)
+        dt = time.perf_counter() - t0
+        n = rounds * cams
+        out[label] = {"cameras": cams, "ms_per_frame": round(dt / n * 1e3, 4), "frames_per_s_aggregate": round(n / dt, 1), "mpixels_per_s": round(n * ROWS * COLS / dt / 1e6, 1)}
+        e.close()
     return out
 
 

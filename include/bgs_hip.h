@@ -300,6 +300,18 @@ int64_t bgs_group_frames_seen(const bgs_group* g);
 int bgs_group_enable_kernel_timing(bgs_group* g, int on);
 int bgs_group_kernel_timing(bgs_group* g, double* avg_ms, int64_t* launches); /* the fused launches, HIP events on the launch stream */
 
+/*
+ * Several cameras on the host path.  bgs_submit queues one frame of one stream - upload, kernels, download - on that stream's own
+ * lane (HIP stream, pinned staging, device images) and returns; bgs_wait blocks until that submission is done and the outputs are
+ * in the caller's images (out_flags as for bgs_process).  Submissions of different streams overlap: while camera A's frame is on
+ * the bus camera B's kernel runs and camera C's mask comes back, where a synchronous bgs_process per camera takes turns.
+ * Same arguments and results as bgs_process; the caller's buffers must stay valid and untouched until bgs_wait; one submission per
+ * stream in flight (bgs_process on such a stream collects it first).  Frames prepared by bgs_set_ingest go through bgs_process.
+ */
+int bgs_submit(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols, int channels, size_t in_step, uint8_t* fg, size_t fg_step,
+               uint8_t* bg, size_t bg_step);
+int bgs_wait(bgs_engine* e, int stream, uint32_t* out_flags);
+
 /* One camera of the batch starts over - what `delete bgs; bgs = new <Class>;` is for one stream in the reference
  * (FrameProcessor.cpp:342-482 / :35-155, ustc_src/ustc_bgs.cpp:75-77): its frame count returns to 0 and its NEXT frame, on the
  * HIP stream of that call and in order with everything queued before it, re-initialises its model and restarts its warm-up

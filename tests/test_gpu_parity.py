@@ -792,3 +792,60 @@ def test_host_path_with_registered_caller_buffers(name, golden_frames):
     ofg, _ = orc.process(golden_frames[16])
     assert np.array_equal(fg2, ofg)
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["MixtureOfGaussianV2BGS", "WeightedMovingVarianceBGS", "SuBSENSEBGS", "AdaptiveSelectiveBackgroundLearning"])
+@pytest.mark.parametrize("register", [0, 7])
+def test_submit_wait_several_cameras_overlap(name, register, golden_frames):
+    """bgs_submit / bgs_wait: four cameras on the host path, every camera's frame t queued before any is collected (their uploads,
+    kernels and downloads overlap on per-camera lanes), one camera lagging a frame behind, one synchronous bgs_process in between.
+    Every camera equals its own oracle; with BGS_OPT_HOST_REGISTER the per-camera buffers are used in place."""
+    algo = dict(ALGOS, SuBSENSEBGS=capi.SUBSENSE)[name]
+    S, T = 4, 9
+    H, W = golden_frames.shape[1:3]
+    clips = [np.ascontiguousarray(golden_frames[2 * s:2 * s + T]) for s in range(S)]
+    eng = Engine(algo, n_streams=S)
+    eng.set_option(capi.OPT_HOST_REGISTER, register)
+    orcs = [pyoracle.Oracle(algo) for _ in range(S)]
+    bg_c = 1 if algo == capi.ASBL else 3
+    frames = [np.empty((H, W, 3), np.uint8) for _ in range(S)]  # one frame / mask / background buffer per camera, kept allocated
+    fgs = [np.full((H, W), 9, np.uint8) for _ in range(S)]
+    bgs_ = [np.full((H, W, bg_c), 9, np.uint8) for _ in range(S)]
+    fed = [0] * S
+    for t in range(T):
+        cams = [s for s in range(S) if not (s == 2 and t == 0)]  # camera 2 comes up one step late
+        for s in cams:
+            frames[s][...] = clips[s][fed[s]]
+            fgs[s][...] = 9
+            eng.submit(frames[s], fgs[s], bgs_[s], stream=s)
+        if t == 4:  # a synchronous call on a camera with a submission in flight collects that one first, then runs
+            s = 1
+            fl = eng.wait(stream=s)
+            ofg, obg = orcs[s].process(clips[s][fed[s]])
+            assert bool(fl & capi.FG_VALID) == (ofg is not None)
+            if ofg is not None:
+                assert np.array_equal(fgs[s], ofg)
+            fed[s] += 1
+            fg2, _ = eng.process(clips[s][fed[s]], stream=s)
+            ofg, _ = orcs[s].process(clips[s][fed[s]])
+            assert (fg2 is None) == (ofg is None) and (ofg is None or np.array_equal(fg2, ofg))
+            fed[s] += 1
+            cams = [c for c in cams if c != s]
+        for s in cams:
+            fl = eng.wait(stream=s)
+            ofg, obg = orcs[s].process(clips[s][fed[s]])
+            assert bool(fl & capi.FG_VALID) == (ofg is not None) and bool(fl & capi.BG_VALID) == (obg is not None), (name, t, s, fl)
+            if ofg is not None:
+                assert np.array_equal(fgs[s], ofg), (name, t, s)
+            else:
+                assert (fgs[s] == 9).all(), (name, t, s)
+            if obg is not None:
+                assert np.array_equal(bgs_[s].reshape(obg.shape), obg), (name, t, s)
+            fed[s] += 1
+        if fed[1] >= T - 1:
+            break
+    with pytest.raises(capi.BgsError):
+        eng.submit(frames[0], fgs[0], None, stream=0)
+        eng.submit(frames[0], fgs[0], None, stream=0)  # second submission while the first is in flight
+    eng.wait(stream=0)
+    eng.close()

@@ -100,8 +100,18 @@ def one_case(rng, case_seed):
     except capi.BgsError as e:
         eng.close()
         return "%s %dx%d not supported: %s" % (name, W, H, str(e)[:60])
+    if name == "MixtureOfGaussianV2BGS":  # round 3: which MOG2 kernel loads the model (dense / eager / count / auto / filter)
+        level = int(rng.choice([0, 1, 2, 3, 4]))
+        eng.set_option(capi.OPT_MOG2_SPARSE, level)
+        kw["sparse"] = level
+    resets = rng.random() < 0.35  # round 3: cameras of a batch are reset independently, so the streams of one call have different ages
     t = 0
     while t < T:
+        if resets and t > 0 and rng.random() < 0.3:
+            r = int(rng.integers(0, S))
+            eng.reset_stream(r)
+            orcs[r].close()
+            orcs[r] = pyoracle.Oracle(algo, params=p)
         m = mode if mode != "mixed" else rng.choice(["host", "batch", "clip"])
         n = 1
         if m == "host":
@@ -121,14 +131,17 @@ def one_case(rng, case_seed):
                 flags = eng.process_clip_device(d, n, fg, None, bits)
             torch.cuda.synchronize()
             fgh = fg.cpu().numpy()
-            outs = [[(fgh[j, s] if flags[j] & capi.FG_VALID else None, None) for j in range(n)] for s in range(S)]
+            outs = [[(fgh[j, s], None) for j in range(n)] for s in range(S)]  # validity per stream: an untouched output keeps the marker 7
             if want_bits:
                 bh = np.unpackbits(bits.cpu().numpy().view(np.uint8).reshape(n, S, -1), axis=2, bitorder="little").reshape(n, S, H, W)
         for s in range(S):
             for j in range(n):
                 ofg, obg = orcs[s].process(clips[s, t + j])
                 fg_j, bg_j = outs[s][j]
-                assert (fg_j is None) == (ofg is None), "%s frame %d stream %d: mask validity" % (name, t + j, s)
+                if m == "host":
+                    assert (fg_j is None) == (ofg is None), "%s frame %d stream %d: mask validity" % (name, t + j, s)
+                elif ofg is None:
+                    assert (fg_j == 7).all(), "%s frame %d stream %d (%s): a warm-up frame must leave the mask untouched" % (name, t + j, s, m)
                 if ofg is not None:
                     assert np.array_equal(fg_j, ofg), "%s frame %d stream %d (%s): %d mask pixels differ" % (name, t + j, s, m, int((fg_j != ofg).sum()))
                     if m != "host" and want_bits:
@@ -152,7 +165,7 @@ def one_case(rng, case_seed):
         else:
             check_state(name, eng, orcs[s], H * W, stream=s)
     eng.close()
-    return "%s %dx%d x%d streams, %d frames, %s %s: ok" % (name, W, H, S, T, mode, kw)
+    return "%s %dx%d x%d streams, %d frames, %s%s %s: ok" % (name, W, H, S, T, mode, " +resets" if resets else "", kw)
 
 
 def main():

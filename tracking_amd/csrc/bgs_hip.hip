@@ -102,9 +102,13 @@ struct bgs_engine {
   int mog2_sparse_want = 2;        // what the last poll asked for (a switch needs two polls in a row)
   unsigned mog2_launches = 0;      // auto mode: per-frame launches so far (every 16th one samples)
   unsigned* d_stat = nullptr;      // device: {record slots sampled, modes live, records needed after the summaries}
-  unsigned* h_stat = nullptr;      // pinned copy
-  hipEvent_t stat_ev = nullptr;
-  bool stat_pending = false;
+  // pinned copies of the counters, a ring of kStatSlots posts (one per sampling launch, each with its event): a host that runs far
+  // ahead of the device still finds the most recent sample that has COMPLETED when it looks
+  static constexpr int kStatSlots = 8;
+  unsigned* h_stat = nullptr;      // [kStatSlots][3]
+  hipEvent_t stat_ev[kStatSlots] = {nullptr};
+  bool stat_posted[kStatSlots] = {false};
+  unsigned stat_seq = 0;           // posts so far
   int model_chunk_mb = 256;        // big models are built from physical chunks of this size (model_allocate); 0: one plain hipMalloc
   bool poison = false;             // BGS_DEBUG_POISON: every fresh device buffer is filled with 0xA5 (see dmalloc)
   // a model built from fixed-size physical chunks with the virtual memory API (model_allocate)
@@ -122,7 +126,20 @@ struct bgs_engine {
     const void* ptr = nullptr;   // what the previous call passed for this role
     size_t bytes = 0;
     bool pinned = false, refused = false;
-  } pin[3];                       // 0 input, 1 mask, 2 background
+  };
+  std::vector<HostPin> pin;       // [stream][3]: 0 input, 1 mask, 2 background (every camera has its own buffers)
+  // bgs_submit / bgs_wait: one lane per camera - its own HIP stream, staging and device images - so that the uploads, kernels and
+  // downloads of different cameras overlap; created at a stream's first bgs_submit
+  struct Lane {
+    hipStream_t hs = nullptr;
+    hipEvent_t done = nullptr;
+    uint8_t *h_in = nullptr, *h_fg = nullptr, *h_bg = nullptr, *d_in = nullptr, *d_fg = nullptr, *d_bg = nullptr;
+    bool pending = false, fg_direct = false, bg_direct = false;
+    uint8_t *fg = nullptr, *bg = nullptr;  // the caller's output images of the pending submission
+    size_t fg_step = 0, bg_step = 0;
+    uint32_t flags = 0;
+  };
+  std::vector<Lane> lanes;
   int host_register = 0;          // BGS_OPT_HOST_REGISTER: roles that may be page-locked in place (bit 0 input, 1 mask, 2 background); 0 = always stage
   bool ingest_on = false;             // bgs_set_ingest: bgs_process takes raw frames
   bgs_ingest ingest{};
@@ -171,12 +188,27 @@ void free_all(bgs_engine* e) {
   ss_free(e);
   if (e->d_stat) (void)hipFree(e->d_stat), e->d_stat = nullptr;
   if (e->h_stat) (void)hipHostFree(e->h_stat), e->h_stat = nullptr;
-  if (e->stat_ev) (void)hipEventDestroy(e->stat_ev), e->stat_ev = nullptr;
+  for (int i = 0; i < bgs_engine::kStatSlots; ++i) {
+    if (e->stat_ev[i]) (void)hipEventDestroy(e->stat_ev[i]), e->stat_ev[i] = nullptr;
+    e->stat_posted[i] = false;
+  }
   for (auto& ev : e->band_ev)
     if (ev) (void)hipEventDestroy(ev), ev = nullptr;
   for (auto& hp : e->pin) {
     if (hp.pinned) (void)hipHostUnregister(const_cast<void*>(hp.ptr));
     hp = bgs_engine::HostPin();
+  }
+  for (auto& ln : e->lanes) {
+    if (ln.hs) (void)hipStreamSynchronize(ln.hs);
+    void* host[] = {ln.h_in, ln.h_fg, ln.h_bg};
+    for (void* h : host)
+      if (h) (void)hipHostFree(h);
+    void* dv[] = {ln.d_in, ln.d_fg, ln.d_bg};
+    for (void* d : dv)
+      if (d) (void)hipFree(d);
+    if (ln.done) (void)hipEventDestroy(ln.done);
+    if (ln.hs) (void)hipStreamDestroy(ln.hs);
+    ln = bgs_engine::Lane();
   }
 }
 
@@ -234,9 +266,17 @@ struct Timed {
 // that purpose).  The host never blocks: the counters come back through a pinned buffer and an event that is queried before
 // every launch; it switches at once on clear evidence, else when two samples in a row ask for the same other mode.
 void mog2_stat_read(bgs_engine* e) {
-  if (!(e->stat_pending && hipEventQuery(e->stat_ev) == hipSuccess)) return;
-  e->stat_pending = false;
-  const unsigned total = e->h_stat[0], live = e->h_stat[1], need = e->h_stat[2];
+  // the newest post whose copy has completed; everything older is dropped with it
+  int slot = -1;
+  for (unsigned back = 1; back <= (unsigned)bgs_engine::kStatSlots && back <= e->stat_seq; ++back) {
+    const int i = (int)((e->stat_seq - back) % bgs_engine::kStatSlots);
+    if (!e->stat_posted[i]) break;  // already consumed (and so is everything older)
+    if (slot < 0 && hipEventQuery(e->stat_ev[i]) == hipSuccess) slot = i;
+    if (slot >= 0) e->stat_posted[i] = false;
+  }
+  if (slot < 0) return;
+  const unsigned* hs = e->h_stat + 3 * slot;
+  const unsigned total = hs[0], live = hs[1], need = hs[2];
   if (total < 64 * 5) return;
   const float lf = (float)live / (float)total, nf = (float)need / (float)total;
   const int want = (nf < 0.5f * lf && lf - nf > 0.1f) ? 4 : lf < 0.7f ? 2 : 1;
@@ -248,11 +288,12 @@ void mog2_stat_read(bgs_engine* e) {
   e->mog2_sparse_want = want;
 }
 void mog2_stat_post(bgs_engine* e, hipStream_t s) {
-  if (e->stat_pending) return;
-  (void)hipMemcpyAsync(e->h_stat, e->d_stat, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, s);
+  const int i = (int)(e->stat_seq % bgs_engine::kStatSlots);  // the oldest slot is reused (its event re-recorded) if nobody read it
+  (void)hipMemcpyAsync(e->h_stat + 3 * i, e->d_stat, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, s);
   (void)hipMemsetAsync(e->d_stat, 0, 3 * sizeof(unsigned), s);
-  (void)hipEventRecord(e->stat_ev, s);
-  e->stat_pending = true;
+  (void)hipEventRecord(e->stat_ev[i], s);
+  e->stat_posted[i] = true;
+  e->stat_seq++;
 }
 
 int launch_mog2(bgs_engine* e, bgs::Mog2Args& a, hipStream_t s, bool timed = true) {
@@ -401,8 +442,8 @@ int mog2_allocate(bgs_engine* e) {
   const size_t bytes = mog2_state_bytes(e);
   HIP_TRY(hipMalloc((void**)&e->d_stat, 3 * sizeof(unsigned)));
   HIP_TRY(hipMemsetAsync(e->d_stat, 0, 3 * sizeof(unsigned), e->stream));  // ordered: allocate() drains e->stream before it returns
-  HIP_TRY(hipHostMalloc((void**)&e->h_stat, 3 * sizeof(unsigned), hipHostMallocDefault));
-  HIP_TRY(hipEventCreateWithFlags(&e->stat_ev, hipEventDisableTiming));
+  HIP_TRY(hipHostMalloc((void**)&e->h_stat, 3 * bgs_engine::kStatSlots * sizeof(unsigned), hipHostMallocDefault));
+  for (int i = 0; i < bgs_engine::kStatSlots; ++i) HIP_TRY(hipEventCreateWithFlags(&e->stat_ev[i], hipEventDisableTiming));
   return model_allocate(e, (void**)&e->mog2_state, bytes);
 }
 
@@ -505,9 +546,9 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
 // OPT-IN per role (BGS_OPT_HOST_REGISTER): the engine cannot see a buffer being freed and another one mapped at the same address,
 // so the caller promises that a buffer it passes in an enabled role stays allocated until it passes a different one or destroys
 // the engine.
-bool host_pin(bgs_engine* e, int role, const void* ptr, size_t bytes) {
+bool host_pin(bgs_engine* e, int stream, int role, const void* ptr, size_t bytes, hipStream_t user = nullptr) {
   if (!((e->host_register >> role) & 1) || !ptr || !bytes) return false;
-  bgs_engine::HostPin& hp = e->pin[role];
+  bgs_engine::HostPin& hp = e->pin[(size_t)stream * 3 + role];
   if (hp.ptr == ptr && hp.bytes == bytes) {
     if (hp.pinned) return true;
     if (hp.refused) return false;
@@ -517,7 +558,7 @@ bool host_pin(bgs_engine* e, int role, const void* ptr, size_t bytes) {
     return false;
   }
   if (hp.pinned) {
-    (void)hipStreamSynchronize(e->stream);
+    (void)hipStreamSynchronize(user ? user : e->stream);
     (void)hipHostUnregister(const_cast<void*>(hp.ptr));
   }
   hp = bgs_engine::HostPin();
@@ -1203,6 +1244,8 @@ int bgs_create(bgs_algo algo, const bgs_params* params, int hip_device, int n_st
   e->S = n_streams;
   e->seen.assign(n_streams, 0);
   e->rpos.assign(n_streams, 0);
+  e->pin.assign((size_t)n_streams * 3, bgs_engine::HostPin());
+  e->lanes.assign(n_streams, bgs_engine::Lane());
   e->last_flags.assign(n_streams, 0);
   e->counter.assign(n_streams, 0);
   e->flip.assign(n_streams, 0);
@@ -1277,8 +1320,9 @@ int bgs_set_option(bgs_engine* e, int option, int64_t value) {
     case 7: e->clip_fuse = value != 0; return BGS_OK;
     case 8:
       if (hipSetDevice(e->device) == hipSuccess && e->stream) (void)hipStreamSynchronize(e->stream);
-      for (int r = 0; r < 3; ++r)
-        if (!((value >> r) & 1) && e->pin[r].pinned) (void)hipHostUnregister(const_cast<void*>(e->pin[r].ptr)), e->pin[r] = bgs_engine::HostPin();
+      (void)hipDeviceSynchronize();
+      for (size_t i = 0; i < e->pin.size(); ++i)
+        if (!((value >> (i % 3)) & 1) && e->pin[i].pinned) (void)hipHostUnregister(const_cast<void*>(e->pin[i].ptr)), e->pin[i] = bgs_engine::HostPin();
       e->host_register = (int)(value & 7);
       return BGS_OK;
     case 5: return BGS_OK;  // BGS_OPT_PLACEMENT_PROBE of rounds 1-2: accepted and ignored (placement is deterministic since round 3: model_allocate)
@@ -1307,6 +1351,8 @@ int bgs_process_batch_device(bgs_engine* e, const void* d_frames, void* d_fg, vo
   return process_range(e, 0, e->S, (const uint8_t*)d_frames, (uint8_t*)d_fg, (uint8_t*)d_bg, (uint64_t*)d_fg_bits, (hipStream_t)hip_stream, out_flags);
 }
 
+static int lane_wait(bgs_engine* e, int stream, uint32_t* out_flags);  // bgs_submit / bgs_wait, below
+
 int bgs_process(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols, int channels, size_t in_step, uint8_t* fg, size_t fg_step, uint8_t* bg,
                 size_t bg_step, uint32_t* out_flags) {
   if (out_flags) *out_flags = 0;
@@ -1330,6 +1376,10 @@ int bgs_process(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols
   const bool ingest_on_device = ingest && (pl.mode != 0 || e->ingest.equalize_hist || e->ingest.gaussian_blur);
   int rc = bgs_set_geometry(e, rows, cols, channels);
   if (rc) return rc;
+  if (e->lanes[stream].pending) {  // a bgs_submit of this stream is still in flight: its result is collected (and dropped) first
+    rc = lane_wait(e, stream, nullptr);
+    if (rc) return rc;
+  }
   rc = ensure_staging(e);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(e->device));
@@ -1358,7 +1408,7 @@ int bgs_process(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols
     // staging is pipelined: while the DMA engine moves band k, the CPU copies band k+1 of the caller's (pageable, possibly
     // strided) image into the pinned buffer.  Flip (rows reversed) and ROI (a window of the raw frame) cost nothing extra: they
     // only change which source row and column each staged row starts at.
-    if (!ingest && in_step == rb && host_pin(e, 0, in, fb)) {
+    if (!ingest && in_step == rb && host_pin(e, stream, 0, in, fb)) {
       HIP_TRY(hipMemcpyAsync(dst, in, fb, hipMemcpyHostToDevice, e->stream));  // straight from the caller's page-locked frame buffer
     } else {
       const int bands = rows >= 64 ? 8 : 1;
@@ -1386,8 +1436,8 @@ int bgs_process(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols
   // the caller's image while band k+1 is still on the bus; a mask alone (2 MB) is not worth the events
   bool out_fg = fg && (flags & BGS_FG_VALID), out_bg = bg && (flags & BGS_BG_VALID);
   // outputs the caller keeps allocated (same buffer as last call, contiguous rows) are written by the DMA engine directly
-  const bool fg_direct = out_fg && fg_step == (size_t)cols && host_pin(e, 1, fg, e->n);
-  const bool bg_direct = out_bg && bg_step == (size_t)cols * bg_ch && host_pin(e, 2, bg, e->n * bg_ch);
+  const bool fg_direct = out_fg && fg_step == (size_t)cols && host_pin(e, stream, 1, fg, e->n);
+  const bool bg_direct = out_bg && bg_step == (size_t)cols * bg_ch && host_pin(e, stream, 2, bg, e->n * bg_ch);
   if (fg_direct) HIP_TRY(hipMemcpyAsync(fg, e->d_fg, e->n, hipMemcpyDeviceToHost, e->stream));
   if (bg_direct) HIP_TRY(hipMemcpyAsync(bg, e->d_bg, e->n * bg_ch, hipMemcpyDeviceToHost, e->stream));
   if (fg_direct) out_fg = false;
@@ -1416,6 +1466,87 @@ int bgs_process(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols
   }
   if (out_flags) *out_flags = flags;
   return BGS_OK;
+}
+
+// ---- several cameras on the host path: bgs_submit queues one frame of one stream and returns, bgs_wait collects it ----------
+// Each camera has its own lane (HIP stream, pinned staging, device images), so while camera A's frame is on the bus camera B's
+// kernel runs and camera C's mask comes back: the copy engines and the CUs work side by side instead of taking turns, which is all
+// a synchronous bgs_process per camera can do.  One submission per stream in flight; bgs_process on a stream first collects it.
+static int lane_wait(bgs_engine* e, int stream, uint32_t* out_flags) {
+  bgs_engine::Lane& ln = e->lanes[stream];
+  if (out_flags) *out_flags = 0;
+  if (!ln.pending) return BGS_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipEventSynchronize(ln.done));
+  ln.pending = false;
+  const int bg_ch = e->algo == BGS_ASBL ? 1 : e->ch;
+  if (ln.fg && !ln.fg_direct && (ln.flags & BGS_FG_VALID))
+    for (int y = 0; y < e->rows; ++y) std::memcpy(ln.fg + (size_t)y * ln.fg_step, ln.h_fg + (size_t)y * e->cols, (size_t)e->cols);
+  if (ln.bg && !ln.bg_direct && (ln.flags & BGS_BG_VALID))
+    for (int y = 0; y < e->rows; ++y) std::memcpy(ln.bg + (size_t)y * ln.bg_step, ln.h_bg + (size_t)y * e->cols * bg_ch, (size_t)e->cols * bg_ch);
+  if (out_flags) *out_flags = ln.flags;
+  return BGS_OK;
+}
+
+int bgs_submit(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols, int channels, size_t in_step, uint8_t* fg, size_t fg_step, uint8_t* bg,
+               size_t bg_step) {
+  if (!e) return fail(BGS_ERR_INVALID, "engine is NULL");
+  if (stream < 0 || stream >= e->S) return fail(BGS_ERR_INVALID, "stream %d outside 0..%d", stream, e->S - 1);
+  if (e->ingest_on) return fail(BGS_ERR_UNSUPPORTED, "bgs_submit takes prepared frames (bgs_set_ingest is served by bgs_process)");
+  if (e->lanes[stream].pending) return fail(BGS_ERR_STATE, "stream %d has a submission in flight: bgs_wait first", stream);
+  if (!in || rows <= 0 || cols <= 0) return BGS_OK;  // if(img_input.empty()) return;
+  if (channels != 1 && channels != 3) return fail(BGS_ERR_UNSUPPORTED, "channels must be 1 or 3");
+  if (in_step < (size_t)cols * channels) return fail(BGS_ERR_INVALID, "in_step %zu < cols*channels", in_step);
+  int rc = bgs_set_geometry(e, rows, cols, channels);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(e->device));
+  bgs_engine::Lane& ln = e->lanes[stream];
+  const size_t rb = (size_t)cols * channels, fb = e->n * channels;
+  const int bg_ch = e->algo == BGS_ASBL ? 1 : channels;
+  if (!ln.hs) {
+    HIP_TRY(hipStreamCreateWithFlags(&ln.hs, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc((void**)&ln.h_in, fb, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&ln.h_fg, e->n, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&ln.h_bg, e->n * bg_ch, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&ln.d_in, fb));
+    HIP_TRY(hipMalloc((void**)&ln.d_fg, e->n));
+    HIP_TRY(hipMalloc((void**)&ln.d_bg, e->n * bg_ch));
+  }
+  uint8_t* dst = ln.d_in;
+  if (e->nring) dst = e->ring[e->rpos[stream] % e->nring] + (size_t)stream * fb;  // history classes: straight into their ring slot
+  if (in_step == rb && host_pin(e, stream, 0, in, fb, ln.hs)) {
+    HIP_TRY(hipMemcpyAsync(dst, in, fb, hipMemcpyHostToDevice, ln.hs));
+  } else {
+    const int bands = rows >= 64 ? 8 : 1;  // the CPU stages band k+1 while the DMA engine moves band k
+    for (int b = 0; b < bands; ++b) {
+      const int y0 = (int)((int64_t)rows * b / bands), y1 = (int)((int64_t)rows * (b + 1) / bands);
+      for (int y = y0; y < y1; ++y) std::memcpy(ln.h_in + (size_t)y * rb, in + (size_t)y * in_step, rb);
+      HIP_TRY(hipMemcpyAsync(dst + (size_t)y0 * rb, ln.h_in + (size_t)y0 * rb, (size_t)(y1 - y0) * rb, hipMemcpyHostToDevice, ln.hs));
+    }
+  }
+  uint32_t flags = 0;
+  const bool saved_borrow = e->borrow;
+  e->borrow = false;
+  if (e->last_fg_stream == stream) e->last_fg_stream = -1;  // bgs_last_mask_blobs serves the synchronous call's mask
+  rc = process_range(e, stream, 1, dst, ln.d_fg, bg ? ln.d_bg : nullptr, nullptr, ln.hs, &flags);
+  e->borrow = saved_borrow;
+  if (rc) return rc;
+  ln.flags = flags, ln.fg = fg, ln.bg = bg, ln.fg_step = fg_step, ln.bg_step = bg_step;
+  ln.fg_direct = fg && (flags & BGS_FG_VALID) && fg_step == (size_t)cols && host_pin(e, stream, 1, fg, e->n, ln.hs);
+  ln.bg_direct = bg && (flags & BGS_BG_VALID) && bg_step == (size_t)cols * bg_ch && host_pin(e, stream, 2, bg, e->n * bg_ch, ln.hs);
+  if (fg && (flags & BGS_FG_VALID)) HIP_TRY(hipMemcpyAsync(ln.fg_direct ? fg : ln.h_fg, ln.d_fg, e->n, hipMemcpyDeviceToHost, ln.hs));
+  if (bg && (flags & BGS_BG_VALID)) HIP_TRY(hipMemcpyAsync(ln.bg_direct ? bg : ln.h_bg, ln.d_bg, e->n * bg_ch, hipMemcpyDeviceToHost, ln.hs));
+  HIP_TRY(hipEventRecord(ln.done, ln.hs));
+  ln.pending = true;
+  return BGS_OK;
+}
+
+int bgs_wait(bgs_engine* e, int stream, uint32_t* out_flags) {
+  if (out_flags) *out_flags = 0;
+  if (!e) return fail(BGS_ERR_INVALID, "engine is NULL");
+  if (stream < 0 || stream >= e->S) return fail(BGS_ERR_INVALID, "stream %d outside 0..%d", stream, e->S - 1);
+  return lane_wait(e, stream, out_flags);
 }
 
 int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, size_t cap) {

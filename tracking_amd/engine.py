@@ -96,6 +96,18 @@ class Engine:
                                           bg.ctypes.data_as(C.c_void_p) if bg is not None else None, bg.strides[0] if bg is not None else 0, C.byref(flags)))
         return flags.value
 
+    def submit(self, frame, fg, bg=None, stream=0):
+        """bgs_submit: queue one frame of `stream` (caller-owned contiguous arrays, valid until wait())."""
+        rows, cols = frame.shape[:2]
+        ch = 1 if frame.ndim == 2 else frame.shape[2]
+        capi.check(capi.lib().bgs_submit(self._h, stream, frame.ctypes.data_as(C.c_void_p), rows, cols, ch, frame.strides[0], fg.ctypes.data_as(C.c_void_p), fg.strides[0],
+                                         bg.ctypes.data_as(C.c_void_p) if bg is not None else None, bg.strides[0] if bg is not None else 0))
+
+    def wait(self, stream=0):
+        flags = C.c_uint32(0)
+        capi.check(capi.lib().bgs_wait(self._h, stream, C.byref(flags)))
+        return flags.value
+
     def process_mask_only_on_device(self, frame, stream=0):
         """bgs_process with fg = bg = NULL: the mask stays on the device (for last_mask_blobs).  Returns the out_flags."""
         rows, cols = frame.shape[:2]
