@@ -289,6 +289,26 @@ def test_asbl_ragged_sizes(shape):
     run_pair(capi.ASBL, frames, params=_params(capi.ASBL, learning_frames=2))
 
 
+@pytest.mark.parametrize("shape,ch", [((40, 300), 3), ((9, 260), 3), ((70, 516), 3), ((33, 256), 3), ((20, 4), 3), ((41, 520), 1), ((2, 8), 1)])
+def test_asbl_strip_geometries(shape, ch):
+    """Rows of 4n pixels take the wave-per-strip table kernel (kernel_stencil.h: strips of 256 columns, a partial last strip, strips
+    that end at the image border, fewer rows than a strip is tall); both phases, and a change of both alphas mid-run (the two tables
+    are rebuilt)."""
+    frames = synth.random_frames(10, shape[0], shape[1], ch, seed=shape[1])
+    p = _params(capi.ASBL, learning_frames=4, threshold=12)
+    eng = Engine(capi.ASBL, params=p)
+    orc = pyoracle.Oracle(capi.ASBL, params=p)
+    for t, f in enumerate(frames):
+        if t == 6:
+            p = _params(capi.ASBL, learning_frames=4, threshold=12, alpha_learn=0.2, alpha_detection=0.4)
+            eng.set_params(p), orc.set_params(p)
+        fg, bg = eng.process(f)
+        ofg, obg = orc.process(f)
+        assert np.array_equal(fg, ofg), "frame %d: %d mask pixels differ" % (t, int((fg != ofg).sum()))
+        assert np.array_equal(bg, obg), "frame %d: %d background bytes differ" % (t, int((bg != obg).sum()))
+    eng.close()
+
+
 # ----------------------------------------------------------------------------- LBSP descriptors (pinned by the reference's own code)
 
 

@@ -459,6 +459,9 @@ def main():
         run(capi.FRAME_DIFF, "FrameDifferenceBGS", 2160, 3840, S, 7, cpu_frames=0)
         run(capi.SIGMA_DELTA, "SigmaDeltaBGS", 2160, 3840, S, 16, borrow=False, cpu_frames=0)
         run(capi.ASBL, "AdaptiveSelectiveBackgroundLearning", 2160, 3840, S, 6, borrow=False, cpu_frames=0)
+        det = capi.default_params(capi.ASBL)
+        det.learning_frames = 4
+        run(capi.ASBL, "ASBL (detection phase)", 2160, 3840, S, 6, borrow=False, cpu_frames=0, params=det)
         return
     if args.only in ("clip8sat", "clip8surv"):  # one short leg, for counter passes
         run_clip(kind=args.only[5:], steps=6, Ts=(8,))
@@ -509,6 +512,12 @@ def main():
         run_subsense(8, groups=2)
         run_subsense(8, groups=4)
         run_subsense(8, kind="smooth", groups=2)
+        return
+    if args.only == "subsense8agedx2":  # aged model: phase B (sample writes, HBM-bound) of one range beside phase A (VALU-bound) of the other
+        run_subsense(8, warm=300)
+        run_subsense(8, warm=300, groups=2)
+        run_subsense(8, warm=300, groups=4)
+        run_subsense(8, warm=300, groups=8)
         return
     if args.only == "subsense8aged":  # the model after 300 frames: update rates have settled, far fewer sample writes per frame
         run_subsense(8, warm=300)

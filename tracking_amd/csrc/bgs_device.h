@@ -20,6 +20,12 @@ __device__ __forceinline__ float div_rn(float a, float b) { return a / b; }
 
 // cv::cvtColor(CV_BGR2GRAY) on 8U: fixed point, shift 14
 __device__ __forceinline__ int gray_bgr(int b, int g, int r) { return (b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14; }
+// the same value from a dword whose bytes 0..2 are B, G, R (byte 3 is ignored): the three weights split into low and high bytes,
+// two v_dot4_u32_u8 (1868 = 0x074C, 9617 = 0x2591, 4899 = 0x1323)
+__device__ __forceinline__ uint32_t gray_bgr_dword(uint32_t px) {
+  const uint32_t lo = __builtin_amdgcn_udot4(px, 0x0023914Cu, 1u << 13, false), hi = __builtin_amdgcn_udot4(px, 0x00132507u, 0u, false);
+  return ((hi << 8) + lo) >> 14;
+}
 
 // cv::saturate_cast<uchar>(float): cvRound (half-to-even) then clamp
 __device__ __forceinline__ int sat_u8(float v) {

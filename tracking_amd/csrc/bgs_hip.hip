@@ -81,7 +81,8 @@ struct bgs_engine {
   uint8_t* bgstate = nullptr;
   int state_ch = 0;
   uint8_t* abl_lut = nullptr;   // ABL: 256 x 256 table of background bytes for the current alpha (kernel_pointwise.h)
-  double abl_lut_alpha = 0;     // the alpha it was built for
+  double abl_lut_alpha = 0;     // the alpha it was built for (ASBL: two tables of 257 rows, learning then detection phase)
+  double asbl_lut_alpha[2] = {0, 0};
   bool abl_lut_valid = false;
   int n_cu = 256;
   uint8_t* bgstate2 = nullptr;  // ASBL: second buffer of the ping-pong pair (the 3x3 median reads neighbours' OLD background)
@@ -461,6 +462,20 @@ int abl_build_lut(bgs_engine* e) {
   return BGS_OK;
 }
 
+// ASBL's two tables (learning / detection phase), same rules
+int asbl_build_lut(bgs_engine* e) {
+  const size_t one = (size_t)bgs::kAsblLutRows * 256;
+  if (!e->abl_lut) HIP_TRY(hipMalloc((void**)&e->abl_lut, 2 * one));
+  const bgs_params& p = e->p;
+  for (int learn = 1; learn >= 0; --learn)
+    hipLaunchKernelGGL(bgs::asbl_lut_kernel, dim3(bgs::kAsblLutRows), dim3(bgs::kBlock), 0, e->stream, e->abl_lut + (learn ? 0 : one), learn, p.alpha_learn, 1 - p.alpha_learn,
+                       p.alpha_detection, 1 - p.alpha_detection);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->asbl_lut_alpha[0] = p.alpha_learn, e->asbl_lut_alpha[1] = p.alpha_detection, e->abl_lut_valid = true;
+  return BGS_OK;
+}
+
 int allocate(bgs_engine* e, int rows, int cols, int ch) {
   if (rows <= 0 || cols <= 0) return fail(BGS_ERR_INVALID, "bad geometry %dx%d", rows, cols);
   if (ch != 1 && ch != 3) return fail(BGS_ERR_UNSUPPORTED, "channels must be 1 or 3, got %d", ch);
@@ -501,7 +516,13 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
     int rc = abl_build_lut(e);
     if (rc) return rc;
   }
-  if (e->algo == BGS_ASBL) DMALLOC(e->bgstate2, P);
+  if (e->algo == BGS_ASBL) {
+    DMALLOC(e->bgstate2, P);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, e->device) == hipSuccess && prop.multiProcessorCount > 0) e->n_cu = prop.multiProcessorCount;
+    int rc = asbl_build_lut(e);
+    if (rc) return rc;
+  }
   if (e->algo == BGS_SIGMA_DELTA) DMALLOC(e->bgstate2, P * 3);  // Vt
   if (e->algo == BGS_GMG) {
     const size_t F = (size_t)e->p.gmg_max_features;
@@ -868,11 +889,30 @@ int process_run(bgs_engine* e, int first, int count, const uint8_t* d_frames, ui
       q.aL = p.alpha_learn, q.bL = 1 - p.alpha_learn, q.aD = p.alpha_detection, q.bD = 1 - p.alpha_detection;
       {
         Timed tm(e, s, "asbl_kernel");
-        const dim3 grid((e->cols + bgs::kAsblTW - 1) / bgs::kAsblTW, (e->rows + bgs::kAsblTH - 1) / bgs::kAsblTH, count);
-        if (C == 3)
-          hipLaunchKernelGGL((bgs::asbl_kernel<3>), grid, dim3(bgs::kBlock), 0, s, q);
-        else
-          hipLaunchKernelGGL((bgs::asbl_kernel<1>), grid, dim3(bgs::kBlock), 0, s, q);
+        static const bool table = !(getenv("BGS_ASBL_TABLE") && atoi(getenv("BGS_ASBL_TABLE")) == 0);
+        const uintptr_t ptrs = (uintptr_t)q.frame | (uintptr_t)q.bg_in | (uintptr_t)q.bg_out | (uintptr_t)q.fg | (uintptr_t)q.bg_img;
+        // the table kernel moves whole dwords: rows of 4n pixels, aligned images (also the stream offset inside them: n % 4 == 0 then)
+        if (table && e->cols % 4 == 0 && e->cols >= 4 && ptrs % 4 == 0) {
+          // one wave per strip of 256 columns x R rows; 2 resident workgroups of 16 waves per CU (67 KB of LDS each): R such that the
+          // strips of this launch fill them once, at least 8 rows (each strip re-reads the rows above and below it)
+          const size_t waves = (size_t)2 * e->n_cu * (bgs::kAsbl2Block / bgs::kWave), nsx = (e->cols + bgs::kAsblSW - 1) / bgs::kAsblSW;
+          const size_t blocks_y = std::max<size_t>(1, waves / ((size_t)count * nsx));
+          const int R = (int)std::max<size_t>(8, (e->rows + blocks_y - 1) / blocks_y);
+          const size_t nstrips = (size_t)count * nsx * ((e->rows + R - 1) / R), per_wg = bgs::kAsbl2Block / bgs::kWave;
+          if (nstrips >= (1u << 31)) return fail(BGS_ERR_UNSUPPORTED, "AdaptiveSelectiveBackgroundLearning: launch too large");
+          const dim3 grid((unsigned)std::min<size_t>((nstrips + per_wg - 1) / per_wg, (size_t)2 * e->n_cu));
+          const uint8_t* lut = e->abl_lut + (q.learn ? 0 : (size_t)bgs::kAsblLutRows * 256);
+          if (C == 3)
+            hipLaunchKernelGGL((bgs::asbl_stream_kernel<3>), grid, dim3(bgs::kAsbl2Block), 0, s, q, lut, count, R);
+          else
+            hipLaunchKernelGGL((bgs::asbl_stream_kernel<1>), grid, dim3(bgs::kAsbl2Block), 0, s, q, lut, count, R);
+        } else {
+          const dim3 grid((e->cols + bgs::kAsblTW - 1) / bgs::kAsblTW, (e->rows + bgs::kAsblTH - 1) / bgs::kAsblTH, count);
+          if (C == 3)
+            hipLaunchKernelGGL((bgs::asbl_kernel<3>), grid, dim3(bgs::kBlock), 0, s, q);
+          else
+            hipLaunchKernelGGL((bgs::asbl_kernel<1>), grid, dim3(bgs::kBlock), 0, s, q);
+        }
       }
       if (d_bits) {
         if (!d_fg) return fail(BGS_ERR_UNSUPPORTED, "AdaptiveSelectiveBackgroundLearning: the packed mask is made from the byte mask, pass d_fg too");
@@ -1283,6 +1323,11 @@ int bgs_set_params(bgs_engine* e, const bgs_params* params) {
       p.dp_sampling_rate = old.dp_sampling_rate, p.learning_frames = old.learning_frames;
     }
     if (e->algo == BGS_GMG) p.gmg_max_features = old.gmg_max_features;  // sizes the histogram planes
+    if (e->algo == BGS_ASBL && (!e->abl_lut_valid || p.alpha_learn != e->asbl_lut_alpha[0] || p.alpha_detection != e->asbl_lut_alpha[1])) {
+      if (hipSetDevice(e->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(BGS_ERR_HIP, "device sync failed");
+      rc = asbl_build_lut(e);
+      if (rc) return rc;
+    }
     if (e->algo == BGS_ABL && (!e->abl_lut_valid || p.alpha != e->abl_lut_alpha)) {
       // a launch still in flight on some stream may be reading the table: let the device drain before it is rewritten
       if (hipSetDevice(e->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(BGS_ERR_HIP, "device sync failed");

@@ -61,7 +61,14 @@ __device__ __forceinline__ void gray_thr_store_to(const PxGroup<G, C>& d, int th
   uint32_t bits = 0;
 #pragma unroll
   for (int j = 0; j < G; ++j) {
-    const int g = (C == 3) ? gray_bgr(d.b.get(3 * j), d.b.get(3 * j + 1), d.b.get(3 * j + 2)) : d.b.get(j);
+    int g;
+    if constexpr (C == 3 && G % 4 == 0) {  // four BGR pixels = three dwords: each pixel's bytes brought to bits 0..23 (gray_bgr_dword)
+      const uint32_t w0 = d.b.w[j / 4 * 3], w1 = d.b.w[j / 4 * 3 + 1], w2 = d.b.w[j / 4 * 3 + 2];
+      const uint32_t px = j % 4 == 0 ? w0 : j % 4 == 1 ? __builtin_amdgcn_alignbyte(w1, w0, 3) : j % 4 == 2 ? __builtin_amdgcn_alignbyte(w2, w1, 2) : w2 >> 8;
+      g = (int)gray_bgr_dword(px);
+    } else {
+      g = (C == 3) ? gray_bgr(d.b.get(3 * j), d.b.get(3 * j + 1), d.b.get(3 * j + 2)) : d.b.get(j);
+    }
     const int v = thr_bin(g, thr, enable_thr);
     m.b.set(j, v);
     bits |= (uint32_t)(v != 0) << j;

@@ -12,6 +12,7 @@
 // halo is loaded once into LDS with coalesced dword loads, every output is then computed from LDS.
 #pragma once
 #include "bgs_device.h"
+#include "kernel_pointwise.h"
 
 namespace bgs {
 
@@ -42,6 +43,14 @@ __device__ __forceinline__ int asbl_raw(int gray, int bg8, int thr, float& i_f, 
   i_f = (float)gray * sf, b_f = (float)bg8 * sf;
   // saturate(|i/255 - b/255| * 255) == |i - b| for every byte pair (CPU test test_unit_absdiff_is_integer_absdiff)
   return abs(gray - bg8) > thr ? 1 : 0;
+}
+
+// the background update of one pixel, :69 / :83-86 (m = the pixel's mask value after the median); a foreground pixel of the detection
+// phase keeps its value
+__device__ __forceinline__ float asbl_update(float i_f, float b_f, int learn, int m, double aL, double bL, double aD, double bD) {
+  if (learn) return add_weighted(i_f, aL, b_f, bL);                                              // :69  (MatExpr -> addWeighted)
+  if (m == 0) return (float)__dadd_rn(__dmul_rn(aD, (double)i_f), __dmul_rn(bD, (double)b_f));  // :83-86 scalar double expression
+  return b_f;
 }
 
 // One workgroup = 64 x 16 pixels.  Stage 1: every lane computes the thresholded difference of its 4 pixels (dword loads
@@ -113,11 +122,7 @@ __global__ __launch_bounds__(kBlock) void asbl_kernel(const AsblArgs a) {
 #pragma unroll
   for (int o = 0; o < 4; ++o) {
     const int m = ((cnt4 >> (8 * o)) & 0xffu) >= 5 ? 255 : 0;
-    float bf = b_f[o];
-    if (a.learn)
-      bf = add_weighted(i_f[o], a.aL, bf, a.bL);  // :69  (MatExpr -> addWeighted)
-    else if (m == 0)
-      bf = (float)__dadd_rn(__dmul_rn(a.aD, (double)i_f[o]), __dmul_rn(a.bD, (double)bf));  // :83-86 scalar double expression
+    const float bf = asbl_update(i_f[o], b_f[o], a.learn, m, a.aL, a.bL, a.aD, a.bD);
     out_b |= (uint32_t)sat_u8(bf * 255.f) << (8 * o);  // :92-94
     out_m |= (uint32_t)m << (8 * o);
   }
@@ -137,6 +142,159 @@ __global__ __launch_bounds__(kBlock) void asbl_kernel(const AsblArgs a) {
       a.bg_out[p + o] = (uint8_t)(out_b >> (8 * o));
       if (a.bg_img) a.bg_img[p + o] = (uint8_t)(out_b >> (8 * o));
       if (a.fg) a.fg[p + o] = (uint8_t)(out_m >> (8 * o));
+    }
+  }
+}
+
+// ---- round 3: the update through a table, 1024-lane persistent workgroups (the form abl_kernel took in round 2).
+// asbl_kernel above issues 56 vector instructions per pixel, most of them the float / double round trip of the background update
+// (profiles/r02_byte_kernels_pmc.txt: 58 M wave-instructions per 8 x 4K launch = ~95 of its 133 us).  The updated byte is a pure
+// function of (gray, background byte) for a fixed alpha and phase, so asbl_lut_kernel tabulates it with exactly the statements of
+// asbl_kernel: rows 0..255 = background byte, column = gray value; row 256 = the byte a detection-phase FOREGROUND pixel keeps
+// (its background only makes the float round trip of :92-94).  The gray conversion is two v_dot4_u32_u8 per pixel.
+constexpr int kAsblLutRows = 257;
+constexpr int kAsblSW = 256, kAsbl2Block = 1024;  // a wave's strip: 64 lanes x 4 consecutive pixels
+
+// lut[b * 256 + g]; grid 257 x block 256
+__global__ __launch_bounds__(kBlock) void asbl_lut_kernel(uint8_t* lut, int learn, double aL, double bL, double aD, double bD) {
+  const int g = threadIdx.x, b = blockIdx.x;
+  float i_f, b_f;
+  if (b == 256) {
+    asbl_raw(0, g, 0, i_f, b_f);
+    lut[256 * 256 + g] = (uint8_t)sat_u8(asbl_update(i_f, b_f, learn, 255, aL, bL, aD, bD) * 255.f);
+    return;
+  }
+  asbl_raw(g, b, 0, i_f, b_f);
+  lut[b * 256 + g] = (uint8_t)sat_u8(asbl_update(i_f, b_f, learn, 0, aL, bL, aD, bD) * 255.f);
+}
+
+// The frame is cut into strips of 256 columns x R rows, one WAVE per strip: a lane owns 4 consecutive pixels (one dword of gray,
+// background, mask) and walks down the rows with the thresholded differences of the row above, its own and the row below in
+// registers; the 3x3 majority is a byte-wise sum of those three dwords plus the two neighbouring lanes' sums (DPP wave shifts), the
+// columns left and right of the strip come from one extra pixel per row loaded by lanes 0 and 63.  No LDS besides the table, no
+// barrier after it is loaded; the rows two and three ahead are in flight while a row is worked on.
+// Requires cols % 4 == 0, cols >= 4, every image pointer 4-byte aligned (the host launches asbl_kernel otherwise).
+template <int C>
+struct AsblQuad {
+  uint32_t w[C == 3 ? 3 : 1];  // the 4 pixels' frame bytes as they lie in memory
+  uint32_t b;                  // their background bytes
+  uint32_t hw, hb;             // lanes 0 / 63: the dword of frame / background bytes that holds the column beside the strip
+};
+
+// Row y of a strip: the lane's quad at column x, and for the strip's side columns the quad at hx (dword hk of its frame bytes).
+// Coordinates are clamped into the image (BORDER_REPLICATE) - always the same loads, none in a divergent branch, so none is
+// waited for before it is needed.
+template <int C>
+__device__ __forceinline__ AsblQuad<C> asbl_fetch(const AsblArgs& a, size_t img, int x, int hx, int hk, int y) {
+  AsblQuad<C> q;
+  const size_t row = img + (size_t)min(max(y, 0), a.rows - 1) * a.cols;
+  const size_t p = row + min(max(x, 0), a.cols - 4), hp = row + hx;
+  q.b = *reinterpret_cast<const uint32_t*>(a.bg_in + p);
+  const uint32_t* fp = reinterpret_cast<const uint32_t*>(a.frame + p * C);
+#pragma unroll
+  for (int k = 0; k < (C == 3 ? 3 : 1); ++k) q.w[k] = fp[k];
+  q.hb = *reinterpret_cast<const uint32_t*>(a.bg_in + hp);
+  q.hw = reinterpret_cast<const uint32_t*>(a.frame + hp * C)[hk];
+  return q;
+}
+
+template <int C>
+__device__ __forceinline__ uint32_t asbl_gray4(const AsblQuad<C>& q) {
+  if constexpr (C == 3)
+    return gray_bgr_dword(q.w[0]) | (gray_bgr_dword(__builtin_amdgcn_alignbyte(q.w[1], q.w[0], 3)) << 8) | (gray_bgr_dword(__builtin_amdgcn_alignbyte(q.w[2], q.w[1], 2)) << 16) |
+           (gray_bgr_dword(q.w[2] >> 8) << 24);
+  else
+    return q.w[0];
+}
+
+// bytes of 0 / 1: |gray - background| > thr for the 4 pixels
+__device__ __forceinline__ uint32_t asbl_raw4(uint32_t g4, uint32_t b4, int thr) {
+  uint32_t packed = 0;
+#pragma unroll
+  for (int o = 0; o < 4; ++o) packed |= (uint32_t)(abs((int)((g4 >> (8 * o)) & 0xffu) - (int)((b4 >> (8 * o)) & 0xffu)) > thr) << (8 * o);
+  return packed;
+}
+
+template <int C>
+__global__ __launch_bounds__(kAsbl2Block) void asbl_stream_kernel(const AsblArgs a, const uint8_t* __restrict__ lut, int nimg, int R) {
+  __shared__ uint8_t T[kAsblLutRows * kAblLutStride];
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(lut);
+    for (int i = threadIdx.x; i < kAsblLutRows * 16; i += kAsbl2Block) {
+      const uint4 v = src[i];
+      uint32_t* dst = reinterpret_cast<uint32_t*>(T + (i >> 4) * kAblLutStride + (i & 15) * 16);
+      dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t nsx = (a.cols + kAsblSW - 1) / kAsblSW, nby = (a.rows + R - 1) / R;
+  const uint32_t per_img = nsx * nby, nstrips = (uint32_t)nimg * per_img;
+  const uint32_t nwaves = gridDim.x * (kAsbl2Block / kWave);
+  const size_t img_px = (size_t)a.rows * a.cols;
+  for (uint32_t strip = blockIdx.x * (kAsbl2Block / kWave) + threadIdx.x / kWave; strip < nstrips; strip += nwaves) {
+    const uint32_t im = strip / per_img, rem = strip % per_img;
+    const int x0 = (int)(rem % nsx) * kAsblSW, y0 = (int)(rem / nsx) * R, y1 = min(y0 + R, a.rows);
+    const int x = x0 + 4 * lane;
+    const size_t img = im * img_px;
+    // the column beside the strip (lanes 0..31: left, 32..63: right): the quad that holds it, which of its pixels it is (first / last),
+    // replicated from the image's own first / last column at the image border
+    const bool hlast = lane < 32 ? x0 > 0 : x0 + kAsblSW >= a.cols;
+    const int hx = lane < 32 ? max(x0 - 4, 0) : min(x0 + kAsblSW, a.cols - 4);
+    const int hk = (C == 3 && hlast) ? 2 : 0;
+    auto side_raw = [&](const AsblQuad<C>& q) -> uint32_t {  // 0 / 1 for that one pixel
+      uint32_t g;
+      if constexpr (C == 3)
+        g = gray_bgr_dword(hlast ? q.hw >> 8 : q.hw);
+      else
+        g = hlast ? q.hw >> 24 : q.hw & 0xffu;
+      const uint32_t b = hlast ? q.hb >> 24 : q.hb & 0xffu;
+      return (uint32_t)(abs((int)g - (int)b) > a.thr);
+    };
+    auto main_raw = [&](uint32_t g4, uint32_t b4) -> uint32_t {
+      uint32_t r = asbl_raw4(g4, b4, a.thr);
+      if (x >= a.cols) r >>= 24;  // a quad right of the image was loaded from the row's last quad: its neighbour reads byte 0 = the border pixel
+      return r;
+    };
+    AsblQuad<C> q = asbl_fetch<C>(a, img, x, hx, hk, y0 - 1);
+    uint32_t rp = main_raw(asbl_gray4<C>(q), q.b), hp = side_raw(q);
+    q = asbl_fetch<C>(a, img, x, hx, hk, y0);
+    uint32_t gc = asbl_gray4<C>(q), bc = q.b;
+    uint32_t rc = main_raw(gc, bc), hc = side_raw(q);
+    AsblQuad<C> qa = asbl_fetch<C>(a, img, x, hx, hk, y0 + 1), qb = asbl_fetch<C>(a, img, x, hx, hk, y0 + 2);
+    // one output row; qn holds row y + 1 on entry and is refilled IN PLACE with row y + 3 (two register sets used in turn, below: a
+    // rotation qa = qb would copy registers a load has just been issued for, and the copy waits for the load)
+    auto row = [&](int y, AsblQuad<C>& qn) {
+      const uint32_t gn = asbl_gray4<C>(qn), bn = qn.b;
+      const uint32_t rn = main_raw(gn, bn), hn = side_raw(qn);
+      qn = asbl_fetch<C>(a, img, x, hx, hk, y + 3);
+      // cv::medianBlur(k=3) of a {0,255} image = majority of the 9 cells: column sums of the three rows (bytes <= 3), then the three columns
+      const uint32_t s = rp + rc + rn, hs = hp + hc + hn;
+      uint32_t left = __builtin_amdgcn_update_dpp(0u, s, 0x138, 0xf, 0xf, true) >> 24;  // wave_shr:1 = lane - 1's sums, its last column
+      uint32_t right = __builtin_amdgcn_update_dpp(0u, s, 0x130, 0xf, 0xf, true) & 0xffu;  // wave_shl:1 = lane + 1's first column
+      if (lane == 0) left = hs;
+      if (lane == 63) right = hs;
+      const uint32_t cnt4 = s + ((s << 8) | left) + ((s >> 8) | (right << 24));  // per byte: c[o-1] + c[o] + c[o+1] (<= 9)
+      if (x < a.cols) {
+        uint32_t out_b = 0, out_m = 0;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          const int m = ((cnt4 >> (8 * o)) & 0xffu) >= 5 ? 255 : 0;
+          const int g = (gc >> (8 * o)) & 0xffu, b = (bc >> (8 * o)) & 0xffu;
+          const int idx = (m != 0 && !a.learn) ? 256 * kAblLutStride + b : b * kAblLutStride + g;
+          out_b |= (uint32_t)T[idx] << (8 * o);
+          out_m |= (uint32_t)m << (8 * o);
+        }
+        const size_t p = img + (size_t)y * a.cols + x;
+        *reinterpret_cast<uint32_t*>(a.bg_out + p) = out_b;
+        if (a.bg_img) *reinterpret_cast<uint32_t*>(a.bg_img + p) = out_b;
+        if (a.fg) *reinterpret_cast<uint32_t*>(a.fg + p) = out_m;
+      }
+      rp = rc, rc = rn, hp = hc, hc = hn, gc = gn, bc = bn;
+    };
+    for (int y = y0; y < y1; y += 2) {
+      row(y, qa);
+      if (y + 1 < y1) row(y + 1, qb);
     }
   }
 }

@@ -729,7 +729,20 @@ __global__ __launch_bounds__(kBlock) void ss_phase_b_kernel(const SsArgs a) {
 #pragma unroll
     for (int c = 0; c < C; ++c) col[c] = lc[ly][lx][c], dsc[c] = ld[ly][lx][c];
     const size_t p = (size_t)(y0 + tly - 2) * a.cols + (size_t)(x0 + tlx - 2);
+#ifdef BGS_SS_B_NT
+    {
+      const SsSample<C> smp = SsSample<C>::make(col, dsc);
+      if constexpr (C == 3) {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        u4 vv = {smp.v.x, smp.v.y, smp.v.z, smp.v.w};
+        __builtin_nontemporal_store(vv, reinterpret_cast<u4*>(a.samples) + ss_rec(a, stream, N, p, (int)slot));
+      } else {
+        __builtin_nontemporal_store(smp.v, reinterpret_cast<uint32_t*>(a.samples) + ss_rec(a, stream, N, p, (int)slot));
+      }
+    }
+#else
     SsSample<C>::make(col, dsc).store(a.samples, ss_rec(a, stream, N, p, (int)slot));  // one 16-byte (4-byte) store per update
+#endif
   }
 }
 
