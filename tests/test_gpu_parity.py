@@ -480,12 +480,13 @@ def test_subsense_854x480_not_a_multiple_of_8():
     check_subsense_state(eng, orc, 480, 854)
 
 
-@pytest.mark.parametrize("shape", [(64, 64), (37, 53), (1, 1), (3, 200), (130, 257), (200, 70), (300, 520)])
+@pytest.mark.parametrize("shape", [(64, 64), (37, 53), (1, 1), (3, 200), (130, 257), (200, 70), (300, 520), (1100, 130), (2100, 70), (4200, 64)])
 def test_floodfill_from_origin_vs_oracle(shape):
     """cv::floodFill(mask, Point(0,0), 255): mazes with long snaking corridors, enclosed holes, origin on either value,
     sizes that are not multiples of the 64x64 bit-packed tile.  The serpentine walls make the fill cross tile borders far more
     often than the fixed batch of relaxation launches covers (kSsFloodBatch x kSsFloodRounds tile steps), so ss_flood_finish_kernel does the rest
-    (at 300x520: 45 tiles over the finish kernel's 16 waves)."""
+    (at 300x520: 45 tiles over the finish kernel's 16 waves).  Heights above 1024 give a strip workgroup's waves several tiles
+    each (ss_flood_strip_kernel), above 4096 rows the tile kernel runs instead."""
     torch = _torch()
     from tracking_amd.engine import mask_morph_device, MORPH_FLOODFILL_ORIGIN, MORPH_MEDIAN_BINARY
     rng = np.random.default_rng(shape[0] * 1000 + shape[1])

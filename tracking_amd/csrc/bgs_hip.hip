@@ -1829,8 +1829,7 @@ int bgs_mask_morph_device(int hip_device, const void* d_src, void* d_dst, int ro
     hipLaunchKernelGGL(bgs::ss_flood_pack_kernel, dim3(blocks_for((size_t)rows * W64 * bgs::kWave)), dim3(bgs::kBlock), 0, s, (const uint8_t*)d_src, mb, rb, rows, cols, W64);
     hipLaunchKernelGGL(bgs::ss_flood_seed_kernel, dim3(1), dim3(bgs::kBlock), 0, s, (const uint64_t*)mb, rb, rows, cols, W64);
     // the same host-free sequence as SuBSENSE's post-processing (engine_subsense.h): a fixed batch, then the finish kernel
-    for (int k = 0; k < bgs::kSsFloodBatch; ++k)
-      hipLaunchKernelGGL(bgs::ss_flood_kernel, dim3(blocks_for((size_t)tilesY * W64 * bgs::kWave)), dim3(bgs::kBlock), 0, s, (const uint64_t*)mb, rb, rows, W64, fl, k);
+    for (int k = 0; k < bgs::kSsFloodBatch; ++k) ss_launch_flood(dim3(blocks_for((size_t)tilesY * W64 * bgs::kWave)), 1, tilesY, s, mb, rb, rows, W64, fl, k);
     hipLaunchKernelGGL(bgs::ss_flood_finish_kernel, dim3(1), dim3(1024), 0, s, (const uint64_t*)mb, rb, rows, W64, fl, bgs::kSsFloodBatch);
     hipLaunchKernelGGL(bgs::ss_flood_paint_kernel, dim3(blocks_for((size_t)rows * cols)), dim3(bgs::kBlock), 0, s, (const uint8_t*)d_src, (const uint64_t*)rb, (uint8_t*)d_dst, rows, cols, W64);
     hipError_t er = hipStreamSynchronize(s);

@@ -131,6 +131,16 @@ void ss_initial_lut(const bgs_params& p, int channels, uint8_t lut[256]) {
 }
 
 // refreshModel (kernel_subsense.h): the full refresh of SuBSENSE's record layout takes the 16 pixels x 16 columns form
+// One relaxation launch of the flood fill (kernel_subsense.h): a workgroup per 64-pixel column strip for images up to 4096 rows,
+// a wave per 64x64 tile otherwise (BGS_SS_FLOOD_TILES=1 forces the latter: A/B and test knob).
+void ss_launch_flood(dim3 tile_grid, int count, int tilesY, hipStream_t s, const uint64_t* mbits, uint64_t* rbits, int rows, int W64, int* fl, int k) {
+  static const bool tiles_only = getenv("BGS_SS_FLOOD_TILES") && atoi(getenv("BGS_SS_FLOOD_TILES")) == 1;
+  if (tilesY <= 16 * bgs::kSsFloodKT && !tiles_only)
+    hipLaunchKernelGGL(bgs::ss_flood_strip_kernel, dim3(W64, count), dim3(1024), 0, s, mbits, rbits, rows, W64, fl, k);
+  else
+    hipLaunchKernelGGL(bgs::ss_flood_kernel, tile_grid, dim3(bgs::kBlock), 0, s, mbits, rbits, rows, W64, fl, k);
+}
+
 int ss_launch_refresh(bgs_engine* e, const bgs::SsArgs& a, size_t N, int count, int mode, hipStream_t s) {
   const bool fast = mode == 0 && a.pixelMajor && a.nS > bgs::kSsBatch;
   const dim3 grid(fast ? (unsigned)((N + 15) / 16) : blocks_for(N), 1, count), block(bgs::kBlock);
@@ -259,7 +269,7 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
   int* fl = d->flood_flags + (size_t)first * bgs::kSsFloodFlags;
   HIP_TRY(hipMemsetAsync(fl, 0, (size_t)count * bgs::kSsFloodFlags * sizeof(int), s));
   static const int batch = getenv("BGS_SS_FLOOD_BATCH") ? std::max(0, std::min(bgs::kSsFloodBatch, atoi(getenv("BGS_SS_FLOOD_BATCH")))) : bgs::kSsFloodBatch;  // test knob: 0/1 force the finish kernel to do the work
-  for (int k = 0; k < batch; ++k) hipLaunchKernelGGL(bgs::ss_flood_kernel, fgrid, block, 0, s, (const uint64_t*)mbits, rbits, e->rows, W64, fl, k);
+  for (int k = 0; k < batch; ++k) ss_launch_flood(fgrid, count, tilesY, s, mbits, rbits, e->rows, W64, fl, k);
   hipLaunchKernelGGL(bgs::ss_flood_finish_kernel, dim3(count), dim3(1024), 0, s, (const uint64_t*)mbits, rbits, e->rows, W64, fl, batch);
   // erode x3 :632 = one 7x7 box -> b_tmp;  :631-634 -> b_cur
   hipLaunchKernelGGL((bgs::ss_bits_box_kernel<0, 3>), wgrid, block, 0, s, (const uint64_t*)b_pre, b_tmp, e->rows, e->cols, W64, nwords);

@@ -729,20 +729,7 @@ __global__ __launch_bounds__(kBlock) void ss_phase_b_kernel(const SsArgs a) {
 #pragma unroll
     for (int c = 0; c < C; ++c) col[c] = lc[ly][lx][c], dsc[c] = ld[ly][lx][c];
     const size_t p = (size_t)(y0 + tly - 2) * a.cols + (size_t)(x0 + tlx - 2);
-#ifdef BGS_SS_B_NT
-    {
-      const SsSample<C> smp = SsSample<C>::make(col, dsc);
-      if constexpr (C == 3) {
-        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-        u4 vv = {smp.v.x, smp.v.y, smp.v.z, smp.v.w};
-        __builtin_nontemporal_store(vv, reinterpret_cast<u4*>(a.samples) + ss_rec(a, stream, N, p, (int)slot));
-      } else {
-        __builtin_nontemporal_store(smp.v, reinterpret_cast<uint32_t*>(a.samples) + ss_rec(a, stream, N, p, (int)slot));
-      }
-    }
-#else
     SsSample<C>::make(col, dsc).store(a.samples, ss_rec(a, stream, N, p, (int)slot));  // one 16-byte (4-byte) store per update
-#endif
   }
 }
 
@@ -891,6 +878,25 @@ __device__ __forceinline__ uint64_t ss_hfill(uint64_t r, uint64_t m) {
   return r | up | dn;
 }
 
+// The same along a column of the tile (lane = row): reached[y] = r[y] | (m[y] & reached[y -+ 1]) for all 64 bit columns at once, as
+// two log-step scans over the lanes with (G, P) = (reached, passable): a segment of rows hands down G | (P & G_above), P & P_above.
+// Round 2 walked one row per trip (up to 63 trips for an empty tile filled from its top edge); this is 6 + 6 steps.
+__device__ __forceinline__ uint64_t ss_shfl64(uint64_t v, int src_lane) {
+  return ((uint64_t)(uint32_t)__shfl((int)(v >> 32), src_lane, kWave) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src_lane, kWave);
+}
+__device__ __forceinline__ uint64_t ss_vfill(uint64_t r, uint64_t m, int lane) {
+  uint64_t gd = r & m, pd = m, gu = gd, pu = m;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const bool has_up = lane >= d, has_dn = lane + d < kWave;
+    const uint64_t gs = ss_shfl64(gd, lane - d), ps = ss_shfl64(pd, lane - d);  // (out-of-range source lanes wrap: masked by has_*)
+    const uint64_t gt = ss_shfl64(gu, lane + d), pt = ss_shfl64(pu, lane + d);
+    gd |= has_up ? (pd & gs) : 0, pd &= has_up ? ps : 0;
+    gu |= has_dn ? (pu & gt) : 0, pu &= has_dn ? pt : 0;
+  }
+  return gd | gu;
+}
+
 __global__ __launch_bounds__(kBlock) void ss_flood_pack_kernel(const uint8_t* mask, uint64_t* mbits, uint64_t* rbits, int rows, int cols, int W64) {
   // one wave per word: lane = pixel; padded pixels (x >= cols) are 0 in mbits
   const int img = blockIdx.z;
@@ -960,13 +966,8 @@ __device__ __forceinline__ bool ss_flood_tile(const uint64_t* mb, uint64_t* rb, 
   if (lane == 0 && y > 0 && in) vert = rd((size_t)(y - 1) * W64 + w);
   if (lane == 63 && y + 1 < rows) vert = rd((size_t)(y + 1) * W64 + w);
   uint64_t r = ss_hfill(r0 | ((side | vert) & m), m);
-  for (;;) {
-    const uint32_t lo = (uint32_t)r, hi = (uint32_t)(r >> 32);
-    uint64_t up = ((uint64_t)__shfl_up(hi, 1, kWave) << 32) | __shfl_up(lo, 1, kWave);
-    uint64_t dn = ((uint64_t)__shfl_down(hi, 1, kWave) << 32) | __shfl_down(lo, 1, kWave);
-    if (lane == 0) up = 0;
-    if (lane == 63) dn = 0;
-    const uint64_t rn = ss_hfill(r | ((up | dn) & m), m);
+  for (;;) {  // whole columns, then whole rows, until neither adds a pixel (the least fixed point, whatever the order of the steps)
+    const uint64_t rn = ss_hfill(ss_vfill(r, m, lane), m);
     const bool ch = rn != r;
     r = rn;
     if (!__any(ch)) break;
@@ -986,7 +987,7 @@ __device__ __forceinline__ bool ss_flood_tile(const uint64_t* mb, uint64_t* rb, 
 // launch k-1 changed nothing (the fill has converged: typical masks need 2-4 launches, the wavefront crosses up to kSsFloodRounds
 // tiles per launch from every side), and the finish kernel only works when the last batch launch still changed something - then ONE workgroup
 // per image keeps relaxing all tiles until nothing changes (slow, but any mask converges; spiral masks in the tests).
-constexpr int kSsFloodBatch = 8, kSsFloodRounds = 4;
+constexpr int kSsFloodBatch = 6, kSsFloodRounds = 10;
 constexpr int kSsFloodFlags = kSsFloodBatch + 1;  // per stream; the last one: "the finish kernel had to work" (diagnostics)
 
 __global__ __launch_bounds__(kBlock) void ss_flood_kernel(const uint64_t* mbits, uint64_t* rbits, int rows, int W64, int* flags, int k) {
@@ -1006,6 +1007,101 @@ __global__ __launch_bounds__(kBlock) void ss_flood_kernel(const uint64_t* mbits,
   for (int round = 0; round < kSsFloodRounds; ++round)
     grew |= ss_flood_tile<true>(mbits + base, rbits + base, rows, W64, (int)(tile / W64), (int)(tile % W64), lane);
   if (grew && lane == 0) fl[k] = 1;
+}
+
+// Round 3: one 1024-lane workgroup per COLUMN STRIP (64 pixels wide, the whole image height) instead of one wave per tile.  The
+// tiles of a strip (wave v owns tiles v, v + 16, ...; their rows stay in registers) hand their first / last rows to each other
+// through LDS, so the fill runs down or up a whole strip inside the launch at barrier speed; only the columns beside the strip
+// come from memory (the neighbouring strips' words, read past the L1).  A relaxation round of the tile kernel above cost a trip
+// to memory (its launches ran 40-70 us with ten rounds each, 170 us per frame for 8 x 1080p); here the ring-seeded fill of an
+// empty 1080p mask - the common case - is complete after the first pass over the strip.  Same flags, same finish kernel.
+constexpr int kSsFloodKT = 4;  // tiles per wave: images up to 16 * 4 * 64 = 4096 rows (taller ones take ss_flood_kernel)
+__global__ __launch_bounds__(1024) void ss_flood_strip_kernel(const uint64_t* mbits, uint64_t* rbits, int rows, int W64, int* flags, int k) {
+  int* fl = flags + (size_t)blockIdx.y * kSsFloodFlags;
+  if (k > 0 && fl[k - 1] == 0) return;  // converged in an earlier launch
+  __shared__ uint64_t top[16 * kSsFloodKT], bot[16 * kSsFloodKT];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, w = blockIdx.x;
+  const int tilesY = (rows + 63) / 64;
+  const size_t base = (size_t)blockIdx.y * rows * W64;
+  const uint64_t* mb = mbits + base;
+  uint64_t* rb = rbits + base;
+  auto rd = [&](size_t idx) -> uint64_t { return __hip_atomic_load(reinterpret_cast<unsigned long long*>(rb + idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  uint64_t m[kSsFloodKT], r[kSsFloodKT], stored[kSsFloodKT], side_seen[kSsFloodKT];
+#pragma unroll
+  for (int j = 0; j < kSsFloodKT; ++j) {
+    const int t = wave + 16 * j, y = t * 64 + lane;
+    const bool in = t < tilesY && y < rows;
+    m[j] = in ? mb[(size_t)y * W64 + w] : 0;
+    stored[j] = in ? rd((size_t)y * W64 + w) : 0;
+    r[j] = ss_hfill(stored[j], m[j]);
+    side_seen[j] = 0;
+  }
+  bool grew_any = false;
+  for (int round = 0; round < kSsFloodRounds; ++round) {
+    // the columns beside the strip as they stand in memory now
+    bool news = round == 0;
+#pragma unroll
+    for (int j = 0; j < kSsFloodKT; ++j) {
+      const int t = wave + 16 * j, y = t * 64 + lane;
+      uint64_t side = 0;
+      if (t < tilesY && y < rows) {
+        if (w > 0 && (rd((size_t)y * W64 + w - 1) >> 63)) side |= 1ull;
+        if (w < W64 - 1 && (rd((size_t)y * W64 + w + 1) & 1ull)) side |= 1ull << 63;
+      }
+      news |= side != side_seen[j];
+      side_seen[j] = side;
+      r[j] |= side & m[j];
+    }
+    if (!__syncthreads_or(news)) break;  // nothing new came in from the sides: whatever the neighbours still do is the next launch's business
+    unsigned dirty = (1u << kSsFloodKT) - 1;  // tiles that received pixels since they were last relaxed (wave-uniform)
+    for (;;) {  // the strip to its fixed point: tiles to theirs, first / last rows across tile borders through LDS
+      bool ch = false;
+#pragma unroll
+      for (int j = 0; j < kSsFloodKT; ++j) {
+        const int t = wave + 16 * j;
+        if (t < tilesY && ((dirty >> j) & 1u)) {  // (wave-uniform)
+          if (__all(m[j] == ~0ull) && __any(r[j] != 0)) {
+            r[j] = ~0ull;  // an empty 64 x 64 tile with a reached pixel anywhere: all of it (the common case, no scan needed)
+          } else {
+            for (;;) {
+              const uint64_t rn = ss_hfill(ss_vfill(r[j], m[j], lane), m[j]);
+              const bool c = rn != r[j];
+              r[j] = rn;
+              if (!__any(c)) break;
+            }
+          }
+          if (lane == 0) top[t] = r[j];
+          if (lane == 63) bot[t] = r[j];
+        }
+      }
+      dirty = 0;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < kSsFloodKT; ++j) {
+        const int t = wave + 16 * j;
+        if (t < tilesY) {
+          uint64_t v = 0;
+          if (lane == 0 && t > 0) v = bot[t - 1];
+          if (lane == 63 && t + 1 < tilesY) v = top[t + 1];
+          const uint64_t rn = r[j] | (v & m[j]);
+          if (__any(rn != r[j])) dirty |= 1u << j, ch = true;
+          r[j] = rn;
+        }
+      }
+      if (!__syncthreads_or(ch)) break;  // (also keeps the next trip's LDS writes behind this trip's reads)
+    }
+    bool grew = false;
+#pragma unroll
+    for (int j = 0; j < kSsFloodKT; ++j) {
+      const int t = wave + 16 * j, y = t * 64 + lane;
+      if (t < tilesY && y < rows && r[j] != stored[j]) {
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(rb + (size_t)y * W64 + w), r[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stored[j] = r[j], grew = true;
+      }
+    }
+    grew_any |= grew;
+  }
+  if (__syncthreads_or(grew_any) && threadIdx.x == 0) fl[k] = 1;
 }
 
 __global__ __launch_bounds__(1024) void ss_flood_finish_kernel(const uint64_t* mbits, uint64_t* rbits, int rows, int W64, int* flags, int batch) {
