@@ -519,6 +519,9 @@ def main():
         run_subsense(8, warm=300, groups=4)
         run_subsense(8, warm=300, groups=8)
         return
+    if args.only == "subsense8aged1":  # one leg, for counter passes
+        run_subsense(8, warm=300, steps=10)
+        return
     if args.only == "subsense8aged":  # the model after 300 frames: update rates have settled, far fewer sample writes per frame
         run_subsense(8, warm=300)
         run_subsense(8, kind="smooth", warm=300)

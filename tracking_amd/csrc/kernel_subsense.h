@@ -666,70 +666,131 @@ __global__ __launch_bounds__(kBlock) void lob_phase_a_kernel(const SsArgs a) {
 // a list in LDS, and one lane per list entry decides whether its request is the last one in that order for its (target, slot) - it
 // looks at the up to 50 requests that could aim at the same target - and if so performs the write.  Same result, the work follows
 // the number of requests instead of the number of pixels.
+// Round 3 (profiles/r03_subsense_phase_b_pmc.txt: 0.7 ms on the aged model, where half of the pixels make a request; only 0.5 + 0.5 GB
+// of HBM traffic, 400 lane-instructions per pixel, waves waiting 65 % of their cycles): the colour / descriptor of a source is loaded
+// by the lane that performs its write (one 4-byte and one 8-byte load) instead of being staged in LDS behind the request load it
+// depended on; list slots are handed out per wave (ballot + one LDS atomic) instead of per request; every target counts the requests
+// aimed at it while the list is built, and only the requests of targets with more than one - a quarter of them on the aged model -
+// go through the search for a later request to the same slot (a second, dense list); away from the image border that search tests
+// 25 instead of 50 requests (a source's self update aims at itself, its diffusion at one of the 24 pixels around it; the other
+// combinations only arise when a target is clamped into the image).
 constexpr int kSsBTH = 16;
+
+// is request `key` (slot `slot`, target (tly, tlx) of the halo'd tile) the last one in the reference's order for that target and slot?
+template <int HW, bool INTERIOR>
+__device__ __forceinline__ bool ss_req_is_last(const uint32_t (*rq)[HW], int tly, int tlx, uint32_t slot, int key) {
+  bool last = true;
+#pragma unroll
+  for (int dy = -2; dy <= 2; ++dy)
+#pragma unroll
+    for (int dx = -2; dx <= 2; ++dx) {
+      const int sy = tly + dy, sx = tlx + dx;  // inside the halo'd tile: the target is inside the tile
+      const uint32_t both = rq[sy][sx];
+      const uint32_t aimed = SS_REQ_VALID | (slot << 8) | (uint32_t)(12 - 5 * dy - dx);  // a request of (sy, sx) for this target and slot
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        if (INTERIOR && qq != ((dy == 0 && dx == 0) ? 0 : 1)) continue;
+        if (((both >> (16 * qq)) & (SS_REQ_VALID | 0x3f00u | 0x1fu)) == aimed && (sy * HW + sx) * 2 + qq > key) last = false;
+      }
+    }
+  return last;
+}
+
+// append to a list in LDS, one atomic per wave; every lane of the wave must make the call
+__device__ __forceinline__ void ss_list_push(uint32_t* list, unsigned* n, bool push, uint32_t value, int lane) {
+  const unsigned long long mask = __ballot(push);
+  if (mask) {  // (wave-uniform)
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(n, (unsigned)__popcll(mask));
+    base = (unsigned)__shfl((int)base, 0, kWave);
+    if (push) list[base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = value;
+  }
+}
 
 template <int C>
 __global__ __launch_bounds__(kBlock) void ss_phase_b_kernel(const SsArgs a) {
   constexpr int HW = kSsTW + 4, HH = kSsBTH + 4;
-  __shared__ uint32_t rq[HH][HW];     // both requests of a source pixel in one dword
-  __shared__ uint8_t lc[HH][HW][C];   // what a requesting source writes: its current colour / intra descriptor (phase A left
-  __shared__ uint16_t ld[HH][HW][C];  // them in lastColor / lastDesc)
-  __shared__ uint32_t list[HH * HW * 2];  // ly << 16 | lx << 8 | q of every request whose target is in this tile
-  __shared__ unsigned nlist;
+  static_assert(kSsTW * kSsBTH / 4 == kBlock, "one dword of target counters per lane");
+  __shared__ uint32_t rq[HH][HW];          // both requests of a source pixel in one dword
+  __shared__ uint32_t list[HH * HW * 2];   // ly << 16 | lx << 8 | q of every request whose target is in this tile
+  __shared__ uint32_t list2[HH * HW * 2];  // those whose target has other requests too
+  __shared__ uint32_t cnt[kBlock];         // requests aimed at each target of the tile, one byte each (<= 26)
+  __shared__ unsigned nlist, nlist2;
   const int stream = a.first + blockIdx.z;
   const size_t N = (size_t)a.rows * a.cols, sN = (size_t)stream * N;
   const int x0 = blockIdx.x * kSsTW, y0 = blockIdx.y * kSsBTH;
-  if (threadIdx.x == 0) nlist = 0;
+  const int lane = threadIdx.x & (kWave - 1);
+  if (threadIdx.x == 0) nlist = 0, nlist2 = 0;
+  cnt[threadIdx.x] = 0;
   __syncthreads();
-  for (int i = threadIdx.x; i < HH * HW; i += kBlock) {
+  for (int i0 = 0; i0 < HH * HW; i0 += kBlock) {  // (every lane makes every trip: the ballots see whole waves)
+    const int i = i0 + (int)threadIdx.x;
     const int ly = i / HW, lx = i - ly * HW;
     const int y = y0 + ly - 2, x = x0 + lx - 2;
     uint32_t v = 0;
-    if (y >= 2 && y < a.rows - 2 && x >= 2 && x < a.cols - 2) {
-      const size_t src = sN + (size_t)y * a.cols + x;
-      v = *reinterpret_cast<const uint32_t*>(a.req + src * 2);
-      if (v) {
+    if (i < HH * HW && y >= 2 && y < a.rows - 2 && x >= 2 && x < a.cols - 2) v = *reinterpret_cast<const uint32_t*>(a.req + (sN + (size_t)y * a.cols + x) * 2);
+    if (i < HH * HW) rq[ly][lx] = v;
 #pragma unroll
-        for (int c = 0; c < C; ++c) lc[ly][lx][c] = a.lastColor[src * C + c], ld[ly][lx][c] = a.lastDesc[src * C + c];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {  // self request first, then the neighbour request
-          const uint32_t r = (v >> (16 * q)) & 0xffffu;
-          if (!(r & SS_REQ_VALID)) continue;
-          const int code = (int)(r & 0x1fu), tly = ly + code / 5 - 2, tlx = lx + code % 5 - 2;  // code = (dy + 2) * 5 + (dx + 2) of the target
-          if (tly >= 2 && tly < 2 + kSsBTH && tlx >= 2 && tlx < 2 + kSsTW) list[atomicAdd(&nlist, 1u)] = ((uint32_t)ly << 16) | ((uint32_t)lx << 8) | (uint32_t)q;
-        }
+    for (int q = 0; q < 2; ++q) {  // self request first, then the neighbour request
+      const uint32_t r = (v >> (16 * q)) & 0xffffu;
+      const int code = (int)(r & 0x1fu), tly = ly + code / 5 - 2, tlx = lx + code % 5 - 2;  // code = (dy + 2) * 5 + (dx + 2) of the target
+      const bool push = (r & SS_REQ_VALID) && tly >= 2 && tly < 2 + kSsBTH && tlx >= 2 && tlx < 2 + kSsTW;
+      if (push) {
+        const int t = (tly - 2) * kSsTW + (tlx - 2);
+        atomicAdd(&cnt[t >> 2], 1u << (8 * (t & 3)));
       }
+      ss_list_push(list, &nlist, push, ((uint32_t)ly << 16) | ((uint32_t)lx << 8) | (uint32_t)q, lane);
     }
-    rq[ly][lx] = v;
   }
   __syncthreads();
+  auto write = [&](int ly, int lx, int tly, int tlx, uint32_t slot) {
+    // what a requesting source writes: its current colour / intra descriptor (phase A left them in lastColor / lastDesc)
+    const size_t src = sN + (size_t)(y0 + ly - 2) * a.cols + (size_t)(x0 + lx - 2);
+    int col[C];
+    unsigned dsc[C];
+    if constexpr (C == 3) {  // one 4-byte and one 8-byte load (no alignment needed; 8 spare bytes behind both maps: ss_refresh_one)
+      typedef uint32_t __attribute__((aligned(1))) u32u;
+      typedef uint64_t __attribute__((aligned(2))) u64u;
+      const uint32_t cw = *reinterpret_cast<const u32u*>(a.lastColor + src * 3);
+      const uint64_t dw = *reinterpret_cast<const u64u*>(a.lastDesc + src * 3);
+      col[0] = (int)(cw & 0xffu), col[1] = (int)((cw >> 8) & 0xffu), col[2] = (int)((cw >> 16) & 0xffu);
+      dsc[0] = (unsigned)(dw & 0xffffu), dsc[1] = (unsigned)((dw >> 16) & 0xffffu), dsc[2] = (unsigned)((dw >> 32) & 0xffffu);
+    } else {
+#pragma unroll
+      for (int c = 0; c < C; ++c) col[c] = a.lastColor[src * C + c], dsc[c] = a.lastDesc[src * C + c];
+    }
+    const size_t p = (size_t)(y0 + tly - 2) * a.cols + (size_t)(x0 + tlx - 2);
+    SsSample<C>::make(col, dsc).store(a.samples, ss_rec(a, stream, N, p, (int)slot));  // one 16-byte (4-byte) store per update
+  };
   const unsigned n = nlist;
-  for (unsigned e = threadIdx.x; e < n; e += kBlock) {
-    const uint32_t ent = list[e];
+  for (unsigned e0 = 0; e0 < n; e0 += kBlock) {  // the only request of its target: write; else: second list
+    const unsigned e = e0 + threadIdx.x;
+    bool contested = false;
+    uint32_t ent = 0;
+    if (e < n) {
+      ent = list[e];
+      const int ly = (int)(ent >> 16), lx = (int)((ent >> 8) & 0xffu), q = (int)(ent & 1u);
+      const uint32_t r = (rq[ly][lx] >> (16 * q)) & 0xffffu;
+      const int code = (int)(r & 0x1fu), tly = ly + code / 5 - 2, tlx = lx + code % 5 - 2;
+      const int t = (tly - 2) * kSsTW + (tlx - 2);
+      contested = ((cnt[t >> 2] >> (8 * (t & 3))) & 0xffu) > 1u;
+      if (!contested) write(ly, lx, tly, tlx, (r >> 8) & 0x3fu);
+    }
+    ss_list_push(list2, &nlist2, contested, ent, lane);
+  }
+  __syncthreads();
+  const unsigned n2 = nlist2;
+  // no source of this tile (+ halo) had a diffusion target clamped into the image: x +- 2, y +- 2 of every source lie in [2, cols - 3] x [2, rows - 3]
+  const bool interior = x0 - 4 >= 2 && x0 + kSsTW + 3 <= a.cols - 3 && y0 - 4 >= 2 && y0 + kSsBTH + 3 <= a.rows - 3;
+  for (unsigned e = threadIdx.x; e < n2; e += kBlock) {
+    const uint32_t ent = list2[e];
     const int ly = (int)(ent >> 16), lx = (int)((ent >> 8) & 0xffu), q = (int)(ent & 1u);
     const uint32_t r = (rq[ly][lx] >> (16 * q)) & 0xffffu;
     const int code = (int)(r & 0x1fu), tly = ly + code / 5 - 2, tlx = lx + code % 5 - 2;
     const uint32_t slot = (r >> 8) & 0x3fu;
     const int key = (ly * HW + lx) * 2 + q;  // position in the reference's order of writes
-    bool last = true;
-#pragma unroll
-    for (int dy = -2; dy <= 2; ++dy)
-#pragma unroll
-      for (int dx = -2; dx <= 2; ++dx) {
-        const int sy = tly + dy, sx = tlx + dx;  // inside the halo'd tile: the target is inside the tile
-        const uint32_t both = rq[sy][sx];
-        const uint32_t aimed = SS_REQ_VALID | (slot << 8) | (uint32_t)(12 - 5 * dy - dx);  // a request of (sy, sx) for this target and slot
-#pragma unroll
-        for (int qq = 0; qq < 2; ++qq)
-          if (((both >> (16 * qq)) & (SS_REQ_VALID | 0x3f00u | 0x1fu)) == aimed && (sy * HW + sx) * 2 + qq > key) last = false;
-      }
-    if (!last) continue;
-    int col[C];
-    unsigned dsc[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) col[c] = lc[ly][lx][c], dsc[c] = ld[ly][lx][c];
-    const size_t p = (size_t)(y0 + tly - 2) * a.cols + (size_t)(x0 + tlx - 2);
-    SsSample<C>::make(col, dsc).store(a.samples, ss_rec(a, stream, N, p, (int)slot));  // one 16-byte (4-byte) store per update
+    const bool last = interior ? ss_req_is_last<HW, true>(rq, tly, tlx, slot, key) : ss_req_is_last<HW, false>(rq, tly, tlx, slot, key);
+    if (last) write(ly, lx, tly, tlx, slot);
   }
 }
 
