@@ -503,6 +503,34 @@ def test_floodfill_from_origin_vs_oracle(shape):
         assert np.array_equal(mask_morph_device(torch.from_numpy(b).cuda(), MORPH_MEDIAN_BINARY, ksize=k).cpu().numpy(), pyoracle.median_blur(b, k))
 
 
+def test_wmv_every_byte_triple_matches_oracle():
+    """wmv_kernel takes the byte of a moving pixel from integer arithmetic unless it lies near a rounding boundary of the reference's
+    float pipeline (kernel_pointwise.h: wmv_fast_byte).  Every one of the 2^24 (current, previous, before-previous) byte triples, as
+    three 4096 x 4096 one-channel frames with the threshold off (the mask then IS the byte), against the oracle's float pipeline."""
+    p = np.arange(1 << 24, dtype=np.uint32).reshape(4096, 4096)
+    frames = [(p >> 16).astype(np.uint8), ((p >> 8) & 255).astype(np.uint8), (p & 255).astype(np.uint8)]  # t-2, t-1, t
+    prm = _params(capi.WMV, enable_threshold=0)
+    eng, orc = Engine(capi.WMV, params=prm), pyoracle.Oracle(capi.WMV, params=prm)
+    for f in frames:
+        fg, _ = eng.process(f)
+        ofg, _ = orc.process(f)
+    bad = np.flatnonzero(fg != ofg)
+    assert bad.size == 0, "%d of 2^24 triples differ, first at %s: %d vs %d" % (bad.size, hex(int(bad[0])), int(fg.flat[bad[0]]), int(ofg.flat[bad[0]]))
+    eng.close()
+
+
+@pytest.mark.parametrize("thr", [0, 1, 7, 15, 60, 128, 250])
+def test_wmv_mask_band_around_threshold(thr):
+    """Threshold on: wmv_kernel settles a moving pixel's mask from the integer bytes unless their gray value is within 2 of the
+    threshold, and sends only those pixels' bytes through the float pipeline.  Full-range random frames put ~2 % of the pixels
+    into that band at every threshold; 3 channels and 1."""
+    rng = np.random.default_rng(1000 + thr)
+    frames = rng.integers(0, 256, (6, 96, 256, 3), dtype=np.uint8)
+    frames[3:] = (frames[3:].astype(np.int32) // 4 + frames[2].astype(np.int32) * 3 // 4).astype(np.uint8)  # smaller steps too: low gray values
+    run_pair(capi.WMV, frames, params=_params(capi.WMV, threshold=thr))
+    run_pair(capi.WMV, frames[:, :, :, 1], params=_params(capi.WMV, threshold=thr))
+
+
 @pytest.mark.parametrize("thr", [1, 2, 15, 40, 127, 200])
 def test_wmv_quiet_pixel_shortcut_is_exact(thr):
     """wmv_kernel skips the float pipeline when every channel's temporal range is < 2*thr (proof in kernel_pointwise.h).

@@ -205,17 +205,124 @@ __device__ __forceinline__ void wmv_body(const PxGroup<G, C>& x, const PxGroup<G
   }
 }
 
+// ---- round 3: the moving pixels' bytes without the float pipeline, where that is provably the same result.
+// With the default weights the byte is round(255 * sd), 255 * sd = sqrt(N) / 10 with the INTEGER
+//   N = 10 * (5 b0^2 + 3 b1^2 + 2 b2^2) - (5 b0 + 3 b1 + 2 b2)^2      (100 * 255^2 * weighted variance, 0 .. 6 502 500),
+// and the reference's float pipeline (to_unit, addWeighted in double, three wvar terms, sqrt, * 255: ~55 instructions per byte) differs
+// from the real number by well under 1e-4 in that byte (in units of N: < 6 at the top of the range, < 1 near 0).  So
+// k = rint(sqrt(N) / 10) IS the reference's byte unless N lies within W = 6 + N / 65536 of a rounding boundary (10 k +- 5)^2, and
+// is never more than 1 away from it.
+//   * threshold on (the default): a pixel's mask is gray(bytes) > thr, gray is a convex combination, so gray(k's) further than 2
+//     from thr settles the mask; only the pixels inside that band need their exact bytes;
+//   * threshold off (the mask is the gray value itself): the bytes near a rounding boundary need the float pipeline - 1-2 % of a
+//     moving scene.
+// The few bytes that need it are appended to a per-workgroup list in LDS and computed with the float pipeline by as many lanes as
+// there are entries, one byte each (a lane that computed its own rare bytes in place would hold up the other 63), and patched into
+// the owners' registers through a staging copy in LDS.  A workgroup whose list overflows (adversarial input) takes the float
+// pipeline for everything, as before.  Tests: every one of the 2^24 byte triples against the oracle with the threshold off
+// (test_wmv_every_byte_triple_matches_oracle), thresholds 0..255 on a dense grid of triples with it on, besides the clips.
+constexpr int kWmvListCap = 512, kWmvStageStride = 13;  // entries per workgroup; dwords per lane in the staging copy (odd: no bank conflicts)
+
+__device__ __forceinline__ int wmv_exact_byte(int b0, int b1, int b2, double w0, double w1, double w2) {
+  const float i0 = to_unit(b0), i1 = to_unit(b1), i2 = to_unit(b2);
+  const float m = mean3<false>(i0, i1, i2, w0, w1, w2);
+  const float v = (wvar(i0, m, w0) + wvar(i1, m, w1)) + wvar(i2, m, w2);  // :83
+  return sat_u8(sqrt_rn(v) * 255.f);                                      // :95, :99
+}
+
+// default weights only.  Returns k; `near` (if asked for) = too close to a rounding boundary to be taken without the float pipeline.
+template <bool NEAR>
+__device__ __forceinline__ int wmv_fast_byte(int b0, int b1, int b2, bool& near) {
+  const int d01 = b0 - b1, d02 = b0 - b2, d12 = b1 - b2;
+  const int n = 15 * d01 * d01 + 10 * d02 * d02 + 6 * d12 * d12;  // = 10 * (5 b0^2 + 3 b1^2 + 2 b2^2) - (5 b0 + 3 b1 + 2 b2)^2
+  const int k = __float2int_rn(__builtin_amdgcn_sqrtf((float)n) * 0.1f);  // (v_sqrt_f32: 1 ulp, far inside the window below)
+  if constexpr (NEAR) {
+    const int lo = 10 * k - 5, hi = 10 * k + 5, w = 6 + (n >> 16);
+    near = (k > 0 && n <= lo * lo + w) || n >= hi * hi - w;
+  }
+  return min(k, 255);
+}
+
 template <int G, int C>
 __global__ __launch_bounds__(kBlock) void wmv_kernel(const FrameArgs a) {
+  constexpr int NW = PxGroup<G, C>::NB / 4;
+  static_assert(NW <= kWmvStageStride, "staging row too short");
+  __shared__ uint32_t stage[kBlock * kWmvStageStride];
+  __shared__ uint32_t list[kWmvListCap];  // b0 | b1 << 8 | b2 << 16 | byte index << 24, and who owns the byte:
+  __shared__ uint8_t owner[kWmvListCap];
+  __shared__ unsigned count;
   const size_t p0 = (xcd_block(a.xcd_swizzle) * kBlock + threadIdx.x) * G;
   const bool active = p0 < a.npix;
-  PxGroup<G, C> d;
+  PxGroup<G, C> d, x, y, z;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) d.b.w[i] = x.b.w[i] = y.b.w[i] = z.b.w[i] = 0;
   if (active) {
-    PxGroup<G, C> x, y, z;
     x.load(a.cur + p0 * C);
     y.load(a.p1 + p0 * C);
     z.load(a.p2 + p0 * C);
-    wmv_body<G, C>(x, y, z, a.enable_weight, a.enable_thr, a.thr, d);
+  }
+  const bool fast = a.enable_weight != 0 && G * C <= 64;  // (the byte index travels in 6 bits)  [launch-uniform]
+  if (!fast) {
+    if (active) wmv_body<G, C>(x, y, z, a.enable_weight, a.enable_thr, a.thr, d);
+  } else {
+    if (threadIdx.x == 0) count = 0;
+    __syncthreads();
+    auto push = [&](int i, int b0, int b1, int b2) {
+      const unsigned pos = atomicAdd(&count, 1u);
+      if (pos < (unsigned)kWmvListCap) list[pos] = (uint32_t)b0 | ((uint32_t)b1 << 8) | ((uint32_t)b2 << 16) | ((uint32_t)i << 24), owner[pos] = (uint8_t)threadIdx.x;
+    };
+    const bool shortcut = a.enable_thr && a.thr >= 1;
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      bool quiet = shortcut;
+      if (shortcut) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const int b0 = x.b.get(j * C + c), b1 = y.b.get(j * C + c), b2 = z.b.get(j * C + c);
+          quiet = quiet && (max(b0, max(b1, b2)) - min(b0, min(b1, b2)) < 2 * a.thr);
+        }
+      }
+      if (quiet) continue;  // (a quiet pixel keeps its zero bytes: any value <= thr gives the same mask - wmv_body)
+      int kk[C];
+      bool nr[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const int i = j * C + c;
+        nr[c] = false;
+        kk[c] = a.enable_thr ? wmv_fast_byte<false>(x.b.get(i), y.b.get(i), z.b.get(i), nr[c]) : wmv_fast_byte<true>(x.b.get(i), y.b.get(i), z.b.get(i), nr[c]);
+        d.b.set(i, kk[c]);
+      }
+      if (a.enable_thr) {  // every byte is within 1 of k, gray's weights sum to 1: the mask is settled unless gray(k) is within 2 of thr
+        int g;
+        if constexpr (C == 3)
+          g = gray_bgr(kk[0], kk[1], kk[2]);
+        else
+          g = kk[0];
+        const bool band = g >= a.thr - 2 && g <= a.thr + 2;
+#pragma unroll
+        for (int c = 0; c < C; ++c) nr[c] = band;
+      }
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+        if (nr[c]) push(j * C + c, x.b.get(j * C + c), y.b.get(j * C + c), z.b.get(j * C + c));
+    }
+    __syncthreads();
+    const unsigned n = count;  // (workgroup-uniform)
+    if (n > (unsigned)kWmvListCap) {
+      wmv_body<G, C>(x, y, z, a.enable_weight, a.enable_thr, a.thr, d);
+    } else if (n > 0) {
+#pragma unroll
+      for (int i = 0; i < NW; ++i) stage[threadIdx.x * kWmvStageStride + i] = d.b.w[i];
+      __syncthreads();
+      uint8_t* sb = reinterpret_cast<uint8_t*>(stage);
+      for (unsigned e = threadIdx.x; e < n; e += kBlock) {
+        const uint32_t ent = list[e];
+        sb[(owner[e] * kWmvStageStride) * 4 + (ent >> 24)] = (uint8_t)wmv_exact_byte((int)(ent & 0xffu), (int)((ent >> 8) & 0xffu), (int)((ent >> 16) & 0xffu), 0.5, 0.3, 0.2);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NW; ++i) d.b.w[i] = stage[threadIdx.x * kWmvStageStride + i];
+    }
   }
   gray_thr_store<G, C>(d, a, p0, active, a.fg_bits != nullptr);
 }
