@@ -503,6 +503,24 @@ def test_floodfill_from_origin_vs_oracle(shape):
         assert np.array_equal(mask_morph_device(torch.from_numpy(b).cuda(), MORPH_MEDIAN_BINARY, ksize=k).cpu().numpy(), pyoracle.median_blur(b, k))
 
 
+@pytest.mark.parametrize("weighted", [1, 0])
+def test_wmm_every_byte_triple_matches_oracle(weighted):
+    """wmm_kernel takes the background byte from integer arithmetic except on exact ties of the weighted mean (M = 5 b0 + 3 b1 + 2 b2
+    ending in 5), which go through the float pipeline (kernel_pointwise.h).  Every one of the 2^24 byte triples, background image and
+    unthresholded mask, against the oracle's float pipeline; weighted and unweighted."""
+    p = np.arange(1 << 24, dtype=np.uint32).reshape(4096, 4096)
+    frames = [(p >> 16).astype(np.uint8), ((p >> 8) & 255).astype(np.uint8), (p & 255).astype(np.uint8)]  # t-2, t-1, t
+    prm = _params(capi.WMM, enable_threshold=0, enable_weight=weighted)
+    eng, orc = Engine(capi.WMM, params=prm), pyoracle.Oracle(capi.WMM, params=prm)
+    for f in frames:
+        fg, bg = eng.process(f)
+        ofg, obg = orc.process(f)
+    for name, got, want in (("background", bg, obg), ("mask", fg, ofg)):
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, "%s: %d of 2^24 triples differ, first at %s: %d vs %d" % (name, bad.size, hex(int(bad[0])), int(got.flat[bad[0]]), int(want.flat[bad[0]]))
+    eng.close()
+
+
 def test_wmv_every_byte_triple_matches_oracle():
     """wmv_kernel takes the byte of a moving pixel from integer arithmetic unless it lies near a rounding boundary of the reference's
     float pipeline (kernel_pointwise.h: wmv_fast_byte).  Every one of the 2^24 (current, previous, before-previous) byte triples, as

@@ -146,6 +146,9 @@ __device__ __forceinline__ void wmm_body(const PxGroup<G, C>& x, const PxGroup<G
   }
 }
 
+// (Round 3 tried wmv_kernel's integer shortcut here: byte = round(M / 10), M = 5 b0 + 3 b1 + 2 b2, exact except when M ends in 5 - an
+// exact tie that the float pipeline's own rounding errors decide.  That is one byte in ten on a live scene, not one in fifty: the
+// list traffic in LDS cost more than the float pipeline it replaced, 0.210 against 0.171 ms on 8 x 4K.  All 2^24 triples matched.)
 template <int G, int C>
 __global__ __launch_bounds__(kBlock) void wmm_kernel(const FrameArgs a) {
   const size_t p0 = (xcd_block(a.xcd_swizzle) * kBlock + threadIdx.x) * G;
