@@ -488,6 +488,12 @@ def main():
         run(capi.ABL, "AdaptiveBackgroundLearning", 2160, 3840, 32, 10, borrow=False, cpu_frames=0, steps=30)
         run(capi.FRAME_DIFF, "FrameDifferenceBGS", 2160, 3840, 32, 7, cpu_frames=0, steps=30)
         return
+    if args.only in ("mog1", "mog1sat", "mog1surv"):  # MixtureOfGaussianV1BGS update kernel on both inputs (no CPU leg: kernel iteration / counter passes)
+        if args.only != "mog1surv":
+            run(capi.MOG1, "MixtureOfGaussianV1BGS (S_sat)", 1080, 1920, 16, 324, borrow=False, kind="sat", cpu_frames=0)
+        if args.only != "mog1sat":
+            run(capi.MOG1, "MixtureOfGaussianV1BGS (S_surv)", 1080, 1920, 16, 324, borrow=False, cpu_frames=0)
+        return
     if args.only == "lbsp":
         run_lbsp()
         return

@@ -531,9 +531,9 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
     DMALLOC(e->gmg_nfeat, P);
   }
   if (e->algo == BGS_MOG1) {
-    const size_t planes = ch == 3 ? bgs::mog1_planes<3>() : bgs::mog1_planes<1>();
+    const size_t tile_floats = ch == 3 ? bgs::mog1_tile_floats<3>() : bgs::mog1_tile_floats<1>();
     const size_t tiles = (P + bgs::kMog1Tile - 1) / bgs::kMog1Tile;
-    const size_t bytes = tiles * planes * bgs::kMog1Tile * sizeof(float);
+    const size_t bytes = tiles * tile_floats * sizeof(float);
     int rc = model_allocate(e, (void**)&e->mog1_state, bytes);
     if (rc) return rc;
   }
@@ -943,15 +943,9 @@ int process_run(bgs_engine* e, int first, int count, const uint8_t* d_frames, ui
       mog1_fill_args(e, m, lr);
       {
         Timed tm(e, s, "mog1_update_kernel");
-        // one pixel per lane: with write-backs that follow what a pixel changed, pixel-granular stores move fewer bytes and the
-        // kernel keeps 2+ waves per SIMD (1.19 vs 1.55 ms on S_surv, 1.50 vs 1.75 ms on S_sat); BGS_MOG1_PX=2 for A/B runs
-        static const bool want_px2 = getenv("BGS_MOG1_PX") && atoi(getenv("BGS_MOG1_PX")) == 2;
-        const bool px2 = want_px2 && npix % 2 == 0 && off % 2 == 0;
-        const dim3 grid(blocks_for(px2 ? npix / 2 : npix)), block(bgs::kBlock);
-        if (C == 3 && px2) hipLaunchKernelGGL((bgs::mog1_update_kernel<3, 2>), grid, block, 0, s, m);
-        if (C == 3 && !px2) hipLaunchKernelGGL((bgs::mog1_update_kernel<3, 1>), grid, block, 0, s, m);
-        if (C == 1 && px2) hipLaunchKernelGGL((bgs::mog1_update_kernel<1, 2>), grid, block, 0, s, m);
-        if (C == 1 && !px2) hipLaunchKernelGGL((bgs::mog1_update_kernel<1, 1>), grid, block, 0, s, m);
+        const dim3 grid(blocks_for(npix)), block(bgs::kBlock);
+        if (C == 3) hipLaunchKernelGGL((bgs::mog1_update_kernel<3>), grid, block, 0, s, m);
+        if (C == 1) hipLaunchKernelGGL((bgs::mog1_update_kernel<1>), grid, block, 0, s, m);
       }
       if (nframes == 1)  // re-initialisation restarts the count (the streams of a run may otherwise have different ages: launch_key)
         for (int i = first; i < first + count; ++i) e->seen[i] = 0;
@@ -1683,24 +1677,34 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
       return (int64_t)(n * F * 4);
     }
   }
-  if (e->algo == BGS_MOG1) {
-    const int R = 2 + 2 * C, NP = bgs::kMog1K * R;
-    int f0 = -1, nf = 0;  // field offset inside a mode record, floats per mode
-    if (!strcmp(plane, "sortkey")) f0 = 0, nf = 1;
-    if (!strcmp(plane, "w")) f0 = 1, nf = 1;
-    if (!strcmp(plane, "mu")) f0 = 2, nf = C;
-    if (!strcmp(plane, "var")) f0 = 2 + C, nf = C;
-    if (f0 >= 0) {
-      const size_t need = (size_t)bgs::kMog1K * nf * n * 4;
+  if (e->algo == BGS_MOG1) {  // exported in the reference's order: [rank][channel][pixel] (kernel_mog1.h keeps records by slot)
+    const int K = bgs::kMog1K;
+    int kind = -1, nf = 0;
+    if (!strcmp(plane, "sortkey")) kind = 0, nf = 1;
+    if (!strcmp(plane, "w")) kind = 1, nf = 1;
+    if (!strcmp(plane, "mu")) kind = 2, nf = C;
+    if (!strcmp(plane, "var")) kind = 3, nf = C;
+    if (kind >= 0) {
+      const size_t need = (size_t)K * nf * n * 4;
       if (cap < need) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
-      const size_t T = bgs::kMog1Tile, TF = (size_t)NP * T, t0 = off / T, t1 = (off + n + T - 1) / T;
+      const size_t T = bgs::kMog1Tile, TF = C == 3 ? bgs::mog1_tile_floats<3>() : bgs::mog1_tile_floats<1>(), t0 = off / T, t1 = (off + n + T - 1) / T;
       std::vector<float> tiles((t1 - t0) * TF);
       if (hipMemcpy(tiles.data(), e->mog1_state + t0 * TF, tiles.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
       for (size_t i = 0; i < n; ++i) {
-        const size_t sp = off + i;
-        const float* tb = tiles.data() + (sp / T - t0) * TF + sp % T;
-        for (int k = 0; k < bgs::kMog1K; ++k)
-          for (int c = 0; c < nf; ++c) ((float*)dst)[((size_t)k * nf + c) * n + i] = tb[(size_t)(k * R + f0 + c) * T];
+        const size_t sp = off + i, l = sp % T;
+        const float* tb = tiles.data() + (sp / T - t0) * TF;
+        const unsigned meta = reinterpret_cast<const uint16_t*>(tb + 2 * K * T + K * T * 2 * C)[l];
+        for (int k = 0; k < K; ++k) {
+          const int slot = (int)((meta >> (3 * k)) & 7u) - 1;  // -1: this rank never held a mode (all zeros in the reference)
+          for (int c = 0; c < nf; ++c) {
+            float v;
+            if (kind <= 1)
+              v = tb[(size_t)(kind * K + k) * T + l];
+            else
+              v = slot < 0 ? 0.f : tb[2 * K * T + (size_t)slot * T * 2 * C + l * 2 * C + (kind == 3 ? C : 0) + c];
+            ((float*)dst)[((size_t)k * nf + c) * n + i] = v;
+          }
+        }
       }
       return (int64_t)need;
     }

@@ -6,10 +6,17 @@
 // sortKey = w_old / sqrt(sum var); otherwise replace the weakest; renormalise; foreground iff the hit lies past the
 // background prefix (cumulative weight > T).
 //
-// Layout: tiled AoSoA like MOG2 (kernel_mog2.h): tile = 256 pixels x NP planes, NP = K*(2+2C) floats per pixel
-// (40 for BGR, 20 for gray); plane index of mode k: sortKey = k*R, weight = k*R+1, mean[c] = k*R+2+c, var[c] = k*R+2+C+c.
-// One lane owns PX = 2 consecutive pixels (8-byte accesses; 40 floats x 2 px already fill 80 VGPRs).
-// Algorithmic traffic (BGR): r 3 + 160, w 160 + 1 = 324 B/pixel/frame — HBM-bound, no MFMA, no LDS.
+// Layout (round 3, the form MOG2 took in kernel_mog2.h): tile = 256 pixels; per tile
+//   sortKey[K][256], weight[K][256]   planes in RANK order (the reference's sorted order; they change every frame anyway)
+//   record[K slots][256][2C floats]   {mean[C], var[C]} of the mode that lives in that SLOT - a mode never moves once created
+//   meta[256] uint16                  rank -> slot, 3 bits per rank, slot + 1 (0: this rank never held a mode)
+// = 162 B/pixel for BGR, 82 for gray.  Rounds 1-2 kept means and variances as 2C more planes per RANK: the bubble of a matched mode
+// dragged whole records through the sort, and - what cost more - a frame issued up to 30 predicated 4-byte loads and 40
+// predicated stores per pixel: the kernel was bound by instruction issue at 47 % (S_surv) / 72 % (S_sat) of the achievable
+// HBM rate for the bytes it moved (profiles/r03_mog1_pmc.txt).  Now a mode's record is two 12-byte loads, the one record a frame
+// changes (the matched or created mode) two 12-byte stores.  Assigned slots are a prefix of the ranks (a mode is created at the
+// first rank whose weight is below FLT_EPSILON: a dead mode's slot is reused, else the next free slot is taken).
+// One pixel per lane.  Traffic (BGR, data-dependent): r 3 + 2 + 40 + 24 x (ranks loaded), w 40 (changed planes only) + 24 + 2 + 1.
 #pragma once
 #include <cfloat>
 
@@ -32,7 +39,8 @@ struct Mog1Args {
 
 template <int C>
 struct Mog1Px {
-  float sk[kMog1K], w[kMog1K], mu[kMog1K][C], var[kMog1K][C];
+  float sk[kMog1K], w[kMog1K], mu[kMog1K][C], var[kMog1K][C];  // by rank
+  int sl[kMog1K];                                               // slot + 1 of the mode at each rank, 0 = none yet
 };
 
 template <int C>
@@ -40,6 +48,8 @@ __device__ __forceinline__ void mog1_swap(Mog1Px<C>& s, int i, int j) {
   float t;
   t = s.sk[i], s.sk[i] = s.sk[j], s.sk[j] = t;
   t = s.w[i], s.w[i] = s.w[j], s.w[j] = t;
+  const int u = s.sl[i];
+  s.sl[i] = s.sl[j], s.sl[j] = u;
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     t = s.mu[i][c], s.mu[i][c] = s.mu[j][c], s.mu[j][c] = t;
@@ -55,11 +65,13 @@ __device__ __forceinline__ float mog1_varsum(const Mog1Px<C>& s, int k) {
     return s.var[k][0];
 }
 
-// one pixel, same statement order as process8uC3 so every float rounds identically; returns 0 / 255
+// one pixel, same statement order as process8uC3 so every float rounds identically; returns 0 / 255.
+// hit = the rank (after the re-sort) of the one mode whose mean / variance this frame wrote (matched or created), -1 if none.
 template <int C>
-__device__ __forceinline__ int mog1_pixel(Mog1Px<C>& s, const float (&pix)[C], const Mog1Args& a, const float alpha) {
+__device__ __forceinline__ int mog1_pixel(Mog1Px<C>& s, const float (&pix)[C], const Mog1Args& a, const float alpha, int& hit) {
   constexpr int K = kMog1K;
   int kHit = -1, kForeground = -1;
+  hit = -1;
   if (alpha > 0) {
     float wsum = 0;
     bool done = false;
@@ -102,6 +114,9 @@ __device__ __forceinline__ int mog1_pixel(Mog1Px<C>& s, const float (&pix)[C], c
     if (kHit < 0) {  // no match: replace the first empty mode, else the last one
       const int kk = k_end < K - 1 ? k_end : K - 1;
       kHit = kk;
+      int na = 0;  // slots in use: the ranks that ever held a mode are a prefix
+#pragma unroll
+      for (int k = 0; k < K; ++k) na += s.sl[k] != 0;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         if (k == kk) {
@@ -110,6 +125,7 @@ __device__ __forceinline__ int mog1_pixel(Mog1Px<C>& s, const float (&pix)[C], c
 #pragma unroll
           for (int c = 0; c < C; ++c) s.mu[k][c] = pix[c], s.var[k][c] = a.var0;
           s.sk[k] = a.sk0;
+          if (s.sl[k] == 0) s.sl[k] = na + 1;  // (then k == na: every rank below holds a mode)
         }
       }
     } else {
@@ -117,6 +133,7 @@ __device__ __forceinline__ int mog1_pixel(Mog1Px<C>& s, const float (&pix)[C], c
       for (int k = 0; k < K; ++k)
         if (k >= k_end) wsum += s.w[k];
     }
+    hit = kHit;
     const float wscale = div_rn(1.f, wsum);
     wsum = 0;
 #pragma unroll
@@ -160,117 +177,138 @@ __device__ __forceinline__ int mog1_pixel(Mog1Px<C>& s, const float (&pix)[C], c
   return (kHit < 0 || kHit >= kForeground) ? 255 : 0;
 }
 
+// ---- tile layout (floats)
 template <int C>
-__host__ __device__ constexpr int mog1_planes() { return kMog1K * (2 + 2 * C); }
-
+__host__ __device__ constexpr int mog1_tile_floats() { return kMog1K * kMog1Tile * 2 + kMog1K * kMog1Tile * 2 * C + kMog1Tile / 2; }
 template <int C>
-__device__ __forceinline__ size_t mog1_plane_off(int p, size_t sp) {
-  return (sp >> 8) * (size_t)(mog1_planes<C>() * kMog1Tile) + (size_t)p * kMog1Tile + (sp & 255);
+struct Mog1Ptr {
+  float* skw;      // + rank * 256: sortKey; + (K + rank) * 256: weight   (already at the pixel)
+  float* rec;      // + slot * 256 * 2C: the pixel's record in that slot
+  uint16_t* meta;  // the pixel's rank -> slot word
+};
+template <int C>
+__device__ __forceinline__ Mog1Ptr<C> mog1_ptr(float* state, size_t sp) {
+  float* tile = state + (sp >> 8) * (size_t)mog1_tile_floats<C>();
+  const int l = (int)(sp & 255);
+  Mog1Ptr<C> p;
+  p.skw = tile + l;
+  p.rec = tile + 2 * kMog1K * kMog1Tile + l * 2 * C;
+  p.meta = reinterpret_cast<uint16_t*>(tile + 2 * kMog1K * kMog1Tile + kMog1K * kMog1Tile * 2 * C) + l;
+  return p;
 }
 
-// grid: ceil(npix / PX / kBlock); npix % PX == 0 and state_off % PX == 0 (host picks PX = 1 otherwise)
-template <int C, int PX>
+// a record = {mean[C], var[C]}: two 12-byte accesses for BGR, one 8-byte access for gray
+template <int C>
+__device__ __forceinline__ void mog1_rec_load(const float* p, float (&mu)[C], float (&var)[C]) {
+  if constexpr (C == 3) {
+    typedef float f3 __attribute__((ext_vector_type(3)));
+    typedef f3 __attribute__((aligned(4))) f3u;
+    const f3 m = *reinterpret_cast<const f3u*>(p), v = *reinterpret_cast<const f3u*>(p + 3);
+    mu[0] = m.x, mu[1] = m.y, mu[2] = m.z, var[0] = v.x, var[1] = v.y, var[2] = v.z;
+  } else {
+    const float2 r = *reinterpret_cast<const float2*>(p);
+    mu[0] = r.x, var[0] = r.y;
+  }
+}
+template <int C>
+__device__ __forceinline__ void mog1_rec_store(float* p, const float (&mu)[C], const float (&var)[C]) {
+  if constexpr (C == 3) {
+    typedef float f3 __attribute__((ext_vector_type(3)));
+    typedef f3 __attribute__((aligned(4))) f3u;
+    f3 m = {mu[0], mu[1], mu[2]}, v = {var[0], var[1], var[2]};
+    *reinterpret_cast<f3u*>(p) = m, *reinterpret_cast<f3u*>(p + 3) = v;
+  } else {
+    *reinterpret_cast<float2*>(p) = make_float2(mu[0], var[0]);
+  }
+}
+
+// Load a pixel's model in rank order.  ALL: every rank's record; else only ranks 0 and 1 (the caller knows that no lane of the
+// wave holds more than two modes).  Every load is unconditional - a rank without a mode reads slot 0, whose values are never
+// used (its weight is 0: the reference's scan stops there) - so that none of them is waited for before the last is issued.
+template <int C, bool ALL>
+__device__ __forceinline__ void mog1_load(const Mog1Ptr<C>& q, unsigned meta, Mog1Px<C>& s) {
+#pragma unroll
+  for (int k = 0; k < kMog1K; ++k) {
+    s.sl[k] = (int)((meta >> (3 * k)) & 7u);
+    if (ALL || k < 2) {
+      mog1_rec_load<C>(q.rec + (size_t)(s.sl[k] ? s.sl[k] - 1 : 0) * (kMog1Tile * 2 * C), s.mu[k], s.var[k]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < C; ++c) s.mu[k][c] = 0.f, s.var[k][c] = 0.f;
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned mog1_meta_pack(const int (&sl)[kMog1K]) {
+  unsigned m = 0;
+#pragma unroll
+  for (int k = 0; k < kMog1K; ++k) m |= (unsigned)sl[k] << (3 * k);
+  return m;
+}
+
+// grid: ceil(npix / kBlock), one pixel per lane
+template <int C>
 __global__ __launch_bounds__(kBlock) void mog1_update_kernel(const Mog1Args a) {
-  constexpr int K = kMog1K, R = 2 + 2 * C, NP = K * R;
+  constexpr int K = kMog1K;
   size_t blk = blockIdx.x;
   if (a.xcd_swizzle) {  // each XCD streams one contiguous eighth of the launch (see kernel_mog2.h)
     const size_t per = gridDim.x >> 3, main = per << 3;
     if (blk < main) blk = (blk & 7) * per + (blk >> 3);
   }
-  const size_t p0 = (blk * kBlock + threadIdx.x) * PX;
+  const size_t p0 = blk * kBlock + threadIdx.x;
   const bool active = p0 < a.npix;
-  uint32_t bits = 0;
+  const size_t pc = active ? p0 : a.npix - 1;  // lanes past the end work on the last pixel and store nothing
+  const Mog1Ptr<C> q = mog1_ptr<C>(a.state, a.state_off + pc);
+  const unsigned meta = *q.meta;
+  float sk0[K], w0[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) sk0[k] = q.skw[k * kMog1Tile], w0[k] = q.skw[(K + k) * kMog1Tile];
+  uint8_t px[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) px[c] = a.frame[pc * C + c];
+  Mog1Px<C> s;
+  // one wave-uniform choice: does any lane hold more than two modes?  (S_surv: hardly any wave does)
+  if (__any((meta >> 6) != 0))
+    mog1_load<C, true>(q, meta, s);
+  else
+    mog1_load<C, false>(q, meta, s);
+#pragma unroll
+  for (int k = 0; k < K; ++k) s.sk[k] = sk0[k], s.w[k] = w0[k];
+  float pix[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) pix[c] = (float)px[c];
+  int hit;
+  const int m = thr_bin(mog1_pixel<C>(s, pix, a, a.alpha, hit), a.thr, a.enable_thr);
   if (active) {
-    const size_t sp = a.state_off + p0;
-    // Data-dependent traffic (exact).  The reference never reads the mean / variance of a mode whose weight is below
-    // FLT_EPSILON (its scan stops there, bgfg_gaussmix.cpp) - it only ever creates a mode in such a slot, writing every
-    // field.  So the weight and sort-key planes of all K modes are loaded first, and the 2C mean / variance planes of mode k
-    // only if one of this lane's pixels has a live mode k.  A slot the lane did not load is written per pixel (scalar
-    // stores) by the pixel that created a mode there, so with PX = 2 the lane's other pixel keeps its stale, unread entries.
-    float st[NP][PX];
-    unsigned need = 0;
+    // write-back is data-dependent (exact): a sortKey / weight plane only if its bits changed (a quiet pixel has one or two modes,
+    // the planes of the others stay 0), the one record the frame wrote, the rank -> slot word if the order changed
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      load_f<PX>(a.state + mog1_plane_off<C>(k * R, sp), st[k * R]);
-      load_f<PX>(a.state + mog1_plane_off<C>(k * R + 1, sp), st[k * R + 1]);
+      if (__float_as_uint(s.sk[k]) != __float_as_uint(sk0[k])) q.skw[k * kMog1Tile] = s.sk[k];
+      if (__float_as_uint(s.w[k]) != __float_as_uint(w0[k])) q.skw[(K + k) * kMog1Tile] = s.w[k];
     }
+    if (hit >= 0) {
+      float mu[C], var[C];
+      int slot = 0;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      bool live = false;
+      for (int k = 0; k < K; ++k)
+        if (k == hit) {
+          slot = s.sl[k] - 1;
 #pragma unroll
-      for (int j = 0; j < PX; ++j) live = live || st[k * R + 1][j] >= FLT_EPSILON;
-      need |= (unsigned)live << k;
-#pragma unroll
-      for (int f = 2; f < R; ++f) {
-        if (live) {
-          load_f<PX>(a.state + mog1_plane_off<C>(k * R + f, sp), st[k * R + f]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < PX; ++j) st[k * R + f][j] = 0.f;
+          for (int c = 0; c < C; ++c) mu[c] = s.mu[k][c], var[c] = s.var[k][c];
         }
-      }
+      mog1_rec_store<C>(q.rec + (size_t)slot * (kMog1Tile * 2 * C), mu, var);
     }
-    uint8_t px[PX * C];
-#pragma unroll
-    for (int i = 0; i < PX * C; ++i) px[i] = a.frame[p0 * C + i];
-    uint32_t mword = 0;
-    uint64_t dirty = 0;  // NP <= 40 planes
-#pragma unroll
-    for (int j = 0; j < PX; ++j) {
-      Mog1Px<C> s;
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        s.sk[k] = st[k * R][j], s.w[k] = st[k * R + 1][j];
-#pragma unroll
-        for (int c = 0; c < C; ++c) s.mu[k][c] = st[k * R + 2 + c][j], s.var[k][c] = st[k * R + 2 + C + c][j];
-      }
-      float pix[C];
-#pragma unroll
-      for (int c = 0; c < C; ++c) pix[c] = (float)px[j * C + c];
-      const int m = thr_bin(mog1_pixel<C>(s, pix, a, a.alpha), a.thr, a.enable_thr);
-      mword |= (uint32_t)m << (8 * j);
-      bits |= (uint32_t)(m != 0) << j;
-      // write-back is data-dependent (exact): a plane is stored only if one of this lane's pixels changed its bits.  On a
-      // quiet scene one mode matches and only the weights / sort keys of the others move; their means and variances stay.
-      auto put = [&](int q, float v) {
-        dirty |= (uint64_t)(__float_as_uint(st[q][j]) != __float_as_uint(v)) << q;
-        st[q][j] = v;
-      };
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        put(k * R, s.sk[k]), put(k * R + 1, s.w[k]);
-#pragma unroll
-        for (int c = 0; c < C; ++c) put(k * R + 2 + c, s.mu[k][c]), put(k * R + 2 + C + c, s.var[k][c]);
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-#pragma unroll
-      for (int f = 0; f < R; ++f) {
-        const int q = k * R + f;
-        if (f < 2 || ((need >> k) & 1u)) {
-          if ((dirty >> q) & 1ull) store_f<PX>(a.state + mog1_plane_off<C>(q, sp), st[q]);
-        } else {
-          // mean / variance of a slot this lane did not load: the pixel that now owns a mode there writes its own element,
-          // whatever the value (a created field may equal the zero the register was filled with)
-#pragma unroll
-          for (int j = 0; j < PX; ++j)
-            if (st[k * R + 1][j] >= FLT_EPSILON) a.state[mog1_plane_off<C>(q, sp) + j] = st[q][j];
-        }
-      }
-    }
-    if (a.fg) {
-#pragma unroll
-      for (int j = 0; j < PX; ++j) a.fg[p0 + j] = (uint8_t)(mword >> (8 * j));
-    }
+    const unsigned meta_new = mog1_meta_pack(s.sl);
+    if (meta_new != meta) *q.meta = (uint16_t)meta_new;
+    if (a.fg) a.fg[p0] = (uint8_t)m;
   }
-  if (a.packed) store_packed_mask<PX>(a.fg_bits, p0, bits, active);
+  if (a.packed) store_packed_mask<1>(a.fg_bits, p0, (uint32_t)(m != 0), active);
 }
 
 // ---- clip launches (bgs_process_clip_device): T consecutive frames of every stream in one launch, the model of a pixel loaded
 // once, updated T times in registers with the statements of the single-frame kernel, written back once - see kernel_mog2.h.
-// One pixel per lane; the data-dependent loads / stores are the single-frame kernel's: a plane is stored if any frame of the clip
-// changed its bits, a mean / variance slot that was not loaded is written by the pixel that owns a mode there at the end.
+// Every record that some frame of the clip wrote goes back to its slot.
 constexpr int kMog1ClipMax = 8;
 struct Mog1ClipArgs {
   Mog1Args m;                            // frame / fg / fg_bits point at the first frame of the launch
@@ -280,7 +318,7 @@ struct Mog1ClipArgs {
 
 template <int C, int T>
 __global__ __launch_bounds__(kBlock) void mog1_clip_kernel(const Mog1ClipArgs c) {
-  constexpr int K = kMog1K, R = 2 + 2 * C, NP = K * R;
+  constexpr int K = kMog1K;
   const Mog1Args& a = c.m;
   size_t blk = blockIdx.x;
   if (a.xcd_swizzle) {
@@ -289,7 +327,7 @@ __global__ __launch_bounds__(kBlock) void mog1_clip_kernel(const Mog1ClipArgs c)
   }
   const size_t p0 = blk * kBlock + threadIdx.x;
   if (p0 >= a.npix) return;  // wave-uniform whenever masks are bit-packed (npix % 64 == 0)
-  const size_t sp = a.state_off + p0;
+  const Mog1Ptr<C> q = mog1_ptr<C>(a.state, a.state_off + p0);
   uint32_t pixw[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -299,62 +337,53 @@ __global__ __launch_bounds__(kBlock) void mog1_clip_kernel(const Mog1ClipArgs c)
     else
       pixw[t] = f[0];
   }
-  float st[NP];
-  unsigned need = 0;
+  const unsigned meta = *q.meta;
+  float sk0[K], w0[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) st[k * R] = a.state[mog1_plane_off<C>(k * R, sp)], st[k * R + 1] = a.state[mog1_plane_off<C>(k * R + 1, sp)];
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const bool live = st[k * R + 1] >= FLT_EPSILON;
-    need |= (unsigned)live << k;
-#pragma unroll
-    for (int f = 2; f < R; ++f) st[k * R + f] = live ? a.state[mog1_plane_off<C>(k * R + f, sp)] : 0.f;
-  }
+  for (int k = 0; k < K; ++k) sk0[k] = q.skw[k * kMog1Tile], w0[k] = q.skw[(K + k) * kMog1Tile];
   Mog1Px<C> s;
+  mog1_load<C, true>(q, meta, s);
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    s.sk[k] = st[k * R], s.w[k] = st[k * R + 1];
-#pragma unroll
-    for (int cc = 0; cc < C; ++cc) s.mu[k][cc] = st[k * R + 2 + cc], s.var[k][cc] = st[k * R + 2 + C + cc];
-  }
-  unsigned everLive = 0;
+  for (int k = 0; k < K; ++k) s.sk[k] = sk0[k], s.w[k] = w0[k];
+  unsigned wrote = 0;  // bit (slot + 1): some frame of the clip wrote that slot's record
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     float pix[C];
 #pragma unroll
     for (int cc = 0; cc < C; ++cc) pix[cc] = (float)((pixw[t] >> (8 * cc)) & 0xffu);
-    const int m = thr_bin(mog1_pixel<C>(s, pix, a, c.alpha[t]), a.thr, a.enable_thr);
+    int hit;
+    const int m = thr_bin(mog1_pixel<C>(s, pix, a, c.alpha[t], hit), a.thr, a.enable_thr);
     if (a.fg) a.fg[(size_t)t * c.fg_stride + p0] = (uint8_t)m;
     if (a.packed) store_packed_mask<1>(a.fg_bits + (size_t)t * c.bits_stride, p0, (uint32_t)(m != 0), true);
 #pragma unroll
-    for (int k = 0; k < K; ++k) everLive |= (unsigned)(s.w[k] >= FLT_EPSILON) << k;
+    for (int k = 0; k < K; ++k)
+      if (k == hit) wrote |= 1u << s.sl[k];
   }
-  auto put = [&](int q, float v) {  // store a plane only if the clip changed its bits
-    if (__float_as_uint(st[q]) != __float_as_uint(v)) a.state[mog1_plane_off<C>(q, sp)] = v;
-  };
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    put(k * R, s.sk[k]), put(k * R + 1, s.w[k]);
-    if ((need >> k) & 1u) {
-#pragma unroll
-      for (int cc = 0; cc < C; ++cc) put(k * R + 2 + cc, s.mu[k][cc]), put(k * R + 2 + C + cc, s.var[k][cc]);
-    } else if ((everLive >> k) & 1u) {  // not loaded, in use after some frame of the clip (the reference wrote it then): every field
-#pragma unroll
-      for (int cc = 0; cc < C; ++cc) {
-        a.state[mog1_plane_off<C>(k * R + 2 + cc, sp)] = s.mu[k][cc];
-        a.state[mog1_plane_off<C>(k * R + 2 + C + cc, sp)] = s.var[k][cc];
-      }
-    }
+    if (__float_as_uint(s.sk[k]) != __float_as_uint(sk0[k])) q.skw[k * kMog1Tile] = s.sk[k];
+    if (__float_as_uint(s.w[k]) != __float_as_uint(w0[k])) q.skw[(K + k) * kMog1Tile] = s.w[k];
   }
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    if (s.sl[k] && ((wrote >> s.sl[k]) & 1u)) mog1_rec_store<C>(q.rec + (size_t)(s.sl[k] - 1) * (kMog1Tile * 2 * C), s.mu[k], s.var[k]);
+  const unsigned meta_new = mog1_meta_pack(s.sl);
+  if (meta_new != meta) *q.meta = (uint16_t)meta_new;
 }
 
+// needToInitialize: bgmodel = zeros (a zero rank -> slot word: no mode anywhere)
 template <int C>
 __global__ __launch_bounds__(kBlock) void mog1_clear_kernel(const Mog1Args a) {
   const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= a.npix) return;
-  const size_t sp = a.state_off + p;
+  const Mog1Ptr<C> q = mog1_ptr<C>(a.state, a.state_off + p);
 #pragma unroll
-  for (int q = 0; q < mog1_planes<C>(); ++q) a.state[mog1_plane_off<C>(q, sp)] = 0.f;
+  for (int k = 0; k < 2 * kMog1K; ++k) q.skw[k * kMog1Tile] = 0.f;
+#pragma unroll
+  for (int k = 0; k < kMog1K; ++k)
+#pragma unroll
+    for (int f = 0; f < 2 * C; ++f) q.rec[(size_t)k * (kMog1Tile * 2 * C) + f] = 0.f;
+  *q.meta = 0;
 }
 
 }  // namespace bgs
