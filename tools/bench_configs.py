@@ -503,6 +503,11 @@ def main():
     if args.only == "dp":
         run_dp()
         return
+    if args.only in ("dpzsat", "dpzsurv", "dpgsat", "dpgsurv"):  # one dp GMM leg (counter passes)
+        algo, bpp, nm = (capi.DP_ZIVKOVIC_AGMM, 126, "DPZivkovicAGMMBGS") if args.only[2] == "z" else (capi.DP_GRIMSON_GMM, 150, "DPGrimsonGMMBGS")
+        kind = args.only[3:]
+        run(algo, "%s (K=3, S_%s)" % (nm, kind), 1080, 1920, 16, bpp, borrow=False, kind=kind, cpu_frames=0)
+        return
     if args.only == "cc":
         run_cc()
         return
