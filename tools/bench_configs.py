@@ -500,6 +500,11 @@ def main():
     if args.only == "pipeline":
         run_pipeline()
         return
+    if args.only in ("gmg", "gmgsat"):  # GMG in normal operation (counter passes / kernel iteration)
+        pg = capi.default_params(capi.GMG)
+        pg.gmg_init_frames = 4
+        run(capi.GMG, "GMG (data-dependent traffic)", 1080, 1920, 8, 16, borrow=False, cpu_frames=0, params=pg, kind="sat" if args.only == "gmgsat" else "surv")
+        return
     if args.only == "dp":
         run_dp()
         return

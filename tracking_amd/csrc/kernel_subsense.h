@@ -868,9 +868,52 @@ __global__ __launch_bounds__(kBlock) void ss_refresh_kernel(const SsArgs a, int 
   if (!(x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2)) return;
   if (a.lastFG[sN + p]) return;  // bForceFGUpdate = false
   if constexpr (FAST) {
+    // A lane's samples are s (first batch, s < 4), 4 + s, 20 + s, 36 + s, ...: the first four go through three STAGES - position
+    // table, the neighbours' foreground bytes, the neighbours' colour / descriptor - each stage's loads issued together (one sample
+    // after the other was three dependent memory round trips per sample, ~10 in a row per lane: the kernel was latency-bound at 0.3
+    // of the rate its 13.8 GB of stores need).  Loads are unconditional; a sample that does not exist or whose neighbour is
+    // foreground reads the pixel's own entries and stores nothing.
     const int s = threadIdx.x & 15;
-    if (s < kSsBatch) ss_refresh_one<C>(a, stream, N, sN, p, x, y, s, 0);
-    for (int m = kSsBatch + s; m < a.nS; m += 16) ss_refresh_one<C>(a, stream, N, sN, p, x, y, m, 0);
+    int mm[4], jx[4];
+    size_t jj[4];
+    bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      mm[k] = k == 0 ? s : kSsBatch + s + 16 * (k - 1);
+      ok[k] = k == 0 ? s < kSsBatch : mm[k] < a.nS;
+      jx[k] = kSsPosTab.v[ss_rand(a.frameIndex, p, 16u + (uint32_t)(ok[k] ? mm[k] : 0)) % 512u];
+    }
+    uint8_t fgb[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int xs = min(max((jx[k] >> 4) + x - 3, 2), a.cols - 3), ys = min(max((jx[k] & 15) + y - 3, 2), a.rows - 3);
+      jj[k] = sN + (size_t)ys * a.cols + xs;
+      fgb[k] = a.lastFG[jj[k]];
+    }
+    if constexpr (C == 3) {
+      typedef uint32_t __attribute__((aligned(1))) u32u;
+      typedef uint64_t __attribute__((aligned(2))) u64u;
+      uint32_t cw[4];
+      uint64_t dw[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        ok[k] = ok[k] && !fgb[k];
+        const size_t j = ok[k] ? jj[k] : sN + p;
+        cw[k] = *reinterpret_cast<const u32u*>(a.lastColor + j * 3), dw[k] = *reinterpret_cast<const u64u*>(a.lastDesc + j * 3);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (ok[k]) {
+          const int col[3] = {(int)(cw[k] & 0xffu), (int)((cw[k] >> 8) & 0xffu), (int)((cw[k] >> 16) & 0xffu)};
+          const unsigned dsc[3] = {(unsigned)(dw[k] & 0xffffu), (unsigned)((dw[k] >> 16) & 0xffffu), (unsigned)((dw[k] >> 32) & 0xffffu)};
+          SsSample<C>::make(col, dsc).store(a.samples, ss_rec(a, stream, N, p, mm[k]));
+        }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (ok[k]) ss_refresh_one<C>(a, stream, N, sN, p, x, y, mm[k], 0);
+    }
+    for (int m = kSsBatch + s + 48; m < a.nS; m += 16) ss_refresh_one<C>(a, stream, N, sN, p, x, y, m, 0);  // (more than 52 samples)
   } else {
     const int nRefresh = mode == 1 ? (int)(0.1f * a.nS) : a.nS;
     const int start = mode == 1 ? (int)(ss_rand(a.frameIndex, 0xFFFFFFFFu, 0) % (uint32_t)a.nS) : 0;
