@@ -107,6 +107,8 @@ void ss_fill_args(const bgs_engine* e, bgs::SsArgs& a, int first, int cur_pp, un
   a.rows = e->rows, a.cols = e->cols, a.nS = p.subsense_n_samples, a.nReq = p.subsense_n_required, a.nMinColor = p.subsense_min_color_dist_threshold;
   a.nDescOff = p.subsense_desc_dist_threshold_offset, a.nMov = p.subsense_samples_for_moving_avgs, a.lbspOff = p.lbsp_threshold_offset;
   a.use3x3 = d->use3x3, a.lrScaling = d->lrScaling, a.medK = d->medK, a.relT = p.lbsp_rel_threshold;
+  static const bool self_in_a = !(getenv("BGS_SS_SELF_IN_A") && atoi(getenv("BGS_SS_SELF_IN_A")) == 0);
+  a.selfInA = (e->algo == BGS_SUBSENSE && self_in_a) ? 1 : 0;  // (LOBSTER's phase A leaves every write to phase B)
   static const int refill = getenv("BGS_SS_REFILL") ? std::max(1, std::min(64, atoi(getenv("BGS_SS_REFILL")))) : bgs::kSsRefill;  // tuning knob
   a.refill = refill;
   a.frameIndex = frameIndex, a.first = first;

@@ -60,6 +60,7 @@ struct SsArgs {
   float relT, fLT, fST;
   unsigned frameIndex;
   int first;             // first stream of this launch (blockIdx.z is relative to it)
+  int selfInA;           // 1: phase A itself stores a pixel's SELF update (SuBSENSE, round 3); phase B then only applies the diffusion
 };
 
 __host__ __device__ __forceinline__ uint32_t ss_rand(uint32_t frame, uint32_t pixel, uint32_t draw) {
@@ -492,6 +493,17 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
       a.DminLT[i] = dminLT, a.DminST[i] = dminST, a.RawLT[i] = rawLT, a.RawSTNew[i] = rawST;
       a.raw[i] = isfg ? 255 : 0;
       a.req[i * 2] = reqSelf, a.req[i * 2 + 1] = reqNbr;
+      // Round 3: the self update is stored HERE.  No other pixel reads this pixel's samples in phase A (every pixel tests its own
+      // model only, and this lane is done with it), so the write cannot be seen early; a diffusion request of another source for
+      // the same slot is ordered against it in phase B exactly as before (the request stays in a.req: an earlier source's loses
+      // there, a later source's is applied after this launch and wins).  It takes half of the scattered 16-byte writes out of
+      // phase B, whose only limit they are, into a kernel that is bound by vector issue.
+      if (a.selfInA && reqSelf) {
+        unsigned dsc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) dsc[c] = intra[c];
+        SsSample<C>::make(cur, dsc).store(a.samples, ss_rec(a, stream, N, p, (int)((reqSelf >> 8) & 0x3fu)));
+      }
       // feedback :553-576
       const float dmin_min = dminLT < dminST ? dminLT : dminST, dmin_max = dminLT > dminST ? dminLT : dminST;
       if (lastfg || (dmin_min < 0.1f && isfg)) {
@@ -734,11 +746,12 @@ __global__ __launch_bounds__(kBlock) void ss_phase_b_kernel(const SsArgs a) {
     for (int q = 0; q < 2; ++q) {  // self request first, then the neighbour request
       const uint32_t r = (v >> (16 * q)) & 0xffffu;
       const int code = (int)(r & 0x1fu), tly = ly + code / 5 - 2, tlx = lx + code % 5 - 2;  // code = (dy + 2) * 5 + (dx + 2) of the target
-      const bool push = (r & SS_REQ_VALID) && tly >= 2 && tly < 2 + kSsBTH && tlx >= 2 && tlx < 2 + kSsTW;
-      if (push) {
+      const bool aimed = (r & SS_REQ_VALID) && tly >= 2 && tly < 2 + kSsBTH && tlx >= 2 && tlx < 2 + kSsTW;
+      if (aimed) {  // (self updates count too: they compete for their slot even when phase A has already stored them)
         const int t = (tly - 2) * kSsTW + (tlx - 2);
         atomicAdd(&cnt[t >> 2], 1u << (8 * (t & 3)));
       }
+      const bool push = aimed && !(q == 0 && a.selfInA);
       ss_list_push(list, &nlist, push, ((uint32_t)ly << 16) | ((uint32_t)lx << 8) | (uint32_t)q, lane);
     }
   }
