@@ -14,6 +14,8 @@
 // instead of the reference's sequential libc rand(); a frame is two phases (classify everything against the model as it
 // stood at the start of the frame, then apply all sample writes, the highest source pixel index winning a conflict);
 // a pixel reads its random neighbour's D_last / raw-segmentation means from the previous frame's copy.
+// (Round 3: the SELF updates are physically stored by phase A - nobody else reads a pixel's samples there - which changes no
+// result: see the comment at the store in ss_phase_a_kernel.)
 //
 // Background samples are RECORDS: colour and LBSP descriptor of one sample of one pixel together in 16 bytes (BGR: b g r 0 |
 // d0 d1 | d2 0 | 0; 4 bytes for gray: c 0 | d), one vector load per sample in the sample-consensus loops, one store per model
