@@ -276,11 +276,21 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
   // erode x3 :632 = one 7x7 box -> b_tmp;  :631-634 -> b_cur
   hipLaunchKernelGGL((bgs::ss_bits_box_kernel<0, 3>), wgrid, block, 0, s, (const uint64_t*)b_pre, b_tmp, e->rows, e->cols, W64, nwords);
   hipLaunchKernelGGL(bgs::ss_bits_combine_kernel, wgrid, block, 0, s, (const uint64_t*)b_raw, (const uint64_t*)b_pre, (const uint64_t*)rbits, (const uint64_t*)b_tmp, b_cur, e->cols, W64, nwords);
-  {  // medianBlur :635 of the binary mask: counts in LDS (morph_box_kernel), input straight from the bit plane, output the byte map phase A reads
+  // medianBlur :635 of the binary mask -> the byte map phase A reads (lastFG) and its bit plane (b_fg): bit-sliced on the planes
+  // (round 3); BGS_SS_MEDIAN_BITS=0: round 2's counts in LDS (morph_box_kernel) + a pack launch
+  static const bool median_bits = !(getenv("BGS_SS_MEDIAN_BITS") && atoi(getenv("BGS_SS_MEDIAN_BITS")) == 0);
+  if (median_bits && d->medK >= 3 && d->medK <= 13) {
+    switch (d->medK / 2) {
+#define SS_MEDIAN_CASE(RV) \
+  case RV: hipLaunchKernelGGL((bgs::ss_bits_median_kernel<RV>), wgrid, block, 0, s, (const uint64_t*)b_cur, b_fg, lastFG, e->rows, e->cols, W64, nwords); break;
+      SS_MEDIAN_CASE(1) SS_MEDIAN_CASE(2) SS_MEDIAN_CASE(3) SS_MEDIAN_CASE(4) SS_MEDIAN_CASE(5) SS_MEDIAN_CASE(6)
+#undef SS_MEDIAN_CASE
+    }
+  } else {
     bgs::MorphArgs m{nullptr, lastFG, e->rows, e->cols, 3, d->medK, b_cur, W64};
     bgs::morph_launch(m, count, s);
+    pack(lastFG, b_fg);
   }
-  pack(lastFG, b_fg);
   hipLaunchKernelGGL((bgs::ss_bits_box_kernel<1, 3>), wgrid, block, 0, s, (const uint64_t*)b_fg, b_dil, e->rows, e->cols, W64, nwords);  // dilate x3 :636
   if (v4)  // :637-642
     hipLaunchKernelGGL(bgs::ss_finish_kernel<4>, dim3(blocks_for(npix / 4)), block, 0, s, a, (const uint64_t*)b_dil, W64, npix);

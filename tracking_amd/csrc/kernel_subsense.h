@@ -1319,6 +1319,102 @@ __global__ __launch_bounds__(kBlock) void ss_bits_box_kernel(const uint64_t* in,
   out[wid] = (w == W64 - 1) ? (acc & lastmask) : acc;
 }
 
+// cv::medianBlur(k) of a BINARY mask on bit planes: a pixel is set iff at least (k*k + 1) / 2 of the k x k cells around it are set,
+// cells outside the image taking the nearest pixel's value (BORDER_REPLICATE).  One lane = one 64-pixel word: the column sums of the
+// k rows as a 4-plane bit-sliced counter for the word and its two neighbours, then the k shifted copies added into an 8-plane
+// accumulator, then a bit-sliced compare with the threshold - ~25 instructions per pixel for 13 x 13, no LDS.  Writes the bit plane
+// and the byte map (0 / 255) the next frame's phase A reads.  (Round 2 counted in LDS from bytes: morph_box_kernel, 84 us for
+// 8 x 1080p at k = 13 - the longest kernel of the post-processing chain; this one takes its place at any odd k <= 13.)
+template <int R>
+__global__ __launch_bounds__(kBlock) void ss_bits_median_kernel(const uint64_t* in, uint64_t* out_bits, uint8_t* out_bytes, int rows, int cols, int W64, size_t nwords) {
+  constexpr int K = 2 * R + 1, T = (K * K + 1) / 2;
+  const size_t wid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (wid >= nwords) return;
+  const int w = (int)(wid % W64);
+  const size_t row = wid / W64, img = row / rows;
+  const int y = (int)(row % rows);
+  const int mbits = cols - (W64 - 1) * 64;  // valid bits of a row's last word (1..64)
+  const uint64_t lastmask = mbits == 64 ? ~0ull : ((1ull << mbits) - 1);
+  // column sums (0..K) of the rows y-R..y+R (clamped) for the words w-1, w, w+1, every word extended beyond the image by replication
+  uint64_t V[3][4];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) V[j][b] = 0;
+#pragma unroll
+  for (int dy = -R; dy <= R; ++dy) {
+    const uint64_t* r = in + (img * rows + (size_t)min(max(y + dy, 0), rows - 1)) * W64;
+    const uint64_t first = r[0], last = r[W64 - 1];
+    const uint64_t left_fill = (first & 1ull) ? ~0ull : 0ull, right_fill = ((last >> (mbits - 1)) & 1ull) ? ~0ull : 0ull;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int ww = w + j - 1;
+      uint64_t x = ww < 0 ? left_fill : ww >= W64 ? right_fill : r[ww];
+      if (ww == W64 - 1) x |= right_fill & ~lastmask;
+      uint64_t carry = x;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const uint64_t t = V[j][b] & carry;
+        V[j][b] ^= carry, carry = t;
+      }
+    }
+  }
+  // window sums: the K horizontally shifted copies of the centre word's column sums
+  uint64_t acc[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) acc[b] = b < 4 ? V[1][b] : 0;
+#pragma unroll
+  for (int d = 1; d <= R; ++d)
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      uint64_t v[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) v[b] = side == 0 ? (V[1][b] << d) | (V[0][b] >> (64 - d)) : (V[1][b] >> d) | (V[2][b] << (64 - d));  // pixels x - d / x + d
+      uint64_t carry = 0;
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        if (b < 4) {
+          const uint64_t axb = acc[b] ^ v[b];
+          const uint64_t c2 = (acc[b] & v[b]) | (carry & axb);
+          acc[b] = axb ^ carry, carry = c2;
+        } else {
+          const uint64_t t = acc[b] & carry;
+          acc[b] ^= carry, carry = t;
+        }
+      }
+    }
+  // acc >= T, bit-sliced: from the top bit down, "greater so far" | "equal so far"
+  uint64_t gt = 0, eq = ~0ull;
+#pragma unroll
+  for (int b = 7; b >= 0; --b) {
+    if ((T >> b) & 1)
+      eq &= acc[b];
+    else
+      gt |= eq & acc[b], eq &= ~acc[b];
+  }
+  uint64_t res = gt | eq;
+  if (w == W64 - 1) res &= lastmask;
+  if (out_bits) out_bits[wid] = res;
+  uint8_t* ob = out_bytes + (img * rows + y) * (size_t)cols + (size_t)w * 64;
+  const int nvalid = w == W64 - 1 ? mbits : 64;
+  if ((cols & 15) == 0 && (reinterpret_cast<uintptr_t>(out_bytes) & 15) == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q * 16 < nvalid) {
+        uint32_t dw[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t nib = (uint32_t)(res >> (q * 16 + k * 4)) & 0xfu;
+          dw[k] = ((nib * 0x00204081u) & 0x01010101u) * 0xffu;  // bit i of the nibble -> byte i = 0 / 255
+        }
+        *reinterpret_cast<uint4*>(ob + q * 16) = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+      }
+    }
+  } else {
+    for (int i = 0; i < nvalid; ++i) ob[i] = ((res >> i) & 1ull) ? 255 : 0;
+  }
+}
+
 // flood fill operands from the closed mask: mbits = pixels that have the seed's value (the value at (0,0)), rbits = nothing reached yet
 __global__ __launch_bounds__(kBlock) void ss_bits_flood_prepare_kernel(const uint64_t* pre, uint64_t* mbits, uint64_t* rbits, int rows, int cols, int W64, size_t nwords) {
   const size_t wid = (size_t)blockIdx.x * kBlock + threadIdx.x;
