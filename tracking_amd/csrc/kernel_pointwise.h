@@ -222,8 +222,9 @@ __device__ __forceinline__ void wmv_body(const PxGroup<G, C>& x, const PxGroup<G
 // The few bytes that need it are appended to a per-workgroup list in LDS and computed with the float pipeline by as many lanes as
 // there are entries, one byte each (a lane that computed its own rare bytes in place would hold up the other 63), and patched into
 // the owners' registers through a staging copy in LDS.  A workgroup whose list overflows (adversarial input) takes the float
-// pipeline for everything, as before.  Tests: every one of the 2^24 byte triples against the oracle with the threshold off
-// (test_wmv_every_byte_triple_matches_oracle), thresholds 0..255 on a dense grid of triples with it on, besides the clips.
+// pipeline for everything, as before.  Tests: every one of the 2^24 byte triples against the CPU restatement's float pipeline with
+// the threshold off (tests/test_gpu_parity.py: test_wmv_every_byte_triple...), full-range random frames at seven thresholds with
+// it on (test_wmv_mask_band_around_threshold), besides the clips.
 constexpr int kWmvListCap = 512, kWmvStageStride = 13;  // entries per workgroup; dwords per lane in the staging copy (odd: no bank conflicts)
 
 __device__ __forceinline__ int wmv_exact_byte(int b0, int b1, int b2, double w0, double w1, double w2) {
