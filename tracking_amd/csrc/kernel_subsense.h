@@ -876,7 +876,19 @@ __global__ __launch_bounds__(kBlock) void ss_refresh_kernel(const SsArgs a, int 
   const int stream = a.first + blockIdx.z;
   const size_t N = (size_t)a.rows * a.cols, sN = (size_t)stream * N;
   if (mode == 1 && !a.sc[stream].doRefresh) return;
-  const uint32_t p = FAST ? blockIdx.x * 16u + (threadIdx.x >> 4) : blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+  if constexpr (!FAST) {  // a bounded grid walks the pixels (the per-frame launch that usually finds doRefresh == 0 stays small)
+    for (uint32_t p = blockIdx.x * (uint32_t)kBlock + threadIdx.x; p < N; p += gridDim.x * (uint32_t)kBlock) {
+      if (mode == 1) a.T[sN + p] = 1.0f;  // m_oUpdateRateFrame = cv::Scalar(1.0f), every pixel (:682)
+      const int x = (int)(p % (uint32_t)a.cols), y = (int)(p / (uint32_t)a.cols);
+      if (!(x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2)) continue;
+      if (a.lastFG[sN + p]) continue;  // bForceFGUpdate = false
+      const int nRefresh = mode == 1 ? (int)(0.1f * a.nS) : a.nS;
+      const int start = mode == 1 ? (int)(ss_rand(a.frameIndex, 0xFFFFFFFFu, 0) % (uint32_t)a.nS) : 0;
+      for (int m = 0; m < nRefresh; ++m) ss_refresh_one<C>(a, stream, N, sN, p, x, y, m, start);
+    }
+    return;
+  }
+  const uint32_t p = blockIdx.x * 16u + (threadIdx.x >> 4);
   if (p >= N) return;
   if (mode == 1) a.T[sN + p] = 1.0f;  // m_oUpdateRateFrame = cv::Scalar(1.0f), every pixel (:682)
   const int x = (int)(p % (uint32_t)a.cols), y = (int)(p / (uint32_t)a.cols);
@@ -929,10 +941,6 @@ __global__ __launch_bounds__(kBlock) void ss_refresh_kernel(const SsArgs a, int 
         if (ok[k]) ss_refresh_one<C>(a, stream, N, sN, p, x, y, mm[k], 0);
     }
     for (int m = kSsBatch + s + 48; m < a.nS; m += 16) ss_refresh_one<C>(a, stream, N, sN, p, x, y, m, 0);  // (more than 52 samples)
-  } else {
-    const int nRefresh = mode == 1 ? (int)(0.1f * a.nS) : a.nS;
-    const int start = mode == 1 ? (int)(ss_rand(a.frameIndex, 0xFFFFFFFFu, 0) % (uint32_t)a.nS) : 0;
-    for (int m = 0; m < nRefresh; ++m) ss_refresh_one<C>(a, stream, N, sN, p, x, y, m, start);
   }
 }
 
@@ -1549,14 +1557,32 @@ __global__ __launch_bounds__(kBlock) void ss_downsample_kernel(const SsArgs a) {
     const int x = idx % dsw, y = idx / dsw;
     const uint8_t* img = a.frame + (size_t)blockIdx.z * a.rows * a.cols * C;
     float d[C];
+    const bool whole = a.rows % 8 == 0 && a.cols % 8 == 0;
+    uint32_t sums[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) sums[c] = 0;
+    if (whole) {  // the cell's 8 rows of 8 pixels as dwords (global loads need no alignment here), channel sums with v_dot4_u32_u8 / v_sad_u8
+      typedef uint32_t __attribute__((aligned(1))) u32u;
+      for (int yy = 0; yy < 8; ++yy) {
+        const u32u* rp = reinterpret_cast<const u32u*>(img + ((size_t)(y * 8 + yy) * a.cols + x * 8) * C);
+        if constexpr (C == 3) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {  // 4 pixels = B G R B | G R B G | R B G R
+            const uint32_t w0 = rp[3 * h], w1 = rp[3 * h + 1], w2 = rp[3 * h + 2];
+            sums[0] = __builtin_amdgcn_udot4(w2, 0x00000100u, __builtin_amdgcn_udot4(w1, 0x00010000u, __builtin_amdgcn_udot4(w0, 0x01000001u, sums[0], false), false), false);
+            sums[1] = __builtin_amdgcn_udot4(w2, 0x00010000u, __builtin_amdgcn_udot4(w1, 0x01000001u, __builtin_amdgcn_udot4(w0, 0x00000100u, sums[1], false), false), false);
+            sums[2] = __builtin_amdgcn_udot4(w2, 0x01000001u, __builtin_amdgcn_udot4(w1, 0x00000100u, __builtin_amdgcn_udot4(w0, 0x00010000u, sums[2], false), false), false);
+          }
+        } else {
+          sums[0] = __builtin_amdgcn_sad_u8(rp[1], 0u, __builtin_amdgcn_sad_u8(rp[0], 0u, sums[0]));
+        }
+      }
+    }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       float v;
-      if (a.rows % 8 == 0 && a.cols % 8 == 0) {  // cv::resize INTER_AREA, integer ratio on both axes (resizeAreaFast_)
-        int sum = 0;
-        for (int yy = 0; yy < 8; ++yy)
-          for (int xx = 0; xx < 8; ++xx) sum += img[((size_t)(y * 8 + yy) * a.cols + (x * 8 + xx)) * C + c];
-        v = (float)sat_u8((float)sum * (1.f / 64));
+      if (whole) {  // cv::resize INTER_AREA, integer ratio on both axes (resizeAreaFast_)
+        v = (float)sat_u8((float)sums[c] * (1.f / 64));
       } else {
         v = (float)sat_u8(ss_area_value<C>(img, a.rows, a.cols, dsh, dsw, y, x, c));
       }
