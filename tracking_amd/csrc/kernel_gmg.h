@@ -46,6 +46,10 @@ __device__ __forceinline__ void gmg_fast(const GmgArgs& a, bool active, size_t s
 #pragma unroll
   for (int i = 0; i < kGmgFast; ++i)
     if (!(active && i < nf)) c[i] = 0, w[i] = 0.f;
+  int c_in[kGmgFast];  // as loaded: a colour is stored again only if it changed (round 3: on a settled pixel none does - the
+  const int nf_in = nf;  // matched colour sits at the front - and rewriting them all was a third of the kernel's write traffic)
+#pragma unroll
+  for (int i = 0; i < kGmgFast; ++i) c_in[i] = c[i];
   int idx = -1;
   float wfound = 0.f;
 #pragma unroll
@@ -101,8 +105,11 @@ __device__ __forceinline__ void gmg_fast(const GmgArgs& a, bool active, size_t s
     }
 #pragma unroll
     for (int i = 0; i < kGmgFast; ++i)
-      if (i < nf) a.colors[(size_t)i * a.plane + sp] = c[i], a.weights[(size_t)i * a.plane + sp] = w[i];
-    a.nfeat[sp] = (uint8_t)nf;
+      if (i < nf) {
+        if (i >= nf_in || c[i] != c_in[i]) a.colors[(size_t)i * a.plane + sp] = c[i];
+        a.weights[(size_t)i * a.plane + sp] = w[i];
+      }
+    if (nf != nf_in) a.nfeat[sp] = (uint8_t)nf;
   }
   if (active) a.raw[p0] = isfg ? 255 : 0;
 }
