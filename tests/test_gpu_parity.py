@@ -371,6 +371,30 @@ def test_subsense_flood_fill_finish_kernel_path(golden_frames, tmp_path):
     assert r.returncode == 0 and "finish-kernel path OK" in r.stdout, r.stdout + r.stderr
 
 
+def test_round2_forms_of_the_round3_kernels_still_match(golden_frames):
+    """Round 3 replaced several kernels and kept the earlier forms behind knobs that are read once per process (A/B builds, and the
+    fallbacks for geometries the new forms do not take): SuBSENSE with the self updates in phase B, the tile flood fill and the
+    LDS-count median; AdaptiveSelectiveBackgroundLearning through the LDS-tile kernel.  One child process with all of them set:
+    same masks, backgrounds and models as the oracle."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from gpu_helpers import run_pair, check_subsense_state, capi\n"
+            "from tools import synth\n"
+            "f = np.load(%r)['frames'][:12]\n"
+            "eng, orc, _ = run_pair(capi.SUBSENSE, f)\n"
+            "check_subsense_state(eng, orc, f.shape[1], f.shape[2])\n"
+            "g = synth.numpy_frames('surv', 14, 240, 320, seed=5)\n"
+            "eng, orc, _ = run_pair(capi.SUBSENSE, g)\n"
+            "check_subsense_state(eng, orc, 240, 320)\n"
+            "run_pair(capi.ASBL, synth.random_frames(8, 40, 300, 3, seed=2))\n"
+            "print('round-2 forms OK')\n") % (os.path.dirname(here), here, os.path.join(here, "golden", "frames_96x80.npz"))
+    env = dict(os.environ, BGS_SS_SELF_IN_A="0", BGS_SS_FLOOD_TILES="1", BGS_SS_MEDIAN_BITS="0", BGS_ASBL_TABLE="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "round-2 forms OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_subsense_qvga_with_frame_level_block():
     """320x240 = QVGA: learning-rate scaling + auto model reset enabled; a scene cut at frame 12 triggers refreshModel(0.1)."""
     a = synth.numpy_frames("surv", 30, 240, 320, seed=21) // 6          # dark scene, long enough for ST (1/25) and LT (1/30) to part
