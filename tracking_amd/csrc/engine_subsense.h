@@ -145,7 +145,7 @@ void ss_launch_flood(dim3 tile_grid, int count, int tilesY, hipStream_t s, const
 
 int ss_launch_refresh(bgs_engine* e, const bgs::SsArgs& a, size_t N, int count, int mode, hipStream_t s) {
   const bool fast = mode == 0 && a.pixelMajor && a.nS > bgs::kSsBatch;
-  const dim3 grid(fast ? (unsigned)((N + 15) / 16) : std::min<unsigned>(blocks_for(N), 512u), 1, count), block(bgs::kBlock);
+  const dim3 grid(fast ? (unsigned)(((N + 15) / 16 + bgs::kSsRefreshGroups - 1) / bgs::kSsRefreshGroups) : std::min<unsigned>(blocks_for(N), 512u), 1, count), block(bgs::kBlock);
   if (e->ch == 3) {
     if (fast) hipLaunchKernelGGL((bgs::ss_refresh_kernel<3, true>), grid, block, 0, s, a, mode);
     else hipLaunchKernelGGL((bgs::ss_refresh_kernel<3, false>), grid, block, 0, s, a, mode);

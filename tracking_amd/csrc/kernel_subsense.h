@@ -871,6 +871,7 @@ __device__ __forceinline__ void ss_refresh_one(const SsArgs& a, int stream, size
 // runs of 256 contiguous bytes (round 2: one lane walked a pixel's 50 samples serially, each store 768 bytes from its neighbour's,
 // each sample through a <= 49-step scan of the pattern: 26 ms for 8 x 1080p, 0.06 of what the 13 GB it writes need).
 // Otherwise (10 % refresh: 5 samples; LOBSTER's sample-major planes): one lane per pixel.
+constexpr int kSsRefreshGroups = 8;
 template <int C, bool FAST>
 __global__ __launch_bounds__(kBlock) void ss_refresh_kernel(const SsArgs a, int mode) {
   const int stream = a.first + blockIdx.z;
@@ -888,12 +889,20 @@ __global__ __launch_bounds__(kBlock) void ss_refresh_kernel(const SsArgs a, int 
     }
     return;
   }
-  const uint32_t p = blockIdx.x * 16u + (threadIdx.x >> 4);
-  if (p >= N) return;
+  // the position table in LDS: 64 lanes with 64 different table indices are one LDS access there, and one more scattered global load
+  // on the vector memory path otherwise - the kernel's limit (17 scattered loads per wave: counters in DESIGN.md 7c)
+  __shared__ uint8_t tab[512];
+  tab[threadIdx.x] = kSsPosTab.v[threadIdx.x], tab[threadIdx.x + 256] = kSsPosTab.v[threadIdx.x + 256];
+  __syncthreads();
+  // (a workgroup walks kSsRefreshGroups groups of 16 pixels: with one group per workgroup the 1 M tiny workgroups of an 8 x 1080p
+  // launch kept only 1.6 waves per SIMD resident - SQ_WAVE_CYCLES / duration - and the kernel ran at 2 TB/s of its stores)
+  for (int grp = 0; grp < kSsRefreshGroups; ++grp) {
+  const uint32_t p = (blockIdx.x * (uint32_t)kSsRefreshGroups + (uint32_t)grp) * 16u + (threadIdx.x >> 4);
+  if (p >= N) continue;
   if (mode == 1) a.T[sN + p] = 1.0f;  // m_oUpdateRateFrame = cv::Scalar(1.0f), every pixel (:682)
   const int x = (int)(p % (uint32_t)a.cols), y = (int)(p / (uint32_t)a.cols);
-  if (!(x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2)) return;
-  if (a.lastFG[sN + p]) return;  // bForceFGUpdate = false
+  if (!(x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2)) continue;
+  if (a.lastFG[sN + p]) continue;  // bForceFGUpdate = false
   if constexpr (FAST) {
     // A lane's samples are s (first batch, s < 4), 4 + s, 20 + s, 36 + s, ...: the first four go through three STAGES - position
     // table, the neighbours' foreground bytes, the neighbours' colour / descriptor - each stage's loads issued together (one sample
@@ -907,7 +916,7 @@ __global__ __launch_bounds__(kBlock) void ss_refresh_kernel(const SsArgs a, int 
     for (int k = 0; k < 4; ++k) {
       mm[k] = k == 0 ? s : kSsBatch + s + 16 * (k - 1);
       ok[k] = k == 0 ? s < kSsBatch : mm[k] < a.nS;
-      jx[k] = kSsPosTab.v[ss_rand(a.frameIndex, p, 16u + (uint32_t)(ok[k] ? mm[k] : 0)) % 512u];
+      jx[k] = tab[ss_rand(a.frameIndex, p, 16u + (uint32_t)(ok[k] ? mm[k] : 0)) % 512u];
     }
     // per-stream bases once, 32-bit offsets per sample (N < 2^31), the record assembled from the loaded words as they are (a
     // record is the colour dword with byte 3 cleared, d0 | d1 << 16, d2): ~60 instead of ~170 instructions per sample
@@ -951,6 +960,7 @@ __global__ __launch_bounds__(kBlock) void ss_refresh_kernel(const SsArgs a, int 
         if (ok[k]) ss_refresh_one<C>(a, stream, N, sN, p, x, y, mm[k], 0);
     }
     for (int m = kSsBatch + s + 48; m < a.nS; m += 16) ss_refresh_one<C>(a, stream, N, sN, p, x, y, m, 0);  // (more than 52 samples)
+  }
   }
 }
 
