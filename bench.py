@@ -315,7 +315,7 @@ def main():
     torch.cuda.set_device(dev)
 
     from tracking_amd import Engine, capi
-    from tracking_amd.sharding import MaskGather, stream_block
+    from tracking_amd.sharding import MaskGather, packed_words, stream_block
 
     S = args.streams
     first_global, _ = stream_block(S * world, world, rank)
@@ -328,7 +328,7 @@ def main():
         eng.set_option(capi.OPT_MOG2_PIXELS_PER_LANE, args.px)
     fg = torch.empty((S, ROWS, COLS), dtype=torch.uint8, device=dev)
     bg = torch.empty((S, ROWS, COLS, CH), dtype=torch.uint8, device=dev) if args.with_bg else None
-    words = ROWS * COLS // 64
+    words = packed_words(ROWS, COLS)
     gather = MaskGather(S, words, "cpu" if rehearse else dev, always_collective=selftest) if (world > 1 or selftest) else None
     bits_dev = torch.empty((S, words), dtype=torch.int64, device=dev) if rehearse else None
 

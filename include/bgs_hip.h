@@ -195,6 +195,9 @@ int bgs_set_params(bgs_engine* e, const bgs_params* params);
 #define BGS_OPT_CLIP_FUSE 7     /* 1 (default): bgs_process_clip_device runs 8 / 4 / 2 consecutive frames of a mixture model per launch with the
                                    model held in registers; 0: one launch per frame.  Identical results, only speed differs. */
 #define BGS_OPT_MODEL_CHUNK_MB 9
+#define BGS_OPT_MODEL_CHUNK_MIN_MB 10 /* models smaller than this many MiB take one plain allocation (default 768: below that a good part of the
+                                   model sits in the 256 MiB Infinity Cache and placement does not matter); before the geometry is set.
+                                   Lowered by the test that exercises the chunked construction and its release on a small model. */
 #define BGS_OPT_HOST_REGISTER 8 /* bgs_process (host buffers): bit 0 input frame, bit 1 mask, bit 2 background image.  A buffer passed in an
                                    enabled role that comes back with the same address and size as in the previous call is page-locked once
                                    (hipHostRegister) and from then on read / written by the DMA engine in place - no staging copy by the
@@ -226,7 +229,10 @@ int bgs_process(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols
  *   d_frames  [n_streams][rows][cols][channels] uint8, contiguous
  *   d_fg      [n_streams][rows][cols] uint8 or NULL
  *   d_bg      [n_streams][rows][cols][channels] uint8 or NULL
- *   d_fg_bits [n_streams][ceil(rows*cols/64)] uint64, bit i of word j = pixel 64j+i foreground, or NULL
+ *   d_fg_bits [n_streams][W] uint64, W = ceil(rows*cols/64): bit i of word j of a stream = its pixel 64j+i is foreground; the bits of
+ *             a stream's last word past pixel rows*cols-1 are zero; or NULL.  (rows*cols a multiple of 64 - 1080p, 4K, 720p, VGA,
+ *             320x176 ... - is the fast case: the update kernels write the words from wave ballots; for any other size the words are
+ *             made from the byte mask by one extra small launch, through an engine-owned buffer when d_fg is NULL.)
  * The streams need NOT be in lock-step: cameras join, drop frames and are reset independently (the reference creates and deletes
  * one IBGS object per stream whenever it likes, FrameProcessor.cpp:35-155, :342-482).  Streams whose next frame needs the same
  * kernel arguments share a launch - for the mixture models that is "first frame or not" plus the learning rate, i.e. every
@@ -249,7 +255,7 @@ int bgs_process_range_device(bgs_engine* e, int first, int count, const void* d_
  * bgs_process_range_device calls (masks, backgrounds, model state, frame counts).
  *   d_frames  [nframes][count][rows][cols][channels]   frame t of all streams, then frame t+1 ...
  *   d_fg      [nframes][count][rows][cols] or NULL;  d_bg [nframes][count][rows][cols][channels] or NULL
- *   d_fg_bits [nframes][count][rows*cols/64] or NULL;  out_flags: nframes words or NULL
+ *   d_fg_bits [nframes][count][ceil(rows*cols/64)] or NULL;  out_flags: nframes words or NULL
  * The mixture models (MixtureOfGaussianV2BGS, MixtureOfGaussianV1BGS, DPZivkovicAGMMBGS, DPGrimsonGMMBGS) take runs of 8 / 4 / 2
  * frames through ONE launch that loads each pixel's model once, applies the frames in order in registers and writes the model back
  * once (model traffic per frame / 8, / 4, / 2); FrameDifference / WeightedMovingMean / WeightedMovingVariance take their frame history
@@ -306,7 +312,10 @@ int bgs_group_kernel_timing(bgs_group* g, double* avg_ms, int64_t* launches); /*
  * in the caller's images (out_flags as for bgs_process).  Submissions of different streams overlap: while camera A's frame is on
  * the bus camera B's kernel runs and camera C's mask comes back, where a synchronous bgs_process per camera takes turns.
  * Same arguments and results as bgs_process; the caller's buffers must stay valid and untouched until bgs_wait; one submission per
- * stream in flight (bgs_process on such a stream collects it first).  Frames prepared by bgs_set_ingest go through bgs_process.
+ * stream in flight (bgs_process on such a stream collects it first; the device-path calls - bgs_process_batch_device / _range_device /
+ * _clip_device - REFUSE a range that covers a stream with a submission in flight, BGS_ERR_STATE: they run on the caller's HIP stream
+ * and would race with the lane).  All bgs_submit / bgs_wait calls of one engine come from ONE host thread (an engine is not thread-safe,
+ * like an IBGS instance).  Frames prepared by bgs_set_ingest go through bgs_process.
  */
 int bgs_submit(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols, int channels, size_t in_step, uint8_t* fg, size_t fg_step,
                uint8_t* bg, size_t bg_step);
@@ -330,6 +339,24 @@ int bgs_kernel_timing(bgs_engine* e, double* avg_ms, int64_t* launches, const ch
  * last reset into ms[] and returns how many were written (negative = error).  bench.py commits the series behind its
  * burst / sustained figures from this (profiles/rNN_mog2_launch_series.csv). */
 int64_t bgs_kernel_timing_series(bgs_engine* e, float* ms, int64_t cap);
+
+/*
+ * Measurement aids: what THIS box delivers, measured by the library in the process that benchmarks it (bench.py `calibration`,
+ * `host_path`).  Boxes of one pool differ by several percent, and so does the physical placement of a multi-GB allocation; a figure
+ * that is to be compared across boxes needs the box's own yardstick beside it.
+ *   bgs_calibrate_copy  float4 copy kernel over `bytes` bytes (bytes/2 read + bytes/2 written per launch; mean of `iters` launches after
+ *                       two warm-ups, HIP events): through ONE plain hipMalloc (chunk_mb = 0) or through one virtual range backed by
+ *                       physical chunks of chunk_mb MiB - the construction the big models use (BGS_OPT_MODEL_CHUNK_MB).  *gbps in GB/s.
+ *   bgs_calibrate_pcie  `iters` copies of `bytes` bytes each way between the device and page-locked host memory: hipHostMalloc
+ *                       (registered = 0: the engine's own staging) or ordinary memory page-locked in place with hipHostRegister
+ *                       (registered = 1: a caller buffer under BGS_OPT_HOST_REGISTER; *register_ms = what that call took).
+ * bgs_get_state(e, 0, "hostpath", double[14]) returns an engine's host-path counters since creation: buffers currently page-locked in
+ * place per role [0..2] (input, mask, background) and refused per role [3..5], hipHostRegister calls [6] and their total ms [7],
+ * hipHostUnregister calls [8], frames [9], bytes host-to-device [10] and device-to-host [11], CPU ms spent copying into [12] and out
+ * of [13] pinned staging.
+ */
+int bgs_calibrate_copy(int hip_device, size_t bytes, int chunk_mb, int iters, double* gbps);
+int bgs_calibrate_pcie(int hip_device, size_t bytes, int registered, int iters, double* h2d_gbps, double* d2h_gbps, double* register_ms);
 
 void bgs_destroy(bgs_engine* e);
 

@@ -38,7 +38,7 @@ static inline uint8_t sat_u8_f(float v); /* cv::saturate_cast<uchar>(float), bel
  * each, a right partial cell (index r, weight ar; r = -1: none) - in that order, which is the order resizeArea_ accumulates in. */
 typedef struct { int l, s1, s2, r; float al, af, ar; } area_span_t;
 static area_span_t area_span(int ssize, int dsize, int d) {
-  const double scale = (double)ssize / dsize;
+  const double scale = 1.0 / ((double)dsize / ssize);  /* as cv::resize computes it: inv_scale = dsize / ssize, scale = 1 / inv_scale (differs from ssize / dsize in the last ulp for some sizes) */
   const double fsx1 = d * scale, fsx2 = fsx1 + scale;
   const double cell = scale < ssize - fsx1 ? scale : ssize - fsx1;
   int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
@@ -178,7 +178,7 @@ struct ss_state {
 };
 
 #define REQ_VALID 0x8000u
-#define REQ(slot, code) (uint16_t)(REQ_VALID | ((unsigned)(slot) << 8) | (unsigned)(code))
+#define REQ(slot, code) (uint16_t)(REQ_VALID | ((unsigned)(slot) << 5) | (unsigned)(code)) /* bits 5..14: sample slot (nBGSamples up to 1023), bits 0..4: target */
 
 static float* fmap(size_t n, float v) {
   float* p = (float*)malloc(n * sizeof(float));
@@ -453,7 +453,7 @@ static void ss_phase_b(ss_state* s) {
           for (int q = 0; q < 2; ++q) { /* self request first, then the neighbour request */
             const unsigned r = s->req[i * 2 + q];
             if (!(r & REQ_VALID)) continue;
-            const int code = (int)(r & 0x1f), slot = (int)((r >> 8) & 0x3f);
+            const int code = (int)(r & 0x1f), slot = (int)((r >> 5) & 0x3ff);
             const int ty = ys + code / 5 - 2, tx = xs + code % 5 - 2;
             if (ty != y || tx != x) continue;
             const uint8_t* srcC = s->lobster ? s->curColor : s->lastColor; /* = current frame colour of the source */

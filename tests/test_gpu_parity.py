@@ -249,6 +249,59 @@ def test_device_batch_matches_oracle(name, borrow):
             check_mog2_state(eng, orcs[s], H * W, stream=s)
 
 
+RAGGED = ["MixtureOfGaussianV2BGS", "MixtureOfGaussianV1BGS", "FrameDifferenceBGS", "WeightedMovingVarianceBGS", "AdaptiveBackgroundLearning",
+          "AdaptiveSelectiveBackgroundLearning", "GMG", "SigmaDeltaBGS", "DPZivkovicAGMMBGS", "DPAdaptiveMedianBGS", "SuBSENSEBGS", "LOBSTERBGS"]
+
+
+@pytest.mark.parametrize("name", RAGGED)
+@pytest.mark.parametrize("with_fg", [True, False])
+def test_packed_masks_of_frames_that_are_not_a_multiple_of_64_pixels(name, with_fg):
+    """350 x 233 = 81 550 pixels = 1 274 words + 14 bits (VideoCapture resizes by a percentage, VideoCapture.cpp:158-207: any size can
+    reach IBGS::process).  Stream k of a call owns words [k W, (k + 1) W), W = ceil(n / 64); the bits of its last word past pixel
+    n - 1 are zero.  Per-frame calls over 3 streams, then one clip call; with and without a byte mask beside the packed one."""
+    torch = _torch()
+    algo = dict(ALGOS, SuBSENSEBGS=capi.SUBSENSE, LOBSTERBGS=capi.LOBSTER)[name]
+    S, T, NC, H, W = 3, 5, 3, 233, 350
+    n, words = H * W, (H * W + 63) // 64
+    clips = np.stack([synth.random_frames(T + NC, H, W, 3, seed=640 + s) for s in range(S)])
+    eng = Engine(algo, n_streams=S)
+    eng.set_geometry(H, W, 3)
+    orcs = [pyoracle.Oracle(algo) for _ in range(S)]
+
+    def unpack(t_bits):
+        raw = t_bits.cpu().numpy().view(np.uint8).reshape(-1, words * 8)
+        bits = np.unpackbits(raw, axis=1, bitorder="little")
+        assert not bits[:, n:].any(), "tail bits of the last word must be zero"
+        return bits[:, :n].reshape(-1, H, W)
+
+    for t in range(T):
+        d_frames = torch.from_numpy(np.ascontiguousarray(clips[:, t])).cuda()
+        d_fg = torch.full((S, H, W), 9, dtype=torch.uint8, device="cuda") if with_fg else None
+        d_bits = torch.full((S, words), -1, dtype=torch.int64, device="cuda")
+        flags = eng.process_batch_device(d_frames, d_fg, None, d_bits)
+        torch.cuda.synchronize()
+        for s in range(S):
+            ofg, _ = orcs[s].process(clips[s, t], want_bg=False)
+            assert bool(flags & capi.FG_VALID) == (ofg is not None), (name, t)
+            if ofg is None:
+                assert bool((d_bits[s] == -1).all()), (name, t, "a warm-up frame leaves the words untouched")
+                continue
+            assert np.array_equal(unpack(d_bits[s:s + 1])[0] * 255, np.where(ofg != 0, 255, 0)), (name, t, s)
+            if with_fg:
+                assert np.array_equal(d_fg[s].cpu().numpy(), ofg), (name, t, s)
+    slab = torch.from_numpy(np.ascontiguousarray(clips[:, T:T + NC].transpose(1, 0, 2, 3, 4))).cuda()  # [NC][S][H][W][3]
+    d_fgc = torch.full((NC, S, H, W), 9, dtype=torch.uint8, device="cuda") if with_fg else None
+    d_bitsc = torch.full((NC, S, words), -1, dtype=torch.int64, device="cuda")
+    eng.process_clip_device(slab, NC, d_fgc, None, d_bitsc)
+    torch.cuda.synchronize()
+    got = unpack(d_bitsc.reshape(NC * S, words)).reshape(NC, S, H, W)
+    for t in range(NC):
+        for s in range(S):
+            ofg, _ = orcs[s].process(clips[s, T + t], want_bg=False)
+            assert np.array_equal(got[t, s] * 255, np.where(ofg != 0, 255, 0)), (name, "clip", t, s)
+    eng.close()
+
+
 @pytest.mark.parametrize("px", [1, 2, 4])
 def test_mog2_pixels_per_lane_variants_agree(px):
     frames = synth.numpy_frames("sat", 12, 16, 64, seed=7)
@@ -420,7 +473,7 @@ def test_subsense_ragged_sizes(shape):
     check_subsense_state(eng, orc, shape[0], shape[1])
 
 
-@pytest.mark.parametrize("kw", [dict(subsense_n_samples=20), dict(subsense_n_samples=3), dict(subsense_n_samples=5), dict(subsense_n_samples=63),  # 3 / 5 / 63: not whole batches of four
+@pytest.mark.parametrize("kw", [dict(subsense_n_samples=20), dict(subsense_n_samples=3), dict(subsense_n_samples=5), dict(subsense_n_samples=63), dict(subsense_n_samples=100), dict(subsense_n_samples=130),  # 3 / 5 / 63: not whole batches of four; 100 / 130: past the 6-bit slot field of rounds 1-3
                                 dict(subsense_n_required=3), dict(subsense_min_color_dist_threshold=15),
                                 dict(subsense_desc_dist_threshold_offset=1), dict(lbsp_rel_threshold=0.2), dict(subsense_samples_for_moving_avgs=20)])
 def test_subsense_param_variants(kw, golden_frames):
@@ -705,7 +758,7 @@ def test_lobster_ragged_sizes(shape):
     check_lobster_state(eng, orc, shape[0], shape[1])
 
 
-@pytest.mark.parametrize("kw", [dict(subsense_n_samples=8, subsense_n_required=1), dict(subsense_n_samples=20, subsense_n_required=4), dict(subsense_min_color_dist_threshold=12),
+@pytest.mark.parametrize("kw", [dict(subsense_n_samples=8, subsense_n_required=1), dict(subsense_n_samples=20, subsense_n_required=4), dict(subsense_n_samples=100), dict(subsense_min_color_dist_threshold=12),
                                 dict(subsense_desc_dist_threshold_offset=1), dict(lbsp_rel_threshold=0.2, lbsp_threshold_offset=6)])
 def test_lobster_param_variants(kw, golden_frames):
     p = _params(capi.LOBSTER, **kw)

@@ -15,7 +15,7 @@ FRAME_DIFF, STATIC_FRAME_DIFF, WMM, WMV, ABL, ASBL, MOG2, MOG1, GMG, SUBSENSE, L
 DP_ZIVKOVIC_AGMM, DP_GRIMSON_GMM, DP_WREN_GA, DP_MEAN, DP_ADAPTIVE_MEDIAN = range(12, 17)
 LOBSTER = 17
 FG_VALID, BG_VALID = 1, 2
-OPT_BORROW_FRAMES, OPT_MOG2_PIXELS_PER_LANE, OPT_MOG2_TILED, OPT_XCD_SWIZZLE, OPT_PLACEMENT_PROBE, OPT_MOG2_SPARSE, OPT_CLIP_FUSE, OPT_HOST_REGISTER, OPT_MODEL_CHUNK_MB = 1, 2, 3, 4, 5, 6, 7, 8, 9
+OPT_BORROW_FRAMES, OPT_MOG2_PIXELS_PER_LANE, OPT_MOG2_TILED, OPT_XCD_SWIZZLE, OPT_PLACEMENT_PROBE, OPT_MOG2_SPARSE, OPT_CLIP_FUSE, OPT_HOST_REGISTER, OPT_MODEL_CHUNK_MB, OPT_MODEL_CHUNK_MIN_MB = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_GEOMETRY, ERR_HIP, ERR_NOMEM, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
 
@@ -98,6 +98,8 @@ SYMBOLS = [
     ("bgs_enable_kernel_timing", C.c_int, [_P, C.c_int]),
     ("bgs_kernel_timing", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_char_p)]),
     ("bgs_kernel_timing_series", C.c_int64, [_P, C.POINTER(C.c_float), C.c_int64]),
+    ("bgs_calibrate_copy", C.c_int, [C.c_int, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    ("bgs_calibrate_pcie", C.c_int, [C.c_int, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("bgs_destroy", None, [_P]),
     ("bgs_last_error", C.c_char_p, []),
     ("bgs_lbsp_describe_device", C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
@@ -191,3 +193,17 @@ def default_params(algo):
     p.struct_size = C.sizeof(BgsParams)
     check(lib().bgs_default_params(algo, C.byref(p)))
     return p
+
+
+def calibrate_copy(device, nbytes, chunk_mb, iters=5):
+    """bgs_calibrate_copy: GB/s of a float4 copy over nbytes through a plain (chunk_mb = 0) or chunked allocation."""
+    g = C.c_double(0)
+    check(lib().bgs_calibrate_copy(device, nbytes, chunk_mb, iters, C.byref(g)))
+    return g.value
+
+
+def calibrate_pcie(device, nbytes, registered, iters=20):
+    """bgs_calibrate_pcie: (H2D GB/s, D2H GB/s, hipHostRegister ms)"""
+    u, d, r = C.c_double(0), C.c_double(0), C.c_double(0)
+    check(lib().bgs_calibrate_pcie(device, nbytes, 1 if registered else 0, iters, C.byref(u), C.byref(d), C.byref(r)))
+    return u.value, d.value, r.value

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -59,6 +60,14 @@ namespace {
 struct SsDevice;  // engine_subsense.h
 }
 
+
+// One virtual address range backed by separately created physical chunks (hipMemAddressReserve + hipMemCreate x n + hipMemMap): how
+// the big models are placed (model_allocate) and what bgs_calibrate_copy measures beside a plain hipMalloc.
+struct VmmRange {
+  std::vector<hipMemGenericAllocationHandle_t> handles;
+  void* base = nullptr;
+  size_t bytes = 0, chunk = 0, mapped = 0;  // mapped: chunks actually mapped (a failure half-way leaves fewer than handles)
+};
 
 struct bgs_engine {
   bgs_algo algo;
@@ -113,9 +122,8 @@ struct bgs_engine {
   int model_chunk_mb = 256;        // big models are built from physical chunks of this size (model_allocate); 0: one plain hipMalloc
   bool poison = false;             // BGS_DEBUG_POISON: every fresh device buffer is filled with 0xA5 (see dmalloc)
   // a model built from fixed-size physical chunks with the virtual memory API (model_allocate)
-  std::vector<hipMemGenericAllocationHandle_t> vmm_handles;
-  void* vmm_base = nullptr;
-  size_t vmm_bytes = 0, vmm_chunk = 0;
+  VmmRange vmm;
+  size_t model_chunk_min_bytes = (size_t)768 << 20;     // models below this take one plain hipMalloc (BGS_MODEL_CHUNK_MIN_MB: test knob)
 
   // host staging (bgs_process)
   uint8_t *h_in = nullptr, *h_fg = nullptr, *h_bg = nullptr;
@@ -141,11 +149,17 @@ struct bgs_engine {
     uint32_t flags = 0;
   };
   std::vector<Lane> lanes;
+  // host-path diagnostics (bgs_get_state "hostpath"; bench.py host_path): what hipHostRegister cost and how often it ran, how long the
+  // CPU spent copying images into / out of pinned staging, bytes that crossed the bus each way
+  double diag_reg_ms = 0, diag_stage_in_ms = 0, diag_stage_out_ms = 0;
+  int64_t diag_reg_calls = 0, diag_unreg_calls = 0, diag_h2d_bytes = 0, diag_d2h_bytes = 0, diag_frames = 0;
   int host_register = 0;          // BGS_OPT_HOST_REGISTER: roles that may be page-locked in place (bit 0 input, 1 mask, 2 background); 0 = always stage
   bool ingest_on = false;             // bgs_set_ingest: bgs_process takes raw frames
   bgs_ingest ingest{};
   int raw_rows = 0, raw_cols = 0;     // geometry of the raw frames (fixed by the first one)
   uint8_t *h_raw = nullptr, *d_raw = nullptr, *d_ingest_ws = nullptr;  // raw staging for configurations that need device work
+  uint8_t* pack_fg = nullptr;         // frames of rows*cols % 64 != 0 pixels: the byte masks a packed-only caller's bit masks are made from
+  size_t pack_fg_bytes = 0;
   int last_fg_stream = -1;            // bgs_last_mask_blobs: whose mask d_fg holds (-1: none valid)
   void* cc_work = nullptr;            // its device scratch: workspace | boxes | moments | count
   int cc_cap = 0;                     // boxes the scratch has room for
@@ -159,22 +173,36 @@ struct bgs_engine {
 namespace {
 
 void ss_free(bgs_engine* e);  // engine_subsense.h
-void vmm_free(bgs_engine* e);  // below (placement experiment)
+void vmm_free(VmmRange& v);  // below
+
+void lane_release(bgs_engine::Lane& ln) {  // whatever of a lane came to be (bgs_submit's set-up may have failed half-way)
+  if (ln.hs) (void)hipStreamSynchronize(ln.hs);
+  void* host[] = {ln.h_in, ln.h_fg, ln.h_bg};
+  for (void* h : host)
+    if (h) (void)hipHostFree(h);
+  void* dv[] = {ln.d_in, ln.d_fg, ln.d_bg};
+  for (void* d : dv)
+    if (d) (void)hipFree(d);
+  if (ln.done) (void)hipEventDestroy(ln.done);
+  if (ln.hs) (void)hipStreamDestroy(ln.hs);
+  ln = bgs_engine::Lane();
+}
 
 void free_all(bgs_engine* e) {
   for (auto& r : e->ring)
     if (r) (void)hipFree(r), r = nullptr;
   if (e->abl_lut) (void)hipFree(e->abl_lut), e->abl_lut = nullptr, e->abl_lut_valid = false;
   if (e->cc_work) (void)hipFree(e->cc_work), e->cc_work = nullptr, e->cc_cap = 0;
+  if (e->pack_fg) (void)hipFree(e->pack_fg), e->pack_fg = nullptr, e->pack_fg_bytes = 0;
   if (e->h_raw) (void)hipHostFree(e->h_raw), e->h_raw = nullptr;
   if (e->d_raw) (void)hipFree(e->d_raw), e->d_raw = nullptr;
   if (e->d_ingest_ws) (void)hipFree(e->d_ingest_ws), e->d_ingest_ws = nullptr;
   e->last_fg_stream = -1;
-  if (e->vmm_base) {  // a model built by model_allocate from physical chunks: not hipFree's to release
-    if ((void*)e->mog2_state == e->vmm_base) e->mog2_state = nullptr;
-    if ((void*)e->mog1_state == e->vmm_base) e->mog1_state = nullptr;
-    if ((void*)e->dp_state == e->vmm_base) e->dp_state = nullptr;
-    vmm_free(e);
+  if (e->vmm.base) {  // a model built by model_allocate from physical chunks: not hipFree's to release
+    if ((void*)e->mog2_state == e->vmm.base) e->mog2_state = nullptr;
+    if ((void*)e->mog1_state == e->vmm.base) e->mog1_state = nullptr;
+    if ((void*)e->dp_state == e->vmm.base) e->dp_state = nullptr;
+    vmm_free(e->vmm);
   }
   void* dev[] = {e->dp_state, e->gmg_colors, e->gmg_weights, e->gmg_nfeat, e->bgstate, e->bgstate2, e->mog1_state, e->mog2_state, e->d_in, e->d_fg, e->d_bg};
   for (void* d : dev)
@@ -199,18 +227,7 @@ void free_all(bgs_engine* e) {
     if (hp.pinned) (void)hipHostUnregister(const_cast<void*>(hp.ptr));
     hp = bgs_engine::HostPin();
   }
-  for (auto& ln : e->lanes) {
-    if (ln.hs) (void)hipStreamSynchronize(ln.hs);
-    void* host[] = {ln.h_in, ln.h_fg, ln.h_bg};
-    for (void* h : host)
-      if (h) (void)hipHostFree(h);
-    void* dv[] = {ln.d_in, ln.d_fg, ln.d_bg};
-    for (void* d : dv)
-      if (d) (void)hipFree(d);
-    if (ln.done) (void)hipEventDestroy(ln.done);
-    if (ln.hs) (void)hipStreamDestroy(ln.hs);
-    ln = bgs_engine::Lane();
-  }
+  for (auto& ln : e->lanes) lane_release(ln);
 }
 
 int check_params(bgs_algo algo, const bgs_params& p) {
@@ -392,11 +409,11 @@ size_t mog2_state_bytes(const bgs_engine* e) {
 // (1.103-1.110 ms per 32 x 1080p MOG2 launch), 3 of 3 in the slow class with 4 GiB chunks (1.21 ms), while plain hipMalloc gave
 // 1.11 1.11 1.12 1.19 1.21 1.21.  So: chunks of 256 MiB (BGS_MODEL_CHUNK_MB; 0 = one plain hipMalloc), no probe, no transient memory.
 // one virtual range backed by separately created physical chunks of `chunk` bytes each
-int vmm_allocate(bgs_engine* e, void** out, size_t bytes, size_t chunk) {
+int vmm_allocate(VmmRange& v, int device, void** out, size_t bytes, size_t chunk) {
   hipMemAllocationProp prop = {};
   prop.type = hipMemAllocationTypePinned;
   prop.location.type = hipMemLocationTypeDevice;
-  prop.location.id = e->device;
+  prop.location.id = device;
   size_t gran = 0;
   HIP_TRY(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
   if (!gran) gran = 2u << 20;
@@ -404,36 +421,47 @@ int vmm_allocate(bgs_engine* e, void** out, size_t bytes, size_t chunk) {
   const size_t total = (bytes + chunk - 1) / chunk * chunk;
   void* base = nullptr;
   HIP_TRY(hipMemAddressReserve(&base, total, 0, nullptr, 0));
-  e->vmm_base = base, e->vmm_bytes = total, e->vmm_chunk = chunk;
+  v.base = base, v.bytes = total, v.chunk = chunk, v.mapped = 0;
   for (size_t off = 0; off < total; off += chunk) {
     hipMemGenericAllocationHandle_t h;
     HIP_TRY(hipMemCreate(&h, chunk, &prop, 0));
-    e->vmm_handles.push_back(h);
+    v.handles.push_back(h);
     HIP_TRY(hipMemMap((char*)base + off, chunk, 0, h, 0));
+    v.mapped++;  // vmm_free unmaps exactly the (address, size) pairs that were mapped, also after a failure half-way
   }
   hipMemAccessDesc acc = {};
   acc.location = prop.location;
   acc.flags = hipMemAccessFlagsProtReadWrite;
   HIP_TRY(hipMemSetAccess(base, total, &acc, 1));
-  if (e->poison) HIP_TRY(hipMemsetAsync(base, 0xA5, total, e->stream));
   *out = base;
   return BGS_OK;
 }
-void vmm_free(bgs_engine* e) {
-  if (!e->vmm_base) return;
-  (void)hipMemUnmap(e->vmm_base, e->vmm_bytes);
-  for (auto& h : e->vmm_handles) (void)hipMemRelease(h);
-  (void)hipMemAddressFree(e->vmm_base, e->vmm_bytes);
-  e->vmm_handles.clear(), e->vmm_base = nullptr, e->vmm_bytes = 0;
+void vmm_free(VmmRange& v) {
+  if (!v.base) return;
+  // HIP's virtual memory API is Beta: release in the portable order - every chunk unmapped with the (address, size) it was mapped
+  // with, then every handle released, then the range freed - and say so when a step fails (a silent failure here leaks gigabytes)
+  auto warn = [](const char* what, hipError_t er) {
+    if (er != hipSuccess) {
+      fprintf(stderr, "[bgs] %s failed while releasing a chunked range: %s\n", what, hipGetErrorString(er));
+      (void)hipGetLastError();
+    }
+  };
+  for (size_t i = 0; i < v.mapped; ++i) warn("hipMemUnmap", hipMemUnmap((char*)v.base + i * v.chunk, v.chunk));
+  for (auto& h : v.handles) warn("hipMemRelease", hipMemRelease(h));
+  warn("hipMemAddressFree", hipMemAddressFree(v.base, v.bytes));
+  v.handles.clear(), v.base = nullptr, v.bytes = 0, v.mapped = 0;
 }
 
 // A model of `bytes`: chunked (see above) from 768 MB up - smaller ones sit in the 256 MiB Infinity Cache for a good part and are
 // not HBM-bound - else, or when the virtual memory API refuses, one hipMalloc.  An engine has at most one such model.
 int model_allocate(bgs_engine* e, void** out, size_t bytes) {
-  if (e->model_chunk_mb > 0 && bytes >= ((size_t)768 << 20) && !e->vmm_base) {
-    if (vmm_allocate(e, out, bytes, (size_t)e->model_chunk_mb << 20) == BGS_OK) return BGS_OK;
+  if (e->model_chunk_mb > 0 && bytes >= e->model_chunk_min_bytes && !e->vmm.base) {
+    if (vmm_allocate(e->vmm, e->device, out, bytes, (size_t)e->model_chunk_mb << 20) == BGS_OK) {
+      if (e->poison) HIP_TRY(hipMemsetAsync(*out, 0xA5, e->vmm.bytes, e->stream));
+      return BGS_OK;
+    }
     (void)hipGetLastError();
-    vmm_free(e);  // whatever part of it came to be
+    vmm_free(e->vmm);  // whatever part of it came to be
     *out = nullptr;
   }
   return dmalloc(e, out, bytes);
@@ -573,7 +601,11 @@ bool host_pin(bgs_engine* e, int stream, int role, const void* ptr, size_t bytes
   if (hp.ptr == ptr && hp.bytes == bytes) {
     if (hp.pinned) return true;
     if (hp.refused) return false;
-    if (hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) return hp.pinned = true;
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t er = hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault);
+    e->diag_reg_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    e->diag_reg_calls++;
+    if (er == hipSuccess) return hp.pinned = true;
     (void)hipGetLastError();  // not registrable (e.g. already registered by the caller, read-only mapping): keep staging
     hp.refused = true;
     return false;
@@ -581,6 +613,7 @@ bool host_pin(bgs_engine* e, int stream, int role, const void* ptr, size_t bytes
   if (hp.pinned) {
     (void)hipStreamSynchronize(user ? user : e->stream);
     (void)hipHostUnregister(const_cast<void*>(hp.ptr));
+    e->diag_unreg_calls++;
   }
   hp = bgs_engine::HostPin();
   hp.ptr = ptr, hp.bytes = bytes;  // a candidate: registered when it comes back
@@ -675,6 +708,23 @@ uint64_t launch_key(const bgs_engine* e, int i) {
 
 int process_run(bgs_engine* e, int first, int count, const uint8_t* d_frames, uint8_t* d_fg, uint8_t* d_bg, uint64_t* d_bits, hipStream_t s, uint32_t* out_flags);
 
+// engine-owned byte masks for packed-only callers of frames whose pixel count is not a multiple of 64 (see process_range); grown on
+// demand, ordered on the call's stream like every other engine buffer
+int pack_scratch(bgs_engine* e, size_t bytes, hipStream_t s) {
+  if (e->pack_fg_bytes >= bytes) return BGS_OK;
+  if (e->pack_fg) {
+    HIP_TRY(hipStreamSynchronize(s));
+    (void)hipFree(e->pack_fg), e->pack_fg = nullptr, e->pack_fg_bytes = 0;
+  }
+  HIP_TRY(hipMalloc((void**)&e->pack_fg, bytes));
+  e->pack_fg_bytes = bytes;
+  return BGS_OK;
+}
+void pack_ragged(bgs_engine* e, const uint8_t* fg, uint64_t* bits, size_t images, hipStream_t s) {
+  const size_t W = (e->n + 63) / 64;
+  hipLaunchKernelGGL(bgs::mask_pack_ragged_kernel, dim3(blocks_for(images * W * bgs::kWave)), dim3(bgs::kBlock), 0, s, fg, bits, e->n, W, images);
+}
+
 // One frame for streams [first, first+count), device pointers, asynchronous on s: one launch per run of streams (see launch_key).
 int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, uint8_t* d_fg, uint8_t* d_bg, uint64_t* d_bits, hipStream_t s,
                   uint32_t* out_flags) {
@@ -682,7 +732,18 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
   if (!e->n) return fail(BGS_ERR_INVALID, "geometry not set: call bgs_set_geometry or bgs_process first");
   if (first < 0 || count <= 0 || first + count > e->S) return fail(BGS_ERR_INVALID, "stream range [%d,%d) outside 0..%d", first, first + count, e->S);
   if (!d_frames) return fail(BGS_ERR_INVALID, "d_frames is NULL");
-  if (d_bits && e->n % 64) return fail(BGS_ERR_UNSUPPORTED, "packed mask needs rows*cols %% 64 == 0");
+  // Packed masks: stream k of the call owns words [k W, (k + 1) W), W = ceil(rows*cols / 64).  When rows*cols is a multiple of 64
+  // (1080p, 4K, 720p, VGA, the reference's 320x176 video ...) the kernels write the words themselves from wave ballots; otherwise a
+  // wave's 64 pixels straddle two words (and two streams), so the kernels write byte masks - the caller's d_fg, or the engine's own
+  // buffer when it passed none - and mask_pack_ragged_kernel makes the words from them, tail bits zero.
+  const size_t W = (e->n + 63) / 64;
+  const bool ragged = d_bits && (e->n % 64) != 0;
+  const bool via_bytes = e->algo == BGS_GMG || e->algo == BGS_ASBL;  // their packed mask is always made from the finished byte mask (median after the pixel loop)
+  if (d_bits && !d_fg && (ragged || via_bytes)) {
+    int rc = pack_scratch(e, (size_t)count * e->n, s);
+    if (rc) return rc;
+    d_fg = e->pack_fg;
+  }
   uint32_t all = ~0u;
   const size_t C = (size_t)e->ch, bgC = e->algo == BGS_ASBL ? 1 : C;
   for (int a = first; a < first + count;) {
@@ -693,8 +754,9 @@ int process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, 
       return fail(BGS_ERR_INVALID, "borrowed frame history needs streams in lock-step (streams %d and %d are not)", a, b);
     const size_t o = (size_t)(a - first) * e->n;
     uint32_t fl = 0;
-    int rc = process_run(e, a, b - a, d_frames + o * C, d_fg ? d_fg + o : nullptr, d_bg ? d_bg + o * bgC : nullptr, d_bits ? d_bits + o / 64 : nullptr, s, &fl);
+    int rc = process_run(e, a, b - a, d_frames + o * C, d_fg ? d_fg + o : nullptr, d_bg ? d_bg + o * bgC : nullptr, (d_bits && !ragged) ? d_bits + (size_t)(a - first) * W : nullptr, s, &fl);
     if (rc) return rc;
+    if (ragged && (fl & BGS_FG_VALID)) pack_ragged(e, d_fg + o, d_bits + (size_t)(a - first) * W, (size_t)(b - a), s);
     all &= fl;
     a = b;
   }
@@ -711,7 +773,7 @@ int process_run(bgs_engine* e, int first, int count, const uint8_t* d_frames, ui
   const bgs_params& p = e->p;
   const int C = e->ch;
   const size_t npix = e->n * count, off = e->n * first, fb = npix * C;
-  if (d_bits && npix % 64) return fail(BGS_ERR_UNSUPPORTED, "packed mask needs rows*cols %% 64 == 0");
+  if (d_bits && npix % 64) return fail(BGS_ERR_INVALID, "internal: a ragged packed mask reached process_run");  // process_range packs those itself
   uint32_t flags = 0;
 
   bgs::FrameArgs a{};
@@ -997,15 +1059,24 @@ int process_clip(bgs_engine* e, int first, int count, int nframes, const uint8_t
   if (!e->n) return fail(BGS_ERR_INVALID, "geometry not set: call bgs_set_geometry or bgs_process first");
   if (first < 0 || count <= 0 || first + count > e->S) return fail(BGS_ERR_INVALID, "stream range [%d,%d) outside 0..%d", first, first + count, e->S);
   if (!d_frames) return fail(BGS_ERR_INVALID, "d_frames is NULL");
-  if (d_bits && e->n % 64) return fail(BGS_ERR_UNSUPPORTED, "packed mask needs rows*cols %% 64 == 0");
+  const size_t W = (e->n + 63) / 64;
+  const bool ragged = d_bits && (e->n % 64) != 0;  // as in process_range: byte masks first, then mask_pack_ragged_kernel
+  if (d_bits && !d_fg && (ragged || e->algo == BGS_GMG || e->algo == BGS_ASBL)) {
+    int rc = pack_scratch(e, (size_t)nframes * count * e->n, s);
+    if (rc) return rc;
+    d_fg = e->pack_fg;
+  }
   const size_t C = (size_t)e->ch, bgC = e->algo == BGS_ASBL ? 1 : C;
   std::vector<uint32_t> fl((size_t)nframes), all((size_t)nframes, ~0u);
   for (int a = first; a < first + count;) {
     int b = a + 1;
     while (b < first + count && e->seen[b] == e->seen[a] && launch_key(e, b) == launch_key(e, a)) ++b;
     const size_t o = (size_t)(a - first) * e->n;
-    int rc = process_clip_run(e, a, b - a, count, nframes, d_frames + o * C, d_fg ? d_fg + o : nullptr, d_bg ? d_bg + o * bgC : nullptr, d_bits ? d_bits + o / 64 : nullptr, s, fl.data());
+    int rc = process_clip_run(e, a, b - a, count, nframes, d_frames + o * C, d_fg ? d_fg + o : nullptr, d_bg ? d_bg + o * bgC : nullptr, (d_bits && !ragged) ? d_bits + (size_t)(a - first) * W : nullptr, s, fl.data());
     if (rc) return rc;
+    if (ragged)
+      for (int t = 0; t < nframes; ++t)
+        if (fl[t] & BGS_FG_VALID) pack_ragged(e, d_fg + (size_t)t * count * e->n + o, d_bits + ((size_t)t * count + (size_t)(a - first)) * W, (size_t)(b - a), s);
     for (int t = 0; t < nframes; ++t) all[t] &= fl[t];
     a = b;
   }
@@ -1287,6 +1358,7 @@ int bgs_create(bgs_algo algo, const bgs_params* params, int hip_device, int n_st
   if (const char* env = getenv("BGS_XCD_SWIZZLE")) e->xcd_swizzle = atoi(env);
   if (const char* env = getenv("BGS_MOG2_SPARSE")) e->mog2_sparse = atoi(env);
   if (const char* env = getenv("BGS_MODEL_CHUNK_MB")) e->model_chunk_mb = atoi(env);
+  if (const char* env = getenv("BGS_MODEL_CHUNK_MIN_MB")) e->model_chunk_min_bytes = (size_t)std::max(atoi(env), 0) << 20;
   if (const char* env = getenv("BGS_CLIP_FUSE")) e->clip_fuse = atoi(env) != 0;
   if (const char* env = getenv("BGS_DEBUG_POISON")) e->poison = atoi(env) != 0;
   if (const char* env = getenv("BGS_HOST_REGISTER")) e->host_register = atoi(env) & 7;
@@ -1369,24 +1441,39 @@ int bgs_set_option(bgs_engine* e, int option, int64_t value) {
       if (e->n) return fail(BGS_ERR_INVALID, "the model is allocated when the geometry is set");
       e->model_chunk_mb = (int)std::max<int64_t>(value, 0);
       return BGS_OK;
+    case 10:
+      if (e->n) return fail(BGS_ERR_INVALID, "the model is allocated when the geometry is set");
+      e->model_chunk_min_bytes = (size_t)std::max<int64_t>(value, 0) << 20;
+      return BGS_OK;
     default: return fail(BGS_ERR_INVALID, "unknown option %d", option);
   }
+}
+
+// A bgs_submit still in flight runs on its lane's own non-blocking HIP stream: a device-path call over the same camera would race
+// with it on that camera's model, ring slot and frame count.  The device entry points refuse instead (bgs_wait first).
+static int range_busy(const bgs_engine* e, int first, int count) {
+  for (int i = std::max(first, 0); i < first + count && i < e->S; ++i)
+    if (e->lanes[i].pending) return fail(BGS_ERR_STATE, "stream %d has a bgs_submit in flight: bgs_wait before a device-path call that covers it", i);
+  return BGS_OK;
 }
 
 int bgs_process_range_device(bgs_engine* e, int first, int count, const void* d_frames, void* d_fg, void* d_bg, void* d_fg_bits, void* hip_stream,
                              uint32_t* out_flags) {
   if (!e) return fail(BGS_ERR_INVALID, "engine is NULL");
+  if (int rc = range_busy(e, first, count)) return rc;
   return process_range(e, first, count, (const uint8_t*)d_frames, (uint8_t*)d_fg, (uint8_t*)d_bg, (uint64_t*)d_fg_bits, (hipStream_t)hip_stream, out_flags);
 }
 
 int bgs_process_clip_device(bgs_engine* e, int first, int count, int nframes, const void* d_frames, void* d_fg, void* d_bg, void* d_fg_bits,
                             void* hip_stream, uint32_t* out_flags) {
   if (!e) return fail(BGS_ERR_INVALID, "engine is NULL");
+  if (int rc = range_busy(e, first, count)) return rc;
   return process_clip(e, first, count, nframes, (const uint8_t*)d_frames, (uint8_t*)d_fg, (uint8_t*)d_bg, (uint64_t*)d_fg_bits, (hipStream_t)hip_stream, out_flags);
 }
 
 int bgs_process_batch_device(bgs_engine* e, const void* d_frames, void* d_fg, void* d_bg, void* d_fg_bits, void* hip_stream, uint32_t* out_flags) {
   if (!e) return fail(BGS_ERR_INVALID, "engine is NULL");
+  if (int rc = range_busy(e, 0, e->S)) return rc;
   return process_range(e, 0, e->S, (const uint8_t*)d_frames, (uint8_t*)d_fg, (uint8_t*)d_bg, (uint64_t*)d_fg_bits, (hipStream_t)hip_stream, out_flags);
 }
 
@@ -1447,9 +1534,11 @@ int bgs_process(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols
     // staging is pipelined: while the DMA engine moves band k, the CPU copies band k+1 of the caller's (pageable, possibly
     // strided) image into the pinned buffer.  Flip (rows reversed) and ROI (a window of the raw frame) cost nothing extra: they
     // only change which source row and column each staged row starts at.
+    e->diag_frames++, e->diag_h2d_bytes += (int64_t)fb;
     if (!ingest && in_step == rb && host_pin(e, stream, 0, in, fb)) {
       HIP_TRY(hipMemcpyAsync(dst, in, fb, hipMemcpyHostToDevice, e->stream));  // straight from the caller's page-locked frame buffer
     } else {
+      const auto st0 = std::chrono::steady_clock::now();
       const int bands = rows >= 64 ? 8 : 1;
       for (int b = 0; b < bands; ++b) {
         const int y0 = (int)((int64_t)rows * b / bands), y1 = (int)((int64_t)rows * (b + 1) / bands);
@@ -1460,6 +1549,7 @@ int bgs_process(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols
         }
         HIP_TRY(hipMemcpyAsync(dst + (size_t)y0 * rb, e->h_in + (size_t)y0 * rb, (size_t)(y1 - y0) * rb, hipMemcpyHostToDevice, e->stream));
       }
+      e->diag_stage_in_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - st0).count();
     }
   }
   uint32_t flags = 0;
@@ -1477,6 +1567,7 @@ int bgs_process(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols
   // outputs the caller keeps allocated (same buffer as last call, contiguous rows) are written by the DMA engine directly
   const bool fg_direct = out_fg && fg_step == (size_t)cols && host_pin(e, stream, 1, fg, e->n);
   const bool bg_direct = out_bg && bg_step == (size_t)cols * bg_ch && host_pin(e, stream, 2, bg, e->n * bg_ch);
+  e->diag_d2h_bytes += (int64_t)((out_fg ? e->n : 0) + (out_bg ? e->n * bg_ch : 0));
   if (fg_direct) HIP_TRY(hipMemcpyAsync(fg, e->d_fg, e->n, hipMemcpyDeviceToHost, e->stream));
   if (bg_direct) HIP_TRY(hipMemcpyAsync(bg, e->d_bg, e->n * bg_ch, hipMemcpyDeviceToHost, e->stream));
   if (fg_direct) out_fg = false;
@@ -1519,10 +1610,12 @@ static int lane_wait(bgs_engine* e, int stream, uint32_t* out_flags) {
   HIP_TRY(hipEventSynchronize(ln.done));
   ln.pending = false;
   const int bg_ch = e->algo == BGS_ASBL ? 1 : e->ch;
+  const auto st0 = std::chrono::steady_clock::now();
   if (ln.fg && !ln.fg_direct && (ln.flags & BGS_FG_VALID))
     for (int y = 0; y < e->rows; ++y) std::memcpy(ln.fg + (size_t)y * ln.fg_step, ln.h_fg + (size_t)y * e->cols, (size_t)e->cols);
   if (ln.bg && !ln.bg_direct && (ln.flags & BGS_BG_VALID))
     for (int y = 0; y < e->rows; ++y) std::memcpy(ln.bg + (size_t)y * ln.bg_step, ln.h_bg + (size_t)y * e->cols * bg_ch, (size_t)e->cols * bg_ch);
+  e->diag_stage_out_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - st0).count();
   if (out_flags) *out_flags = ln.flags;
   return BGS_OK;
 }
@@ -1543,26 +1636,35 @@ int bgs_submit(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols,
   const size_t rb = (size_t)cols * channels, fb = e->n * channels;
   const int bg_ch = e->algo == BGS_ASBL ? 1 : channels;
   if (!ln.hs) {
-    HIP_TRY(hipStreamCreateWithFlags(&ln.hs, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
-    HIP_TRY(hipHostMalloc((void**)&ln.h_in, fb, hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void**)&ln.h_fg, e->n, hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void**)&ln.h_bg, e->n * bg_ch, hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void**)&ln.d_in, fb));
-    HIP_TRY(hipMalloc((void**)&ln.d_fg, e->n));
-    HIP_TRY(hipMalloc((void**)&ln.d_bg, e->n * bg_ch));
+    // all or nothing: a lane whose stream exists but whose buffers do not would send the next submission through null pointers
+    hipError_t er = hipStreamCreateWithFlags(&ln.hs, hipStreamNonBlocking);
+    if (er == hipSuccess) er = hipEventCreateWithFlags(&ln.done, hipEventDisableTiming);
+    if (er == hipSuccess) er = hipHostMalloc((void**)&ln.h_in, fb, hipHostMallocDefault);
+    if (er == hipSuccess) er = hipHostMalloc((void**)&ln.h_fg, e->n, hipHostMallocDefault);
+    if (er == hipSuccess) er = hipHostMalloc((void**)&ln.h_bg, e->n * bg_ch, hipHostMallocDefault);
+    if (er == hipSuccess) er = hipMalloc((void**)&ln.d_in, fb);
+    if (er == hipSuccess) er = hipMalloc((void**)&ln.d_fg, e->n);
+    if (er == hipSuccess) er = hipMalloc((void**)&ln.d_bg, e->n * bg_ch);
+    if (er != hipSuccess) {
+      (void)hipGetLastError();
+      lane_release(ln);
+      return fail(BGS_ERR_HIP, "bgs_submit: setting up the lane of stream %d failed: %s", stream, hipGetErrorString(er));
+    }
   }
   uint8_t* dst = ln.d_in;
   if (e->nring) dst = e->ring[e->rpos[stream] % e->nring] + (size_t)stream * fb;  // history classes: straight into their ring slot
+  e->diag_frames++, e->diag_h2d_bytes += (int64_t)fb;
   if (in_step == rb && host_pin(e, stream, 0, in, fb, ln.hs)) {
     HIP_TRY(hipMemcpyAsync(dst, in, fb, hipMemcpyHostToDevice, ln.hs));
   } else {
+    const auto st0 = std::chrono::steady_clock::now();
     const int bands = rows >= 64 ? 8 : 1;  // the CPU stages band k+1 while the DMA engine moves band k
     for (int b = 0; b < bands; ++b) {
       const int y0 = (int)((int64_t)rows * b / bands), y1 = (int)((int64_t)rows * (b + 1) / bands);
       for (int y = y0; y < y1; ++y) std::memcpy(ln.h_in + (size_t)y * rb, in + (size_t)y * in_step, rb);
       HIP_TRY(hipMemcpyAsync(dst + (size_t)y0 * rb, ln.h_in + (size_t)y0 * rb, (size_t)(y1 - y0) * rb, hipMemcpyHostToDevice, ln.hs));
     }
+    e->diag_stage_in_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - st0).count();
   }
   uint32_t flags = 0;
   const bool saved_borrow = e->borrow;
@@ -1574,6 +1676,7 @@ int bgs_submit(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols,
   ln.flags = flags, ln.fg = fg, ln.bg = bg, ln.fg_step = fg_step, ln.bg_step = bg_step;
   ln.fg_direct = fg && (flags & BGS_FG_VALID) && fg_step == (size_t)cols && host_pin(e, stream, 1, fg, e->n, ln.hs);
   ln.bg_direct = bg && (flags & BGS_BG_VALID) && bg_step == (size_t)cols * bg_ch && host_pin(e, stream, 2, bg, e->n * bg_ch, ln.hs);
+  e->diag_d2h_bytes += (int64_t)(((fg && (flags & BGS_FG_VALID)) ? e->n : 0) + ((bg && (flags & BGS_BG_VALID)) ? e->n * bg_ch : 0));
   if (fg && (flags & BGS_FG_VALID)) HIP_TRY(hipMemcpyAsync(ln.fg_direct ? fg : ln.h_fg, ln.d_fg, e->n, hipMemcpyDeviceToHost, ln.hs));
   if (bg && (flags & BGS_BG_VALID)) HIP_TRY(hipMemcpyAsync(ln.bg_direct ? bg : ln.h_bg, ln.d_bg, e->n * bg_ch, hipMemcpyDeviceToHost, ln.hs));
   HIP_TRY(hipEventRecord(ln.done, ln.hs));
@@ -1600,8 +1703,17 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
     if (hipMemcpy(dst, src, nb, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
     return (int64_t)nb;
   };
+  if (!strcmp(plane, "hostpath")) {  // diagnostics of bgs_process / bgs_submit since creation: 14 doubles (see bench.py host_path)
+    double rec[14] = {0};
+    for (size_t i = 0; i < e->pin.size(); ++i) rec[i % 3] += e->pin[i].pinned, rec[3 + i % 3] += e->pin[i].refused;  // per role: input, mask, background
+    rec[6] = (double)e->diag_reg_calls, rec[7] = e->diag_reg_ms, rec[8] = (double)e->diag_unreg_calls, rec[9] = (double)e->diag_frames;
+    rec[10] = (double)e->diag_h2d_bytes, rec[11] = (double)e->diag_d2h_bytes, rec[12] = e->diag_stage_in_ms, rec[13] = e->diag_stage_out_ms;
+    if (cap < sizeof(rec)) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
+    memcpy(dst, rec, sizeof(rec));
+    return (int64_t)sizeof(rec);
+  }
   if (!strcmp(plane, "placement")) {  // diagnostics: [0] chunk size in MiB of the chunked model (0: one plain allocation), [1] number of chunks
-    float rec[2] = {e->vmm_base ? (float)(e->vmm_chunk >> 20) : 0.f, (float)e->vmm_handles.size()};
+    float rec[2] = {e->vmm.base ? (float)(e->vmm.chunk >> 20) : 0.f, (float)e->vmm.handles.size()};
     if (cap < sizeof(rec)) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
     memcpy(dst, rec, sizeof(rec));
     return (int64_t)sizeof(rec);
@@ -1793,6 +1905,116 @@ void bgs_destroy(bgs_engine* e) {
   delete e;
 }
 
+// ---- measurement aids (bench.py `calibration`): what THIS box's memory system and bus deliver, measured by the library that is being
+// benchmarked, in the process that benchmarks it --------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void calib_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+}  // namespace
+
+int bgs_calibrate_copy(int hip_device, size_t bytes, int chunk_mb, int iters, double* gbps) {
+  if (!gbps || bytes < (1u << 20) || iters < 1 || chunk_mb < 0) return fail(BGS_ERR_INVALID, "bgs_calibrate_copy: bad argument");
+  *gbps = 0;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(BGS_ERR_HIP, "no HIP device visible: libbgs_hip has no CPU path");
+  HIP_TRY(hipSetDevice(hip_device));
+  const size_t half = bytes / 2 / 4096 * 4096, n = half / 16;
+  VmmRange v;
+  void* base = nullptr;
+  if (chunk_mb > 0) {
+    if (vmm_allocate(v, hip_device, &base, 2 * half, (size_t)chunk_mb << 20) != BGS_OK) {
+      vmm_free(v);
+      return BGS_ERR_HIP;  // text set by vmm_allocate
+    }
+  } else {
+    HIP_TRY(hipMalloc(&base, 2 * half));
+  }
+  hipStream_t s = nullptr;
+  hipEvent_t a = nullptr, b = nullptr;
+  hipError_t er = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (er == hipSuccess) er = hipEventCreate(&a);
+  if (er == hipSuccess) er = hipEventCreate(&b);
+  if (er == hipSuccess) er = hipMemsetAsync(base, 1, 2 * half, s);
+  float ms = 0;
+  if (er == hipSuccess) {
+    const dim3 grid((unsigned)((n + 255) / 256));
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(calib_copy_kernel, grid, dim3(256), 0, s, (const float4*)base, (float4*)((char*)base + half), n);
+    er = hipEventRecord(a, s);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(calib_copy_kernel, grid, dim3(256), 0, s, (const float4*)base, (float4*)((char*)base + half), n);
+    if (er == hipSuccess) er = hipEventRecord(b, s);
+    if (er == hipSuccess) er = hipEventSynchronize(b);
+    if (er == hipSuccess) er = hipEventElapsedTime(&ms, a, b);
+    if (er == hipSuccess) er = hipGetLastError();
+  }
+  if (a) (void)hipEventDestroy(a);
+  if (b) (void)hipEventDestroy(b);
+  if (s) (void)hipStreamSynchronize(s), (void)hipStreamDestroy(s);
+  if (chunk_mb > 0)
+    vmm_free(v);
+  else
+    (void)hipFree(base);
+  if (er != hipSuccess) return fail(BGS_ERR_HIP, "bgs_calibrate_copy: %s", hipGetErrorString(er));
+  *gbps = ms > 0 ? 2.0 * (double)half * iters / (ms * 1e-3) / 1e9 : 0.0;  // half read + half written per launch
+  return BGS_OK;
+}
+
+int bgs_calibrate_pcie(int hip_device, size_t bytes, int registered, int iters, double* h2d_gbps, double* d2h_gbps, double* register_ms) {
+  if (bytes < 4096 || iters < 1) return fail(BGS_ERR_INVALID, "bgs_calibrate_pcie: bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(BGS_ERR_HIP, "no HIP device visible: libbgs_hip has no CPU path");
+  HIP_TRY(hipSetDevice(hip_device));
+  void *h = nullptr, *d = nullptr;
+  double reg = 0;
+  if (registered) {  // the caller-buffer case of BGS_OPT_HOST_REGISTER: ordinary pageable memory, page-locked in place
+    if (posix_memalign(&h, 4096, bytes)) return fail(BGS_ERR_NOMEM, "out of host memory");
+    std::memset(h, 1, bytes);
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t er = hipHostRegister(h, bytes, hipHostRegisterDefault);
+    reg = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (er != hipSuccess) {
+      free(h);
+      return fail(BGS_ERR_HIP, "hipHostRegister failed: %s", hipGetErrorString(er));
+    }
+  } else {
+    HIP_TRY(hipHostMalloc(&h, bytes, hipHostMallocDefault));
+    std::memset(h, 1, bytes);
+  }
+  hipStream_t s = nullptr;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  hipError_t er = hipMalloc(&d, bytes);
+  if (er == hipSuccess) er = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  for (auto& e1 : ev)
+    if (er == hipSuccess) er = hipEventCreate(&e1);
+  float up = 0, down = 0;
+  if (er == hipSuccess) {
+    (void)hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s);  // warm
+    (void)hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s);
+    (void)hipEventRecord(ev[0], s);
+    for (int i = 0; i < iters; ++i) (void)hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s);
+    (void)hipEventRecord(ev[1], s);
+    for (int i = 0; i < iters; ++i) (void)hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s);
+    er = hipEventRecord(ev[2], s);
+    if (er == hipSuccess) er = hipEventSynchronize(ev[2]);
+    if (er == hipSuccess) er = hipEventElapsedTime(&up, ev[0], ev[1]);
+    if (er == hipSuccess) er = hipEventElapsedTime(&down, ev[1], ev[2]);
+  }
+  for (auto& e1 : ev)
+    if (e1) (void)hipEventDestroy(e1);
+  if (s) (void)hipStreamSynchronize(s), (void)hipStreamDestroy(s);
+  if (d) (void)hipFree(d);
+  if (registered)
+    (void)hipHostUnregister(h), free(h);
+  else
+    (void)hipHostFree(h);
+  if (er != hipSuccess) return fail(BGS_ERR_HIP, "bgs_calibrate_pcie: %s", hipGetErrorString(er));
+  if (h2d_gbps) *h2d_gbps = up > 0 ? (double)bytes * iters / (up * 1e-3) / 1e9 : 0.0;
+  if (d2h_gbps) *d2h_gbps = down > 0 ? (double)bytes * iters / (down * 1e-3) / 1e9 : 0.0;
+  if (register_ms) *register_ms = reg;
+  return BGS_OK;
+}
+
 int bgs_lbsp_describe_device(int hip_device, const void* d_img, int rows, int cols, int channels, const uint8_t* t_lut, void* d_desc, void* hip_stream) {
   return bgs_lbsp_describe_batch_device(hip_device, d_img, 1, rows, cols, channels, t_lut, d_desc, hip_stream);
 }
@@ -1959,6 +2181,7 @@ int bgs_last_mask_blobs(bgs_engine* e, int stream, int connectivity, int min_w, 
   for (int pass = 0; pass < 2; ++pass) {
     if (!e->cc_work || e->cc_cap < cap) {
       if (e->cc_work) (void)hipFree(e->cc_work), e->cc_work = nullptr, e->cc_cap = 0;
+  if (e->pack_fg) (void)hipFree(e->pack_fg), e->pack_fg = nullptr, e->pack_fg_bytes = 0;
       HIP_TRY(hipMalloc(&e->cc_work, ws + (size_t)cap * (sizeof(bgs_box) + sizeof(bgs_moments)) + 16));
       e->cc_cap = cap;
     }

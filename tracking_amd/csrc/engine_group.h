@@ -31,6 +31,7 @@ struct bgs_group {
   hipStream_t stream = nullptr;
   // host staging (single-stream groups)
   uint8_t *h_in = nullptr, *d_in = nullptr;
+  bool staged = false;  // bgs_group_process: the whole staging set exists
   std::vector<uint8_t*> h_fg, h_bg, d_fg, d_bg;
   // kernel timing of the fused launch
   bool timing = false;
@@ -51,11 +52,8 @@ unsigned fan_bit_of(bgs_algo a) {
   }
 }
 
-void group_free(bgs_group* g) {
-  void* dev[] = {g->ring[0], g->ring[1], g->ring[2], g->sfd_bg, g->abl_state, g->abl_lut, g->sd_mt, g->sd_vt, g->d_in};
-  for (void* d : dev)
-    if (d) (void)hipFree(d);
-  g->ring[0] = g->ring[1] = g->ring[2] = nullptr, g->sfd_bg = g->abl_state = g->abl_lut = g->sd_mt = g->sd_vt = g->d_in = nullptr;
+void group_free_staging(bgs_group* g) {  // bgs_group_process's host staging, whatever of it came to be
+  if (g->d_in) (void)hipFree(g->d_in), g->d_in = nullptr;
   if (g->h_in) (void)hipHostFree(g->h_in), g->h_in = nullptr;
   for (auto* v : {&g->h_fg, &g->h_bg})
     for (uint8_t*& p : *v)
@@ -63,6 +61,15 @@ void group_free(bgs_group* g) {
   for (auto* v : {&g->d_fg, &g->d_bg})
     for (uint8_t*& p : *v)
       if (p) (void)hipFree(p), p = nullptr;
+  g->staged = false;
+}
+
+void group_free(bgs_group* g) {
+  void* dev[] = {g->ring[0], g->ring[1], g->ring[2], g->sfd_bg, g->abl_state, g->abl_lut, g->sd_mt, g->sd_vt};
+  for (void* d : dev)
+    if (d) (void)hipFree(d);
+  g->ring[0] = g->ring[1] = g->ring[2] = nullptr, g->sfd_bg = g->abl_state = g->abl_lut = g->sd_mt = g->sd_vt = nullptr;
+  group_free_staging(g);
   for (auto& ev : g->events) (void)hipEventDestroy(ev.first), (void)hipEventDestroy(ev.second);
   g->events.clear();
   g->abl_lut_valid = false;
@@ -121,8 +128,12 @@ template <int G, int C>
 void group_launch_fan(bgs_group* g, const bgs::FanArgs& a, hipStream_t s) {
   const bool lut = (a.mask & bgs::kFanABL) && a.abl_update;
   if (lut) {
-    static int per_cu = 0;
-    if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bgs::fan_kernel<G, C, true>, bgs::kAblBlock, 0) != hipSuccess || per_cu < 1)) per_cu = 1;
+    static std::atomic<int> per_cu_cache{0};  // a property of the code object; atomic because groups may be driven from several host threads
+    int per_cu = per_cu_cache.load(std::memory_order_relaxed);
+    if (!per_cu) {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bgs::fan_kernel<G, C, true>, bgs::kAblBlock, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+      per_cu_cache.store(per_cu, std::memory_order_relaxed);
+    }
     const size_t per_tile = (size_t)bgs::kAblBlock * G, ntiles = (a.npix + per_tile - 1) / per_tile;
     const dim3 grid((unsigned)std::min<size_t>(ntiles, (size_t)per_cu * g->n_cu));
     hipLaunchKernelGGL((bgs::fan_kernel<G, C, true>), grid, dim3(bgs::kAblBlock), 0, s, a, (const uint8_t*)g->abl_lut);
@@ -354,16 +365,23 @@ int bgs_group_process(bgs_group* g, const uint8_t* in, int rows, int cols, int c
   int rc = bgs_group_set_geometry(g, rows, cols, channels);
   if (rc) return rc;
   const size_t fb = g->n * channels, row = (size_t)cols * channels;
-  if (!g->h_in) {
-    HIP_TRY(hipHostMalloc((void**)&g->h_in, fb, hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void**)&g->d_in, fb));
-    for (int i = 0; i < K; ++i) {
+  if (!g->staged) {
+    // all or nothing: a staging set with some class's buffers missing would silently drop that class's outputs
+    hipError_t er = hipHostMalloc((void**)&g->h_in, fb, hipHostMallocDefault);
+    if (er == hipSuccess) er = hipMalloc((void**)&g->d_in, fb);
+    for (int i = 0; i < K && er == hipSuccess; ++i) {
       const size_t bgb = g->n * (g->algos[i] == BGS_ASBL ? 1 : channels);
-      HIP_TRY(hipHostMalloc((void**)&g->h_fg[i], g->n, hipHostMallocDefault));
-      HIP_TRY(hipHostMalloc((void**)&g->h_bg[i], bgb, hipHostMallocDefault));
-      HIP_TRY(hipMalloc((void**)&g->d_fg[i], g->n));
-      HIP_TRY(hipMalloc((void**)&g->d_bg[i], bgb));
+      er = hipHostMalloc((void**)&g->h_fg[i], g->n, hipHostMallocDefault);
+      if (er == hipSuccess) er = hipHostMalloc((void**)&g->h_bg[i], bgb, hipHostMallocDefault);
+      if (er == hipSuccess) er = hipMalloc((void**)&g->d_fg[i], g->n);
+      if (er == hipSuccess) er = hipMalloc((void**)&g->d_bg[i], bgb);
     }
+    if (er != hipSuccess) {
+      (void)hipGetLastError();
+      group_free_staging(g);
+      return fail(BGS_ERR_HIP, "bgs_group_process: staging buffers: %s", hipGetErrorString(er));
+    }
+    g->staged = true;
   }
   for (int y = 0; y < rows; ++y) std::memcpy(g->h_in + (size_t)y * row, in + (size_t)y * in_step, row);
   HIP_TRY(hipMemcpyAsync(g->d_in, g->h_in, fb, hipMemcpyHostToDevice, g->stream));  // ONE upload for all the classes

@@ -56,8 +56,8 @@ struct SsDevice {
 int ss_allocate(bgs_engine* e) {
   if (e->rows < 5 || e->cols < 5) return fail(BGS_ERR_UNSUPPORTED, "SuBSENSE needs at least 5x5 pixels (LBSP::validateROI)");
   const bgs_params& p = e->p;
-  if (p.subsense_n_samples < 1 || p.subsense_n_samples > 63 || p.subsense_n_required > p.subsense_n_samples)
-    return fail(BGS_ERR_UNSUPPORTED, "SuBSENSE: nBGSamples must be 1..63 and nRequiredBGSamples <= nBGSamples");
+  if (p.subsense_n_samples < 1 || p.subsense_n_samples > bgs::kSsMaxSamples || p.subsense_n_required > p.subsense_n_samples)
+    return fail(BGS_ERR_UNSUPPORTED, "SuBSENSE: nBGSamples must be 1..%d and nRequiredBGSamples <= nBGSamples", bgs::kSsMaxSamples);
   SsDevice* d = new SsDevice();
   e->ss = d;
   // geometry-dependent switches of BackgroundSubtractorSuBSENSE::initialize (:121-140), ROI = whole frame (SuBSENSE.cpp:36)
@@ -390,8 +390,8 @@ int64_t ss_get_state(bgs_engine* e, int stream, const char* plane, void* dst, si
 int lob_allocate(bgs_engine* e) {
   if (e->rows < 5 || e->cols < 5) return fail(BGS_ERR_UNSUPPORTED, "LOBSTER needs at least 5x5 pixels (LBSP::validateROI)");
   const bgs_params& p = e->p;
-  if (p.subsense_n_samples < 1 || p.subsense_n_samples > 63 || p.subsense_n_required > p.subsense_n_samples)
-    return fail(BGS_ERR_UNSUPPORTED, "LOBSTER: nBGSamples must be 1..63 and nRequiredBGSamples <= nBGSamples");
+  if (p.subsense_n_samples < 1 || p.subsense_n_samples > bgs::kSsMaxSamples || p.subsense_n_required > p.subsense_n_samples)
+    return fail(BGS_ERR_UNSUPPORTED, "LOBSTER: nBGSamples must be 1..%d and nRequiredBGSamples <= nBGSamples", bgs::kSsMaxSamples);
   SsDevice* d = new SsDevice();
   e->ss = d;
   const size_t N = e->n, P = N * e->S, nS = (size_t)p.subsense_n_samples, C = (size_t)e->ch;

@@ -495,6 +495,16 @@ __global__ __launch_bounds__(kBlock) void mask_pack_kernel(const uint8_t* src, u
   if ((threadIdx.x & (kWave - 1)) == 0 && p < n) dst[p >> 6] = w;
 }
 
+// The same for `count` images of n pixels each when n is NOT a multiple of 64: image k owns words [k W, (k + 1) W), W = ceil(n / 64),
+// and the bits of its last word past pixel n - 1 are zero.  One wave per word.
+__global__ __launch_bounds__(kBlock) void mask_pack_ragged_kernel(const uint8_t* src, uint64_t* dst, size_t n, size_t W, size_t count) {
+  const size_t word = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;  // wave-uniform
+  if (word >= W * count) return;
+  const size_t img = word / W, i = (word - img * W) * 64 + (threadIdx.x & (kWave - 1));
+  const unsigned long long w = __ballot(i < n && src[img * n + i] != 0);
+  if ((threadIdx.x & (kWave - 1)) == 0) dst[word] = w;
+}
+
 // host side: one launch over `count` images stored back to back
 inline void morph_launch(const MorphArgs& a, int count, hipStream_t s) {
   if (a.op == 2)

@@ -83,8 +83,12 @@ __device__ __constant__ const int8_t kSsN3[8][2] = {{-1, 1}, {0, 1}, {1, 1}, {-1
 __device__ __constant__ const int8_t kSsN5[24][2] = {{-2, 2},  {-1, 2},  {0, 2},  {1, 2},  {2, 2},  {-2, 1},  {-1, 1},  {0, 1},  {1, 1},  {2, 1},  {-2, 0},  {-1, 0},
                                                      {1, 0},   {2, 0},   {-2, -1}, {-1, -1}, {0, -1}, {1, -1}, {2, -1}, {-2, -2}, {-1, -2}, {0, -2}, {1, -2}, {2, -2}};
 
+// An update request, 16 bits: bit 15 valid | bits 5..14 the sample slot (0..1023: ./config/SuBSENSEBGS.xml may set any nBGSamples,
+// SuBSENSE.cpp:69) | bits 0..4 the target, (dy + 2) * 5 + (dx + 2) relative to the source (12 = the source itself).
 #define SS_REQ_VALID 0x8000u
-__device__ __forceinline__ uint16_t ss_req(unsigned slot, int code) { return (uint16_t)(SS_REQ_VALID | (slot << 8) | (unsigned)code); }
+constexpr int kSsMaxSamples = 1023;
+__device__ __forceinline__ uint16_t ss_req(unsigned slot, int code) { return (uint16_t)(SS_REQ_VALID | (slot << 5) | (unsigned)code); }
+__device__ __forceinline__ unsigned ss_req_slot(unsigned r) { return (r >> 5) & 0x3ffu; }
 
 // One background sample: colour c[C] + descriptor d[C], packed (see the layout note at the top of the file).
 template <int C>
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
         unsigned dsc[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) dsc[c] = intra[c];
-        SsSample<C>::make(cur, dsc).store(a.samples, ss_rec(a, stream, N, p, (int)((reqSelf >> 8) & 0x3fu)));
+        SsSample<C>::make(cur, dsc).store(a.samples, ss_rec(a, stream, N, p, (int)ss_req_slot(reqSelf)));
       }
       // feedback :553-576
       const float dmin_min = dminLT < dminST ? dminLT : dminST, dmin_max = dminLT > dminST ? dminLT : dminST;
@@ -700,11 +704,11 @@ __device__ __forceinline__ bool ss_req_is_last(const uint32_t (*rq)[HW], int tly
     for (int dx = -2; dx <= 2; ++dx) {
       const int sy = tly + dy, sx = tlx + dx;  // inside the halo'd tile: the target is inside the tile
       const uint32_t both = rq[sy][sx];
-      const uint32_t aimed = SS_REQ_VALID | (slot << 8) | (uint32_t)(12 - 5 * dy - dx);  // a request of (sy, sx) for this target and slot
+      const uint32_t aimed = SS_REQ_VALID | (slot << 5) | (uint32_t)(12 - 5 * dy - dx);  // a request of (sy, sx) for this target and slot
 #pragma unroll
       for (int qq = 0; qq < 2; ++qq) {
         if (INTERIOR && qq != ((dy == 0 && dx == 0) ? 0 : 1)) continue;
-        if (((both >> (16 * qq)) & (SS_REQ_VALID | 0x3f00u | 0x1fu)) == aimed && (sy * HW + sx) * 2 + qq > key) last = false;
+        if (((both >> (16 * qq)) & 0xffffu) == aimed && (sy * HW + sx) * 2 + qq > key) last = false;
       }
     }
   return last;
@@ -789,7 +793,7 @@ __global__ __launch_bounds__(kBlock) void ss_phase_b_kernel(const SsArgs a) {
       const int code = (int)(r & 0x1fu), tly = ly + code / 5 - 2, tlx = lx + code % 5 - 2;
       const int t = (tly - 2) * kSsTW + (tlx - 2);
       contested = ((cnt[t >> 2] >> (8 * (t & 3))) & 0xffu) > 1u;
-      if (!contested) write(ly, lx, tly, tlx, (r >> 8) & 0x3fu);
+      if (!contested) write(ly, lx, tly, tlx, ss_req_slot(r));
     }
     ss_list_push(list2, &nlist2, contested, ent, lane);
   }
@@ -802,7 +806,7 @@ __global__ __launch_bounds__(kBlock) void ss_phase_b_kernel(const SsArgs a) {
     const int ly = (int)(ent >> 16), lx = (int)((ent >> 8) & 0xffu), q = (int)(ent & 1u);
     const uint32_t r = (rq[ly][lx] >> (16 * q)) & 0xffffu;
     const int code = (int)(r & 0x1fu), tly = ly + code / 5 - 2, tlx = lx + code % 5 - 2;
-    const uint32_t slot = (r >> 8) & 0x3fu;
+    const uint32_t slot = ss_req_slot(r);
     const int key = (ly * HW + lx) * 2 + q;  // position in the reference's order of writes
     const bool last = interior ? ss_req_is_last<HW, true>(rq, tly, tlx, slot, key) : ss_req_is_last<HW, false>(rq, tly, tlx, slot, key);
     if (last) write(ly, lx, tly, tlx, slot);
@@ -1525,7 +1529,7 @@ struct SsAreaSpan {
   float al, af, ar;
 };
 __device__ __forceinline__ SsAreaSpan ss_area_span(int ssize, int dsize, int d) {
-  const double scale = (double)ssize / dsize;
+  const double scale = 1.0 / ((double)dsize / ssize);  /* as cv::resize computes it: inv_scale = dsize / ssize, scale = 1 / inv_scale (differs from ssize / dsize in the last ulp for some sizes) */
   const double fsx1 = d * scale, fsx2 = fsx1 + scale;
   const double cell = scale < ssize - fsx1 ? scale : ssize - fsx1;
   int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);

@@ -13,6 +13,11 @@ import torch
 import torch.distributed as dist
 
 
+def packed_words(rows, cols):
+    """64-bit words of one stream's bit-packed mask (include/bgs_hip.h: W = ceil(rows*cols / 64), tail bits zero)."""
+    return (rows * cols + 63) // 64
+
+
 def stream_block(total_streams, world_size, rank):
     """Contiguous block [first, first+count) of the global stream ids owned by `rank`."""
     base, extra = divmod(total_streams, world_size)
