@@ -33,14 +33,32 @@ BYTES_PER_PIXEL = 100
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured achievable)
 
 
-def make_pool(kind, streams, period, device, seed0):
-    """[period][streams][ROWS][COLS][3] uint8 in HBM; stream s uses seed seed0+s."""
+def make_source(kind, streams, device, seed0):
+    """A stateful frame source for `streams` cameras of this GPU (tools/synth.py): FRESH noise on every frame it produces.
+    Stream block seeds follow SURVEY.md 8d (config 5: seeds 1234+i / 4321+i): one generator per rank, seeded with the base + its first global stream."""
     from tools import synth
-    fn = synth.s_sat if kind == "sat" else synth.s_surv
-    pool = torch.empty((period, streams, ROWS, COLS, CH), dtype=torch.uint8, device=device)
-    for s in range(streams):
-        pool[:, s] = fn(period, ROWS, COLS, seed=seed0 + s, device=device)
-    return pool
+    cls = {"sat": synth.SatStreams, "surv": synth.SurvStreams, "dense": synth.DenseStreams}[kind]
+    return cls(streams, ROWS, COLS, seed0=seed0, device=device)
+
+
+MODEL_BYTES_PER_PIXEL = 122  # kernel_mog2.h: 20 weights + 20 summaries + 80 records + 2 meta
+
+
+def calibrate(local, streams):
+    """`calibration`: this box's own yardstick, taken in this process BEFORE the model exists - a float4 copy over the model's size
+    through (a) one plain hipMalloc and (b) one virtual range backed by 256 MiB physical chunks, the construction the model itself uses
+    (DESIGN.md 6.2).  Boxes of the pool differ by 5-9 % on every HBM-bound kernel; `roofline.frac_of_box_copy` prices the headline
+    kernel against (b), so the line says whether a slow number is a slow box."""
+    from tracking_amd import capi
+    nbytes = (streams * ROWS * COLS + 255) // 256 * 256 * MODEL_BYTES_PER_PIXEL
+    out = {"bytes": nbytes, "kernel": "float4 copy, bytes/2 read + bytes/2 written per launch, mean of 5 launches after 2 warm-ups (bgs_calibrate_copy)"}
+    for label, chunk in (("copy_GBps_plain", 0), ("copy_GBps_chunked", 256), ("copy_GBps_plain_again", 0)):
+        try:
+            out[label] = round(capi.calibrate_copy(local, nbytes, chunk), 1)
+        except Exception as ex:  # noqa: BLE001 - diagnostics only
+            out[label] = None
+            out[label + "_error"] = repr(ex)
+    return out
 
 
 def host_cores():
@@ -57,13 +75,12 @@ def host_cores():
     return int(env) if env else min(n, 16)
 
 
-def cpu_baseline(pool, kind, budget_s=16.0):
+def cpu_baseline(frames, kind, budget_s=16.0):
     """The oracle (CPU restatement, kind='port') timed on this box's host cores on a bounded sample of the same
-    workload: stream 0's frames, model warmed for 2 periods, then as many 1080p frames as fit in ~budget_s."""
+    workload: stream 0's frames ([period][H][W][3] numpy), model warmed for 2 periods, then as many 1080p frames as fit in ~budget_s."""
     from oracle import pyoracle
     from tracking_amd import capi
     cores = host_cores()
-    frames = pool[:, 0].cpu().numpy()
     period = frames.shape[0]
     res = {}
     for label, threads, share in (("all", cores, 0.7), ("one", 1, 0.3)):
@@ -92,15 +109,38 @@ def cpu_baseline(pool, kind, budget_s=16.0):
     }
 
 
-def host_leg(local, pool, frames_n=120):
+HOSTPATH_FIELDS = ("pinned_input", "pinned_mask", "pinned_background", "refused_input", "refused_mask", "refused_background", "register_calls", "register_ms_total",
+                   "unregister_calls", "frames", "h2d_bytes", "d2h_bytes", "cpu_ms_staging_in", "cpu_ms_staging_out", "arenas")
+
+
+def _hostpath_diag(e):
+    """an engine's host-path counters (bgs_get_state "hostpath"): which buffers are page-locked in place, what registering them cost,
+    how long the CPU copied - so that a slow leg names its own cause"""
+    v = e.get_state("hostpath", (len(HOSTPATH_FIELDS),), np.float64)
+    d = {k: (round(float(x), 3) if "ms" in k else int(x)) for k, x in zip(HOSTPATH_FIELDS, v)}
+    fr = max(1, d["frames"])
+    d["cpu_ms_staging_per_frame"] = round((d["cpu_ms_staging_in"] + d["cpu_ms_staging_out"]) / fr, 4)
+    return d
+
+
+def host_leg(local, clip, frames_n=120):
     """The drop-in call today's IBGS::process callers make - bgs_process, host buffers, one 1080p stream, synchronous - through the
     ctypes binding: staged (default: every image goes through the engine's pinned buffers) and with BGS_OPT_HOST_REGISTER (the caller's
     frame and mask buffers stay allocated, as OpenCV's capture loop keeps them: page-locked once, DMA'd in place).  PCIe-inclusive,
-    never `value`."""
+    never `value`.  clip: [period][H][W][3] numpy, stream 0's frames."""
     from tracking_amd import Engine, capi
-    clip = pool[:, 0].cpu().numpy()  # [period][H][W][3]
     period = clip.shape[0]
-    out = {"note": "bgs_process (host buffers, 1 x 1920x1080x3 stream, mask only, synchronous) through the ctypes binding; PCIe-inclusive; never `value`"}
+    out = {"note": "bgs_process (host buffers, 1 x 1920x1080x3 stream, mask only, synchronous) through the ctypes binding; PCIe-inclusive; never `value`; "
+                   "`diag` = the engine's own counters after the leg (buffers page-locked in place / refused per role, hipHostRegister calls and ms, CPU ms in staging copies)"}
+    fb = ROWS * COLS * CH
+    pcie = {}
+    for label, reg in (("pinned_hipHostMalloc", 0), ("registered_pageable", 1)):
+        try:
+            u, d, r = capi.calibrate_pcie(local, fb, reg)
+            pcie[label] = {"h2d_GBps": round(u, 2), "d2h_GBps": round(d, 2), "hipHostRegister_ms": round(r, 3)}
+        except Exception as ex:  # noqa: BLE001
+            pcie[label] = {"error": repr(ex)}
+    out["pcie_calibration"] = dict(pcie, note="bgs_calibrate_pcie: 20 copies of one 1080p BGR frame (6.2 MB) each way; what the staged and the registered legs can at best reach on this box")
     for label, reg in (("staged", 0), ("registered_buffers", 3)):
         e = Engine(capi.MOG2, device=local)
         e.set_option(capi.OPT_HOST_REGISTER, reg)
@@ -117,20 +157,35 @@ def host_leg(local, pool, frames_n=120):
             fill += time.perf_counter() - f0
             e.process_into(frame, fg)
         dt = time.perf_counter() - t0 - fill
-        out[label] = {"ms_per_frame": round(dt / frames_n * 1e3, 4), "frames_per_s": round(frames_n / dt, 1), "mpixels_per_s": round(frames_n * ROWS * COLS / dt / 1e6, 1)}
+        out[label] = {"ms_per_frame": round(dt / frames_n * 1e3, 4), "frames_per_s": round(frames_n / dt, 1), "mpixels_per_s": round(frames_n * ROWS * COLS / dt / 1e6, 1), "diag": _hostpath_diag(e)}
         e.close()
-    # several cameras: bgs_submit / bgs_wait - every camera's frame queued on its own lane before any is collected
+    # several cameras: bgs_submit / bgs_wait - every camera's frame queued on its own lane before any is collected.  Three ways of
+    # holding the cameras' images: staged; each buffer page-locked on its own (16 registrations for 8 cameras); ONE arena for all input
+    # frames and one for all masks, registered once each (bgs_host_arena)
     cams = 8
-    for label, reg in (("submit_wait_8_cameras_staged", 0), ("submit_wait_8_cameras_registered_buffers", 3)):
+    for label, reg, arena in (("submit_wait_8_cameras_staged", 0, False), ("submit_wait_8_cameras_registered_buffers", 3, False), ("submit_wait_8_cameras_registered_arena", 0, True)):
         e = Engine(capi.MOG2, device=local, n_streams=cams)
         e.set_option(capi.OPT_HOST_REGISTER, reg)
-        frames = [np.ascontiguousarray(clip[(3 * c) % period]) for c in range(cams)]
-        fgs = [np.empty((ROWS, COLS), np.uint8) for _ in range(cams)]
+        if arena:
+            fr_all, fg_all = np.empty((cams, ROWS, COLS, CH), np.uint8), np.empty((cams, ROWS, COLS), np.uint8)
+            for c in range(cams):
+                fr_all[c] = clip[(3 * c) % period]
+            frames, fgs = [fr_all[c] for c in range(cams)], [fg_all[c] for c in range(cams)]
+            try:
+                e.host_arena(fr_all), e.host_arena(fg_all)
+            except Exception as ex:  # noqa: BLE001
+                out[label] = {"error": repr(ex)}
+                e.close()
+                continue
+        else:
+            frames = [np.ascontiguousarray(clip[(3 * c) % period]) for c in range(cams)]
+            fgs = [np.empty((ROWS, COLS), np.uint8) for _ in range(cams)]
         for t in range(12):
             for c in range(cams):
                 e.submit(frames[c], fgs[c], None, stream=c)
             for c in range(cams):
                 e.wait(stream=c)
+        reg_before = _hostpath_diag(e)["register_calls"]
         rounds = max(8, frames_n // cams)
         t0 = time.perf_counter()
         for t in range(rounds):
@@ -140,55 +195,79 @@ def host_leg(local, pool, frames_n=120):
                 e.wait(stream=c)
         dt = time.perf_counter() - t0
         n = rounds * cams
-        out[label] = {"cameras": cams, "ms_per_frame": round(dt / n * 1e3, 4), "frames_per_s_aggregate": round(n / dt, 1), "mpixels_per_s": round(n * ROWS * COLS / dt / 1e6, 1)}
+        diag = _hostpath_diag(e)
+        diag["register_calls_inside_timed_rounds"] = diag["register_calls"] - reg_before
+        out[label] = {"cameras": cams, "ms_per_frame": round(dt / n * 1e3, 4), "frames_per_s_aggregate": round(n / dt, 1), "mpixels_per_s": round(n * ROWS * COLS / dt / 1e6, 1),
+                      "bus_GBps": round(n * (fb + ROWS * COLS) / dt / 1e9, 2), "diag": diag}
         e.close()
     return out
 
 
-def surv_leg(local, S, fg, steps=200, sparse=1):
-    """Same engine on S_surv (static background + sensor noise + moving boxes, SURVEY.md §8d headline-streams input): the
-    kernel skips model planes no pixel of a wave uses or changed, so throughput rises with scene sparsity.  Reported beside
-    `value` (which stays the dense S_sat roofline workload)."""
+UPDATE_LAUNCHES = [0]  # bgs_process_batch_device calls on MOG2 engines so far = mog2_update_kernel dispatches, in order (the PMC child marks its legs by it)
+
+
+def scene_leg(local, S, fg, kind, steps=100, sparse=3, warm=150, pool=None, marks=None):
+    """The same engine on another scene, reported beside `value` (which stays S_sat):
+      surv   SURVEY.md 8d's headline-streams input - static background + sensor noise + moving boxes, ~1.2 live modes per pixel;
+      dense  the WORST case of round 3's summary filter - five modes 8 grey levels apart, all live, none of which a 4-byte summary can
+             rule out (kernel_mog2.h mog2_reject needs ~13 levels in every channel): every record of every pixel is read.
+    `warm` untimed launches on frames generated one by one, then `steps` timed launches over a pool of DISTINCT frames resident in HBM
+    (fresh noise in every frame).  Returns (dict, pool) so that a second leg on the same scene reuses the frames."""
     from tracking_amd import Engine, capi
     dev = torch.device("cuda", local)
-    period = 16
-    pool = make_pool("surv", S, period, dev, 4321)
     eng = Engine(capi.MOG2, device=local, n_streams=S)
     eng.set_option(capi.OPT_MOG2_SPARSE, sparse)
     eng.set_geometry(ROWS, COLS, CH)
-    for t in range(150):
-        eng.process_batch_device(pool[t % period], fg, None, None)
+    src = make_source(kind, S, dev, 4321 if kind == "surv" else 777)
+    cur = torch.empty((S, ROWS, COLS, CH), dtype=torch.uint8, device=dev)
+    for _ in range(warm):
+        eng.process_batch_device(src.into(cur), fg, None, None)
+        UPDATE_LAUNCHES[0] += 1
+    if pool is None:
+        pool = src.pool(steps)
     torch.cuda.synchronize()
     eng.enable_kernel_timing(True)
+    a = UPDATE_LAUNCHES[0]
     t0 = time.perf_counter()
     for t in range(steps):
-        eng.process_batch_device(pool[(150 + t) % period], fg, None, None)
+        eng.process_batch_device(pool[t % pool.shape[0]], fg, None, None)
+        UPDATE_LAUNCHES[0] += 1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if marks is not None:
+        marks[kind if sparse == 3 else "%s_sparse%d" % (kind, sparse)] = [a, UPDATE_LAUNCHES[0]]
     ms, _, _ = eng.kernel_timing()
     nm = eng.get_state("nmodes", (ROWS * COLS,), np.uint8, stream=0)
+    n_live = float(nm.mean())
     mpix = steps * S * ROWS * COLS / dt / 1e6
+    # what the slot layout must move on such a scene (kernel_mog2.h, count / eager kernel): read 3 frame + 2 meta + n (4 weight + 16 record);
+    # write 4 n weights (every live weight decays) + 16 (the ONE record a frame recomputes) + 1 mask (+ 2 meta when the order changes)
+    model = 22.0 + 24.0 * n_live
     out = {"mpixels_per_s": round(mpix, 1), "streams_1080p30": round(mpix / (ROWS * COLS / 1e6) / 30.0, 1), "kernel_ms": round(ms, 4),
-           "mean_live_modes_stream0": round(float(nm.mean()), 3), "foreground_ratio": round(float((fg != 0).float().mean()), 4),
-           # SURVEY.md §8(d) asks for its bytes model `8 + 28 n` (n = mean live modes) beside the S_surv rate
-           "bytes_model_per_pixel": round(8 + 28 * float(nm.mean()), 1), "bytes_model_GBps": round((8 + 28 * float(nm.mean())) * S * ROWS * COLS / (ms * 1e-3) / 1e9, 1),
-           "sparse_mode": sparse,
-           "note": "S_surv input, %d streams; BGS_OPT_MOG2_SPARSE=%d (1 = unchanged planes not written back, 2/4 = also planes of absent modes not read, per wave / per lane, 3 = automatic choice between 1 and 4 [default])" % (S, sparse)}
+           "mean_live_modes_stream0": round(n_live, 3), "foreground_ratio": round(float((fg != 0).float().mean()), 4),
+           "bytes_model_per_pixel": round(model, 1),
+           "bytes_model_derivation": "slot layout, n = mean live modes: r 3 frame + 2 meta + n (4 weight + 16 record) ; w 4 n weights + 16 the one record a frame recomputes + 1 mask (+ 2 meta when the rank order changes) = 22 + 24 n (SURVEY.md 8d's `8 + 28 n` priced the reference's sorted array)",
+           "bytes_model_GBps": round(model * S * ROWS * COLS / (ms * 1e-3) / 1e9, 1), "sparse_mode": sparse, "timed_launches": steps, "distinct_frames": int(pool.shape[0]),
+           "note": "%s input, %d streams, fresh noise in every frame; BGS_OPT_MOG2_SPARSE=%d (1 eager: every record read, 2 count: only the modes a pixel has, 4 filter: summaries first, 3 = automatic [default])" % ("S_" + kind, S, sparse)}
     eng.close()
-    del pool
-    return out
+    return out, pool
 
 
 CLIP_PMC_LAUNCHES = 10  # clip launches per T in the counter passes
 
 
-def pmc_traffic_live(streams, steps, warmup, inp, timeout_s=150):
-    """roofline.traffic (and the clip legs' traffic) measured IN this run: two child passes of this script under `rocprofv3 --kernel-trace
-    --pmc` (FETCH_SIZE, then WRITE_SIZE: they do not fit one pass).  A child runs the timed leg and then CLIP_PMC_LAUNCHES clip launches
-    of 4 and of 8 frames; the last `steps` dispatches of the update kernel and the last CLIP_PMC_LAUNCHES of each clip kernel are averaged and
-    corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts half of a wide streaming read; both are in KiB).
-    Children are ordinary subprocesses (never an exec from this GPU-holding process), each under a timeout; any failure returns None
-    and the caller falls back to the committed constant.  Returns ({kernel key: {hbm_bytes_per_launch, read_bytes, write_bytes}}, note)."""
+PMC_LEG_LAUNCHES = 20   # timed launches of the S_surv / S_dense legs inside a counter pass
+
+
+def pmc_traffic_live(streams, steps, warmup, inp, settle, timeout_s=300):
+    """roofline.traffic (and the traffic of the clip, S_surv and S_dense legs) measured IN this run: two child passes of this script under
+    `rocprofv3 --kernel-trace --pmc` (FETCH_SIZE, then WRITE_SIZE: they do not fit one pass).  A child runs the timed leg WITH THE SAME
+    settle / warm-up as the parent (the counters belong to the model state that is timed), then CLIP_PMC_LAUNCHES clip launches of 4 and
+    of 8 frames, then the S_surv and S_dense legs (PMC_LEG_LAUNCHES timed launches each), and writes which update-kernel dispatches
+    belong to which leg into a side file.  Counters are corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts half of
+    a wide streaming read; both are in KiB).  Children are ordinary subprocesses (never an exec from this GPU-holding process), each under
+    a timeout; any failure returns None and the caller falls back to the committed constant.
+    Returns ({leg: {hbm_bytes_per_launch, read_bytes, write_bytes}}, note)."""
     import csv
     import glob
     import shutil
@@ -198,14 +277,15 @@ def pmc_traffic_live(streams, steps, warmup, inp, timeout_s=150):
         return None, "rocprofv3 not on PATH"
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None, "this process is itself being profiled"
-    want = {"update": ("mog2_update", steps), "clip4": ("mog2_clip_kernel<4>", CLIP_PMC_LAUNCHES), "clip8": ("mog2_clip_kernel<8>", CLIP_PMC_LAUNCHES)}
-    out = {k: {} for k in want}
+    clip_want = {"clip4": "mog2_clip_kernel<4>", "clip8": "mog2_clip_kernel<8>"}
+    acc = {}
     env = dict(os.environ, TMPDIR="/tmp")
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="bgs_pmc_", dir="/tmp")
+        marks_path = os.path.join(d, "marks.json")
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
                sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--streams", str(streams),
-               "--input", inp, "--pmc-child", "--sustain", "0", "--settle", "100", "--no-cpu-baseline"]
+               "--input", inp, "--pmc-child", marks_path, "--sustain", "0", "--settle", str(settle), "--no-cpu-baseline"]
         try:
             p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
@@ -218,23 +298,29 @@ def pmc_traffic_live(streams, steps, warmup, inp, timeout_s=150):
             rows = []
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 rows += [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == ctr]
+            marks = json.load(open(marks_path)) if os.path.exists(marks_path) else {}
             shutil.rmtree(d, ignore_errors=True)
             rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-            for key, (pat, n) in want.items():
+            upd = [float(r["Counter_Value"]) for r in rows if "mog2_update" in r["Kernel_Name"]]
+            if rc != 0 or "update" not in marks or len(upd) < marks["update"][1]:
+                return None, "%s pass: rc=%s, %d update dispatches, marks %s" % (ctr, rc, len(upd), sorted(marks))
+            for leg, (a, b) in marks.items():
+                if b <= len(upd) and b > a:
+                    acc.setdefault(leg, {})[ctr] = sum(upd[a:b]) / (b - a)
+            for leg, pat in clip_want.items():
                 vals = [float(r["Counter_Value"]) for r in rows if pat in r["Kernel_Name"]]
-                if key == "update" and (rc != 0 or len(vals) < n):
-                    return None, "%s pass: rc=%s, %d dispatches" % (ctr, rc, len(vals))
-                if len(vals) >= n:
-                    out[key][ctr] = sum(vals[-n:]) / n
+                if len(vals) >= CLIP_PMC_LAUNCHES:
+                    acc.setdefault(leg, {})[ctr] = sum(vals[-CLIP_PMC_LAUNCHES:]) / CLIP_PMC_LAUNCHES
         except Exception as ex:  # noqa: BLE001 - diagnostics only, the bench line must still be printed
             shutil.rmtree(d, ignore_errors=True)
             return None, "%s pass failed: %r" % (ctr, ex)
     res = {}
-    for key, v in out.items():
+    for leg, v in acc.items():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             rd, wr = v["FETCH_SIZE"] * 1024 * 2, v["WRITE_SIZE"] * 1024
-            res[key] = {"hbm_bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr)}
-    return res, "measured in this run: two child passes under rocprofv3 --kernel-trace --pmc (FETCH_SIZE*1024*2 + WRITE_SIZE*1024, mean of the last %d dispatches of the update kernel / %d of each clip kernel)" % (steps, CLIP_PMC_LAUNCHES)
+            res[leg] = {"hbm_bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr)}
+    return res, ("measured in this run: two child passes under rocprofv3 --kernel-trace --pmc (FETCH_SIZE*1024*2 + WRITE_SIZE*1024; the child ages its model exactly like this "
+                 "process: settle %d; mean over the %d timed dispatches of the update kernel, %d of each clip kernel, %d of the S_surv / S_dense legs)" % (settle, steps, CLIP_PMC_LAUNCHES, PMC_LEG_LAUNCHES))
 
 
 def clip_leg(eng, pool, period, S, T, launches=40, warm=10):
@@ -272,22 +358,27 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--streams", type=int, default=32, help="streams per GPU (config 5: 32)")
-    ap.add_argument("--input", choices=["sat", "surv"], default="sat")
+    ap.add_argument("--input", choices=["sat", "surv", "dense"], default="sat")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-bg", action="store_true", help="also produce the background image every frame (+3 B/px)")
-    ap.add_argument("--main-only", action="store_true", help="only the timed S_sat leg (used under rocprofv3 so the last K launches are the timed ones)")
-    ap.add_argument("--pmc-child", action="store_true", help="what the counter passes run: the timed leg, then a few clip launches of 4 and 8 frames, nothing else")
+    ap.add_argument("--main-only", action="store_true", help="only the timed leg (used under rocprofv3 so the last K launches are the timed ones)")
+    ap.add_argument("--pmc-child", default="", metavar="MARKS.json", help="what the counter passes run: the timed leg, a few clip launches of 4 and 8 frames, short S_surv and S_dense legs; "
+                    "writes which update-kernel dispatches belong to which leg into MARKS.json")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs[2] / configs[3] block")
     ap.add_argument("--settle", type=int, default=340, help="untimed launches after model saturation and before the W warm-up steps: they age the model until the weights have equalised and every frame re-orders the modes (steady-state traffic)")
     ap.add_argument("--sustain", type=int, default=200, help="further launches after the timed K, reported as roofline.sustained")
     ap.add_argument("--series", default="", help="write the per-launch kernel durations (settle, warmup, timed, sustain) to this CSV")
     ap.add_argument("--rehearse", action="store_true", help="N > 1 control flow on one GPU: all ranks on cuda:0, gloo, masks via host (not a benchmark)")
     ap.add_argument("--rccl-selftest", action="store_true", help="one rank, but through the N > 1 code path: RCCL process group, packed-mask gather every step (to itself), barrier and max-reduce of the time - the collective calls on real hardware where only one GPU is available (not a scaling result)")
+    ap.add_argument("--native-node", action="store_true", help="N > 1 (or --rccl-selftest): the gather through libbgs_node (include/bgs_node.h: ncclSend / ncclRecv issued by the C++ node driver, "
+                    "double-buffered on a second HIP stream) instead of torch.distributed.gather; torch.distributed then only carries the 128-byte communicator id, the barriers and the max of the time")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 child passes (then the constant of profiles/pmc_traffic.json is reported)")
+    ap.add_argument("--pool-frames", type=int, default=240, help="cap on the DISTINCT frames kept resident for the warm-up + timed steps (32 streams: 199 MB per frame); beyond it the pool is cycled")
     ap.add_argument("--px", type=int, default=0, help="MOG2 pixels per lane (tuning; 0 = default = 1)")
     args = ap.parse_args()
 
-    if args.pmc_child:
+    pmc_child = bool(args.pmc_child)
+    if pmc_child:
         args.main_only = True
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -296,6 +387,7 @@ def main():
     # host copy): RCCL refuses two ranks on one device, and this box has one.  Numbers from it are not benchmark results.
     rehearse = args.rehearse and world > 1
     selftest = args.rccl_selftest and world == 1
+    native = args.native_node and (world > 1 or selftest) and not rehearse
     if selftest:
         for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "29517")):
             os.environ.setdefault(k, v)
@@ -319,84 +411,124 @@ def main():
 
     S = args.streams
     first_global, _ = stream_block(S * world, world, rank)
-    period = 10 if args.input == "sat" else 16
-    pool = make_pool(args.input, S, period, dev, (1234 if args.input == "sat" else 4321) + first_global)
+    calibration = calibrate(local, S) if (rank == 0 and not pmc_child) else None  # before the model exists
 
-    eng = Engine(capi.MOG2, device=local, n_streams=S)
-    eng.set_geometry(ROWS, COLS, CH)
+    nd = None
+    if native:
+        from tracking_amd import node as bnode
+        uid = [bnode.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)
+        nd = bnode.Node.rank(capi.MOG2, S * world, device=local, rank=rank, world=world, root_rank=0, uid=uid[0], flags=bnode.LOOPBACK if selftest else 0)
+        nd.set_geometry(ROWS, COLS, CH)
+        eng = Engine.from_handle(nd.engine_handle(0), capi.MOG2, S)
+    else:
+        eng = Engine(capi.MOG2, device=local, n_streams=S)
+        eng.set_geometry(ROWS, COLS, CH)
     if args.px:
         eng.set_option(capi.OPT_MOG2_PIXELS_PER_LANE, args.px)
     fg = torch.empty((S, ROWS, COLS), dtype=torch.uint8, device=dev)
     bg = torch.empty((S, ROWS, COLS, CH), dtype=torch.uint8, device=dev) if args.with_bg else None
     words = packed_words(ROWS, COLS)
-    gather = MaskGather(S, words, "cpu" if rehearse else dev, always_collective=selftest) if (world > 1 or selftest) else None
+    gather = MaskGather(S, words, "cpu" if rehearse else dev, always_collective=selftest) if ((world > 1 or selftest) and not native) else None
     bits_dev = torch.empty((S, words), dtype=torch.int64, device=dev) if rehearse else None
 
-    def step(t):
+    def step(frames):
+        UPDATE_LAUNCHES[0] += 1
+        if nd is not None:  # libbgs_node: kernel (packed masks into this step's gather buffer) + its share of the RCCL gather, all enqueued by the C++ driver
+            nd.step_device([frames])
+            return
         bits = bits_dev if rehearse else (gather.next_buffer() if gather else None)
-        eng.process_batch_device(pool[t % period], fg, bg, bits)
+        eng.process_batch_device(frames, fg, bg, bits)
         if rehearse:
             gather.next_buffer().copy_(bits_dev)  # synchronous D2H: rehearsal only
         if gather:
             gather.post()
 
-    t = 0
+    def drain():
+        if gather:
+            gather.drain()
+        if nd is not None:
+            nd.sync()
+        torch.cuda.synchronize()
+
     # Set-up, untimed.  (1) saturation: the mixture model needs ~50 frames of S_sat before all K = 5 modes of every pixel are live.
     # (2) settle = AGEING the model: for its first ~100 frames the five weights of a pixel have not equalised yet, on every fifth
     # frame the matched mode is still the heaviest one, nothing is re-ordered and less is written (rounds 1-2 took this for a clock
     # burst; the round-2 verdict showed it is model age x write skipping: profiles/r02_mog2_launch_series.csv has a strict period of 5).
     # `value` must not depend on whether the driver asks for 20 or 2000 steps, so the model is aged here, on the same kernel, before
     # the W warm-up steps the contract asks for; the young model's first 20 launches are reported as `young_model_first_20`.
+    # Frames: every frame the model ever sees carries FRESH noise (tools/synth.py SatStreams).  The untimed phases generate theirs one
+    # by one into a scratch image; the W + K frames of the warm-up and the timed region are generated beforehand into a pool of DISTINCT
+    # frames resident in HBM (the contract: inputs resident when the clock starts), capped at --pool-frames.
     SATURATE, SETTLE, SUSTAIN = 60, max(0, args.settle), max(0, args.sustain)
+    src = make_source(args.input, S, dev, {"sat": 1234, "surv": 4321, "dense": 777}[args.input] + first_global)
+    cur = torch.empty((S, ROWS, COLS, CH), dtype=torch.uint8, device=dev)
     for _ in range(SATURATE):
-        step(t)
-        t += 1
-    if gather:
-        gather.drain()
-    torch.cuda.synchronize()
+        step(src.into(cur))
+    drain()
     eng.enable_kernel_timing(True)  # every launch from here on is timed (HIP events on the launch stream); slices below
-    for _ in range(SETTLE + args.warmup):
-        step(t)
-        t += 1
-    if gather:
-        gather.drain()
-    torch.cuda.synchronize()
+    for _ in range(SETTLE):
+        step(src.into(cur))
+    drain()
+    del cur
+    period = min(max(25, (args.warmup + args.steps + 4) // 5 * 5), max(25, args.pool_frames // 5 * 5))  # a multiple of 5: S_sat's levels cycle with period 5
+    pool = src.pool(period)
+    ti = 0
+    for _ in range(args.warmup):
+        step(pool[ti % period])
+        ti += 1
+    drain()
     if world > 1 or selftest:
         dist.barrier()
     torch.cuda.synchronize()
     if gather:
         gather.reset_stats()
+    if nd is not None:
+        nd.step_stats(reset=True)
+    mark_a = UPDATE_LAUNCHES[0]
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(t)
-        t += 1
-    if gather:
-        gather.drain()
-    torch.cuda.synchronize()
+        step(pool[ti % period])
+        ti += 1
+    drain()
     if world > 1 or selftest:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    marks = {"update": [mark_a, UPDATE_LAUNCHES[0]]}
     local_elapsed = elapsed
     if world > 1 or selftest:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    gather_wait_ms = gather.blocked_s / max(1, args.steps) * 1e3 if gather else 0.0  # of the timed region only (reset above)
+    if gather:
+        gather_wait_ms = gather.blocked_s / max(1, args.steps) * 1e3  # of the timed region only (reset above)
+    elif nd is not None:
+        gather_wait_ms = nd.step_stats()[0] / max(1, args.steps)      # host ms per step inside bgs_node_step_device (it never blocks on the device)
+    else:
+        gather_wait_ms = 0.0
     # sustained leg (untimed by the contract's clock, reported beside it): SUSTAIN further launches of the same step
     for _ in range(SUSTAIN):
-        step(t)
-        t += 1
-    if gather:
-        gather.drain()
-    torch.cuda.synchronize()
+        step(pool[ti % period])
+        ti += 1
+    drain()
     selftest_ok = None
-    if selftest:  # what came through the RCCL gather is what the kernel wrote (an inverted frame: foreground everywhere, so the words are not all zero)
+    if selftest and gather:  # what came through the RCCL gather is what the kernel wrote (an inverted frame: foreground everywhere, so the words are not all zero)
         bits = gather.next_buffer()
-        eng.process_batch_device(255 - pool[t % period], fg, bg, bits)
+        eng.process_batch_device(255 - pool[ti % period], fg, bg, bits)
+        UPDATE_LAUNCHES[0] += 1
         gather.post()
         got = gather.collect()
         torch.cuda.synchronize()
         selftest_ok = {"gather_equals_kernel_output": bool(torch.equal(got, gather.bufs[gather.last])), "nonzero_words": int(got.ne(0).sum().item()), "words": int(got.numel())}
+    if selftest and nd is not None:  # the loop-back gather of the node driver against the same kernel's byte mask
+        inv = 255 - pool[ti % period]
+        nd.step_device([inv])
+        UPDATE_LAUNCHES[0] += 1
+        got = nd.copy_masks(torch.empty((S, words), dtype=torch.int64, device=dev))
+        torch.cuda.synchronize()
+        selftest_ok = {"transport": "libbgs_node, ncclSend to self + ncclRecv from self", "nonzero_words": int(got.ne(0).sum().item()), "words": int(got.numel()),
+                       "all_foreground_words": int((got == -1).sum().item())}
     _, _, k_name = eng.kernel_timing()
     series = eng.kernel_timing_series()
     eng.enable_kernel_timing(False)
@@ -406,7 +538,7 @@ def main():
     # the library keeps at most 16384 per-launch timings: a very long run gets its kernel figures from a truncated slice (`value` is
     # wall-clock and unaffected); say so instead of silently averaging fewer launches
     timing_truncated = bool(timed_ms.size < args.steps)
-    sus_ms = series[i0 + args.steps:]
+    sus_ms = series[i0 + args.steps:i0 + args.steps + SUSTAIN]
     burst_ms = series[:20]
     if rank == 0 and args.series:
         with open(args.series, "w") as f:
@@ -417,7 +549,7 @@ def main():
                 f.write("%d,%s,%.4f\n" % (i, phase, v))
 
     # N > 1 diagnostics (a sub-linear scaling curve must be explainable from the line alone): every rank's own kernel time over the
-    # timed steps, its elapsed time, and the host time per step that MaskGather.next_buffer() spent blocked on an earlier gather
+    # timed steps, its elapsed time, and the host time per step that the gather cost it
     per_rank = None
     if world > 1 or selftest:
         mine = torch.tensor([k_ms, gather_wait_ms, local_elapsed * 1e3 / max(1, args.steps)], dtype=torch.float64, device="cpu" if rehearse else dev)
@@ -426,32 +558,53 @@ def main():
         if rank == 0:
             per_rank = {"kernel_avg_ms": [round(float(v[0]), 4) for v in allr], "gather_wait_ms_per_step": [round(float(v[1]), 4) for v in allr],
                         "ms_per_step_local": [round(float(v[2]), 4) for v in allr],
-                        "note": "one entry per rank: mean duration of the update kernel over the timed steps (HIP events), host time per step blocked in MaskGather.next_buffer() "
-                                "waiting for the gather that last used the buffer, and the rank's own wall time per step; `ms_per_step` is the MAX over ranks"}
+                        "note": "one entry per rank: mean duration of the update kernel over the timed steps (HIP events); host time per step that the gather cost the rank "
+                                "(torch path: blocked in MaskGather.next_buffer() waiting for the gather that last used the buffer; --native-node: time inside bgs_node_step_device, "
+                                "which enqueues and never waits); the rank's own wall time per step; `ms_per_step` is the MAX over ranks"}
     live_modes = None
     single = None
     host = None
     configs = None
     cpu = None
     surv = None
+    dense = None
     clip = None
     probe = None
+    clip0 = None
     if rank == 0:
         nm = eng.get_state("nmodes", (ROWS * COLS,), np.uint8, stream=0)
         live_modes = float(nm.mean())
         pr = eng.get_state("placement", (2,), np.float32)
         probe = {"chunk_MiB": int(pr[0]), "chunks": int(pr[1]),
-                 "note": "the model is one virtual range backed by separately created physical chunks (hipMemCreate / hipMemMap): deterministic placement in the fast class "
-                         "(DESIGN.md 6.2; rounds 1-2 probed whole-model candidates instead); chunk_MiB 0 = one plain hipMalloc"}
-    if rank == 0 and args.pmc_child:
+                 "note": "the model is one virtual range backed by separately created physical chunks (hipMemCreate / hipMemMap; DESIGN.md 6.2; chunk_MiB 0 = one plain hipMalloc). "
+                         "`dense_launch` = the placement witness: the same model streamed whole (BGS_OPT_MOG2_SPARSE = 0: every weight, summary, record and meta word read and "
+                         "written back, 248 B/pixel) - its rate against calibration.copy_GBps_chunked says whether this model's placement is as good as a fresh chunked range's"}
+        clip0 = pool[:25, 0].cpu().numpy()  # stream 0's frames for the host-path and CPU legs
+    if rank == 0 and pmc_child:
         for T in (4, 8):
             clip_leg(eng, pool, period, S, T, launches=CLIP_PMC_LAUNCHES, warm=4)
-    if rank == 0 and not args.main_only and not rehearse:
+    if rank == 0 and not args.main_only and not rehearse and nd is None:
         clip = {"note": "supplementary, never `value`: bgs_process_clip_device on the same engine and saturated model - T consecutive frames per launch, model kept in "
                         "registers across them, bit-identical results; for file-fed video or deployments that accept T-1 frame times of latency",
                 "T4": clip_leg(eng, pool, period, S, 4), "T8": clip_leg(eng, pool, period, S, 8)}
+    if rank == 0 and not args.main_only and not rehearse and nd is None and args.input == "sat":
+        # placement witness: the whole model streamed (results unchanged: dense only writes back what it read)
+        eng.set_option(capi.OPT_MOG2_SPARSE, 0)
+        for i in range(3):
+            eng.process_batch_device(pool[i % period], fg, None, None)
+        torch.cuda.synchronize()
+        eng.enable_kernel_timing(True)
+        for i in range(10):
+            eng.process_batch_device(pool[(3 + i) % period], fg, None, None)
+        torch.cuda.synchronize()
+        dms, _, _ = eng.kernel_timing()
+        eng.enable_kernel_timing(False)
+        eng.set_option(capi.OPT_MOG2_SPARSE, 3)
+        dense_bytes = (2 * MODEL_BYTES_PER_PIXEL + 4) * S * ROWS * COLS
+        probe["dense_launch"] = {"kernel_ms": round(dms, 4), "bytes_per_pixel": 2 * MODEL_BYTES_PER_PIXEL + 4, "GBps": round(dense_bytes / (dms * 1e-3) / 1e9, 1) if dms > 0 else None,
+                                 "frac_of_box_copy": round(dense_bytes / (dms * 1e-3) / 1e9 / calibration["copy_GBps_chunked"], 4) if (dms > 0 and calibration and calibration.get("copy_GBps_chunked")) else None}
     if rank == 0 and not args.main_only:
-        # BASELINE configs[1] literally: ONE 1080p stream.  Its 207 MB model fits the 256 MiB Infinity Cache, so this
+        # BASELINE configs[1] literally: ONE 1080p stream.  Its 253 MB model fits the 256 MiB Infinity Cache, so this
         # number is not an HBM measurement; it is reported beside the batched one, never as `value`.
         e1 = Engine(capi.MOG2, device=local, n_streams=1)
         e1.set_geometry(ROWS, COLS, CH)
@@ -469,16 +622,32 @@ def main():
         ms1, _, _ = e1.kernel_timing()
         single = {"mpixels_per_s": round(n1 * ROWS * COLS / d1 / 1e6, 1), "kernel_ms": round(ms1, 4),
                   "kernel_GBps_moved": round(BYTES_PER_PIXEL * ROWS * COLS / (ms1 * 1e-3) / 1e9, 1),
-                  "note": "single stream: 207 MB of model state fits the 256 MiB Infinity Cache (not an HBM figure)"}
+                  "note": "single stream: 253 MB of model state fits the 256 MiB Infinity Cache (not an HBM figure)"}
         e1.close()
-        if args.input == "sat":
-            surv = {"default": surv_leg(local, S, fg, sparse=3), "stores_only": surv_leg(local, S, fg, sparse=1)}
-        if world == 1:
-            host = host_leg(local, pool)
-        if world == 1 and not args.no_configs:
+    if rank == 0 and (not args.main_only or pmc_child) and args.input == "sat":
+        n_leg = PMC_LEG_LAUNCHES if pmc_child else 100
+        del pool  # the scene legs bring their own frames
+        pool = None
+        torch.cuda.empty_cache()
+        sv, spool = scene_leg(local, S, fg, "surv", steps=n_leg, sparse=3, marks=marks)
+        surv = {"default": sv}
+        if not pmc_child:
+            surv["stores_only"], _ = scene_leg(local, S, fg, "surv", steps=n_leg, sparse=1, pool=spool, marks=marks)
+        del spool
+        torch.cuda.empty_cache()
+        dense, dpool = scene_leg(local, S, fg, "dense", steps=n_leg, sparse=3, warm=200, marks=marks)
+        del dpool
+        torch.cuda.empty_cache()
+    if pmc_child and rank == 0:
+        with open(args.pmc_child, "w") as f:
+            json.dump(marks, f)
+    if rank == 0 and not args.main_only:
+        if world == 1 and not selftest:
+            host = host_leg(local, clip0)
+        if world == 1 and not args.no_configs and not selftest:
             # BASELINE configs[2] (WMV + ABL at 3840x2160) and configs[3] (SuBSENSE / LBSP at 1080p) in the driver-timed line, never `value`
             from tools import bench_configs
-            eng.close()  # the 6.8 GB MOG2 model is not needed any more (its state was read above)
+            eng.close()  # the 8.1 GB MOG2 model is not needed any more (its state was read above)
             eng = None
             try:
                 configs = bench_configs.configs_block(device=local, cpu=not args.no_cpu_baseline)
@@ -486,9 +655,9 @@ def main():
                 configs = {"error": repr(ex)}
         if not args.no_cpu_baseline and not rehearse:
             # N > 1: a shorter sample on rank 0 (the other ranks wait in the final barrier), so the line stays self-contained
-            cpu = cpu_baseline(pool, args.input, budget_s=16.0 if world == 1 else 6.0)
+            cpu = cpu_baseline(clip0, args.input, budget_s=16.0 if world == 1 else 6.0)
 
-    if rank == 0:
+    if rank == 0 and not pmc_child:
         px_per_step_rank = S * ROWS * COLS
         total_px = px_per_step_rank * world * args.steps
         mpix = total_px / elapsed / 1e6
@@ -496,8 +665,8 @@ def main():
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic, traffic_source, traffic_detail = None, "none", None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if world == 1 and not args.main_only and not args.no_pmc and not args.with_bg:
-            pmc_all, why = pmc_traffic_live(S, args.steps, args.warmup, args.input)
+        if world == 1 and not args.main_only and not args.no_pmc and not args.with_bg and not selftest:
+            pmc_all, why = pmc_traffic_live(S, args.steps, args.warmup, args.input, SETTLE)
             if pmc_all and "update" in pmc_all:
                 traffic_detail = pmc_all["update"]
                 traffic, traffic_source = traffic_detail["hbm_bytes_per_launch"], why
@@ -508,6 +677,13 @@ def main():
                         leg_c["traffic"] = tb
                         leg_c["traffic_B_per_pixel_frame"] = round(tb["hbm_bytes_per_launch"] / (px_per_step_rank * T), 2)
                         leg_c["hbm_GBps_measured"] = round(tb["hbm_bytes_per_launch"] / (leg_c["kernel_avg_ms"] * 1e-3) / 1e9, 1)
+                for key, leg_s in (("surv", surv and surv.get("default")), ("dense", dense)):  # PMC traffic of the scene legs (the child's own, shorter, leg on the same scene)
+                    if leg_s and key in pmc_all:
+                        tb = pmc_all[key]
+                        leg_s["traffic"] = tb
+                        leg_s["traffic_B_per_pixel"] = round(tb["hbm_bytes_per_launch"] / px_per_step_rank, 2)
+                        leg_s["hbm_GBps_measured"] = round(tb["hbm_bytes_per_launch"] / (leg_s["kernel_ms"] * 1e-3) / 1e9, 1)
+                        leg_s["hbm_frac_of_peak_measured"] = round(tb["hbm_bytes_per_launch"] / (leg_s["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
             else:
                 traffic_source = "live PMC passes unavailable (%s); " % why
         if traffic is None and os.path.exists(pmc):
@@ -524,41 +700,58 @@ def main():
             a = algo_bytes / (float(ms.mean()) * 1e-3) / 1e9
             return {"launches": int(len(ms)), "kernel_avg_ms": round(float(ms.mean()), 4), "kernel_min_ms": round(float(ms.min()), 4), "kernel_max_ms": round(float(ms.max()), 4),
                     "achieved": round(a, 1), "frac": round(a / HBM_PEAK_GBPS, 4)}
+        box_copy = calibration.get("copy_GBps_chunked") if calibration else None
+        in_name = {"sat": "S_sat", "surv": "S_surv", "dense": "S_dense"}[args.input]
+        if world > 1:
+            gather_desc = ("REHEARSAL: gloo gather through host copies, all ranks on one GPU - not a benchmark" if rehearse else
+                           "libbgs_node (include/bgs_node.h): root posts one ncclRecv per peer, every peer one ncclSend, grouped, on a second HIP stream, double-buffered" if native else
+                           "RCCL gather of bit-packed masks to rank 0 every step (torch.distributed.gather), overlapped")
+        else:
+            gather_desc = (("RCCL SELF-TEST through libbgs_node: one rank, its block sent to itself and received from itself every step" if native else
+                            "RCCL SELF-TEST: one rank, gather / barrier / all-reduce issued anyway (the N > 1 code path on one GPU; not a scaling result)") if selftest else "none (1 GPU)")
         out = {
             "metric": "MixtureOfGaussianV2BGS throughput (Mpixels/s; concurrent 1080p30 streams in streams_1080p30)",
             "value": round(mpix, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "MixtureOfGaussianV2BGS (MOG2 K=5, alpha=0.05, threshold 15) on 1920x1080x3 uint8, %s synthetic input, %d streams per GPU batched in one launch "
-                                   "(BASELINE configs[1] geometry x %d = the per-GPU share of configs[4]); frames resident in HBM" % ("S_sat" if args.input == "sat" else "S_surv", S, S),
+                                   "(BASELINE configs[1] geometry x %d = the per-GPU share of configs[4]); frames resident in HBM" % (in_name, S, S),
                        "streams_per_gpu": S, "rows": ROWS, "cols": COLS, "channels": CH, "K": 5, "input": args.input,
-                       "mask_gather": ("REHEARSAL: gloo gather through host copies, all ranks on one GPU - not a benchmark" if rehearse else "RCCL gather of bit-packed masks to rank 0 every step, overlapped") if world > 1 else ("RCCL SELF-TEST: one rank, gather / barrier / all-reduce issued anyway (the N > 1 code path on one GPU; not a scaling result)" if selftest else "none (1 GPU)")},
+                       "frames": "fresh noise in every frame the model sees (tools/synth.py); %d distinct frames resident in HBM for the %d warm-up + %d timed steps%s" % (
+                           period, args.warmup, args.steps, "" if period >= args.warmup + args.steps else " (cycled: --pool-frames %d)" % args.pool_frames),
+                       "mask_gather": gather_desc},
             "streams_1080p30": round(mpix / (ROWS * COLS / 1e6) / 30.0, 1),
             "frames_per_s": round(mpix * 1e6 / (ROWS * COLS), 1),
             "mean_live_modes_stream0": live_modes,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": traffic, "traffic_source": traffic_source, "traffic_read_write": traffic_detail, "kernel": k_name, "kernel_avg_ms": round(k_ms, 4), "kernel_launches": k_n, "kernel_timing_truncated": timing_truncated,
                          "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_pixel": BYTES_PER_PIXEL + (3 if args.with_bg else 0),
-                         "bytes_per_pixel_derivation": "r 3 frame + 2 meta + 20 weights + 20 summaries + 16 the one record the summaries cannot rule out; w 20 weights + 16 that record + 2 meta + 1 mask (+4 when its summary is rewritten: rare) (DESIGN.md 6.1)",
+                         "bytes_per_pixel_derivation": "r 3 frame + 2 meta + 20 weights + 20 summaries + 16 the one record the summaries cannot rule out; w 20 weights + 16 that record + 2 meta + 1 mask (+4 when its summary is rewritten) (DESIGN.md 6.1)",
                          "frac_of_achievable_6290": round(achieved / 6290.0, 4),
+                         "frac_of_box_copy": round(achieved / box_copy, 4) if box_copy else None,
+                         "frac_of_box_copy_note": "achieved / calibration.copy_GBps_chunked: the same kernel time against what a float4 copy reaches on THIS box through the model's own allocation scheme",
                          "vs_survey_206B": {"note": "the same kernel time priced at SURVEY.md 8(d)'s 206 B/pixel (the reference's sorted-array formulation): an EQUIVALENT rate, comparable with rounds 1-2, not bytes moved - it may exceed the peak",
                                             "equivalent_GBps": round(SURVEY_BYTES_PER_PIXEL * px_per_step_rank / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else 0.0,
                                             "equivalent_frac_of_peak": round(SURVEY_BYTES_PER_PIXEL * px_per_step_rank / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if k_ms > 0 else 0.0},
                          "timed_region": "the K timed steps, after %d saturation + %d model-ageing (settle) + %d warm-up launches: steady-state traffic" % (SATURATE, SETTLE, args.warmup),
                          "sustained": leg(sus_ms), "young_model_first_20": leg(burst_ms)},
             "cpu_baseline": cpu,
+            "calibration": calibration,
             "per_rank": per_rank,
             "model_placement": probe,
             "rccl_selftest_gather_matches_kernel_output": selftest_ok,
             "single_stream": single,
             "host_path": host,
             "s_surv": surv,
+            "s_dense": dense,
             "clip": clip,
             "configs": configs,
         }
         print(json.dumps(out), flush=True)
     if eng is not None:
         eng.close()
+    if nd is not None:
+        nd.close()
     if world > 1 or selftest:
         dist.barrier()
         dist.destroy_process_group()

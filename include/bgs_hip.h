@@ -321,6 +321,13 @@ int bgs_submit(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols,
                uint8_t* bg, size_t bg_step);
 int bgs_wait(bgs_engine* e, int stream, uint32_t* out_flags);
 
+/* A caller that keeps the images of ALL its cameras in one allocation (a capture ring, a frame pool) registers that allocation once:
+ * [ptr, ptr + bytes) is page-locked as a whole (one hipHostRegister instead of one per camera and role) and from then on every input
+ * frame, mask or background image of bgs_process / bgs_submit that lies inside it with contiguous rows is read / written by the DMA
+ * engine in place - whatever BGS_OPT_HOST_REGISTER says, and without the "same buffer as last call" test.  on = 0 drops the
+ * registration (same ptr).  The arena stays allocated until then or until bgs_destroy. */
+int bgs_host_arena(bgs_engine* e, void* ptr, size_t bytes, int on);
+
 /* One camera of the batch starts over - what `delete bgs; bgs = new <Class>;` is for one stream in the reference
  * (FrameProcessor.cpp:342-482 / :35-155, ustc_src/ustc_bgs.cpp:75-77): its frame count returns to 0 and its NEXT frame, on the
  * HIP stream of that call and in order with everything queued before it, re-initialises its model and restarts its warm-up
@@ -350,10 +357,10 @@ int64_t bgs_kernel_timing_series(bgs_engine* e, float* ms, int64_t cap);
  *   bgs_calibrate_pcie  `iters` copies of `bytes` bytes each way between the device and page-locked host memory: hipHostMalloc
  *                       (registered = 0: the engine's own staging) or ordinary memory page-locked in place with hipHostRegister
  *                       (registered = 1: a caller buffer under BGS_OPT_HOST_REGISTER; *register_ms = what that call took).
- * bgs_get_state(e, 0, "hostpath", double[14]) returns an engine's host-path counters since creation: buffers currently page-locked in
+ * bgs_get_state(e, 0, "hostpath", double[15]) returns an engine's host-path counters since creation: buffers currently page-locked in
  * place per role [0..2] (input, mask, background) and refused per role [3..5], hipHostRegister calls [6] and their total ms [7],
  * hipHostUnregister calls [8], frames [9], bytes host-to-device [10] and device-to-host [11], CPU ms spent copying into [12] and out
- * of [13] pinned staging.
+ * of [13] pinned staging, arenas registered [14].
  */
 int bgs_calibrate_copy(int hip_device, size_t bytes, int chunk_mb, int iters, double* gbps);
 int bgs_calibrate_pcie(int hip_device, size_t bytes, int registered, int iters, double* h2d_gbps, double* d2h_gbps, double* register_ms);

@@ -265,6 +265,58 @@ def test_mog2_summary_filter_boundary_and_invariants(level):
     eng.close()
 
 
+def test_the_state_bench_times_aged_1080p_s_sat_model_filter_kernel_steady():
+    """What bench.py's timed region runs on: 1080p S_sat streams whose model is OLDER than 100 frames (the five weights of a pixel have
+    equalised, every frame re-orders the modes) with auto mode settled on the filter kernel - the earlier 1080p tests stop at 20 / 6
+    frames, where count and filter launches still alternate.  2 streams x 140 frames with fresh noise in every frame (the bench's
+    own source, tools/synth.py SatStreams); the oracle replays 4 096 sampled pixels of each stream: every mask bit-exact, the sampled
+    model state equal, and over ALL pixels the summaries' invariants, sorted weights, variance clamps."""
+    torch = _torch()
+    S, H, W, T, NS = 2, 1080, 1920, 140, 4096
+    eng = Engine(capi.MOG2, n_streams=S)
+    eng.set_geometry(H, W, 3)
+    src = synth.SatStreams(S, H, W, seed0=1234, device="cuda")
+    rng = np.random.default_rng(31)
+    idx = np.sort(rng.choice(H * W, NS, replace=False))
+    idx[0], idx[-1] = 0, H * W - 1
+    d_idx = torch.from_numpy(idx).cuda()
+    orcs = [pyoracle.Oracle(capi.MOG2) for _ in range(S)]
+    cur = torch.empty((S, H, W, 3), dtype=torch.uint8, device="cuda")
+    d_fg = torch.empty((S, H, W), dtype=torch.uint8, device="cuda")
+    samp = torch.empty((T, S, NS, 3), dtype=torch.uint8, device="cuda")
+    got = torch.empty((T, S, NS), dtype=torch.uint8, device="cuda")
+    eng.enable_kernel_timing(True)
+    for t in range(T):
+        src.into(cur)
+        eng.process_batch_device(cur, d_fg, None, None)
+        samp[t] = cur.reshape(S, H * W, 3)[:, d_idx]
+        got[t] = d_fg.reshape(S, H * W)[:, d_idx]
+    torch.cuda.synchronize()
+    samp, got = samp.cpu().numpy(), got.cpu().numpy()
+    for s in range(S):
+        for t in range(T):
+            ofg, _ = orcs[s].process(samp[t, s].reshape(64, 64, 3), want_bg=False)
+            assert np.array_equal(got[t, s].reshape(64, 64), ofg), (s, t, int((got[t, s].reshape(64, 64) != ofg).sum()))
+    n = H * W
+    for s in range(S):
+        w = eng.get_state("w", (5, n), np.float32, stream=s)
+        var = eng.get_state("var", (5, n), np.float32, stream=s)
+        mu = eng.get_state("mu", (5, 3, n), np.float32, stream=s)
+        nm = eng.get_state("nmodes", (n,), np.uint8, stream=s)
+        for name, a, shape in (("w", w[:, idx], (5, NS)), ("var", var[:, idx], (5, NS)), ("mu", mu[:, :, idx], (5, 3, NS))):
+            err = max_err(a, orcs[s].get_state(name, shape, np.float32))
+            assert err <= STATE_TOL, (s, name, err)
+        assert np.array_equal(nm[idx], orcs[s].get_state("nmodes", (NS,), np.uint8))
+        assert (nm == 5).mean() > 0.999, "S_sat: all five modes live"
+        assert (np.diff(w, axis=0) <= 0).all(), "modes stay sorted by weight"
+        assert (var >= 4.0).all() and (var <= 75.0).all()
+        # the aged model's steady state: auto mode has settled on the filter kernel, so every pixel's summaries are valid and cover its records
+        assert _mog2_summary_invariants(eng, n, stream=s) == 1.0
+    series = eng.kernel_timing_series()
+    assert len(series) == T
+    eng.close()
+
+
 @pytest.mark.parametrize("algo,S,T", [(capi.SUBSENSE, 8, 3), (capi.MOG1, 16, 4), (capi.DP_GRIMSON_GMM, 32, 3)])
 def test_large_batches_match_single_stream_engines(algo, S, T):
     """Models past 4 GB (SuBSENSE: 8 x 1080p x 50 samples = 7.5 GB; MOG1: 16 x 1080p = 5.3 GB; Grimson: 32 x 1080p = 4.8 GB): the

@@ -35,6 +35,21 @@ def test_bench_line_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mpixels/s" and "sample" in c
     assert d["clip"]["T4"]["frames_per_launch"] == 4 and d["clip"]["T8"]["kernel"] == "mog2_clip_kernel"
+    # round 4: the line explains itself - this box's own copy rate through both allocation schemes, the headline against it, the whole
+    # model streamed as the placement witness, the filter's worst-case scene, the quiet scene with the slot layout's byte model
+    cal = d["calibration"]
+    assert cal["copy_GBps_plain"] > 0 and cal["copy_GBps_chunked"] > 0 and cal["bytes"] >= 2 * 1920 * 1080 * 122
+    assert abs(r["frac_of_box_copy"] - r["achieved"] / cal["copy_GBps_chunked"]) < 1e-3
+    assert d["model_placement"]["dense_launch"]["kernel_ms"] > 0 and d["model_placement"]["dense_launch"]["bytes_per_pixel"] == 248
+    assert d["s_dense"]["mean_live_modes_stream0"] > 4.0 and d["s_dense"]["kernel_ms"] > 0
+    sv = d["s_surv"]["default"]
+    assert 1.0 <= sv["mean_live_modes_stream0"] < 3.0 and abs(sv["bytes_model_per_pixel"] - (22 + 24 * sv["mean_live_modes_stream0"])) < 0.1
+    hp = d["host_path"]
+    assert hp["pcie_calibration"]["registered_pageable"]["h2d_GBps"] > 0
+    assert hp["registered_buffers"]["diag"]["pinned_input"] == 1 and hp["registered_buffers"]["diag"]["pinned_mask"] == 1 and hp["staged"]["diag"]["pinned_input"] == 0
+    assert hp["submit_wait_8_cameras_registered_buffers"]["diag"]["pinned_input"] == 8 and hp["submit_wait_8_cameras_registered_buffers"]["diag"]["register_calls_inside_timed_rounds"] == 0
+    assert hp["submit_wait_8_cameras_registered_arena"]["diag"]["arenas"] == 2 and hp["submit_wait_8_cameras_registered_arena"]["diag"]["register_calls"] == 2
+    assert hp["submit_wait_8_cameras_registered_arena"]["diag"]["cpu_ms_staging_per_frame"] == 0
 
 
 def test_bench_rccl_selftest_gathers_what_the_kernel_wrote():
@@ -44,6 +59,16 @@ def test_bench_rccl_selftest_gathers_what_the_kernel_wrote():
     assert s["gather_equals_kernel_output"] is True and s["nonzero_words"] > 0 and s["words"] == 2 * 1920 * 1080 // 64
     pr = d["per_rank"]  # N > 1 diagnostics, present whenever the collective path runs
     assert len(pr["kernel_avg_ms"]) == 1 and pr["kernel_avg_ms"][0] > 0 and len(pr["gather_wait_ms_per_step"]) == 1 and pr["gather_wait_ms_per_step"][0] >= 0
+
+
+def test_bench_native_node_selftest_runs_the_gather_through_libbgs_node():
+    """--native-node: the step goes through bgs_node_step_device (rank form, ncclCommInitRank with a broadcast id); with one rank the
+    block is sent to itself and received from itself through RCCL every step."""
+    d = _bench("--rccl-selftest", "--native-node", "--main-only")
+    assert "libbgs_node" in d["config"]["mask_gather"]
+    s = d["rccl_selftest_gather_matches_kernel_output"]
+    assert s["words"] == 2 * 1920 * 1080 // 64 and s["all_foreground_words"] == s["words"]  # an inverted frame is foreground everywhere
+    assert d["roofline"]["kernel_launches"] == 4 and d["value"] > 0 and d["per_rank"]["gather_wait_ms_per_step"][0] >= 0
 
 
 def test_bench_rehearsal_two_ranks_reports_per_rank_diagnostics():

@@ -466,6 +466,26 @@ def test_subsense_large_frame_5x5_spread():
     check_subsense_state(eng, orc, 392, 400)
 
 
+def test_subsense_modulo_by_multiplication_is_exact(golden_frames):
+    """ss_feedback_kernel takes its five run-time `x % d` (which sample, which neighbour: BackgroundSubtractorSuBSENSE.cpp:508-551) as
+    x - (mulhi(x, m[d]) >> (ceil(log2 d) - 1)) d with m from a 1024-entry table (Granlund & Montgomery 1994, N = 31).  The table the
+    DEVICE holds, against integer division: every d in 2..1023, x over the edges of [0, 2^31) and 20 000 random draws each."""
+    eng = Engine(capi.SUBSENSE)
+    eng.process(golden_frames[0])
+    m = eng.get_state("magic", (1024,), np.uint32).astype(np.uint64)
+    rng = np.random.default_rng(5)
+    x = np.concatenate([np.array([0, 1, 2, 3, 2**31 - 1, 2**31 - 2, 2**30, 2**30 - 1, 2**30 + 1, 2**16, 2**16 - 1], np.uint64), rng.integers(0, 2**31, 20000).astype(np.uint64)])
+    for d in range(2, 1024):
+        sh = np.uint64((d - 1).bit_length() - 1)  # 31 - clz(d - 1)
+        q = ((x * m[d]) >> np.uint64(32)) >> sh
+        assert np.array_equal(q, x // np.uint64(d)), d
+        # multiples of d just below 2^31 (where an inexact multiplier would slip first)
+        top = (np.uint64(2**31 - 1) // np.uint64(d)) * np.uint64(d)
+        xs = np.array([top, top - np.uint64(1), min(top + np.uint64(d) - np.uint64(1), np.uint64(2**31 - 1))], np.uint64)
+        assert np.array_equal(((xs * m[d]) >> np.uint64(32)) >> sh, xs // np.uint64(d)), d
+    eng.close()
+
+
 @pytest.mark.parametrize("shape", [(48, 64), (37, 53), (5, 5), (9, 131)])
 def test_subsense_ragged_sizes(shape):
     frames = synth.random_frames(8, shape[0], shape[1], 3, seed=shape[1])

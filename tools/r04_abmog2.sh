@@ -1,0 +1,8 @@
+#!/bin/bash
+# The MOG2 headline (fresh frames: timed; the same 25 frames repeating: sustained) with the library of this round's first commit
+# (tracking_amd/lib/ab0, round 3's kernel) against the current one, same box, alternating.
+one() { python bench.py --gpus 1 --steps 20 --warmup 5 --main-only --no-pmc --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('timed(fresh) %.4f  sustained %.4f  min %.4f' % (r['kernel_avg_ms'], r['sustained']['kernel_avg_ms'], r['sustained']['kernel_min_ms']))"; }
+for i in 1 2 3; do
+  echo -n "current   "; one
+  echo -n "round-3   "; BGS_LIB_PATH=$PWD/tracking_amd/lib/ab0/libbgs_hip.so BGS_LIB_PARTIAL_ABI=1 one
+done

@@ -131,6 +131,7 @@ SYMBOLS = [
     ("bgs_group_kernel_timing", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     ("bgs_submit", C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_size_t, _P, C.c_size_t, _P, C.c_size_t]),
     ("bgs_wait", C.c_int, [_P, C.c_int, C.POINTER(C.c_uint32)]),
+    ("bgs_host_arena", C.c_int, [_P, _P, C.c_size_t, C.c_int]),
     ("bgs_reset_stream", C.c_int, [_P, C.c_int]),
     ("bgs_stream_flags", C.c_int, [_P, C.c_int, C.POINTER(C.c_uint32)]),
     ("bgs_last_mask_blobs", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_int32)]),

@@ -137,6 +137,7 @@ struct bgs_engine {
     bool pinned = false, refused = false;
   };
   std::vector<HostPin> pin;       // [stream][3]: 0 input, 1 mask, 2 background (every camera has its own buffers)
+  std::vector<std::pair<const uint8_t*, size_t>> arenas;  // bgs_host_arena: caller memory page-locked as a whole; images inside it are DMA'd in place
   // bgs_submit / bgs_wait: one lane per camera - its own HIP stream, staging and device images - so that the uploads, kernels and
   // downloads of different cameras overlap; created at a stream's first bgs_submit
   struct Lane {
@@ -227,6 +228,8 @@ void free_all(bgs_engine* e) {
     if (hp.pinned) (void)hipHostUnregister(const_cast<void*>(hp.ptr));
     hp = bgs_engine::HostPin();
   }
+  for (auto& a : e->arenas) (void)hipHostUnregister(const_cast<uint8_t*>(a.first));
+  e->arenas.clear();
   for (auto& ln : e->lanes) lane_release(ln);
 }
 
@@ -596,7 +599,10 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
 // so the caller promises that a buffer it passes in an enabled role stays allocated until it passes a different one or destroys
 // the engine.
 bool host_pin(bgs_engine* e, int stream, int role, const void* ptr, size_t bytes, hipStream_t user = nullptr) {
-  if (!((e->host_register >> role) & 1) || !ptr || !bytes) return false;
+  if (!ptr || !bytes) return false;
+  for (const auto& a : e->arenas)  // inside an arena the caller registered as a whole: nothing to do per image
+    if ((const uint8_t*)ptr >= a.first && (const uint8_t*)ptr + bytes <= a.first + a.second) return true;
+  if (!((e->host_register >> role) & 1)) return false;
   bgs_engine::HostPin& hp = e->pin[(size_t)stream * 3 + role];
   if (hp.ptr == ptr && hp.bytes == bytes) {
     if (hp.pinned) return true;
@@ -1684,6 +1690,31 @@ int bgs_submit(bgs_engine* e, int stream, const uint8_t* in, int rows, int cols,
   return BGS_OK;
 }
 
+int bgs_host_arena(bgs_engine* e, void* ptr, size_t bytes, int on) {
+  if (!e || !ptr || (on && !bytes)) return fail(BGS_ERR_INVALID, "bgs_host_arena: bad argument");
+  HIP_TRY(hipSetDevice(e->device));
+  for (size_t i = 0; i < e->arenas.size(); ++i)
+    if (e->arenas[i].first == (const uint8_t*)ptr) {
+      if (on) return e->arenas[i].second == bytes ? BGS_OK : fail(BGS_ERR_INVALID, "bgs_host_arena: this address is registered with another size");
+      (void)hipDeviceSynchronize();  // nothing may still be reading or writing it
+      HIP_TRY(hipHostUnregister(ptr));
+      e->diag_unreg_calls++;
+      e->arenas.erase(e->arenas.begin() + (long)i);
+      return BGS_OK;
+    }
+  if (!on) return fail(BGS_ERR_INVALID, "bgs_host_arena: no such arena");
+  const auto t0 = std::chrono::steady_clock::now();
+  const hipError_t er = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+  e->diag_reg_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  e->diag_reg_calls++;
+  if (er != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(BGS_ERR_HIP, "hipHostRegister of a %zu-byte arena failed: %s", bytes, hipGetErrorString(er));
+  }
+  e->arenas.emplace_back((const uint8_t*)ptr, bytes);
+  return BGS_OK;
+}
+
 int bgs_wait(bgs_engine* e, int stream, uint32_t* out_flags) {
   if (out_flags) *out_flags = 0;
   if (!e) return fail(BGS_ERR_INVALID, "engine is NULL");
@@ -1703,11 +1734,11 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
     if (hipMemcpy(dst, src, nb, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
     return (int64_t)nb;
   };
-  if (!strcmp(plane, "hostpath")) {  // diagnostics of bgs_process / bgs_submit since creation: 14 doubles (see bench.py host_path)
-    double rec[14] = {0};
+  if (!strcmp(plane, "hostpath")) {  // diagnostics of bgs_process / bgs_submit since creation: 15 doubles (see bench.py host_path)
+    double rec[15] = {0};
     for (size_t i = 0; i < e->pin.size(); ++i) rec[i % 3] += e->pin[i].pinned, rec[3 + i % 3] += e->pin[i].refused;  // per role: input, mask, background
     rec[6] = (double)e->diag_reg_calls, rec[7] = e->diag_reg_ms, rec[8] = (double)e->diag_unreg_calls, rec[9] = (double)e->diag_frames;
-    rec[10] = (double)e->diag_h2d_bytes, rec[11] = (double)e->diag_d2h_bytes, rec[12] = e->diag_stage_in_ms, rec[13] = e->diag_stage_out_ms;
+    rec[10] = (double)e->diag_h2d_bytes, rec[11] = (double)e->diag_d2h_bytes, rec[12] = e->diag_stage_in_ms, rec[13] = e->diag_stage_out_ms, rec[14] = (double)e->arenas.size();
     if (cap < sizeof(rec)) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
     memcpy(dst, rec, sizeof(rec));
     return (int64_t)sizeof(rec);

@@ -30,6 +30,9 @@ struct SsDevice {
   uint8_t* u8[SS_NU8] = {nullptr};
   float *dsLT = nullptr, *dsST = nullptr;
   bgs::SsScalars* sc = nullptr;
+  bgs::SsScalars* scSnap = nullptr;  // the scalars as phase A found them (ss_feedback_kernel runs beside the frame-level block that rewrites sc)
+  uint32_t* ho = nullptr;            // [S][N][2] phase A -> ss_feedback_kernel hand-over (kernel_subsense.h)
+  uint32_t* magic = nullptr;         // ss_mod's multipliers
   int* flood_flags = nullptr;  // [S][kSsFloodFlags], see ss_flood_kernel
   hipStream_t side = nullptr;  // phase B runs here, beside the post-processing chain (both only need phase A)
   hipEvent_t evA = nullptr, evB = nullptr;
@@ -39,7 +42,7 @@ struct SsDevice {
   int use3x3 = 1, lrScaling = 0, medK = 9;
   float capLo0 = 4.f, capHi0 = 512.f;
   void release() {
-    void* p[] = {samples, lut, lastColor, curColor, lastDesc, curDesc, req, dsLT, dsST, sc, flood_flags, mbits, rbits, bitws};
+    void* p[] = {samples, lut, lastColor, curColor, lastDesc, curDesc, req, dsLT, dsST, sc, scSnap, ho, magic, flood_flags, mbits, rbits, bitws};
     for (void* q : p)
       if (q) (void)hipFree(q);
     for (auto& q : f32)
@@ -49,7 +52,7 @@ struct SsDevice {
     if (side) (void)hipStreamDestroy(side), side = nullptr;
     if (evA) (void)hipEventDestroy(evA), evA = nullptr;
     if (evB) (void)hipEventDestroy(evB), evB = nullptr;
-    samples = nullptr, lut = lastColor = curColor = nullptr, lastDesc = req = curDesc = nullptr, dsLT = dsST = nullptr, sc = nullptr, flood_flags = nullptr, mbits = rbits = nullptr, bitws = nullptr;
+    samples = nullptr, lut = lastColor = curColor = nullptr, lastDesc = req = curDesc = nullptr, dsLT = dsST = nullptr, sc = nullptr, scSnap = nullptr, ho = nullptr, magic = nullptr, flood_flags = nullptr, mbits = rbits = nullptr, bitws = nullptr;
   }
 };
 
@@ -79,6 +82,15 @@ int ss_allocate(bgs_engine* e) {
   DMALLOC(d->req, P * 2 * 2);
   DMALLOC(d->lut, (size_t)e->S * 256);
   DMALLOC(d->sc, (size_t)e->S * sizeof(bgs::SsScalars));
+  DMALLOC(d->scSnap, (size_t)e->S * sizeof(bgs::SsScalars));
+  DMALLOC(d->ho, P * 2 * sizeof(uint32_t));
+  {
+    uint32_t m[bgs::kSsMagicN];
+    for (uint32_t k = 0; k < (uint32_t)bgs::kSsMagicN; ++k) m[k] = bgs::ss_magic(k);
+    DMALLOC(d->magic, sizeof(m));
+    HIP_TRY(hipMemcpyAsync(d->magic, m, sizeof(m), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));  // m is on this stack frame
+  }
   DMALLOC(d->flood_flags, (size_t)e->S * bgs::kSsFloodFlags * sizeof(int));
   const size_t words = (size_t)e->S * e->rows * ((e->cols + 63) / 64);
   DMALLOC(d->mbits, words * 8);
@@ -97,6 +109,7 @@ void ss_fill_args(const bgs_engine* e, bgs::SsArgs& a, int first, int cur_pp, un
   const SsDevice* d = e->ss;
   const bgs_params& p = e->p;
   a.samples = d->samples, a.nSpad = d->nSpad, a.pixelMajor = d->pixelMajor, a.lastColor = d->lastColor, a.lastDesc = d->lastDesc, a.req = d->req, a.lut = d->lut, a.sc = d->sc;
+  a.scSnap = d->scSnap, a.ho = d->ho, a.magic = d->magic;
   a.R = d->f32[SS_R], a.V = d->f32[SS_V], a.T = d->f32[SS_T];
   a.DlastOld = d->f32[cur_pp ? SS_DLAST1 : SS_DLAST0], a.DlastNew = d->f32[cur_pp ? SS_DLAST0 : SS_DLAST1];
   a.RawSTOld = d->f32[cur_pp ? SS_RAWST1 : SS_RAWST0], a.RawSTNew = d->f32[cur_pp ? SS_RAWST0 : SS_RAWST1];
@@ -217,10 +230,19 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
   ss_fill_args(e, a, first, cur, (unsigned)(t + 1));
   a.frame = d_frames, a.fg = d_fg, a.bgimg = d_bg;
   const dim3 tilesB((e->cols + bgs::kSsTW - 1) / bgs::kSsTW, (e->rows + bgs::kSsBTH - 1) / bgs::kSsBTH, count), block(bgs::kBlock);
+  // BGS_SS_FEEDBACK_SPLIT=1: the rules behind the loop as ss_feedback_kernel in front of phase B instead of stage 3 of phase A
+  // (identical results; measured slower, kernel_subsense.h - kept as an A/B knob)
+  static const bool split = getenv("BGS_SS_FEEDBACK_SPLIT") && atoi(getenv("BGS_SS_FEEDBACK_SPLIT")) == 1;
   {
     Timed tm(e, s, "ss_phase_a_kernel");
     const dim3 tilesA((e->cols + bgs::kSsTW - 1) / bgs::kSsTW, (e->rows + bgs::kSsATH - 1) / bgs::kSsATH, count);
-    SS_LAUNCH(ss_phase_a_kernel, tilesA, block, s, a);
+    if (e->ch == 3) {
+      if (split) hipLaunchKernelGGL((bgs::ss_phase_a_kernel<3, true>), tilesA, block, 0, s, a);
+      else hipLaunchKernelGGL((bgs::ss_phase_a_kernel<3, false>), tilesA, block, 0, s, a);
+    } else {
+      if (split) hipLaunchKernelGGL((bgs::ss_phase_a_kernel<1, true>), tilesA, block, 0, s, a);
+      else hipLaunchKernelGGL((bgs::ss_phase_a_kernel<1, false>), tilesA, block, 0, s, a);
+    }
   }
   // Phase B (the scattered sample writes) and the post-processing chain both depend on phase A only, and the next frame depends
   // on both: phase B goes to a side stream and rejoins at the end, so its memory-bound scatter overlaps the LDS-bound morphology.
@@ -230,12 +252,17 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
     HIP_TRY(hipEventCreateWithFlags(&d->evA, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&d->evB, hipEventDisableTiming));
   }
+  // Round 4: the per-pixel rules behind the loop (:498-576) are ss_feedback_kernel; it produces the update requests phase B applies, so
+  // it goes in front of phase B on the side stream - both beside the post-processing chain, which only needs phase A's `raw`.
+  const dim3 gridF((e->cols + bgs::kBlock - 1) / bgs::kBlock, e->rows, count);
   if (overlap) {
     HIP_TRY(hipEventRecord(d->evA, s));
     HIP_TRY(hipStreamWaitEvent(d->side, d->evA, 0));
+    if (split) SS_LAUNCH(ss_feedback_kernel, gridF, block, d->side, a);
     SS_LAUNCH(ss_phase_b_kernel, tilesB, block, d->side, a);
     HIP_TRY(hipEventRecord(d->evB, d->side));
   } else {
+    if (split) SS_LAUNCH(ss_feedback_kernel, gridF, block, s, a);
     SS_LAUNCH(ss_phase_b_kernel, tilesB, block, s, a);
   }
   // byte maps of this launch as vectors when the pixel count and the caller's buffers allow it (the engine's own planes are 256-byte aligned)
@@ -373,6 +400,11 @@ int64_t ss_get_state(bgs_engine* e, int stream, const char* plane, void* dst, si
     if (cap < nb) return fail(BGS_ERR_STATE, "buffer too small for plane floodflags");
     if (hipMemcpy(dst, d->flood_flags + (size_t)stream * bgs::kSsFloodFlags, nb, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
     return (int64_t)nb;
+  }
+  if (!strcmp(plane, "magic") && d->magic) {  // ss_mod's table (kernel_subsense.h), for the test that checks it against plain integer division
+    if (cap < bgs::kSsMagicN * 4) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
+    if (hipMemcpy(dst, d->magic, bgs::kSsMagicN * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+    return bgs::kSsMagicN * 4;
   }
   if (!strcmp(plane, "scalars")) {
     if (cap < 7 * sizeof(double)) return fail(BGS_ERR_STATE, "buffer too small for plane scalars");

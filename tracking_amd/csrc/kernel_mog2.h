@@ -127,17 +127,30 @@ __device__ __host__ __forceinline__ bool mog2_summary_ok(uint32_t word, float va
   return means && varok;
 }
 // does the summary PROVE dist2 >= Tmax * var, i.e. both of the reference's comparisons false for this pixel value?
-// Margins: 0.01 on every channel distance and 1.0 on the threshold swallow the float rounding of either side (values <= 2e5,
-// relative error ~1e-7).  x0..x2 are the integer pixel values.
-__device__ __host__ __forceinline__ bool mog2_reject(uint32_t word, float x0, float x1, float x2, float Tmax) {
-  const float q0 = (float)(word & 0xffu), q1 = (float)((word >> 8) & 0xffu), q2 = (float)((word >> 16) & 0xffu);
-  const uint32_t vb = word >> 24;
-  float e0 = x0 - q0, e1 = x1 - q1, e2 = x2 - q2;
-  e0 = (e0 < 0.f ? -e0 : e0) - (kMog2SumTol + 0.01f), e1 = (e1 < 0.f ? -e1 : e1) - (kMog2SumTol + 0.01f), e2 = (e2 < 0.f ? -e2 : e2) - (kMog2SumTol + 0.01f);
-  e0 = e0 > 0.f ? e0 : 0.f, e1 = e1 > 0.f ? e1 : 0.f, e2 = e2 > 0.f ? e2 : 0.f;
-  // (this bound is this file's own, not the reference's arithmetic: fused multiply-adds are fine here, the margins cover any rounding)
-  const float L = __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0));
-  return vb != 255 && L > __builtin_fmaf(2.f * Tmax, (float)vb, 1.f);
+// Round 4: in integers, from ONE v_sad_u8.  `pix` = the pixel as b | g << 8 | r << 16 - the packing of the summary's low 24 bits - so
+// S = sad(pix, q) = sum_c |x_c - q_c|.  With |mean_c - q_c| <= 2 (the invariant): sum_c |x_c - mean_c| >= S - 6, and by Cauchy-Schwarz
+// dist2 = sum_c (x_c - mean_c)^2 >= (S - 6)^2 / 3.  So B = S - 7 > 0 (one more for every float rounding on either side: the values are
+// <= 2e5, relative error ~1e-7) and B^2 > 3 (2 Tmax vb + 1) with var <= 2 vb proves dist2 > Tmax var + 1.  c6T = ceil(6 Tmax), clamped to 23
+// bits (a threshold that large rejects nothing).  Twelve integer instructions per mode where the float form of round 3 (per channel
+// max(|x - q| - 2, 0)^2) took twenty-six - five modes per pixel and frame, a fifth of the kernel's vector instructions; the price is a
+// weaker bound when the modes differ in ONE channel only (factor 3), i.e. more records read there, never a different result.
+__device__ __host__ __forceinline__ uint32_t mog2_c6T(float Tmax) {
+  const float c = 6.f * Tmax;
+  return c < 8388607.f ? (uint32_t)(int)c + 1u : 8388607u;  // > 6 Tmax (NaN / negative thresholds end up at the clamp or at 1: both safe)
+}
+__device__ __forceinline__ bool mog2_reject(uint32_t word, uint32_t pix, uint32_t c6T) {
+  const uint32_t S = __builtin_amdgcn_sad_u8(pix, word & 0xffffffu, 0u), vb = word >> 24;
+  const uint32_t B = S - 7u;  // (wraps for S < 7: caught by the first test)
+  return S > 7u && vb != 255u && B * B > c6T * vb + 3u;
+}
+inline bool mog2_reject_host(uint32_t word, uint32_t pix, uint32_t c6T) {  // the same test for host-side checks
+  uint32_t S = 0;
+  for (int c = 0; c < 3; ++c) {
+    const int d = (int)((pix >> (8 * c)) & 0xffu) - (int)((word >> (8 * c)) & 0xffu);
+    S += (uint32_t)(d < 0 ? -d : d);
+  }
+  const uint32_t vb = word >> 24, B = S - 7u;
+  return S > 7u && vb != 255u && B * B > c6T * vb + 3u;
 }
 
 // One pixel's model in registers.  Weights and slot ids in rank order, as MOG2Invoker sees its array.  The records {var, mean0,
@@ -336,6 +349,125 @@ __device__ __forceinline__ int mog2_pixel(Mog2Px& s, Mog2Recs& R, int& nmodes_io
   return 255;
 }
 
+// The same pixel update in LOCK-STEP (round 4), for the per-frame kernels (records by slot or compacted; the clip kernels keep the
+// form above, whose records travel with the bubble).  mog2_pixel is exact but DIVERGENT: the mode a pixel matches sits at a different
+// rank in every lane, so each of the five unrolled rank iterations runs its record fetch (a select chain), distance, division and
+// bubble for SOME lanes of the wave - up to five times the work of one pixel on a scene whose pixels are out of step (the benchmark
+// input S_sat by construction; PMC: 620 vector instructions per pixel and frame, 79 % of the SIMDs' issue slots over the launch).
+// Here everything that touches a record happens outside the rank loop:
+//   1. every record the lane holds (`ncand` of them: all live slots, or what the summaries left) gives dist2 and the two comparisons
+//      dist2 < Tb var, dist2 < Tg var ONCE - they depend on neither the rank nor the running weight sum - kept as bit masks by slot;
+//   2. the rank loop only decays, prunes and sums the weights and looks the two bits of its rank's slot up: the background test reads
+//      totalWeight as it stands when the scan reaches that rank, the first mode in rank order whose match bit is set takes alphaT;
+//   3. the matched record is fetched and recomputed once, then the bubble runs from its rank.
+// Same statements on the same operands for every float, in the same order wherever order matters (the weight sum).  A record behind
+// the matched one in rank order is compared here although the reference never looks at it: a comparison has no side effect.
+// `wave_cand`: wave-uniform upper bound of ncand (the candidate loop's trip count).
+template <int ORD>
+__device__ __forceinline__ int mog2_pixel_lockstep(Mog2Px& s, const Mog2Recs& R, const int ncand, const int wave_cand, int& nmodes_io, float x0, float x1, float x2,
+                                                   const Mog2Args& a, int& hit, float4& out, const float alphaT, const float alpha1, const float prune) {
+  static_assert(ORD == kMog2Compact || ORD == kMog2BySlot, "records by slot or compacted");
+  bool background = false, fitsPDF = false;
+  int nmodes = nmodes_io;
+  const int nNewModes = nmodes;
+  float totalWeight = 0.f;
+  hit = 0;
+  out = make_float4(0.f, 0.f, 0.f, 0.f);
+  unsigned cm = 0, bgm = 0, mm = 0;  // bit (slot + 1): a candidate / dist2 < Tb var / dist2 < Tg var
+#pragma unroll
+  for (int j = 0; j < kMog2K; ++j) {
+    if (j < wave_cand) {  // wave-uniform
+      const float4 v = R.rc[j];
+      const float d0 = v.y - x0, d1 = v.z - x1, d2 = v.w - x2;
+      const float dist2 = d0 * d0 + d1 * d1 + d2 * d2;
+      const int code = ORD == kMog2BySlot ? j + 1 : R.kj[j] + 1;
+      const bool is = j < ncand;
+      cm |= (unsigned)is << code;
+      bgm |= (unsigned)(is && dist2 < a.Tb * v.x) << code;
+      mm |= (unsigned)(is && dist2 < a.Tg * v.x) << code;
+    }
+  }
+  float wmatch = 0.f;
+  int rstar = 0;
+#pragma unroll
+  for (int mode = 0; mode < kMog2K; ++mode) {
+    if (mode < nmodes) {  // nmodes shrinks inside the loop when a mode is pruned (reference quirk)
+      float weight = alpha1 * s.w[mode] + prune;
+      const int code = s.sl[mode];
+      if (!fitsPDF && ((cm >> code) & 1u)) {
+        if (totalWeight < a.TB && ((bgm >> code) & 1u)) background = true;
+        if ((mm >> code) & 1u) {
+          fitsPDF = true;
+          weight += alphaT;
+          wmatch = weight, rstar = mode, hit = code;
+        }
+      }
+      const bool pruned = weight < -prune;
+      if (pruned) nmodes--;
+      s.w[mode] = pruned ? 0.f : weight;
+      totalWeight += pruned ? 0.f : weight;
+    }
+  }
+  if (fitsPDF) {
+    const float4 v = wave_cand == 1 ? R.rc[0] : mog2_pick<ORD == kMog2BySlot>(R, hit);  // (wave-uniform choice; one candidate: it is the match)
+    const float var = v.x;
+    const float d0 = v.y - x0, d1 = v.z - x1, d2 = v.w - x2;
+    const float dist2 = d0 * d0 + d1 * d1 + d2 * d2;
+    const float k = div_rn(alphaT, wmatch);
+    float varnew = var + k * (dist2 - var);
+    varnew = varnew > a.varMin ? varnew : a.varMin;
+    varnew = varnew < a.varMax ? varnew : a.varMax;
+    out = make_float4(varnew, v.y - k * d0, v.z - k * d1, v.w - k * d2);
+    // the reference's bubble, run at the matched rank: it compares the UNPRUNED matched weight with the stored weights in front
+    bool moving = true;
+    Mog2Recs none;  // (the records do not take part in the swaps)
+#pragma unroll
+    for (int i = kMog2K - 1; i > 0; --i) {
+      if (i <= rstar) {
+        moving = moving && !(wmatch < s.w[i - 1]);
+        if (moving) mog2_swap<ORD>(s, none, i, i - 1);
+      }
+    }
+  }
+  totalWeight = div_rn(1.f, totalWeight);
+#pragma unroll
+  for (int mode = 0; mode < kMog2K; ++mode)
+    if (mode < nmodes) s.w[mode] *= totalWeight;
+  nmodes = nNewModes;  // sic: the pruned count is discarded
+  if (!fitsPDF) {
+    // the reference overwrites gmm[K-1] when the array is full, else appends: the new mode takes over the slot of the mode it
+    // replaces, or the next free slot (slots are handed out in creation order)
+    const int slot = (nmodes == kMog2K) ? s.sl[kMog2K - 1] : nmodes + 1;
+    const int mode = (nmodes == kMog2K) ? kMog2K - 1 : nmodes++;
+#pragma unroll
+    for (int k = 0; k < kMog2K; ++k) {
+      if (k == mode) {
+        s.w[k] = (nmodes == 1) ? 1.f : alphaT;
+        s.sl[k] = slot;
+      } else if (nmodes != 1 && k < nmodes - 1) {
+        s.w[k] *= alpha1;
+      }
+    }
+    out = make_float4(a.varInit, x0, x1, x2);
+    hit = slot;
+    bool moving = true;
+    Mog2Recs none;
+#pragma unroll
+    for (int i = kMog2K - 1; i > 0; --i) {
+      if (i <= nmodes - 1) {
+        moving = moving && !(alphaT < s.w[i - 1]);
+        if (moving) mog2_swap<ORD>(s, none, i, i - 1);
+      }
+    }
+  }
+  nmodes_io = nmodes;
+  if (background) return 0;
+  if (a.shadow) {
+    if (mog2_shadow<ORD>(s, R, hit, out, nmodes, x0, x1, x2, a)) return a.shadow_val;
+  }
+  return 255;
+}
+
 // cv::BackgroundSubtractorMOG2::getBackgroundImage, one pixel, from the registers that already hold the model
 template <int ORD>
 __device__ __forceinline__ void mog2_background(const Mog2Px& s, const Mog2Recs& R, int hit, float4 out, int nmodes, float TB, int& b0, int& b1, int& b2) {
@@ -426,6 +558,7 @@ __device__ __forceinline__ void mog2_body(const Mog2Args& a, const size_t frame_
   Mog2Recs R;
   R.cnt = kMog2K;
   unsigned rej = 0;  // bit (slot + 1): rejected by its summary for THIS frame (filter path)
+  int wave_cand = kMog2K;  // wave-uniform bound of the records a lane holds (R.cnt): the candidate loop of mog2_pixel_lockstep
 #pragma unroll
   for (int k = 0; k < kMog2K; ++k) R.kj[k] = k, sm[k] = 0u;
   // Every load below is UNCONDITIONAL per lane and sits in straight-line code: a lane that does not want plane k repeats a load it
@@ -449,6 +582,7 @@ __device__ __forceinline__ void mog2_body(const Mog2Args& a, const size_t frame_
 #pragma unroll
     for (int n = 1; n <= kMog2K; ++n)
       if (__any(nm_in >= n)) wave_nm = n;
+    wave_cand = wave_nm <= 2 ? 2 : wave_nm;
     if (wave_nm <= 2) {
       const size_t idx = (size_t)(1 < nm_in ? 1 : 0) * kMog2Tile;
       wv[1] = mp.w[idx], R.rc[1] = mp.rec[idx];
@@ -469,32 +603,33 @@ __device__ __forceinline__ void mog2_body(const Mog2Args& a, const size_t frame_
     // and not waiting for the meta word saves a whole round trip
 #pragma unroll
     for (int k = 0; k < kMog2K; ++k) wv[k] = mp.w[(size_t)k * kMog2Tile], sm[k] = mp.sum[(size_t)k * kMog2Tile];
-    const float x0 = (float)(pix[0] & 0xffu), x1 = (float)((pix[0] >> 8) & 0xffu), x2 = (float)(pix[0] >> 16);
-    const float Tmax = a.Tb > a.Tg ? a.Tb : a.Tg;
+    const uint32_t c6T = mog2_c6T(a.Tb > a.Tg ? a.Tb : a.Tg);
     unsigned need = 0;  // bit k: the record of slot k must be read
 #pragma unroll
     for (int k = 0; k < kMog2K; ++k) {
       const bool live = k < nm_in;
       wv[k] = live ? wv[k] : 0.f;
       sm[k] = live ? sm[k] : 0u;
-      const bool r = live && valid_in && can_reject && mog2_reject(sm[k], x0, x1, x2, Tmax);
+      const bool r = live && valid_in && can_reject && mog2_reject(sm[k], pix[0], c6T);
       rej |= (unsigned)r << (k + 1);
       need |= (unsigned)(live && !r) << k;
     }
     // the needed slots, compacted: the j-th load of a lane fetches its j-th needed record (a lane with fewer repeats its first)
     R.cnt = __popc(need);
     const int k_first = need ? __ffs(need) - 1 : 0;
-    unsigned left = need;
-#pragma unroll
-    for (int j = 0; j < kMog2K; ++j) {
-      R.kj[j] = left ? __ffs(left) - 1 : k_first;
-      left &= left - 1;
-    }
+    R.kj[0] = k_first;
     if (!__any(R.cnt > 1)) {
-      R.rc[0] = mp.rec[(size_t)R.kj[0] * kMog2Tile];
+      wave_cand = 1;
+      R.rc[0] = mp.rec[(size_t)k_first * kMog2Tile];
 #pragma unroll
-      for (int j = 1; j < kMog2K; ++j) R.rc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 1; j < kMog2K; ++j) R.rc[j] = make_float4(0.f, 0.f, 0.f, 0.f), R.kj[j] = k_first;
     } else {
+      unsigned left = need & (need - 1);
+#pragma unroll
+      for (int j = 1; j < kMog2K; ++j) {
+        R.kj[j] = left ? __ffs(left) - 1 : k_first;
+        left &= left - 1;
+      }
 #pragma unroll
       for (int j = 0; j < kMog2K; ++j) R.rc[j] = mp.rec[(size_t)R.kj[j] * kMog2Tile];
     }
@@ -509,7 +644,7 @@ __device__ __forceinline__ void mog2_body(const Mog2Args& a, const size_t frame_
 #pragma unroll
         for (int j = 0; j < kMog2K; ++j) {
           const float4 c = R.rc[j];
-          if (j < R.cnt && !mog2_reject(mog2_summary(c.x, c.y, c.z, c.w), x0, x1, x2, Tmax)) ++would;
+          if (j < R.cnt && !mog2_reject(mog2_summary(c.x, c.y, c.z, c.w), pix[0], c6T)) ++would;
         }
       }
       unsigned s_live = 0, s_need = 0;
@@ -542,7 +677,11 @@ __device__ __forceinline__ void mog2_body(const Mog2Args& a, const size_t frame_
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     const float x0 = (float)(pix[t] & 0xffu), x1 = (float)((pix[t] >> 8) & 0xffu), x2 = (float)(pix[t] >> 16);
-    const int raw = mog2_pixel<ORD>(s, R, nm, x0, x1, x2, a, hit, out, alphaT[t], alpha1[t], prune[t], rej);
+    int raw;
+    if constexpr (ORD == kMog2Ranked)
+      raw = mog2_pixel<ORD>(s, R, nm, x0, x1, x2, a, hit, out, alphaT[t], alpha1[t], prune[t], rej);
+    else
+      raw = mog2_pixel_lockstep<ORD>(s, R, R.cnt, wave_cand, nm, x0, x1, x2, a, hit, out, alphaT[t], alpha1[t], prune[t]);
     const int m = thr_bin(raw, a.thr, a.enable_thr);
     if (a.fg) a.fg[(size_t)t * fg_stride + p0] = (uint8_t)m;
     if (a.packed) store_packed_mask<1>(a.fg_bits + (size_t)t * bits_stride, p0, (uint32_t)(m != 0), true);

@@ -62,7 +62,10 @@ struct SsArgs {
   float relT, fLT, fST;
   unsigned frameIndex;
   int first;             // first stream of this launch (blockIdx.z is relative to it)
-  int selfInA;           // 1: phase A itself stores a pixel's SELF update (SuBSENSE, round 3); phase B then only applies the diffusion
+  int selfInA;           // 1: a pixel's SELF update is stored before phase B (SuBSENSE: by ss_feedback_kernel; round 3: by phase A itself); phase B then only applies the diffusion
+  uint32_t* ho;          // [S][N][2] hand-over from phase A to ss_feedback_kernel (round 4), see there
+  SsScalars* scSnap;     // [S] the per-stream scalars as they stood when phase A ran (the frame-level block rewrites `sc` beside ss_feedback_kernel)
+  const uint32_t* magic; // [1024] multipliers of ss_mod
 };
 
 __host__ __device__ __forceinline__ uint32_t ss_rand(uint32_t frame, uint32_t pixel, uint32_t draw) {
@@ -75,6 +78,23 @@ __host__ __device__ __forceinline__ uint32_t ss_rand(uint32_t frame, uint32_t pi
   x *= 0xC2B2AE35u;
   x ^= x >> 16;
   return x >> 1;
+}
+
+// x % d for x < 2^31 (every ss_rand draw) and 1 <= d < 1024 without a division: Granlund & Montgomery, "Division by invariant integers
+// using multiplication" (1994), theorem 4.2 with N = 31: for l = ceil(log2 d) and m = ceil(2^(31 + l) / d) < 2^32,
+// floor(x / d) = floor(m x / 2^(31 + l)) for every 0 <= x < 2^31.  m comes from a 1024-entry table built on the host (ss_magic);
+// a runtime 32-bit `%` is ~30 instructions on this hardware and the per-pixel rules take five of them (:508-551).
+constexpr int kSsMagicN = 1024;
+inline uint32_t ss_magic(uint32_t d) {  // host
+  if (d < 2) return 0;
+  int l = 0;
+  while ((1u << l) < d) ++l;
+  return (uint32_t)((((unsigned long long)1 << (31 + l)) + d - 1) / d);
+}
+__device__ __forceinline__ uint32_t ss_mod(uint32_t x, uint32_t d, const uint32_t* magic) {
+  if (d - 2u >= (uint32_t)(kSsMagicN - 2)) return d > 1u ? x % d : 0u;  // d = 1: 0; d >= 1024 (never with the reference's caps): the plain way
+  const uint32_t q = __umulhi(x, magic[d]) >> (31 - __clz((int)(d - 1u)));
+  return x - q * d;
 }
 
 __device__ __constant__ const int8_t kSsPattern[7][7] = {{2, 4, 6, 7, 6, 4, 2},     {4, 8, 12, 14, 12, 8, 4},  {6, 12, 21, 25, 21, 12, 6}, {7, 14, 25, 28, 25, 14, 7},
@@ -161,7 +181,8 @@ constexpr int kSsATH = 32, kSsAPix = kSsTW * kSsATH, kSsRefill = 16;
 constexpr uint32_t kSsNotInterior = 0xffffffffu;
 
 
-template <int C>
+// SPLIT: the per-pixel rules behind the loop (:498-576) run in ss_feedback_kernel instead of stage 3 (see there for what was measured)
+template <int C, bool SPLIT>
 __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
   constexpr int HW = kSsTW + 4, HH = kSsATH + 4;
   constexpr int ROWB = (HW * C + 3 + 3) / 4 * 4;
@@ -193,11 +214,6 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
   lut[threadIdx.x] = a.lut[(size_t)stream * 256 + threadIdx.x];
   if (threadIdx.x == 0) nz_block = 0, qhead = 0;
   __syncthreads();
-  auto at = [&](int ry, int rx, int c) -> int {
-    const uint8_t* rowp = reinterpret_cast<const uint8_t*>(tile[ry]);
-    const int shift = (int)(((long)(y0 + ry - 2) * a.cols * C + rb) & 3L);
-    return rowp[shift + rx * C + c];
-  };
   // current colour and the 16 LBSP neighbours (packed as ss_lbsp wants them) of tile pixel (ly, lx): dword reads of the LDS
   // tile + v_alignbyte / v_perm (bgs_device.h: LbspWin) instead of one ds_read_u8 per byte
   const int rowShift0 = (int)(((long)(y0 - 2) * a.cols * C + rb) & 3L), rowShiftStep = (a.cols * C) & 3;
@@ -212,39 +228,123 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
   };
   auto interior_of = [&](int x, int y) { return x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2; };  // LBSP::validateROI; border pixels are never touched
 
-  // ---- stage 1: thresholds and intra descriptors
-  {
-    float Rs[PPL];
-    int us[PPL];
-#pragma unroll
-    for (int r = 0; r < PPL; ++r) {  // all loads first
-      const int q = r * kBlock + threadIdx.x, x = x0 + (q % kSsTW), y = y0 + (q / kSsTW);
-      const bool in = interior_of(x, y);
-      const size_t i = sN + (size_t)y * a.cols + x;
-      Rs[r] = in ? a.R[i] : 1.0f, us[r] = in ? a.unstable[i] : 0;
-    }
-#pragma unroll
-    for (int r = 0; r < PPL; ++r) {
-      const int q = r * kBlock + threadIdx.x, lx = q % kSsTW, ly = q / kSsTW;
-      if (!interior_of(x0 + lx, y0 + ly)) {
-        ctx[q][2] = kSsNotInterior;
-        continue;
+  __shared__ uint32_t magic[SPLIT ? 1 : kSsMagicN];  // ss_mod's multipliers (stage 3)
+  if constexpr (!SPLIT) {
+    for (int k = threadIdx.x; k < kSsMagicN; k += kBlock) magic[k] = a.magic[k];
+  }
+  unsigned nzcount = 0;
+  if constexpr (SPLIT) {
+    // ---- stage 1: thresholds and intra descriptors; and everything of :498-582 that needs the frame or the pixel's last colour /
+    // descriptor - the distance to the last frame (:498), the new instability flag (:467), the non-zero-descriptor count (:577-578), the
+    // last colour / descriptor themselves (:579-582) - so that the rest of the per-pixel rules can run in a kernel of its own
+    // (ss_feedback_kernel) that needs neither the LDS tile nor this kernel's registers.  Pixels go through in half-batches: the loads of
+    // four pixels are issued before the first of them is worked on.
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.scSnap[stream] = a.sc[stream];
+    {
+      constexpr int HB = PPL / 2;
+  #pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float Rs[HB], rawLT[HB], rawST[HB], finLT[HB], finST[HB];
+        uint32_t us[HB], lfg[HB], blk[HB], lcw[HB];
+        uint2 ldw[HB];
+  #pragma unroll
+        for (int r = 0; r < HB; ++r) {  // all loads first
+          const int q = (h * HB + r) * kBlock + threadIdx.x, x = x0 + (q % kSsTW), y = y0 + (q / kSsTW);
+          const bool in = interior_of(x, y);
+          const size_t i = in ? sN + (size_t)y * a.cols + x : sN;
+          Rs[r] = a.R[i], us[r] = a.unstable[i];
+          rawLT[r] = a.RawLT[i], rawST[r] = a.RawSTOld[i], finLT[r] = a.FinLT[i], finST[r] = a.FinST[i], lfg[r] = a.lastFG[i], blk[r] = a.blinks[i];
+          if constexpr (C == 3) {  // 3 bytes / 3 words with one 4- / 8-byte load (both arrays are padded by 8 bytes)
+            lcw[r] = *reinterpret_cast<const uint32_t*>(a.lastColor + i * 3);
+            ldw[r] = *reinterpret_cast<const uint2*>(a.lastDesc + i * 3);
+          } else {
+            lcw[r] = a.lastColor[i], ldw[r] = make_uint2(a.lastDesc[i], 0u);
+          }
+        }
+  #pragma unroll
+        for (int r = 0; r < HB; ++r) {
+          const int q = (h * HB + r) * kBlock + threadIdx.x, lx = q % kSsTW, ly = q / kSsTW;
+          if (!interior_of(x0 + lx, y0 + ly)) {
+            ctx[q][2] = kSsNotInterior;
+            continue;
+          }
+          const float Rv = Rs[r];
+          const int unst_old = (int)us[r];
+          const int stabOff = a.nMinColor / 5;
+          const uint32_t colorThr = (uint32_t)((Rv * (float)a.nMinColor) - (float)((!unst_old) * stabOff)) / (C == 1 ? 2 : 1);                  // :459 / :328 (trailing /2)
+          const uint32_t descThr = (1u << ((uint32_t)floorf(Rv + 0.5f))) + (uint32_t)a.nDescOff + (uint32_t)(unst_old * a.nDescOff);        // :460
+          int cur[C];
+          uint32_t nb[C][8];
+          gather(ly, lx, cur, nb);
+          unsigned intra[3] = {0, 0, 0};
+  #pragma unroll
+          for (int c = 0; c < C; ++c) intra[c] = ss_lbsp(nb[c], cur[c], lut[cur[c]]);  // :465-466 / :331
+          // the thresholds are only ever compared with distances <= 765: clamping them to 16 bits changes no comparison
+          ctx[q][0] = intra[0] | (intra[1] << 16);
+          ctx[q][1] = intra[2] | (min(colorThr, 0xffffu) << 16);
+          ctx[q][2] = min(descThr, 0xffffu);
+          {
+            const size_t i = sN + (size_t)(y0 + ly) * a.cols + (x0 + lx);
+            uint32_t l1 = 0, hd = 0;  // :498
+            if constexpr (C == 3) {
+              const uint32_t cw = (uint32_t)cur[0] | ((uint32_t)cur[1] << 8) | ((uint32_t)cur[2] << 16);
+              l1 = __builtin_amdgcn_sad_u8(cw, lcw[r] & 0xffffffu, 0u);
+              hd = (uint32_t)__popc((ldw[r].x ^ (intra[0] | (intra[1] << 16)))) + (uint32_t)__popc((ldw[r].y ^ intra[2]) & 0xffffu);
+            } else {
+              l1 = (uint32_t)abs((int)lcw[r] - cur[0]);
+              hd = (uint32_t)__popc((ldw[r].x ^ intra[0]) & 0xffffu);
+            }
+            const uint32_t unst = (Rv > 3.0f || (rawLT[r] - finLT[r]) > 0.1f || (rawST[r] - finST[r]) > 0.1f) ? 1u : 0u;  // :467
+            a.unstable[i] = (uint8_t)unst;
+            a.ho[i * 2 + 1] = l1 | (hd << 10) | (unst << 16) | ((uint32_t)(lfg[r] != 0) << 17) | ((uint32_t)(blk[r] != 0) << 18);
+            if constexpr (C == 3)
+              nzcount += (__popc(intra[0]) + __popc(intra[1]) + __popc(intra[2])) >= 4;  // :577-578
+            else
+              nzcount += __popc(intra[0]) >= 2;  // :430-431
+  #pragma unroll
+            for (int c = 0; c < C; ++c) {  // :579-582
+              a.lastDesc[i * C + c] = (uint16_t)intra[c];
+              a.lastColor[i * C + c] = (uint8_t)cur[c];
+            }
+          }
+        }
       }
-      const float Rv = Rs[r];
-      const int unst_old = us[r];
-      const int stabOff = a.nMinColor / 5;
-      const uint32_t colorThr = (uint32_t)((Rv * (float)a.nMinColor) - (float)((!unst_old) * stabOff)) / (C == 1 ? 2 : 1);                  // :459 / :328 (trailing /2)
-      const uint32_t descThr = (1u << ((uint32_t)floorf(Rv + 0.5f))) + (uint32_t)a.nDescOff + (uint32_t)(unst_old * a.nDescOff);        // :460
-      int cur[C];
-      uint32_t nb[C][8];
-      gather(ly, lx, cur, nb);
-      unsigned intra[3] = {0, 0, 0};
-#pragma unroll
-      for (int c = 0; c < C; ++c) intra[c] = ss_lbsp(nb[c], cur[c], lut[cur[c]]);  // :465-466 / :331
-      // the thresholds are only ever compared with distances <= 765: clamping them to 16 bits changes no comparison
-      ctx[q][0] = intra[0] | (intra[1] << 16);
-      ctx[q][1] = intra[2] | (min(colorThr, 0xffffu) << 16);
-      ctx[q][2] = min(descThr, 0xffffu);
+    }
+  } else {
+    // ---- stage 1: thresholds and intra descriptors
+    {
+      float Rs[PPL];
+      int us[PPL];
+  #pragma unroll
+      for (int r = 0; r < PPL; ++r) {  // all loads first
+        const int q = r * kBlock + threadIdx.x, x = x0 + (q % kSsTW), y = y0 + (q / kSsTW);
+        const bool in = interior_of(x, y);
+        const size_t i = sN + (size_t)y * a.cols + x;
+        Rs[r] = in ? a.R[i] : 1.0f, us[r] = in ? a.unstable[i] : 0;
+      }
+  #pragma unroll
+      for (int r = 0; r < PPL; ++r) {
+        const int q = r * kBlock + threadIdx.x, lx = q % kSsTW, ly = q / kSsTW;
+        if (!interior_of(x0 + lx, y0 + ly)) {
+          ctx[q][2] = kSsNotInterior;
+          continue;
+        }
+        const float Rv = Rs[r];
+        const int unst_old = us[r];
+        const int stabOff = a.nMinColor / 5;
+        const uint32_t colorThr = (uint32_t)((Rv * (float)a.nMinColor) - (float)((!unst_old) * stabOff)) / (C == 1 ? 2 : 1);                  // :459 / :328 (trailing /2)
+        const uint32_t descThr = (1u << ((uint32_t)floorf(Rv + 0.5f))) + (uint32_t)a.nDescOff + (uint32_t)(unst_old * a.nDescOff);        // :460
+        int cur[C];
+        uint32_t nb[C][8];
+        gather(ly, lx, cur, nb);
+        unsigned intra[3] = {0, 0, 0};
+  #pragma unroll
+        for (int c = 0; c < C; ++c) intra[c] = ss_lbsp(nb[c], cur[c], lut[cur[c]]);  // :465-466 / :331
+        // the thresholds are only ever compared with distances <= 765: clamping them to 16 bits changes no comparison
+        ctx[q][0] = intra[0] | (intra[1] << 16);
+        ctx[q][1] = intra[2] | (min(colorThr, 0xffffu) << 16);
+        ctx[q][2] = min(descThr, 0xffffu);
+      }
     }
   }
   __syncthreads();
@@ -421,133 +521,154 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
   }
   __syncthreads();
 
-  // ---- stage 3: everything after the loop, :498-582
-  const SsScalars sc = a.sc[stream];
-  unsigned nzcount = 0;
-#pragma unroll 2
-  for (int r = 0; r < PPL; ++r) {
-    const int qq = r * kBlock + threadIdx.x, lx = qq % kSsTW, ly = qq / kSsTW;
-    const int x = x0 + lx, y = y0 + ly;
-    if (interior_of(x, y)) {
-      const size_t p = (size_t)y * a.cols + x, i = sN + p;
-      const uint32_t fr = a.frameIndex, pi = (uint32_t)p;
-      float Rv = a.R[i], Vv = a.V[i], Tv = a.T[i];
-      const float rawLT_old = a.RawLT[i], rawST_old = a.RawSTOld[i], finLT = a.FinLT[i], finST = a.FinST[i];
-      const float dlast_old = a.DlastOld[i], dminLT_old = a.DminLT[i], dminST_old = a.DminST[i];
-      const int lastfg = a.lastFG[i], blink = a.blinks[i];
-      int lastc[C], cur[C];
-      unsigned lastd[C], intra[C];
-#pragma unroll
-      for (int c = 0; c < C; ++c) lastc[c] = a.lastColor[i * C + c], lastd[c] = a.lastDesc[i * C + c], cur[c] = at(ly + 2, lx + 2, c);
-      const int unst = (Rv > 3.0f || (rawLT_old - finLT) > 0.1f || (rawST_old - finST) > 0.1f) ? 1 : 0;  // :467
-      // the random neighbour of the background branch (:526-551) depends only on `unst`
-      const bool use3 = a.use3x3 && !unst;
-      int xn, yn;
-      {
-        const uint32_t r4 = ss_rand(fr, pi, 4);
-        if (use3) {
-          const int rr = (int)(r4 % 8u);
-          xn = x + kSsN3[rr][0], yn = y + kSsN3[rr][1];
-        } else {
-          const int rr = (int)(r4 % 24u);
-          xn = x + kSsN5[rr][0], yn = y + kSsN5[rr][1];
+  if constexpr (SPLIT) {
+    // ---- stage 3: the outcome of the loop goes to memory: the raw segmentation (the post-processing chain starts from it) and the
+    // hand-over word of ss_feedback_kernel, which applies :498-576 beside that chain
+  #pragma unroll
+    for (int r = 0; r < PPL; ++r) {
+      const int qq = r * kBlock + threadIdx.x, lx = qq % kSsTW, ly = qq / kSsTW;
+      const int x = x0 + lx, y = y0 + ly;
+      if (x < a.cols && y < a.rows) {
+        const size_t i = sN + (size_t)y * a.cols + x;
+        const uint32_t res = ctx[qq][2];
+        const bool in = interior_of(x, y);
+        a.raw[i] = (in && (int)(res & 0xffu) < a.nReq) ? 255 : 0;
+        if (in) a.ho[i * 2] = res;
+      }
+    }
+  } else {
+    // ---- stage 3: everything after the loop, :498-582
+    const SsScalars sc = a.sc[stream];
+    auto at = [&](int ry, int rx, int c) -> int {
+      const uint8_t* rowp = reinterpret_cast<const uint8_t*>(tile[ry]);
+      const int shift = (int)(((long)(y0 + ry - 2) * a.cols * C + rb) & 3L);
+      return rowp[shift + rx * C + c];
+    };
+  #pragma unroll 2
+    for (int r = 0; r < PPL; ++r) {
+      const int qq = r * kBlock + threadIdx.x, lx = qq % kSsTW, ly = qq / kSsTW;
+      const int x = x0 + lx, y = y0 + ly;
+      if (interior_of(x, y)) {
+        const size_t p = (size_t)y * a.cols + x, i = sN + p;
+        const uint32_t fr = a.frameIndex, pi = (uint32_t)p;
+        float Rv = a.R[i], Vv = a.V[i], Tv = a.T[i];
+        const float rawLT_old = a.RawLT[i], rawST_old = a.RawSTOld[i], finLT = a.FinLT[i], finST = a.FinST[i];
+        const float dlast_old = a.DlastOld[i], dminLT_old = a.DminLT[i], dminST_old = a.DminST[i];
+        const int lastfg = a.lastFG[i], blink = a.blinks[i];
+        int lastc[C], cur[C];
+        unsigned lastd[C], intra[C];
+  #pragma unroll
+        for (int c = 0; c < C; ++c) lastc[c] = a.lastColor[i * C + c], lastd[c] = a.lastDesc[i * C + c], cur[c] = at(ly + 2, lx + 2, c);
+        const int unst = (Rv > 3.0f || (rawLT_old - finLT) > 0.1f || (rawST_old - finST) > 0.1f) ? 1 : 0;  // :467
+        // the random neighbour of the background branch (:526-551) depends only on `unst`
+        const bool use3 = a.use3x3 && !unst;
+        int xn, yn;
+        {
+          const uint32_t r4 = ss_rand(fr, pi, 4);
+          if (use3) {
+            const int rr = (int)(r4 % 8u);
+            xn = x + kSsN3[rr][0], yn = y + kSsN3[rr][1];
+          } else {
+            const int rr = (int)(r4 % 24u);
+            xn = x + kSsN5[rr][0], yn = y + kSsN5[rr][1];
+          }
+          xn = min(max(xn, 2), a.cols - 3), yn = min(max(yn, 2), a.rows - 3);
         }
-        xn = min(max(xn, 2), a.cols - 3), yn = min(max(yn, 2), a.rows - 3);
+        const size_t j = sN + (size_t)yn * a.cols + xn;
+        const float nbrLast = a.DlastOld[j], nbrRaw = a.RawSTOld[j];  // previous frame's copy (contract)
+        const uint32_t c0 = ctx[qq][0], c1 = ctx[qq][1], res = ctx[qq][2];
+        intra[0] = c0 & 0xffffu;
+        if constexpr (C == 3) intra[1] = c0 >> 16, intra[2] = c1 & 0xffffu;
+        const int good = (int)(res & 0xffu);
+        const uint32_t minDesc = (res >> 8) & 0xffu, minSum = res >> 16;
+        uint32_t l1 = 0, hd = 0;
+  #pragma unroll
+        for (int c = 0; c < C; ++c) {
+          l1 += (uint32_t)abs(lastc[c] - cur[c]);
+          hd += (uint32_t)__popc((lastd[c] ^ intra[c]) & 0xffffu);
+        }
+        const float fLT = a.fLT, fST = a.fST;
+        const float normLast = ((float)l1 / maxColor + (float)hd / maxDesc) / 2;  // :498
+        a.DlastNew[i] = dlast_old * (1.0f - fST) + normLast * fST;
+        a.unstable[i] = (uint8_t)unst;
+        float dminLT = dminLT_old, dminST = dminST_old, rawLT = rawLT_old, rawST = rawST_old;
+        bool isfg;
+        uint16_t reqSelf = 0, reqNbr = 0;
+        if (good < a.nReq) {  // foreground :500-515
+          float nm = ((float)minSum / maxColor + (float)minDesc / maxDesc) / 2 + (float)(a.nReq - good) / a.nReq;
+          nm = nm > 1.0f ? 1.0f : nm;
+          dminLT = dminLT * (1.0f - fLT) + nm * fLT;
+          dminST = dminST * (1.0f - fST) + nm * fST;
+          rawLT = rawLT * (1.0f - fLT) + fLT;
+          rawST = rawST * (1.0f - fST) + fST;
+          isfg = true;
+          if (sc.cooldown && (ss_rand(fr, pi, 0) % 2u) == 0) reqSelf = ss_req(ss_mod(ss_rand(fr, pi, 1), (uint32_t)a.nS, magic), 12);
+        } else {  // background :516-552
+          const float nm = ((float)minSum / maxColor + (float)minDesc / maxDesc) / 2;
+          dminLT = dminLT * (1.0f - fLT) + nm * fLT;
+          dminST = dminST * (1.0f - fST) + nm * fST;
+          rawLT = rawLT * (1.0f - fLT);
+          rawST = rawST * (1.0f - fST);
+          isfg = false;
+          const uint32_t lr = (uint32_t)ceilf(Tv);  // (the reference computes these in size_t; every value fits 31 bits)
+          if (ss_mod(ss_rand(fr, pi, 2), lr, magic) == 0) reqSelf = ss_req(ss_mod(ss_rand(fr, pi, 3), (uint32_t)a.nS, magic), 12);
+          const uint32_t nrand = ss_rand(fr, pi, 5);
+          if (ss_mod(nrand, use3 ? lr : (lr / 2 + 1), magic) == 0 || (nbrRaw > 0.995f && nbrLast < 0.010f && ss_mod(nrand, (uint32_t)sc.capLo, magic) == 0))
+            reqNbr = ss_req(ss_mod(ss_rand(fr, pi, 6), (uint32_t)a.nS, magic), (yn - y + 2) * 5 + (xn - x + 2));
+        }
+        a.DminLT[i] = dminLT, a.DminST[i] = dminST, a.RawLT[i] = rawLT, a.RawSTNew[i] = rawST;
+        a.raw[i] = isfg ? 255 : 0;
+        a.req[i * 2] = reqSelf, a.req[i * 2 + 1] = reqNbr;
+        // Round 3: the self update is stored HERE.  No other pixel reads this pixel's samples in phase A (every pixel tests its own
+        // model only, and this lane is done with it), so the write cannot be seen early; a diffusion request of another source for
+        // the same slot is ordered against it in phase B exactly as before (the request stays in a.req: an earlier source's loses
+        // there, a later source's is applied after this launch and wins).  It takes half of the scattered 16-byte writes out of
+        // phase B, whose only limit they are, into a kernel that is bound by vector issue.
+        if (a.selfInA && reqSelf) {
+          unsigned dsc[C];
+  #pragma unroll
+          for (int c = 0; c < C; ++c) dsc[c] = intra[c];
+          SsSample<C>::make(cur, dsc).store(a.samples, ss_rec(a, stream, N, p, (int)ss_req_slot(reqSelf)));
+        }
+        // feedback :553-576
+        const float dmin_min = dminLT < dminST ? dminLT : dminST, dmin_max = dminLT > dminST ? dminLT : dminST;
+        if (lastfg || (dmin_min < 0.1f && isfg)) {
+          if (Tv < sc.capHi) Tv += div_rn(0.5f, dmin_max * Vv);
+        } else if (Tv > sc.capLo)
+          Tv -= div_rn(0.25f * Vv, dmin_max);
+        if (Tv < sc.capLo)
+          Tv = sc.capLo;
+        else if (Tv > sc.capHi)
+          Tv = sc.capHi;
+        if (dmin_max > 0.1f && blink)
+          Vv += 1.0f;
+        else if (Vv > 0.1f) {
+          Vv -= lastfg ? 0.1f / 4 : unst ? 0.1f / 2 : 0.1f;
+          if (Vv < 0.1f) Vv = 0.1f;
+        }
+        const float pw = 1.0f + dmin_min * 2;
+        if ((double)Rv < __dmul_rn((double)pw, (double)pw))  // std::pow(float, int) is a double in C++11; the square is exact
+          Rv += 0.01f * (Vv - 0.1f);
+        else {
+          Rv -= div_rn(0.01f, Vv);
+          if (Rv < 1.0f) Rv = 1.0f;
+        }
+        a.R[i] = Rv, a.V[i] = Vv, a.T[i] = Tv;
+        if constexpr (C == 3)
+          nzcount += (__popc(intra[0]) + __popc(intra[1]) + __popc(intra[2])) >= 4;  // :577-578
+        else
+          nzcount += __popc(intra[0]) >= 2;  // :430-431
+  #pragma unroll
+        for (int c = 0; c < C; ++c) {  // :579-582
+          a.lastDesc[i * C + c] = (uint16_t)intra[c];
+          a.lastColor[i * C + c] = (uint8_t)cur[c];
+        }
+      } else if (x < a.cols && y < a.rows) {
+        const size_t i = sN + (size_t)y * a.cols + x;
+        a.raw[i] = 0;
+        a.req[i * 2] = 0, a.req[i * 2 + 1] = 0;
+        a.DlastNew[i] = a.DlastOld[i], a.RawSTNew[i] = a.RawSTOld[i];
       }
-      const size_t j = sN + (size_t)yn * a.cols + xn;
-      const float nbrLast = a.DlastOld[j], nbrRaw = a.RawSTOld[j];  // previous frame's copy (contract)
-      const uint32_t c0 = ctx[qq][0], c1 = ctx[qq][1], res = ctx[qq][2];
-      intra[0] = c0 & 0xffffu;
-      if constexpr (C == 3) intra[1] = c0 >> 16, intra[2] = c1 & 0xffffu;
-      const int good = (int)(res & 0xffu);
-      const uint32_t minDesc = (res >> 8) & 0xffu, minSum = res >> 16;
-      uint32_t l1 = 0, hd = 0;
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        l1 += (uint32_t)abs(lastc[c] - cur[c]);
-        hd += (uint32_t)__popc((lastd[c] ^ intra[c]) & 0xffffu);
-      }
-      const float fLT = a.fLT, fST = a.fST;
-      const float normLast = ((float)l1 / maxColor + (float)hd / maxDesc) / 2;  // :498
-      a.DlastNew[i] = dlast_old * (1.0f - fST) + normLast * fST;
-      a.unstable[i] = (uint8_t)unst;
-      float dminLT = dminLT_old, dminST = dminST_old, rawLT = rawLT_old, rawST = rawST_old;
-      bool isfg;
-      uint16_t reqSelf = 0, reqNbr = 0;
-      if (good < a.nReq) {  // foreground :500-515
-        float nm = ((float)minSum / maxColor + (float)minDesc / maxDesc) / 2 + (float)(a.nReq - good) / a.nReq;
-        nm = nm > 1.0f ? 1.0f : nm;
-        dminLT = dminLT * (1.0f - fLT) + nm * fLT;
-        dminST = dminST * (1.0f - fST) + nm * fST;
-        rawLT = rawLT * (1.0f - fLT) + fLT;
-        rawST = rawST * (1.0f - fST) + fST;
-        isfg = true;
-        if (sc.cooldown && (ss_rand(fr, pi, 0) % 2u) == 0) reqSelf = ss_req(ss_rand(fr, pi, 1) % (uint32_t)a.nS, 12);
-      } else {  // background :516-552
-        const float nm = ((float)minSum / maxColor + (float)minDesc / maxDesc) / 2;
-        dminLT = dminLT * (1.0f - fLT) + nm * fLT;
-        dminST = dminST * (1.0f - fST) + nm * fST;
-        rawLT = rawLT * (1.0f - fLT);
-        rawST = rawST * (1.0f - fST);
-        isfg = false;
-        const uint32_t lr = (uint32_t)ceilf(Tv);  // (the reference computes these in size_t; every value fits 31 bits)
-        if ((ss_rand(fr, pi, 2) % lr) == 0) reqSelf = ss_req(ss_rand(fr, pi, 3) % (uint32_t)a.nS, 12);
-        const uint32_t nrand = ss_rand(fr, pi, 5);
-        if ((nrand % (use3 ? lr : (lr / 2 + 1))) == 0 || (nbrRaw > 0.995f && nbrLast < 0.010f && (nrand % ((uint32_t)sc.capLo)) == 0))
-          reqNbr = ss_req(ss_rand(fr, pi, 6) % (uint32_t)a.nS, (yn - y + 2) * 5 + (xn - x + 2));
-      }
-      a.DminLT[i] = dminLT, a.DminST[i] = dminST, a.RawLT[i] = rawLT, a.RawSTNew[i] = rawST;
-      a.raw[i] = isfg ? 255 : 0;
-      a.req[i * 2] = reqSelf, a.req[i * 2 + 1] = reqNbr;
-      // Round 3: the self update is stored HERE.  No other pixel reads this pixel's samples in phase A (every pixel tests its own
-      // model only, and this lane is done with it), so the write cannot be seen early; a diffusion request of another source for
-      // the same slot is ordered against it in phase B exactly as before (the request stays in a.req: an earlier source's loses
-      // there, a later source's is applied after this launch and wins).  It takes half of the scattered 16-byte writes out of
-      // phase B, whose only limit they are, into a kernel that is bound by vector issue.
-      if (a.selfInA && reqSelf) {
-        unsigned dsc[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) dsc[c] = intra[c];
-        SsSample<C>::make(cur, dsc).store(a.samples, ss_rec(a, stream, N, p, (int)ss_req_slot(reqSelf)));
-      }
-      // feedback :553-576
-      const float dmin_min = dminLT < dminST ? dminLT : dminST, dmin_max = dminLT > dminST ? dminLT : dminST;
-      if (lastfg || (dmin_min < 0.1f && isfg)) {
-        if (Tv < sc.capHi) Tv += div_rn(0.5f, dmin_max * Vv);
-      } else if (Tv > sc.capLo)
-        Tv -= div_rn(0.25f * Vv, dmin_max);
-      if (Tv < sc.capLo)
-        Tv = sc.capLo;
-      else if (Tv > sc.capHi)
-        Tv = sc.capHi;
-      if (dmin_max > 0.1f && blink)
-        Vv += 1.0f;
-      else if (Vv > 0.1f) {
-        Vv -= lastfg ? 0.1f / 4 : unst ? 0.1f / 2 : 0.1f;
-        if (Vv < 0.1f) Vv = 0.1f;
-      }
-      const float pw = 1.0f + dmin_min * 2;
-      if ((double)Rv < __dmul_rn((double)pw, (double)pw))  // std::pow(float, int) is a double in C++11; the square is exact
-        Rv += 0.01f * (Vv - 0.1f);
-      else {
-        Rv -= div_rn(0.01f, Vv);
-        if (Rv < 1.0f) Rv = 1.0f;
-      }
-      a.R[i] = Rv, a.V[i] = Vv, a.T[i] = Tv;
-      if constexpr (C == 3)
-        nzcount += (__popc(intra[0]) + __popc(intra[1]) + __popc(intra[2])) >= 4;  // :577-578
-      else
-        nzcount += __popc(intra[0]) >= 2;  // :430-431
-#pragma unroll
-      for (int c = 0; c < C; ++c) {  // :579-582
-        a.lastDesc[i * C + c] = (uint16_t)intra[c];
-        a.lastColor[i * C + c] = (uint8_t)cur[c];
-      }
-    } else if (x < a.cols && y < a.rows) {
-      const size_t i = sN + (size_t)y * a.cols + x;
-      a.raw[i] = 0;
-      a.req[i * 2] = 0, a.req[i * 2 + 1] = 0;
-      a.DlastNew[i] = a.DlastOld[i], a.RawSTNew[i] = a.RawSTOld[i];
     }
   }
 #pragma unroll
@@ -555,6 +676,137 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
   if ((threadIdx.x & (kWave - 1)) == 0 && nzcount) atomicAdd(&nz_block, nzcount);
   __syncthreads();
   if (threadIdx.x == 0 && nz_block) atomicAdd(&a.sc[stream].nzCount, nz_block);
+}
+
+// ----------------------------------------------------------------------------------------------- feedback (:498-576), round 4
+// Everything BackgroundSubtractorSuBSENSE::operator() does to a pixel after its sample-consensus loop that is not the frame itself:
+// rolling means of the distances and of the raw segmentation (:498-522), the update decisions (:508-551: which of its own samples, which
+// neighbour's), the T / v / R feedback (:553-576).  Rounds 1-3 ran it as stage 3 of phase A, where it was a third of a kernel that is
+// bound by vector issue (~700 of ~2 200 lane-instructions per quiet pixel: seven counter hashes, five run-time `%`, up to eight
+// correctly rounded divisions).  Nothing in it needs the frame tile or phase A's registers, so it is a pointwise kernel of its own now,
+// launched on the side stream in front of phase B - beside the post-processing chain, which only needs `raw`.  What phase A hands over
+// is 8 bytes per pixel (`ho`):
+//   word 0  good | minDesc << 8 | minSum << 16         the outcome of the loop (:469-497)
+//   word 1  l1 | hd << 10 | unstable << 16 | lastFG != 0 << 17 | blink != 0 << 18
+//           l1 / hd: L1 colour distance and Hamming descriptor distance to the pixel's last frame (:498); the three flags are this
+//           frame's inputs of the rules, captured before the chain rewrites the maps they come from (m_oLastFGMask, m_oBlinksFrame;
+//           `unstable` needs the final-segmentation means that ss_finish_kernel updates)
+// and the per-stream scalars as they stood at the start of the frame (scSnap: the frame-level block rewrites `sc` beside this kernel).
+// The statements, their order and every operand are those of stage 3 before: same floats, same draws.  x % d with d in 1..1023 is exact
+// through ss_mod.  grid: (ceil(cols / 256), rows, streams).
+template <int C>
+__global__ __launch_bounds__(kBlock) void ss_feedback_kernel(const SsArgs a) {
+  constexpr uint32_t maxColor = 255 * C, maxDesc = 16 * C;
+  __shared__ uint32_t magic[kSsMagicN];
+  for (int k = threadIdx.x; k < kSsMagicN; k += kBlock) magic[k] = a.magic[k];
+  __syncthreads();
+  const int stream = a.first + blockIdx.z;
+  const size_t N = (size_t)a.rows * a.cols, sN = (size_t)stream * N;
+  const int x = blockIdx.x * kBlock + threadIdx.x, y = blockIdx.y;
+  if (x >= a.cols) return;
+  const size_t p = (size_t)y * a.cols + x, i = sN + p;
+  if (!(x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2)) {  // LBSP::validateROI: border pixels are never touched
+    a.req[i * 2] = 0, a.req[i * 2 + 1] = 0;
+    a.DlastNew[i] = a.DlastOld[i], a.RawSTNew[i] = a.RawSTOld[i];
+    return;
+  }
+  const SsScalars sc = a.scSnap[stream];
+  const uint32_t fr = a.frameIndex, pi = (uint32_t)p;
+  const uint2 hw = *reinterpret_cast<const uint2*>(a.ho + i * 2);
+  float Rv = a.R[i], Vv = a.V[i], Tv = a.T[i];
+  const float rawLT_old = a.RawLT[i], rawST_old = a.RawSTOld[i];
+  const float dlast_old = a.DlastOld[i], dminLT_old = a.DminLT[i], dminST_old = a.DminST[i];
+  const int good = (int)(hw.x & 0xffu);
+  const uint32_t minDesc = (hw.x >> 8) & 0xffu, minSum = hw.x >> 16;
+  const uint32_t l1 = hw.y & 0x3ffu, hd = (hw.y >> 10) & 0x3fu;
+  const int unst = (int)((hw.y >> 16) & 1u), lastfg = (int)((hw.y >> 17) & 1u), blink = (int)((hw.y >> 18) & 1u);
+  // the random neighbour of the background branch (:526-551) depends only on `unst`
+  const bool use3 = a.use3x3 && !unst;
+  int xn, yn;
+  {
+    const uint32_t r4 = ss_rand(fr, pi, 4);
+    if (use3) {
+      const int rr = (int)(r4 % 8u);
+      xn = x + kSsN3[rr][0], yn = y + kSsN3[rr][1];
+    } else {
+      const int rr = (int)(r4 % 24u);
+      xn = x + kSsN5[rr][0], yn = y + kSsN5[rr][1];
+    }
+    xn = min(max(xn, 2), a.cols - 3), yn = min(max(yn, 2), a.rows - 3);
+  }
+  const size_t j = sN + (size_t)yn * a.cols + xn;
+  const float nbrLast = a.DlastOld[j], nbrRaw = a.RawSTOld[j];  // previous frame's copy (contract)
+  const float fLT = a.fLT, fST = a.fST;
+  const float normLast = ((float)l1 / maxColor + (float)hd / maxDesc) / 2;  // :498
+  a.DlastNew[i] = dlast_old * (1.0f - fST) + normLast * fST;
+  float dminLT = dminLT_old, dminST = dminST_old, rawLT = rawLT_old, rawST = rawST_old;
+  bool isfg;
+  uint16_t reqSelf = 0, reqNbr = 0;
+  if (good < a.nReq) {  // foreground :500-515
+    float nm = ((float)minSum / maxColor + (float)minDesc / maxDesc) / 2 + (float)(a.nReq - good) / a.nReq;
+    nm = nm > 1.0f ? 1.0f : nm;
+    dminLT = dminLT * (1.0f - fLT) + nm * fLT;
+    dminST = dminST * (1.0f - fST) + nm * fST;
+    rawLT = rawLT * (1.0f - fLT) + fLT;
+    rawST = rawST * (1.0f - fST) + fST;
+    isfg = true;
+    if (sc.cooldown && (ss_rand(fr, pi, 0) % 2u) == 0) reqSelf = ss_req(ss_mod(ss_rand(fr, pi, 1), (uint32_t)a.nS, magic), 12);
+  } else {  // background :516-552
+    const float nm = ((float)minSum / maxColor + (float)minDesc / maxDesc) / 2;
+    dminLT = dminLT * (1.0f - fLT) + nm * fLT;
+    dminST = dminST * (1.0f - fST) + nm * fST;
+    rawLT = rawLT * (1.0f - fLT);
+    rawST = rawST * (1.0f - fST);
+    isfg = false;
+    const uint32_t lr = (uint32_t)ceilf(Tv);  // (the reference computes these in size_t; every value fits 31 bits)
+    if (ss_mod(ss_rand(fr, pi, 2), lr, magic) == 0) reqSelf = ss_req(ss_mod(ss_rand(fr, pi, 3), (uint32_t)a.nS, magic), 12);
+    const uint32_t nrand = ss_rand(fr, pi, 5);
+    if (ss_mod(nrand, use3 ? lr : (lr / 2 + 1), magic) == 0 || (nbrRaw > 0.995f && nbrLast < 0.010f && ss_mod(nrand, (uint32_t)sc.capLo, magic) == 0))
+      reqNbr = ss_req(ss_mod(ss_rand(fr, pi, 6), (uint32_t)a.nS, magic), (yn - y + 2) * 5 + (xn - x + 2));
+  }
+  a.DminLT[i] = dminLT, a.DminST[i] = dminST, a.RawLT[i] = rawLT, a.RawSTNew[i] = rawST;
+  *reinterpret_cast<uint32_t*>(a.req + i * 2) = (uint32_t)reqSelf | ((uint32_t)reqNbr << 16);
+  // The SELF update is stored here (round 3: by phase A).  Nobody reads a pixel's samples between its consensus loop and phase B, so
+  // the write cannot be seen early; a diffusion request of another source for the same slot is ordered against it in phase B exactly
+  // as before (the request stays in a.req: an earlier source's loses there, a later source's is applied by phase B, after this
+  // launch, and wins).  It keeps half of the scattered 16-byte writes out of phase B, whose only limit they are.
+  if (a.selfInA && reqSelf) {
+    int cur[C];
+    unsigned dsc[C];
+    if constexpr (C == 3) {  // what phase A left as the pixel's last colour / descriptor IS this frame's
+      const uint32_t cw = *reinterpret_cast<const uint32_t*>(a.lastColor + i * 3);
+      const uint2 dw = *reinterpret_cast<const uint2*>(a.lastDesc + i * 3);
+      cur[0] = (int)(cw & 0xffu), cur[1] = (int)((cw >> 8) & 0xffu), cur[2] = (int)((cw >> 16) & 0xffu);
+      dsc[0] = dw.x & 0xffffu, dsc[1] = dw.x >> 16, dsc[2] = dw.y & 0xffffu;
+    } else {
+      cur[0] = a.lastColor[i], dsc[0] = a.lastDesc[i];
+    }
+    SsSample<C>::make(cur, dsc).store(a.samples, ss_rec(a, stream, N, p, (int)ss_req_slot(reqSelf)));
+  }
+  // feedback :553-576
+  const float dmin_min = dminLT < dminST ? dminLT : dminST, dmin_max = dminLT > dminST ? dminLT : dminST;
+  if (lastfg || (dmin_min < 0.1f && isfg)) {
+    if (Tv < sc.capHi) Tv += div_rn(0.5f, dmin_max * Vv);
+  } else if (Tv > sc.capLo)
+    Tv -= div_rn(0.25f * Vv, dmin_max);
+  if (Tv < sc.capLo)
+    Tv = sc.capLo;
+  else if (Tv > sc.capHi)
+    Tv = sc.capHi;
+  if (dmin_max > 0.1f && blink)
+    Vv += 1.0f;
+  else if (Vv > 0.1f) {
+    Vv -= lastfg ? 0.1f / 4 : unst ? 0.1f / 2 : 0.1f;
+    if (Vv < 0.1f) Vv = 0.1f;
+  }
+  const float pw = 1.0f + dmin_min * 2;
+  if ((double)Rv < __dmul_rn((double)pw, (double)pw))  // std::pow(float, int) is a double in C++11; the square is exact
+    Rv += 0.01f * (Vv - 0.1f);
+  else {
+    Rv -= div_rn(0.01f, Vv);
+    if (Rv < 1.0f) Rv = 1.0f;
+  }
+  a.R[i] = Rv, a.V[i] = Vv, a.T[i] = Tv;
 }
 
 // ----------------------------------------------------------------------------------------------- LOBSTER, phase A

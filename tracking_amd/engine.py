@@ -20,10 +20,18 @@ class Engine:
         self.params = params if params is not None else capi.default_params(algo)
         capi.check(capi.lib().bgs_create(algo, C.byref(self.params), device, n_streams, C.byref(self._h)))
 
+    @classmethod
+    def from_handle(cls, handle, algo, n_streams):
+        """A view of a bgs_engine owned by someone else (a bgs_node's per-device engine): close() does not destroy it."""
+        self = cls.__new__(cls)
+        self._h, self.algo, self.n_streams, self.params, self._borrowed = handle, algo, n_streams, capi.default_params(algo), True
+        return self
+
     # -- lifetime ---------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
-            capi.lib().bgs_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                capi.lib().bgs_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -102,6 +110,10 @@ class Engine:
         ch = 1 if frame.ndim == 2 else frame.shape[2]
         capi.check(capi.lib().bgs_submit(self._h, stream, frame.ctypes.data_as(C.c_void_p), rows, cols, ch, frame.strides[0], fg.ctypes.data_as(C.c_void_p), fg.strides[0],
                                          bg.ctypes.data_as(C.c_void_p) if bg is not None else None, bg.strides[0] if bg is not None else 0))
+
+    def host_arena(self, array, on=True):
+        """bgs_host_arena: page-lock a numpy array that holds the images of several cameras, once."""
+        capi.check(capi.lib().bgs_host_arena(self._h, array.ctypes.data_as(C.c_void_p), array.nbytes, 1 if on else 0))
 
     def wait(self, stream=0):
         flags = C.c_uint32(0)
