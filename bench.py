@@ -527,8 +527,8 @@ def main():
         UPDATE_LAUNCHES[0] += 1
         got = nd.copy_masks(torch.empty((S, words), dtype=torch.int64, device=dev))
         torch.cuda.synchronize()
-        selftest_ok = {"transport": "libbgs_node, ncclSend to self + ncclRecv from self", "nonzero_words": int(got.ne(0).sum().item()), "words": int(got.numel()),
-                       "all_foreground_words": int((got == -1).sum().item())}
+        selftest_ok = {"transport": "libbgs_node, ncclSend to self + ncclRecv from self (the gathered words are held against the oracle in tests/test_gpu_07_node.py)",
+                       "nonzero_words": int(got.ne(0).sum().item()), "words": int(got.numel())}
     _, _, k_name = eng.kernel_timing()
     series = eng.kernel_timing_series()
     eng.enable_kernel_timing(False)

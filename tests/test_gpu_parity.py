@@ -448,6 +448,33 @@ def test_round2_forms_of_the_round3_kernels_still_match(golden_frames):
     assert r.returncode == 0 and "round-2 forms OK" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("knob", ["BGS_SS_FEEDBACK_SPLIT", "BGS_SS_QUEUE"])
+def test_subsense_round4_forms_behind_knobs_match_the_oracle(knob):
+    """Round 4 built the two restructurings of phase A the verdict asked for - the rules behind the loop as a kernel of their own
+    (BGS_SS_FEEDBACK_SPLIT=1) and the inter-LBSP tests worked off a per-wave list by whichever lane is free (BGS_SS_QUEUE=1) - measured
+    both slower than the form that runs by default and kept them as A/B knobs.  Knobs are read once per process: one
+    child process each, same masks, backgrounds and whole model as the oracle incl. a scene cut (model reset) and a large frame."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from gpu_helpers import run_pair, check_subsense_state, capi\n"
+            "from tools import synth\n"
+            "f = np.load(%r)['frames'][:12]\n"
+            "eng, orc, _ = run_pair(capi.SUBSENSE, f)\n"
+            "check_subsense_state(eng, orc, f.shape[1], f.shape[2])\n"
+            "a = synth.numpy_frames('surv', 20, 240, 320, seed=21) // 6\n"
+            "b = 255 - synth.numpy_frames('surv', 8, 240, 320, seed=99) // 6\n"
+            "eng, orc, _ = run_pair(capi.SUBSENSE, np.concatenate([a, b]))\n"
+            "check_subsense_state(eng, orc, 240, 320)\n"
+            "g = synth.numpy_frames('surv', 6, 360, 640, seed=7)\n"
+            "eng, orc, _ = run_pair(capi.SUBSENSE, g)\n"
+            "check_subsense_state(eng, orc, 360, 640)\n"
+            "print('knob form OK')\n") % (os.path.dirname(here), here, os.path.join(here, "golden", "frames_96x80.npz"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{knob: "1"}), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "knob form OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_subsense_qvga_with_frame_level_block():
     """320x240 = QVGA: learning-rate scaling + auto model reset enabled; a scene cut at frame 12 triggers refreshModel(0.1)."""
     a = synth.numpy_frames("surv", 30, 240, 320, seed=21) // 6          # dark scene, long enough for ST (1/25) and LT (1/30) to part
@@ -468,14 +495,14 @@ def test_subsense_large_frame_5x5_spread():
 
 def test_subsense_modulo_by_multiplication_is_exact(golden_frames):
     """ss_feedback_kernel takes its five run-time `x % d` (which sample, which neighbour: BackgroundSubtractorSuBSENSE.cpp:508-551) as
-    x - (mulhi(x, m[d]) >> (ceil(log2 d) - 1)) d with m from a 1024-entry table (Granlund & Montgomery 1994, N = 31).  The table the
-    DEVICE holds, against integer division: every d in 2..1023, x over the edges of [0, 2^31) and 20 000 random draws each."""
+    x - (mulhi(x, m[d]) >> (ceil(log2 d) - 1)) d with m from a 576-entry table (Granlund & Montgomery 1994, N = 31).  The table the
+    DEVICE holds, against integer division: every d in 2..575, x over the edges of [0, 2^31) and 20 000 random draws each."""
     eng = Engine(capi.SUBSENSE)
     eng.process(golden_frames[0])
-    m = eng.get_state("magic", (1024,), np.uint32).astype(np.uint64)
+    m = eng.get_state("magic", (576,), np.uint32).astype(np.uint64)
     rng = np.random.default_rng(5)
     x = np.concatenate([np.array([0, 1, 2, 3, 2**31 - 1, 2**31 - 2, 2**30, 2**30 - 1, 2**30 + 1, 2**16, 2**16 - 1], np.uint64), rng.integers(0, 2**31, 20000).astype(np.uint64)])
-    for d in range(2, 1024):
+    for d in range(2, 576):
         sh = np.uint64((d - 1).bit_length() - 1)  # 31 - clz(d - 1)
         q = ((x * m[d]) >> np.uint64(32)) >> sh
         assert np.array_equal(q, x // np.uint64(d)), d

@@ -235,13 +235,18 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
   static const bool split = getenv("BGS_SS_FEEDBACK_SPLIT") && atoi(getenv("BGS_SS_FEEDBACK_SPLIT")) == 1;
   {
     Timed tm(e, s, "ss_phase_a_kernel");
-    const dim3 tilesA((e->cols + bgs::kSsTW - 1) / bgs::kSsTW, (e->rows + bgs::kSsATH - 1) / bgs::kSsATH, count);
+    // BGS_SS_QUEUE=1: BGR frames through the per-wave candidate list (kernel_subsense.h "rounds"; identical results; measured slower: the
+    // candidates a wave holds per trip are too few to fill its lanes) - A/B knob
+    static const bool queue = getenv("BGS_SS_QUEUE") && atoi(getenv("BGS_SS_QUEUE")) == 1;
+    const int ath = (e->ch == 3 && queue && !split) ? bgs::kSsQATH : bgs::kSsATH;
+    const dim3 tilesA((e->cols + bgs::kSsTW - 1) / bgs::kSsTW, (e->rows + ath - 1) / ath, count);
     if (e->ch == 3) {
-      if (split) hipLaunchKernelGGL((bgs::ss_phase_a_kernel<3, true>), tilesA, block, 0, s, a);
-      else hipLaunchKernelGGL((bgs::ss_phase_a_kernel<3, false>), tilesA, block, 0, s, a);
+      if (split) hipLaunchKernelGGL((bgs::ss_phase_a_kernel<3, true, false>), tilesA, block, 0, s, a);
+      else if (queue) hipLaunchKernelGGL((bgs::ss_phase_a_kernel<3, false, true>), tilesA, block, 0, s, a);
+      else hipLaunchKernelGGL((bgs::ss_phase_a_kernel<3, false, false>), tilesA, block, 0, s, a);
     } else {
-      if (split) hipLaunchKernelGGL((bgs::ss_phase_a_kernel<1, true>), tilesA, block, 0, s, a);
-      else hipLaunchKernelGGL((bgs::ss_phase_a_kernel<1, false>), tilesA, block, 0, s, a);
+      if (split) hipLaunchKernelGGL((bgs::ss_phase_a_kernel<1, true, false>), tilesA, block, 0, s, a);
+      else hipLaunchKernelGGL((bgs::ss_phase_a_kernel<1, false, false>), tilesA, block, 0, s, a);
     }
   }
   // Phase B (the scattered sample writes) and the post-processing chain both depend on phase A only, and the next frame depends

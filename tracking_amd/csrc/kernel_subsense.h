@@ -80,11 +80,11 @@ __host__ __device__ __forceinline__ uint32_t ss_rand(uint32_t frame, uint32_t pi
   return x >> 1;
 }
 
-// x % d for x < 2^31 (every ss_rand draw) and 1 <= d < 1024 without a division: Granlund & Montgomery, "Division by invariant integers
+// x % d for x < 2^31 (every ss_rand draw) and 1 <= d < kSsMagicN without a division: Granlund & Montgomery, "Division by invariant integers
 // using multiplication" (1994), theorem 4.2 with N = 31: for l = ceil(log2 d) and m = ceil(2^(31 + l) / d) < 2^32,
-// floor(x / d) = floor(m x / 2^(31 + l)) for every 0 <= x < 2^31.  m comes from a 1024-entry table built on the host (ss_magic);
+// floor(x / d) = floor(m x / 2^(31 + l)) for every 0 <= x < 2^31.  m comes from a table built on the host (ss_magic);
 // a runtime 32-bit `%` is ~30 instructions on this hardware and the per-pixel rules take five of them (:508-551).
-constexpr int kSsMagicN = 1024;
+constexpr int kSsMagicN = 576;  // covers every learning rate (<= 512, the upper cap) and the usual sample counts; larger divisors take the plain way (2.3 KB of LDS in phase A)
 inline uint32_t ss_magic(uint32_t d) {  // host
   if (d < 2) return 0;
   int l = 0;
@@ -92,7 +92,7 @@ inline uint32_t ss_magic(uint32_t d) {  // host
   return (uint32_t)((((unsigned long long)1 << (31 + l)) + d - 1) / d);
 }
 __device__ __forceinline__ uint32_t ss_mod(uint32_t x, uint32_t d, const uint32_t* magic) {
-  if (d - 2u >= (uint32_t)(kSsMagicN - 2)) return d > 1u ? x % d : 0u;  // d = 1: 0; d >= 1024 (never with the reference's caps): the plain way
+  if (d - 2u >= (uint32_t)(kSsMagicN - 2)) return d > 1u ? x % d : 0u;  // d = 1: 0; d >= kSsMagicN (a sample count that large): the plain way
   const uint32_t q = __umulhi(x, magic[d]) >> (31 - __clz((int)(d - 1u)));
   return x - q * d;
 }
@@ -182,22 +182,35 @@ constexpr uint32_t kSsNotInterior = 0xffffffffu;
 
 
 // SPLIT: the per-pixel rules behind the loop (:498-576) run in ss_feedback_kernel instead of stage 3 (see there for what was measured)
-template <int C, bool SPLIT>
+// QUEUE (BGR only): the inter-LBSP tests of a wave go through a per-wave work list in LDS and are computed by WHOEVER is free, 64 at a
+// time (stage 2, "rounds"); the tile is 64 x 16 then (kSsQATH) so that the extra LDS still allows four workgroups per CU.
+constexpr int kSsQATH = 16, kSsQList = 256;
+template <int C, bool SPLIT, bool QUEUE>
 __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
-  constexpr int HW = kSsTW + 4, HH = kSsATH + 4;
+  static_assert(!QUEUE || C == 3, "the candidate queue is built for BGR records");
+  constexpr int ATH = QUEUE ? kSsQATH : kSsATH, APIX = kSsTW * ATH;
+  constexpr int HW = kSsTW + 4, HH = ATH + 4;
   constexpr int ROWB = (HW * C + 3 + 3) / 4 * 4;
   constexpr uint32_t maxColor = 255 * C, maxDesc = 16 * C;  // s_nColorMaxDataRange_*, s_nDescMaxDataRange_*
-  constexpr int PPL = kSsAPix / kBlock;
+  constexpr int PPL = APIX / kBlock;
   __shared__ uint32_t tile[HH][ROWB / 4];
   __shared__ uint8_t lut[256];
   // per pixel: [0] intra0 | intra1 << 16, [1] intra2 | colorThr << 16, [2] descThr, replaced in stage 2 by
   // good | minDesc << 8 | minSum << 16 (3-dword stride: conflict-free for consecutive pixels)
-  __shared__ uint32_t ctx[kSsAPix][3];
+  __shared__ uint32_t ctx[APIX][3];
   __shared__ unsigned nz_block, qhead;
+  // QUEUE: what a worker lane needs of the lane that owns a candidate - its pixel's 48 LBSP neighbours as bytes (12 dwords: channel c
+  // in words 4c .. 4c+3, neighbour k in byte k), its current colour, where its held samples start and whether they are the pixel-major
+  // part - plus, per wave, the work list (lane << 3 | sample) and, per lane, the eight 16-bit results
+  __shared__ uint32_t nbs[QUEUE ? kBlock : 1][12];
+  __shared__ uint32_t hcur[QUEUE ? kBlock : 1], hrec[QUEUE ? kBlock : 1];
+  __shared__ uint16_t hq[QUEUE ? kBlock : 2];
+  __shared__ uint16_t qlist[QUEUE ? (kBlock / kWave) * kSsQList : 2];
+  __shared__ __attribute__((aligned(16))) uint16_t qres[QUEUE ? kBlock * 8 : 8];
   const int stream = a.first + blockIdx.z;
   const size_t N = (size_t)a.rows * a.cols, sN = (size_t)stream * N;
   const uint8_t* img = a.frame + (size_t)blockIdx.z * N * C;
-  const int x0 = blockIdx.x * kSsTW, y0 = blockIdx.y * kSsATH;
+  const int x0 = blockIdx.x * kSsTW, y0 = blockIdx.y * ATH;
   const long imgsz = (long)N * C, rb = (long)(x0 - 2) * C;
   for (int i = threadIdx.x; i < HH * (ROWB / 4); i += kBlock) {
     const int ry = i / (ROWB / 4), rd = i - ry * (ROWB / 4);
@@ -384,10 +397,10 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
         unsigned base = 0;
         if (lane == leader) base = atomicAdd(&qhead, (unsigned)nidle);
         base = (unsigned)__shfl((int)base, leader);
-        if (base + (unsigned)nidle >= (unsigned)kSsAPix) qempty = true;
+        if (base + (unsigned)nidle >= (unsigned)APIX) qempty = true;
         if (!active) {
           const unsigned my = base + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
-          if (my < (unsigned)kSsAPix && ctx[my][2] != kSsNotInterior) {
+          if (my < (unsigned)APIX && ctx[my][2] != kSsNotInterior) {
             q = (int)my;
             const int lx = q % kSsTW, ly = q / kSsTW;
             const uint32_t c0 = ctx[q][0], c1 = ctx[q][1];
@@ -398,6 +411,20 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
             gather(ly, lx, cur, nb);
 #pragma unroll
             for (int c = 0; c < C; ++c) curm[c] = (uint32_t)cur[c] << (8 * c);
+            if constexpr (QUEUE) {  // the neighbours as bytes for whoever computes this pixel's inter-LBSP tests
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                uint32_t w[4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {  // words 0, 1: neighbours 0-3, 4-7 (the high halves of nb[4i .. 4i+3]); words 2, 3: neighbours 8-15 (the low halves)
+                  const uint32_t h01 = __builtin_amdgcn_perm(nb[c][4 * i + 1], nb[c][4 * i], 0x0c0c0602u), h23 = __builtin_amdgcn_perm(nb[c][4 * i + 3], nb[c][4 * i + 2], 0x0c0c0602u);
+                  const uint32_t l01 = __builtin_amdgcn_perm(nb[c][4 * i + 1], nb[c][4 * i], 0x0c0c0400u), l23 = __builtin_amdgcn_perm(nb[c][4 * i + 3], nb[c][4 * i + 2], 0x0c0c0400u);
+                  w[i] = h01 | (h23 << 16), w[2 + i] = l01 | (l23 << 16);
+                }
+                *reinterpret_cast<uint4*>(&nbs[threadIdx.x][4 * c]) = make_uint4(w[0], w[1], w[2], w[3]);
+              }
+              hcur[threadIdx.x] = curm[0] | curm[1] | curm[2];
+            }
             const size_t p = (size_t)(y0 + ly) * a.cols + (x0 + lx);
             rec = ss_rec(a, stream, N, p, 0), rnext = ss_rec(a, stream, N, p, B);
 #pragma unroll
@@ -407,117 +434,223 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
           }
         }
       }
-      if (active) {
-        if (good < a.nReq && idx < a.nS) {  // :469-497 (BGR) / :334-357 (gray)
-          // One trip = the samples a lane holds: batch 0 (four samples, bt) on a pixel's first trip, then EIGHT at a time (bt + nbt,
-          // 128 contiguous bytes of the pixel-major part).  Two passes.  R: the cheap exact rejection tests on all held samples,
-          // every lane busy -> candidate bits.  I: the inter-LBSP test (~150 instructions), one candidate per lane and pass in
-          // sample order, stopping at the nReq-th match exactly like the reference's loop (:469).  Interleaved sample by sample,
-          // nearly every trip of a wave paid the inter-LBSP step for the few lanes that needed it (12 % of the samples get that
-          // far: 94 % of the trips of 64 lanes); per eight samples it is paid ~3.5 times instead of 8.  Rejected samples and
-          // samples behind the nReq-th match have no side effects, and min() does not care about order.
-          const bool wide = idx > 0;
-          auto reject_bits = [&](const SsSample<C>(&bb)[B], int first) -> uint32_t {
-            uint32_t bits = 0;
+      // One trip = the samples a lane holds: batch 0 (four samples, bt) on a pixel's first trip, then EIGHT at a time (bt + nbt,
+      // 128 contiguous bytes of the pixel-major part).  Two passes.  R: the cheap exact rejection tests on all held samples,
+      // every lane busy -> candidate bits.  I: the inter-LBSP test (~150 instructions per channel set), one candidate per lane and
+      // pass in sample order, stopping at the nReq-th match exactly like the reference's loop (:469).  Rejected samples and samples
+      // behind the nReq-th match have no side effects, and min() does not care about order.
+      uint32_t cand = 0;
+      bool wide = false;
+      if (active) {  // :469-497 (BGR) / :334-357 (gray); an active lane always has good < nReq and idx < nS here
+        wide = idx > 0;
+        auto reject_bits = [&](const SsSample<C>(&bb)[B], int first) -> uint32_t {
+          uint32_t bits = 0;
+          if constexpr (C == 1) {
+#pragma unroll
+            for (int j = 0; j < B; ++j) bits |= (uint32_t)(first + j < a.nS && (uint32_t)abs(cur[0] - bb[j].color(0)) <= colorThr) << j;
+          } else {
+            // The reference walks the channels in order and drops the sample at the first failed test (:474-491); a sample is kept
+            // only if every test passes, so the tests may run in any order.  Exact rejections first, from what costs least:
+            // lower bounds with the intra half of the descriptor distance alone (dd >= intraD/2, and sd grows with dd).  The
+            // per-channel colour test cd <= scColorThr is implied by the one on the bound lbsd = min(255, k + cd): either
+            // lbsd = k + cd >= cd, or lbsd = 255 <= scColorThr and cd <= 255.
+            const uint32_t totColorThr = colorThr * 3, totDescThr = descThr * 3, scColorThr = totColorThr / 2;
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+              const uint32_t sx = bb[j].v.x, sy = bb[j].v.y, sz = bb[j].v.z;
+              uint32_t cd[3], lbdd[3], lbsd[3];
+              cd[0] = __builtin_amdgcn_sad_u8(curm[0], sx & 0x0000ffu, 0u);
+              cd[1] = __builtin_amdgcn_sad_u8(curm[1], sx & 0x00ff00u, 0u);
+              cd[2] = __builtin_amdgcn_sad_u8(curm[2], sx & 0xff0000u, 0u);
+              const uint32_t xy = iy ^ sy;
+              lbdd[0] = (uint32_t)__popc(xy & 0xffffu) >> 1, lbdd[1] = (uint32_t)__popc(xy >> 16) >> 1, lbdd[2] = (uint32_t)__popc(iz ^ sz) >> 1;
+#pragma unroll
+              for (int c = 0; c < 3; ++c) lbsd[c] = min((lbdd[c] >> 1) * (255 / 16) + cd[c], 255u);
+              const bool ok = max(max(lbsd[0], lbsd[1]), lbsd[2]) <= scColorThr && lbdd[0] + lbdd[1] + lbdd[2] <= totDescThr && lbsd[0] + lbsd[1] + lbsd[2] <= totColorThr;
+              bits |= (uint32_t)(ok && first + j < a.nS) << j;
+            }
+          }
+          return bits;
+        };
+        cand = reject_bits(bt, idx);
+        if (__any(wide)) {
+          const uint32_t hi = reject_bits(nbt, idx + B);
+          if (wide) cand |= hi << B;
+        }
+      }
+      if constexpr (QUEUE) {
+        // ROUNDS (round 4, BGS_SS_QUEUE=1; NOT the default: measured slower).  One candidate per lane and pass leaves the wave at
+        // ~25 % lane use on a young model (profiles/r04_subsense_phase_a_pmc.txt: 2.65 M passes of ~230 vector instructions per
+        // 8 x 1080p launch for 43 M candidates, half of the kernel's vector instructions).  Here every lane that has candidates puts some
+        // on its wave's list and ALL 64 lanes work the list off, 64 entries at a time, each lane computing whichever candidate falls to
+        // it from what its owner left in LDS (neighbours, colour, thresholds) and the sample re-read from memory (a cache hit: the
+        // owner's load).  A pixel past its first batch enqueues up to four candidates at once - speculation: a candidate behind the
+        // nReq-th match is computed in vain, but such pixels rarely match at all - a pixel on its first batch only as many as it still
+        // needs (at most two).  Results come back as 16 bits per candidate; the owner applies them in sample order and stops at its
+        // nReq-th match, exactly the reference's early exit.  Same integers as the direct form below (parity-tested).
+        // What the counters said: the vector instruction count did not move (1 184 M -> 1 181 M per launch) and 3.9 M list passes ran
+        // where 2.65 M direct ones had - a wave holds only ~20 candidates per trip (a third of its lanes are between pixels or have
+        // none), so a list pass is still two thirds empty and pays ~60 instructions of LDS traffic on top; LDS bank conflicts x 5.
+        // Young 8 x 1080p phase A 2.04 -> 2.42 ms, aged 1.06 -> 1.49 ms.  Filling the lanes needs candidates from SEVERAL trips of a
+        // lane in flight at once, i.e. speculating across sample batches - not built.
+        const int wbase = (int)(threadIdx.x & ~(kWave - 1));
+        uint16_t* wl = qlist + (threadIdx.x / kWave) * kSsQList;
+        const size_t recBase = (size_t)stream * N * (size_t)a.nSpad;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        if (active) hrec[threadIdx.x] = (uint32_t)(rec - recBase), hq[threadIdx.x] = (uint16_t)((unsigned)q | (wide ? 0x8000u : 0u));
+        for (;;) {
+          const bool want = active && cand != 0 && good < a.nReq;
+          if (!__any(want)) break;
+          uint32_t enq = 0;
+          if (want) {
+            const int quota = wide ? 4 : min(a.nReq - good, 2);
+            uint32_t x = cand;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (k < quota && x) enq |= x & (0u - x), x &= x - 1u;
+            cand &= ~enq;
+          }
+          unsigned n_list = 0;  // wave-uniform: at most 4 x 64 = kSsQList entries
+#pragma unroll
+          for (int b = 0; b < 2 * B; ++b) {
+            const bool has = (enq >> b) & 1u;
+            const unsigned long long mb = __ballot(has);
+            if (has) wl[n_list + (unsigned)__popcll(mb & lt)] = (uint16_t)((lane << 3) | b);
+            n_list += (unsigned)__popcll(mb);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          for (unsigned base = 0; base < n_list; base += kWave) {
+            const bool valid = base + (unsigned)lane < n_list;
+            const unsigned ent = valid ? (unsigned)wl[base + lane] : ((unsigned)lane << 3);
+            const int ot = wbase + (int)(ent >> 3), j = (int)(ent & 7u);
+            const unsigned oqw = hq[ot];
+            const int oq = (int)(oqw & 0x7fffu);
+            const size_t srec = recBase + hrec[ot] + ((oqw >> 15) ? (size_t)j : (size_t)j * N);
+            const SsSample<3> sv = SsSample<3>::load(a.samples, valid ? srec : recBase);  // (unconditional, see the prefetch note: a valid address either way)
+            const uint32_t c0w = ctx[oq][0], c1w = ctx[oq][1], oDescThr = ctx[oq][2], oColorThr = c1w >> 16;
+            const uint32_t curw = hcur[ot];
+            const uint32_t totColorThr = oColorThr * 3, totDescThr = oDescThr * 3, scColorThr = totColorThr / 2;
+            uint32_t totDesc = 0, totSum = 0;
+            bool ok = true;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const uint4 w = *reinterpret_cast<const uint4*>(&nbs[ot][4 * c]);
+              uint32_t nbf[8];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                nbf[k] = __builtin_amdgcn_perm(w.x, w.z, 0x0c000c00u | ((uint32_t)(4 + k) << 16) | (uint32_t)k);
+                nbf[4 + k] = __builtin_amdgcn_perm(w.y, w.w, 0x0c000c00u | ((uint32_t)(4 + k) << 16) | (uint32_t)k);
+              }
+              const int cc = (int)((curw >> (8 * c)) & 0xffu), bcc = sv.color(c);
+              const uint32_t ic = c == 0 ? (c0w & 0xffffu) : c == 1 ? (c0w >> 16) : (c1w & 0xffffu);
+              const uint32_t cd = (uint32_t)abs(cc - bcc);
+              const uint32_t intraD = (uint32_t)__popc(ic ^ sv.desc(c));
+              const unsigned inter = ss_lbsp(nbf, bcc, lut[bcc]);
+              const uint32_t interD = (uint32_t)__popc(inter ^ sv.desc(c));
+              const uint32_t dd = (intraD + interD) / 2;
+              uint32_t sd = (dd / 2) * (255 / 16) + cd;
+              sd = sd < 255 ? sd : 255;
+              ok = ok && sd <= scColorThr;
+              totDesc += dd, totSum += sd;
+            }
+            const bool m = ok && !(totDesc > totDescThr || totSum > totColorThr);
+            if (valid) qres[ot * 8 + j] = (uint16_t)(m ? (totDesc | (totSum << 6)) : 0xffffu);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          if (enq) {
+            const uint4 rr = *reinterpret_cast<const uint4*>(&qres[threadIdx.x * 8]);
+            const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+            for (int b = 0; b < 2 * B; ++b) {
+              const uint32_t r = (rw[b >> 1] >> (16 * (b & 1))) & 0xffffu;
+              if (((enq >> b) & 1u) && good < a.nReq && r != 0xffffu) {
+                const uint32_t mDesc = r & 0x3fu, mSum = r >> 6;
+                minDesc = minDesc > mDesc ? mDesc : minDesc;
+                minSum = minSum > mSum ? mSum : minSum;
+                good++;
+              }
+            }
+          }
+          __builtin_amdgcn_wave_barrier();  // (the next round rewrites the list and the results)
+        }
+      }
+      // I passes: one candidate per lane and pass.  (Round 4 tried to fill the idle lanes of a sparse pass by splitting each candidate
+      // over three lanes, one channel each, the helpers reading the owner's neighbours from the frame tile: parity-green, but a
+      // sub-pass of 21 candidates cost ~150 vector + 25 LDS instructions against ~230 for a whole pass, and 40 % of the passes hold 22-42
+      // candidates, i.e. need two: -4 % vector instructions, +90 M bank-conflict cycles, no time gained - profiles/r04_subsense_phase_a_pmc.txt.)
+      if constexpr (!QUEUE) {
+        for (;;) {
+          const bool go = active && cand != 0 && good < a.nReq;
+          const unsigned long long gm = __ballot(go);
+          if (!gm) break;
+          SsSample<C> smp = bt[0];
+          if (go) {
+            const int j = __ffs((int)cand) - 1;
+            cand &= cand - 1;
+  #pragma unroll
+            for (int jj = 1; jj < B; ++jj)
+              if (j == jj) smp = bt[jj];
+  #pragma unroll
+            for (int jj = 0; jj < B; ++jj)
+              if (j == B + jj) smp = nbt[jj];
+          }
+          bool matched = false;
+          uint32_t mDesc = 0, mSum = 0;
+          if (go) {
             if constexpr (C == 1) {
-#pragma unroll
-              for (int j = 0; j < B; ++j) bits |= (uint32_t)(first + j < a.nS && (uint32_t)abs(cur[0] - bb[j].color(0)) <= colorThr) << j;
+              const int bcc = smp.color(0);
+              const unsigned bdc = smp.desc(0);
+              const uint32_t cd = (uint32_t)abs(cur[0] - bcc);
+              const uint32_t intraD = (uint32_t)__popc(intra[0] ^ bdc);
+              const unsigned inter = ss_lbsp(nb[0], bcc, lut[bcc]);
+              const uint32_t dd = (intraD + (uint32_t)__popc(inter ^ bdc)) / 2;
+              if (dd <= descThr) {
+                uint32_t sd = (dd / 4) * (255 / 16) + cd;
+                sd = sd < 255 ? sd : 255;
+                if (sd <= colorThr) matched = true, mDesc = dd, mSum = sd;
+              }
             } else {
-              // The reference walks the channels in order and drops the sample at the first failed test (:474-491); a sample is kept
-              // only if every test passes, so the tests may run in any order.  Exact rejections first, from what costs least:
-              // lower bounds with the intra half of the descriptor distance alone (dd >= intraD/2, and sd grows with dd).  The
-              // per-channel colour test cd <= scColorThr is implied by the one on the bound lbsd = min(255, k + cd): either
-              // lbsd = k + cd >= cd, or lbsd = 255 <= scColorThr and cd <= 255.
               const uint32_t totColorThr = colorThr * 3, totDescThr = descThr * 3, scColorThr = totColorThr / 2;
-#pragma unroll
-              for (int j = 0; j < B; ++j) {
-                const uint32_t sx = bb[j].v.x, sy = bb[j].v.y, sz = bb[j].v.z;
-                uint32_t cd[3], lbdd[3], lbsd[3];
-                cd[0] = __builtin_amdgcn_sad_u8(curm[0], sx & 0x0000ffu, 0u);
-                cd[1] = __builtin_amdgcn_sad_u8(curm[1], sx & 0x00ff00u, 0u);
-                cd[2] = __builtin_amdgcn_sad_u8(curm[2], sx & 0xff0000u, 0u);
-                const uint32_t xy = iy ^ sy;
-                lbdd[0] = (uint32_t)__popc(xy & 0xffffu) >> 1, lbdd[1] = (uint32_t)__popc(xy >> 16) >> 1, lbdd[2] = (uint32_t)__popc(iz ^ sz) >> 1;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) lbsd[c] = min((lbdd[c] >> 1) * (255 / 16) + cd[c], 255u);
-                const bool ok = max(max(lbsd[0], lbsd[1]), lbsd[2]) <= scColorThr && lbdd[0] + lbdd[1] + lbdd[2] <= totDescThr && lbsd[0] + lbsd[1] + lbsd[2] <= totColorThr;
-                bits |= (uint32_t)(ok && first + j < a.nS) << j;
+              uint32_t totDesc = 0, totSum = 0;
+              bool ok = true;
+  #pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                const int bcc = smp.color(c);
+                const uint32_t cd = (uint32_t)abs(cur[c] - bcc);
+                const uint32_t intraD = (uint32_t)__popc(intra[c] ^ smp.desc(c));
+                const unsigned inter = ss_lbsp(nb[c], bcc, lut[bcc]);
+                const uint32_t interD = (uint32_t)__popc(inter ^ smp.desc(c));
+                const uint32_t dd = (intraD + interD) / 2;
+                uint32_t sd = (dd / 2) * (255 / 16) + cd;
+                sd = sd < 255 ? sd : 255;
+                ok = ok && sd <= scColorThr;
+                totDesc += dd, totSum += sd;
               }
-            }
-            return bits;
-          };
-          uint32_t cand = reject_bits(bt, idx);
-          if (__any(wide)) {
-            const uint32_t hi = reject_bits(nbt, idx + B);
-            if (wide) cand |= hi << B;
-          }
-          for (;;) {
-            const bool go = cand != 0 && good < a.nReq;
-            if (!__any(go)) break;
-            if (go) {
-              const int j = __ffs((int)cand) - 1;
-              cand &= cand - 1;
-              SsSample<C> smp = bt[0];
-#pragma unroll
-              for (int jj = 1; jj < B; ++jj)
-                if (j == jj) smp = bt[jj];
-#pragma unroll
-              for (int jj = 0; jj < B; ++jj)
-                if (j == B + jj) smp = nbt[jj];
-              if constexpr (C == 1) {
-                const int bcc = smp.color(0);
-                const unsigned bdc = smp.desc(0);
-                const uint32_t cd = (uint32_t)abs(cur[0] - bcc);
-                const uint32_t intraD = (uint32_t)__popc(intra[0] ^ bdc);
-                const unsigned inter = ss_lbsp(nb[0], bcc, lut[bcc]);
-                const uint32_t dd = (intraD + (uint32_t)__popc(inter ^ bdc)) / 2;
-                if (dd <= descThr) {
-                  uint32_t sd = (dd / 4) * (255 / 16) + cd;
-                  sd = sd < 255 ? sd : 255;
-                  if (sd <= colorThr) {
-                    minDesc = minDesc > dd ? dd : minDesc;
-                    minSum = minSum > sd ? sd : minSum;
-                    good++;
-                  }
-                }
-              } else {
-                const uint32_t totColorThr = colorThr * 3, totDescThr = descThr * 3, scColorThr = totColorThr / 2;
-                uint32_t totDesc = 0, totSum = 0;
-                bool ok = true;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                  const int bcc = smp.color(c);
-                  const uint32_t cd = (uint32_t)abs(cur[c] - bcc);
-                  const uint32_t intraD = (uint32_t)__popc(intra[c] ^ smp.desc(c));
-                  const unsigned inter = ss_lbsp(nb[c], bcc, lut[bcc]);
-                  const uint32_t interD = (uint32_t)__popc(inter ^ smp.desc(c));
-                  const uint32_t dd = (intraD + interD) / 2;
-                  uint32_t sd = (dd / 2) * (255 / 16) + cd;
-                  sd = sd < 255 ? sd : 255;
-                  ok = ok && sd <= scColorThr;
-                  totDesc += dd, totSum += sd;
-                }
-                if (ok && !(totDesc > totDescThr || totSum > totColorThr)) {
-                  minDesc = minDesc > totDesc ? totDesc : minDesc;
-                  minSum = minSum > totSum ? totSum : minSum;
-                  good++;
-                }
-              }
+              if (ok && !(totDesc > totDescThr || totSum > totColorThr)) matched = true, mDesc = totDesc, mSum = totSum;
             }
           }
-          idx += wide ? 2 * B : B;
-          if (good < a.nReq && idx < a.nS) {  // not done: the next eight samples (the first trip leaves the sample-major part here)
-            rec = wide ? rec + 2 * B : rnext;
-#pragma unroll
-            for (int j = 0; j < B; ++j) bt[j] = SsSample<C>::load(a.samples, rec + j), nbt[j] = SsSample<C>::load(a.samples, rec + B + j);
+          if (go && matched) {
+            minDesc = minDesc > mDesc ? mDesc : minDesc;
+            minSum = minSum > mSum ? mSum : minSum;
+            good++;
           }
         }
-        if (!(good < a.nReq && idx < a.nS)) {
+      }
+      if (active) {
+        idx += wide ? 2 * B : B;
+        if (good < a.nReq && idx < a.nS) {  // not done: the next eight samples (the first trip leaves the sample-major part here)
+          rec = wide ? rec + 2 * B : rnext;
+#pragma unroll
+          for (int j = 0; j < B; ++j) bt[j] = SsSample<C>::load(a.samples, rec + j), nbt[j] = SsSample<C>::load(a.samples, rec + B + j);
+        } else {
           ctx[q][2] = (uint32_t)good | (minDesc << 8) | (minSum << 16);
           active = false;
         }
-      }
-    }
+      }    }
   }
   __syncthreads();
 
