@@ -41,6 +41,15 @@ def cpu_rate(algo, frames_np, warm=3, params=None):
     return n * frames_np.shape[1] * frames_np.shape[2] / dt / 1e6, threads
 
 
+# Bytes MOVED per pixel by the kernels whose traffic depends on the data (the mixture models read only the modes a pixel has and write
+# only what changed; GMG walks a per-pixel list): measured with rocprofv3 --pmc (FETCH_SIZE x 2 + WRITE_SIZE) on these very legs -
+# profiles/r03_mog1_pmc.txt, profiles/r03_dp_pmc.txt, DESIGN.md 9 (GMG).  Round 3 priced these legs at the DENSE sorted-array figure of
+# SURVEY.md 8(a) and printed "fractions" of 150-240 %: not fractions of anything.  A leg without a measurement prints no fraction.
+MOVED_BPP = {(capi.MOG1, "surv"): 97, (capi.MOG1, "sat"): 171, (capi.DP_ZIVKOVIC_AGMM, "sat"): 98, (capi.DP_ZIVKOVIC_AGMM, "surv"): 42,
+             (capi.DP_GRIMSON_GMM, "sat"): 122, (capi.GMG, "surv"): 76}
+DATA_DEPENDENT = (capi.MOG1, capi.MOG2, capi.DP_ZIVKOVIC_AGMM, capi.DP_GRIMSON_GMM, capi.GMG)
+
+
 def run(algo, name, rows, cols, S, bpp, steps=60, borrow=True, want_bg=False, cpu_frames=6, cpu_warm=3, params=None, kind="surv"):
     dev = torch.device("cuda", 0)
     T = 10 if kind == "sat" else 8  # S_sat repeats every 5 frames: the pool must wrap at a multiple of 5
@@ -73,8 +82,14 @@ def run(algo, name, rows, cols, S, bpp, steps=60, borrow=True, want_bg=False, cp
         sample = pool[:cpu_frames, 0].cpu().numpy() if T >= cpu_frames else torch.cat([pool[:, 0]] * (cpu_frames // T + 1))[:cpu_frames].cpu().numpy()
         rate, th = cpu_rate(algo, sample, warm=cpu_warm, params=params)
         cpu = " | CPU oracle %.1f Mpix/s (%d thread%s)" % (rate, th, "s" if th > 1 else "")
-    print("%-34s %dx%d x%d streams: kernel %-18s %.4f ms  -> %8.1f Mpix/s  %7.1f GB/s algorithmic (%d B/px) = %.1f%% of 8 TB/s | wall %.1f Mpix/s%s"
-          % (name, cols, rows, S, kname, ms, px / ms / 1e3, bpp * px / ms / 1e6, bpp, bpp * px / ms / 1e6 / 80.0, px * steps / wall / 1e6, cpu))
+    if algo in DATA_DEPENDENT:
+        moved = MOVED_BPP.get((algo, kind))
+        rate = ("%7.1f GB/s moved (%d B/px by PMC on this leg) = %.1f%% of 8 TB/s" % (moved * px / ms / 1e6, moved, moved * px / ms / 1e6 / 80.0)) if moved else "traffic data-dependent, not measured on this leg: no fraction"
+        rate += " [dense sorted-array figure of SURVEY.md 8(a): %d B/px - not moved]" % bpp
+    else:
+        rate = "%7.1f GB/s algorithmic (%d B/px) = %.1f%% of 8 TB/s" % (bpp * px / ms / 1e6, bpp, bpp * px / ms / 1e6 / 80.0)
+    print("%-34s %dx%d x%d streams: kernel %-18s %.4f ms  -> %8.1f Mpix/s  %s | wall %.1f Mpix/s%s"
+          % (name, cols, rows, S, kname, ms, px / ms / 1e3, rate, px * steps / wall / 1e6, cpu))
     e.close()
 
 

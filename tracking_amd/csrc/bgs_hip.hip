@@ -99,8 +99,7 @@ struct bgs_engine {
   float* mog1_state = nullptr;  // MOG1 model (kernel_mog1.h, tiled)
   float* dp_state = nullptr;    // package_bgs/dp models (kernel_dp.h): [S][planes][n]
   SsDevice* ss = nullptr;       // SuBSENSE model (engine_subsense.h)
-  int32_t* gmg_colors = nullptr;  // GMG histograms (kernel_gmg.h)
-  float* gmg_weights = nullptr;
+  int2* gmg_rec = nullptr;        // GMG histograms (kernel_gmg.h): {colour, weight} records [F][P]
   uint8_t* gmg_nfeat = nullptr;
   // MOG2 model (kernel_mog2.h: tiles of ranked weights + fixed-slot records + rank->slot meta words)
   uint8_t* mog2_state = nullptr;
@@ -205,10 +204,10 @@ void free_all(bgs_engine* e) {
     if ((void*)e->dp_state == e->vmm.base) e->dp_state = nullptr;
     vmm_free(e->vmm);
   }
-  void* dev[] = {e->dp_state, e->gmg_colors, e->gmg_weights, e->gmg_nfeat, e->bgstate, e->bgstate2, e->mog1_state, e->mog2_state, e->d_in, e->d_fg, e->d_bg};
+  void* dev[] = {e->dp_state, e->gmg_rec, e->gmg_nfeat, e->bgstate, e->bgstate2, e->mog1_state, e->mog2_state, e->d_in, e->d_fg, e->d_bg};
   for (void* d : dev)
     if (d) (void)hipFree(d);
-  e->dp_state = nullptr, e->gmg_colors = nullptr, e->gmg_weights = nullptr, e->gmg_nfeat = nullptr, e->bgstate = e->bgstate2 = nullptr, e->mog1_state = nullptr, e->mog2_state = nullptr, e->d_in = e->d_fg = e->d_bg = nullptr;
+  e->dp_state = nullptr, e->gmg_rec = nullptr, e->gmg_nfeat = nullptr, e->bgstate = e->bgstate2 = nullptr, e->mog1_state = nullptr, e->mog2_state = nullptr, e->d_in = e->d_fg = e->d_bg = nullptr;
   void* host[] = {e->h_in, e->h_fg, e->h_bg};
   for (void* h : host)
     if (h) (void)hipHostFree(h);
@@ -557,8 +556,7 @@ int allocate(bgs_engine* e, int rows, int cols, int ch) {
   if (e->algo == BGS_SIGMA_DELTA) DMALLOC(e->bgstate2, P * 3);  // Vt
   if (e->algo == BGS_GMG) {
     const size_t F = (size_t)e->p.gmg_max_features;
-    DMALLOC(e->gmg_colors, P * F * sizeof(int32_t));
-    DMALLOC(e->gmg_weights, P * F * sizeof(float));
+    DMALLOC(e->gmg_rec, P * F * sizeof(int2));
     DMALLOC(e->gmg_nfeat, P);
   }
   if (e->algo == BGS_MOG1) {
@@ -871,7 +869,7 @@ int process_run(bgs_engine* e, int first, int count, const uint8_t* d_frames, ui
       const size_t P = e->n * e->S;
       if (t == 0) hipLaunchKernelGGL(bgs::gmg_clear_kernel, dim3(blocks_for(npix)), dim3(bgs::kBlock), 0, s, e->gmg_nfeat + off, npix);  // initialize(): nfeatures = 0
       bgs::GmgArgs g{};
-      g.frame = d_frames, g.raw = e->bgstate + off, g.colors = e->gmg_colors, g.weights = e->gmg_weights, g.nfeat = e->gmg_nfeat;
+      g.frame = d_frames, g.raw = e->bgstate + off, g.rec = e->gmg_rec, g.nfeat = e->gmg_nfeat;
       g.plane = P, g.state_off = off, g.npix = npix, g.F = p.gmg_max_features, g.C = C, g.levels = p.gmg_quantization_levels;
       g.typical = t >= p.gmg_init_frames, g.update = p.gmg_update_background_model != 0, g.normalize_now = t == (int64_t)p.gmg_init_frames - 1;
       g.lr = p.gmg_learning_rate, g.prior = p.gmg_background_prior, g.thr = p.gmg_decision_threshold;
@@ -1800,7 +1798,7 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
     if (e->state_ch == 3 && !strcmp(plane, "median")) return copy_bytes(e->bgstate + off * 3, n * 3);
     return fail(BGS_ERR_STATE, "unknown state plane '%s' for algorithm %d", plane, (int)e->algo);
   }
-  if (e->algo == BGS_GMG && e->gmg_colors) {  // canonical: colors int32 [F][n], weights f32 [F][n] (entries past the count exported as 0), nfeatures int32 [n]
+  if (e->algo == BGS_GMG && e->gmg_rec) {  // canonical: colors int32 [F][n], weights f32 [F][n] (entries past the count exported as 0), nfeatures int32 [n]
     const size_t F = (size_t)e->p.gmg_max_features;
     std::vector<uint8_t> nf(n);
     if (hipMemcpy(nf.data(), e->gmg_nfeat + off, n, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
@@ -1811,11 +1809,11 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
     }
     if (!strcmp(plane, "colors") || !strcmp(plane, "weights")) {
       if (cap < n * F * 4) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
-      const void* base = !strcmp(plane, "colors") ? (const void*)e->gmg_colors : (const void*)e->gmg_weights;
+      const int which = !strcmp(plane, "colors") ? 0 : 1;  // the device holds {colour, weight} records (kernel_gmg.h)
+      std::vector<uint32_t> recs(n * 2);
       for (size_t f = 0; f < F; ++f) {
-        if (hipMemcpy((uint32_t*)dst + f * n, (const uint32_t*)base + f * P + off, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
-        for (size_t i = 0; i < n; ++i)
-          if (f >= nf[i]) ((uint32_t*)dst)[f * n + i] = 0;
+        if (hipMemcpy(recs.data(), e->gmg_rec + f * P + off, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+        for (size_t i = 0; i < n; ++i) ((uint32_t*)dst)[f * n + i] = f >= nf[i] ? 0u : recs[2 * i + which];
       }
       return (int64_t)(n * F * 4);
     }

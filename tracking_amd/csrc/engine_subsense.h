@@ -32,6 +32,7 @@ struct SsDevice {
   bgs::SsScalars* sc = nullptr;
   bgs::SsScalars* scSnap = nullptr;  // the scalars as phase A found them (ss_feedback_kernel runs beside the frame-level block that rewrites sc)
   uint32_t* ho = nullptr;            // [S][N][2] phase A -> ss_feedback_kernel hand-over (kernel_subsense.h)
+  void* lastRec = nullptr;           // [S][N] 16-byte records: the full refresh's packed view of last colour / flag / descriptors (BGR)
   uint32_t* magic = nullptr;         // ss_mod's multipliers
   int* flood_flags = nullptr;  // [S][kSsFloodFlags], see ss_flood_kernel
   hipStream_t side = nullptr;  // phase B runs here, beside the post-processing chain (both only need phase A)
@@ -42,7 +43,7 @@ struct SsDevice {
   int use3x3 = 1, lrScaling = 0, medK = 9;
   float capLo0 = 4.f, capHi0 = 512.f;
   void release() {
-    void* p[] = {samples, lut, lastColor, curColor, lastDesc, curDesc, req, dsLT, dsST, sc, scSnap, ho, magic, flood_flags, mbits, rbits, bitws};
+    void* p[] = {samples, lut, lastColor, curColor, lastDesc, curDesc, req, dsLT, dsST, sc, scSnap, ho, lastRec, magic, flood_flags, mbits, rbits, bitws};
     for (void* q : p)
       if (q) (void)hipFree(q);
     for (auto& q : f32)
@@ -52,7 +53,7 @@ struct SsDevice {
     if (side) (void)hipStreamDestroy(side), side = nullptr;
     if (evA) (void)hipEventDestroy(evA), evA = nullptr;
     if (evB) (void)hipEventDestroy(evB), evB = nullptr;
-    samples = nullptr, lut = lastColor = curColor = nullptr, lastDesc = req = curDesc = nullptr, dsLT = dsST = nullptr, sc = nullptr, scSnap = nullptr, ho = nullptr, magic = nullptr, flood_flags = nullptr, mbits = rbits = nullptr, bitws = nullptr;
+    samples = nullptr, lut = lastColor = curColor = nullptr, lastDesc = req = curDesc = nullptr, dsLT = dsST = nullptr, sc = nullptr, scSnap = nullptr, ho = nullptr, lastRec = nullptr, magic = nullptr, flood_flags = nullptr, mbits = rbits = nullptr, bitws = nullptr;
   }
 };
 
@@ -84,6 +85,7 @@ int ss_allocate(bgs_engine* e) {
   DMALLOC(d->sc, (size_t)e->S * sizeof(bgs::SsScalars));
   DMALLOC(d->scSnap, (size_t)e->S * sizeof(bgs::SsScalars));
   DMALLOC(d->ho, P * 2 * sizeof(uint32_t));
+  if (C == 3) DMALLOC(d->lastRec, P * 16);
   {
     uint32_t m[bgs::kSsMagicN];
     for (uint32_t k = 0; k < (uint32_t)bgs::kSsMagicN; ++k) m[k] = bgs::ss_magic(k);
@@ -109,7 +111,7 @@ void ss_fill_args(const bgs_engine* e, bgs::SsArgs& a, int first, int cur_pp, un
   const SsDevice* d = e->ss;
   const bgs_params& p = e->p;
   a.samples = d->samples, a.nSpad = d->nSpad, a.pixelMajor = d->pixelMajor, a.lastColor = d->lastColor, a.lastDesc = d->lastDesc, a.req = d->req, a.lut = d->lut, a.sc = d->sc;
-  a.scSnap = d->scSnap, a.ho = d->ho, a.magic = d->magic;
+  a.scSnap = d->scSnap, a.ho = d->ho, a.magic = d->magic, a.lastRec = (uint4*)d->lastRec;
   a.R = d->f32[SS_R], a.V = d->f32[SS_V], a.T = d->f32[SS_T];
   a.DlastOld = d->f32[cur_pp ? SS_DLAST1 : SS_DLAST0], a.DlastNew = d->f32[cur_pp ? SS_DLAST0 : SS_DLAST1];
   a.RawSTOld = d->f32[cur_pp ? SS_RAWST1 : SS_RAWST0], a.RawSTNew = d->f32[cur_pp ? SS_RAWST0 : SS_RAWST1];
@@ -160,6 +162,7 @@ int ss_launch_refresh(bgs_engine* e, const bgs::SsArgs& a, size_t N, int count, 
   const bool fast = mode == 0 && a.pixelMajor && a.nS > bgs::kSsBatch;
   const dim3 grid(fast ? (unsigned)(((N + 15) / 16 + bgs::kSsRefreshGroups - 1) / bgs::kSsRefreshGroups) : std::min<unsigned>(blocks_for(N), 512u), 1, count), block(bgs::kBlock);
   if (e->ch == 3) {
+    if (fast) hipLaunchKernelGGL(bgs::ss_lastrec_pack_kernel, dim3(blocks_for(N), 1, count), block, 0, s, a);
     if (fast) hipLaunchKernelGGL((bgs::ss_refresh_kernel<3, true>), grid, block, 0, s, a, mode);
     else hipLaunchKernelGGL((bgs::ss_refresh_kernel<3, false>), grid, block, 0, s, a, mode);
   } else {

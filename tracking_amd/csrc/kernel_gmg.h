@@ -4,9 +4,11 @@
 // decisionThreshold = 0.7); algorithm: OpenCV 2.4 bgfg_gmg.cpp GMG_LoopBody (SURVEY.md App. B.4 — the least certain recall of
 // the whole path; the assumptions G1..G7 are listed in DESIGN.md §5.2).  The median smoothing that follows is morph_box_kernel.
 //
-// Layout: SoA planes  colors int32 [F][P], weights f32 [F][P], nfeatures u8 [P]  (F = maxFeatures <= 64); entry f of every
-// pixel lives in plane f, so each step of the per-pixel list walk is one coalesced 256-byte access per wave.  One lane owns
-// one pixel; all list walks run to the largest count in the wave (wave-uniform trip counts via __any).
+// Layout: planes of 8-byte RECORDS  rec {colour int32, weight f32} [F][P], nfeatures u8 [P]  (F = maxFeatures <= 64); entry f of every
+// pixel lives in plane f, so each step of the per-pixel list walk is one coalesced 512-byte access per wave (round 4; rounds 1-3 kept
+// colours and weights in separate planes: 19 load and 12 store instructions per pixel on a settled scene, now 11 and 12 - a weight that
+// changes while its colour stays is a 4-byte store into the record).  One lane owns one pixel; all list walks run to the largest
+// count in the wave (wave-uniform trip counts via __any).
 // Traffic is data-dependent: ~ (8 B read + 8 B written) x features of the pixel, up to 1 KiB/pixel; HBM-bound.
 #pragma once
 #include "bgs_device.h"
@@ -16,8 +18,7 @@ namespace bgs {
 struct GmgArgs {
   const uint8_t* frame;  // [npix][C]
   uint8_t* raw;          // [npix] unsmoothed mask
-  int32_t* colors;       // [F][plane]
-  float* weights;        // [F][plane]
+  int2* rec;             // [F][plane] {colour, weight (float bits)}
   uint8_t* nfeat;        // [plane]
   size_t plane, state_off, npix;
   int F, C, levels, typical, update, normalize_now;  // typical = frameNum >= init; normalize_now = frameNum == init - 1
@@ -40,8 +41,8 @@ __device__ __forceinline__ void gmg_fast(const GmgArgs& a, bool active, size_t s
   const int lastValid = max(nf - 1, 0);
 #pragma unroll
   for (int i = 0; i < kGmgFast; ++i) {
-    const size_t o = (size_t)min(i, lastValid) * a.plane + sp;
-    c[i] = a.colors[o], w[i] = a.weights[o];
+    const int2 r = a.rec[(size_t)min(i, lastValid) * a.plane + sp];
+    c[i] = r.x, w[i] = __int_as_float(r.y);
   }
 #pragma unroll
   for (int i = 0; i < kGmgFast; ++i)
@@ -106,8 +107,11 @@ __device__ __forceinline__ void gmg_fast(const GmgArgs& a, bool active, size_t s
 #pragma unroll
     for (int i = 0; i < kGmgFast; ++i)
       if (i < nf) {
-        if (i >= nf_in || c[i] != c_in[i]) a.colors[(size_t)i * a.plane + sp] = c[i];
-        a.weights[(size_t)i * a.plane + sp] = w[i];
+        int2* r = a.rec + (size_t)i * a.plane + sp;
+        if (i >= nf_in || c[i] != c_in[i])
+          *r = make_int2(c[i], __float_as_int(w[i]));
+        else
+          reinterpret_cast<float*>(r)[1] = w[i];
       }
     if (nf != nf_in) a.nfeat[sp] = (uint8_t)nf;
   }
@@ -136,7 +140,10 @@ __global__ __launch_bounds__(kBlock) void gmg_kernel(const GmgArgs a) {
   for (int i = 0;; ++i) {
     const bool look = active && i < nf && idx < 0;
     if (!__any(look)) break;
-    if (look && a.colors[(size_t)i * a.plane + sp] == color) idx = i, wfound = a.weights[(size_t)i * a.plane + sp];
+    if (look) {
+      const int2 r = a.rec[(size_t)i * a.plane + sp];
+      if (r.x == color) idx = i, wfound = __int_as_float(r.y);
+    }
   }
   bool isfg = false;
   bool appended = false;
@@ -159,23 +166,21 @@ __global__ __launch_bounds__(kBlock) void gmg_kernel(const GmgArgs a) {
       const bool act = active && i < nf && (a.typical || i <= shift_end);  // training frames touch only what moves
       if (!__any(act)) break;
       if (act) {
-        const size_t o = (size_t)i * a.plane + sp;
-        const int c = a.colors[o];
-        float w = a.weights[o];
+        int2* rp = a.rec + (size_t)i * a.plane + sp;
+        const int2 r = *rp;
+        const int c = r.x;
+        float w = __int_as_float(r.y);
         if (a.typical) w = (float)__dmul_rn((double)w, decay);
         if (i <= shift_end) {
-          a.colors[o] = i == 0 ? color : prev_c;
-          a.weights[o] = i == 0 ? front_w : prev_w;
+          *rp = make_int2(i == 0 ? color : prev_c, __float_as_int(i == 0 ? front_w : prev_w));
           prev_c = c, prev_w = w;
         } else {
-          a.weights[o] = w;
+          reinterpret_cast<float*>(rp)[1] = w;
         }
       }
     }
     if (active && !found && !full) {  // append
-      const size_t o = (size_t)nf * a.plane + sp;
-      a.colors[o] = color;
-      a.weights[o] = ins;
+      a.rec[(size_t)nf * a.plane + sp] = make_int2(color, __float_as_int(ins));
       ++nf;
       appended = true;
     }
@@ -185,14 +190,14 @@ __global__ __launch_bounds__(kBlock) void gmg_kernel(const GmgArgs a) {
     for (int i = 0;; ++i) {
       const bool act = norm && i < nf;
       if (!__any(act)) break;
-      if (act) total += a.weights[(size_t)i * a.plane + sp];
+      if (act) total += reinterpret_cast<const float*>(a.rec + (size_t)i * a.plane + sp)[1];
     }
     for (int i = 0;; ++i) {
       const bool act = norm && total != 0.0f && i < nf;
       if (!__any(act)) break;
       if (act) {
-        const size_t o = (size_t)i * a.plane + sp;
-        a.weights[o] = div_rn(a.weights[o], total);
+        float* wp = reinterpret_cast<float*>(a.rec + (size_t)i * a.plane + sp) + 1;
+        *wp = div_rn(*wp, total);
       }
     }
     if (active) a.nfeat[sp] = (uint8_t)nf;  // G4: the count persists on training frames too

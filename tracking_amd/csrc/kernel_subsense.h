@@ -63,6 +63,7 @@ struct SsArgs {
   unsigned frameIndex;
   int first;             // first stream of this launch (blockIdx.z is relative to it)
   int selfInA;           // 1: a pixel's SELF update is stored before phase B (SuBSENSE: by ss_feedback_kernel; round 3: by phase A itself); phase B then only applies the diffusion
+  uint4* lastRec;        // [S][N] scratch of the full refresh (BGR): a pixel's last colour, foreground flag and descriptors as ONE 16-byte record
   uint32_t* ho;          // [S][N][2] hand-over from phase A to ss_feedback_kernel (round 4), see there
   SsScalars* scSnap;     // [S] the per-stream scalars as they stood when phase A ran (the frame-level block rewrites `sc` beside ss_feedback_kernel)
   const uint32_t* magic; // [1024] multipliers of ss_mod
@@ -1254,6 +1255,22 @@ __device__ __forceinline__ void ss_refresh_one(const SsArgs& a, int stream, size
   }
 }
 
+// The full refresh reads, per sample, a RANDOM neighbour's foreground byte, colour and descriptors - three arrays, three scattered
+// loads; its counters (round 3) put it at the vector memory path's rate for scattered loads (13 per wave).  One
+// streaming pass packs them first: colour | (lastFG != 0) << 24, d0 | d1 << 16, d2 - the sample record itself with the flag in its
+// spare byte - so that a sample costs ONE scattered 16-byte load (round 4).
+__global__ __launch_bounds__(kBlock) void ss_lastrec_pack_kernel(const SsArgs a) {
+  const int stream = a.first + blockIdx.z;
+  const size_t N = (size_t)a.rows * a.cols, sN = (size_t)stream * N;
+  const size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= N) return;
+  typedef uint32_t __attribute__((aligned(1))) u32u;
+  typedef uint64_t __attribute__((aligned(2))) u64u;
+  const uint32_t cw = *reinterpret_cast<const u32u*>(a.lastColor + (sN + p) * 3);
+  const uint64_t dw = *reinterpret_cast<const u64u*>(a.lastDesc + (sN + p) * 3);
+  a.lastRec[sN + p] = make_uint4((cw & 0x00ffffffu) | (a.lastFG[sN + p] ? 0x01000000u : 0u), (uint32_t)dw, (uint32_t)(dw >> 32) & 0xffffu, 0u);
+}
+
 // mode 0: unconditional full refresh (initialisation, frac = 1); mode 1: 10 % refresh if the frame-level block asked for it.
 // Full refresh of SuBSENSE's layout (FAST): a workgroup owns 16 pixels, lane (pixel q, column s) of the 16 x 16 writes plane s of the
 // sample-major first batch (s < 4) and the pixel-major records 4 + s, 4 + s + 16, ...: every store instruction of a wave is four
@@ -1309,41 +1326,33 @@ __global__ __launch_bounds__(kBlock) void ss_refresh_kernel(const SsArgs a, int 
     }
     // per-stream bases once, 32-bit offsets per sample (N < 2^31), the record assembled from the loaded words as they are (a
     // record is the colour dword with byte 3 cleared, d0 | d1 << 16, d2): ~60 instead of ~170 instructions per sample
-    const uint8_t* fgS = a.lastFG + sN;
     uint32_t jo[4];
-    uint8_t fgb[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int xs = min(max((jx[k] >> 4) + x - 3, 2), a.cols - 3), ys = min(max((jx[k] & 15) + y - 3, 2), a.rows - 3);
       jo[k] = (uint32_t)ys * (uint32_t)a.cols + (uint32_t)xs;
-      fgb[k] = fgS[jo[k]];
     }
     if constexpr (C == 3) {
-      typedef uint32_t __attribute__((aligned(1))) u32u;
-      typedef uint64_t __attribute__((aligned(2))) u64u;
-      const uint8_t* colS = a.lastColor + sN * 3;
-      const uint16_t* dscS = a.lastDesc + sN * 3;
-      uint32_t cw[4];
-      uint64_t dw[4];
+      // ONE scattered 16-byte load per sample (ss_lastrec_pack_kernel): the neighbour's record with its foreground flag in byte 3
+      const uint4* lr = a.lastRec + sN;
+      uint4 rv[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        ok[k] = ok[k] && !fgb[k];
-        const uint32_t j3 = (ok[k] ? jo[k] : p) * 3u;
-        cw[k] = *reinterpret_cast<const u32u*>(colS + j3), dw[k] = *reinterpret_cast<const u64u*>(dscS + j3);
-      }
+      for (int k = 0; k < 4; ++k) rv[k] = lr[jo[k]];
       // ss_rec of this pixel's records: the first batch sample-major (plane s at + s * N), the rest pixel-major
       uint4* recs = reinterpret_cast<uint4*>(a.samples) + (size_t)stream * N * (size_t)a.nSpad;
       uint4* mine = recs + (size_t)kSsBatch * N + (size_t)p * (size_t)(a.nSpad - kSsBatch) - kSsBatch;  // + m for m >= kSsBatch
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (ok[k]) {
-          const uint4 v = make_uint4(cw[k] & 0x00ffffffu, (uint32_t)dw[k], (uint32_t)(dw[k] >> 32) & 0xffffu, 0u);
+        if (ok[k] && !(rv[k].x >> 24)) {
+          const uint4 v = make_uint4(rv[k].x & 0x00ffffffu, rv[k].y, rv[k].z, 0u);
           if (k == 0)
             recs[(size_t)s * N + p] = v;
           else
             mine[mm[k]] = v;
         }
     } else {
+      const uint8_t* fgS = a.lastFG + sN;
+      (void)fgS;
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (ok[k]) ss_refresh_one<C>(a, stream, N, sN, p, x, y, mm[k], 0);
