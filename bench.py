@@ -24,12 +24,13 @@ import torch.distributed as dist  # noqa: E402
 
 ROWS, COLS, CH = 1080, 1920, 3
 SURVEY_BYTES_PER_PIXEL = 206  # SURVEY.md §8(d), the reference's formulation (modes physically sorted): r 3 frame + 1 nmodes + 5*8 {w,var} + 5*12 mu ; w 5*8 + 5*12 + 1 nmodes + 1 mask
-# What THIS formulation must move per pixel and frame on the all-modes-live, well-separated input S_sat (DESIGN.md §6.1; kernel_mog2.h:
-# weights by rank, {var, mean} records in fixed slots, a 16-bit rank->slot word, 4-byte summaries that rule modes out without their record):
-#   read  3 frame + 2 meta + 5*4 weights + 5*4 summaries + 16 (the ONE record the summaries cannot rule out) = 61
+# What THIS formulation must move per pixel and frame on the all-modes-live, well-separated input S_sat (DESIGN.md 6.1; kernel_mog2.h:
+# weights by rank, {var, mean} records in fixed slots, a 16-bit rank->slot word, 2-byte summaries that rule modes out without their record):
+#   read  3 frame + 2 meta + 5*4 weights + 5*2 summaries + 16 (the ONE record the summaries cannot rule out) = 51
 #   write 5*4 weights + 16 (that record, updated) + 2 meta (the order changes every frame) + 1 mask = 39
-#   (+ 4 when the record's summary no longer covers it and is rewritten: rare by construction, the PMC counters show 38.8 B written)
-BYTES_PER_PIXEL = 100
+#   (+ 2 when the record's summary no longer covers it and is rewritten)
+# (round 3: 4-byte summaries, 100 B/pixel)
+BYTES_PER_PIXEL = 90
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured achievable)
 
 
@@ -41,7 +42,7 @@ def make_source(kind, streams, device, seed0):
     return cls(streams, ROWS, COLS, seed0=seed0, device=device)
 
 
-MODEL_BYTES_PER_PIXEL = 122  # kernel_mog2.h: 20 weights + 20 summaries + 80 records + 2 meta
+MODEL_BYTES_PER_PIXEL = 112  # kernel_mog2.h: 20 weights + 10 summaries + 80 records + 2 meta
 
 
 def calibrate(local, streams):
@@ -578,7 +579,7 @@ def main():
         probe = {"chunk_MiB": int(pr[0]), "chunks": int(pr[1]),
                  "note": "the model is one virtual range backed by separately created physical chunks (hipMemCreate / hipMemMap; DESIGN.md 6.2; chunk_MiB 0 = one plain hipMalloc). "
                          "`dense_launch` = the placement witness: the same model streamed whole (BGS_OPT_MOG2_SPARSE = 0: every weight, summary, record and meta word read and "
-                         "written back, 248 B/pixel) - its rate against calibration.copy_GBps_chunked says whether this model's placement is as good as a fresh chunked range's"}
+                         "written back, 228 B/pixel) - its rate against calibration.copy_GBps_chunked says whether this model's placement is as good as a fresh chunked range's"}
         clip0 = pool[:25, 0].cpu().numpy()  # stream 0's frames for the host-path and CPU legs
     if rank == 0 and pmc_child:
         for T in (4, 8):
@@ -726,7 +727,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": traffic, "traffic_source": traffic_source, "traffic_read_write": traffic_detail, "kernel": k_name, "kernel_avg_ms": round(k_ms, 4), "kernel_launches": k_n, "kernel_timing_truncated": timing_truncated,
                          "algorithmic_bytes_per_launch": algo_bytes, "bytes_per_pixel": BYTES_PER_PIXEL + (3 if args.with_bg else 0),
-                         "bytes_per_pixel_derivation": "r 3 frame + 2 meta + 20 weights + 20 summaries + 16 the one record the summaries cannot rule out; w 20 weights + 16 that record + 2 meta + 1 mask (+4 when its summary is rewritten) (DESIGN.md 6.1)",
+                         "bytes_per_pixel_derivation": "r 3 frame + 2 meta + 20 weights + 10 summaries + 16 the one record the summaries cannot rule out; w 20 weights + 16 that record + 2 meta + 1 mask (+2 when its summary is rewritten) (DESIGN.md 6.1)",
                          "frac_of_achievable_6290": round(achieved / 6290.0, 4),
                          "frac_of_box_copy": round(achieved / box_copy, 4) if box_copy else None,
                          "frac_of_box_copy_note": "achieved / calibration.copy_GBps_chunked: the same kernel time against what a float4 copy reaches on THIS box through the model's own allocation scheme",

@@ -196,20 +196,24 @@ def test_mog2_sparse_levels_are_exact(level, shape):
 
 
 def _mog2_summary_invariants(eng, n, stream=0):
-    """kernel_mog2.h: where a pixel's meta word says its summaries are valid, every live mode's 4-byte summary {q0, q1, q2, vb}
-    must cover its record - |mean_c - q_c| <= 2 and var <= 2 vb (vb = 255: unbounded) - or the filter path could rule out a mode the
-    reference would have matched.  Returns the fraction of pixels whose summaries are valid."""
+    """Whole-frame check of the summaries the filter kernel relies on (kernel_mog2.h): wherever a pixel's summaries are marked valid, each
+    live slot's 16-bit summary - the 8-level bucket of each channel's mean (5 bits each) and a variance class - must cover its record:
+    8 q_c - 2 <= mean_c <= 8 q_c + 9, and class 0 => var <= 32 - or the filter path could rule out a mode the reference would have
+    matched.  Returns the fraction of pixels whose summaries are valid."""
     nm = eng.get_state("nmodes", (n,), np.uint8, stream=stream).astype(np.int32)
     valid = eng.get_state("summary_valid", (n,), np.uint8, stream=stream).astype(bool)
     mu = eng.get_state("mu", (5, 3, n), np.float32, stream=stream)
     var = eng.get_state("var", (5, n), np.float32, stream=stream)
     sm = eng.get_state("summary", (5, n), np.uint32, stream=stream)
+    assert (sm >> 16).max() == 0, "16-bit words"
     live = (np.arange(5)[:, None] < nm[None, :]) & valid[None, :]
+    cls = (sm >> 15).astype(bool)
+    tight = live & ~cls  # class 1 promises nothing (such a mode is never ruled out)
     for c in range(3):
-        q = ((sm >> (8 * c)) & 0xff).astype(np.float32)
-        assert np.all(np.abs(mu[:, c] - q)[live] <= 2.0), ("mean", c, float(np.abs(mu[:, c] - q)[live].max()))
-    vb = (sm >> 24).astype(np.float32)
-    assert np.all(((vb == 255) | (var <= 2 * vb))[live]), "variance bound"
+        b = (((sm >> (5 * c)) & 0x1f) << 3).astype(np.float32)
+        e = mu[:, c] - b
+        assert np.all((e >= -2.0)[tight]) and np.all((e <= 9.0)[tight]), ("mean", c, float(e[tight].min()), float(e[tight].max()))
+    assert np.all((var <= 32.0)[tight]), "variance class"
     return float(valid.mean())
 
 

@@ -38,9 +38,9 @@ def test_bench_line_contract():
     # round 4: the line explains itself - this box's own copy rate through both allocation schemes, the headline against it, the whole
     # model streamed as the placement witness, the filter's worst-case scene, the quiet scene with the slot layout's byte model
     cal = d["calibration"]
-    assert cal["copy_GBps_plain"] > 0 and cal["copy_GBps_chunked"] > 0 and cal["bytes"] >= 2 * 1920 * 1080 * 122
+    assert cal["copy_GBps_plain"] > 0 and cal["copy_GBps_chunked"] > 0 and cal["bytes"] >= 2 * 1920 * 1080 * 112
     assert abs(r["frac_of_box_copy"] - r["achieved"] / cal["copy_GBps_chunked"]) < 1e-3
-    assert d["model_placement"]["dense_launch"]["kernel_ms"] > 0 and d["model_placement"]["dense_launch"]["bytes_per_pixel"] == 248
+    assert d["model_placement"]["dense_launch"]["kernel_ms"] > 0 and d["model_placement"]["dense_launch"]["bytes_per_pixel"] == 228
     assert d["s_dense"]["mean_live_modes_stream0"] > 4.0 and d["s_dense"]["kernel_ms"] > 0
     sv = d["s_surv"]["default"]
     assert 1.0 <= sv["mean_live_modes_stream0"] < 3.0 and abs(sv["bytes_model_per_pixel"] - (22 + 24 * sv["mean_live_modes_stream0"])) < 0.1

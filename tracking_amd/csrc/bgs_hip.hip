@@ -1753,7 +1753,7 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
     if (!strcmp(plane, "w")) p0 = 0, np = 5;
     if (!strcmp(plane, "var")) p0 = 5, np = 5;
     if (!strcmp(plane, "mu")) p0 = 10, np = 15;
-    if (!strcmp(plane, "summary")) p0 = 100, np = 5;  // uint32 [K][n] by rank: q0 | q1 << 8 | q2 << 16 | vb << 24 (kernel_mog2.h; for the invariant test)
+    if (!strcmp(plane, "summary")) p0 = 100, np = 5;  // uint32 [K][n] by rank: the 16-bit word q0 | q1 << 5 | q2 << 10 | class << 15 (kernel_mog2.h; for the invariant test)
     const bool nm = !strcmp(plane, "nmodes") || !strcmp(plane, "summary_valid");  // bytes [n]; summary_valid: bit 15 of the meta word
     const bool want_valid = !strcmp(plane, "summary_valid");
     if (p0 >= 0 || nm) {
@@ -1770,7 +1770,7 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
         const uint8_t* tb = tiles.data() + (sp / T - t0) * TB;
         const float* w = reinterpret_cast<const float*>(tb) + in;
         const float* rec = reinterpret_cast<const float*>(tb + bgs::kMog2RecOff) + in * 4;
-        const uint32_t* sum = reinterpret_cast<const uint32_t*>(tb + bgs::kMog2SumOff) + in;
+        const uint16_t* sum = reinterpret_cast<const uint16_t*>(tb + bgs::kMog2SumOff) + in;
         const unsigned meta = reinterpret_cast<const uint16_t*>(tb + bgs::kMog2MetaOff)[in];
         if (nm) {
           ((uint8_t*)dst)[i] = want_valid ? (uint8_t)((meta >> 15) & 1u) : (uint8_t)bgs::mog2_meta_count(meta);

@@ -20,21 +20,22 @@
 //   and take part in the reference's bubble; a mode's record is fetched from where it was loaded when its turn in the scan comes
 //   (a select chain), and the one record a frame recomputes or creates goes back to its slot with a single store.
 // SUMMARIES - reading fewer records, exactly.  A record is only ever consulted by two comparisons, dist2 < Tb var (background) and
-//   dist2 < Tg var (match).  Each slot also has a 4-byte SUMMARY {q0, q1, q2, vb}: the mean rounded to bytes and a variance bound,
-//   maintained under the invariants |mean_c - q_c| <= 2 and var <= 2 vb (vb = 255: no bound).  From the summary alone
-//   dist2 >= sum_c max(|x_c - q_c| - 2, 0)^2 =: L, so L > max(Tb, Tg) 2 vb (+ margins for float rounding) PROVES both comparisons
-//   false: such a mode is REJECTED without its record, and the frame proceeds exactly as the reference would (a rejected mode's
-//   record is used by nothing else: only its weight decays).  The per-frame launch loads the summaries of a pixel's live slots, then
-//   only the records of the modes that survive: on well-separated modes (the saturating benchmark input) one record of five.
-//   A summary is rewritten when its record changes AND stops satisfying the invariants with some slack (hysteresis: quiet pixels
-//   rewrite it rarely).  Only the filter path maintains summaries: bit 15 of the meta word says "this pixel's summaries cover its
-//   records"; every other path clears it when it changes a record, and the filter path, finding it clear, loads all the pixel's
-//   records, rebuilds the summaries and sets it.  Shadow detection and the background image read every mode's mean, so launches that
-//   deliver them take the count path; clip launches the eager one (over 4-8 frames nearly every mode is matched by some frame).
-//   Reads 3 + 2 + 20 + 20 (summaries) + 16 n (n = surviving modes, 1 on the benchmark input), writes 20 + 16 + 4 + 2 + 1:
-//   104 B/pixel on the benchmark input.
-// Tiles: pixels are grouped in tiles of kMog2Tile (256); a tile is 5 weight planes and 5 summary planes (T dwords each), 5 record
-//   planes (T float4 each) and T meta words = 122 T contiguous bytes.  One workgroup owns one tile, one lane one pixel: every access
+//   dist2 < Tg var (match).  Each slot also has a 2-byte SUMMARY (round 3: 4 bytes): the 8-level bucket each channel's mean lies in
+//   (5 bits each) and a variance class, maintained under the invariants 8 q_c - 2 <= mean_c <= 8 q_c + 9 and class 0 => var <= 32.
+//   From the summary and the pixel's own buckets alone a lower bound of dist2 follows (mog2_reject: one v_sad_u8); when it exceeds
+//   max(Tb, Tg) 32 (+ margins for float rounding) both comparisons are PROVEN false: such a mode is REJECTED without its record, and the
+//   frame proceeds exactly as the reference would (a rejected mode's record is used by nothing else: only its weight decays).  The
+//   per-frame launch loads the summaries of a pixel's live slots, then only the records of the modes that survive: on well-separated
+//   modes (the saturating benchmark input) one record of five.  A summary is rewritten when its record changes AND stops satisfying
+//   the invariants (two levels of hysteresis: quiet pixels rewrite it rarely).  Only the filter path maintains summaries: bit 15 of the
+//   meta word says "this pixel's summaries cover its records"; every other path clears it when it changes a record, and the filter
+//   path, finding it clear, loads all the pixel's records, rebuilds the summaries and sets it.  Shadow detection and the background
+//   image read every mode's mean, so launches that deliver them take the count path; clip launches the eager one (over 4-8 frames
+//   nearly every mode is matched by some frame).
+//   Reads 3 + 2 + 20 + 10 (summaries) + 16 n (n = surviving modes, 1 on the benchmark input), writes 20 + 16 + 2 + 1 (+ 2 when a summary
+//   is rewritten): 90 B/pixel on the benchmark input.
+// Tiles: pixels are grouped in tiles of kMog2Tile (256); a tile is 5 weight planes (T dwords each), 5 summary planes (T 16-bit words each),
+//   5 record planes (T float4 each) and T meta words = 112 T contiguous bytes.  One workgroup owns one tile, one lane one pixel: every access
 //   is a coalesced wave instruction (dwordx4 for the records), and with the XCD-aware block order each XCD streams one contiguous
 //   eighth of the model.
 // Stores are SECTOR-COMPLETE (args.complete): HBM moves 32-byte sectors, so a lane also writes back an unchanged value of its own
@@ -51,9 +52,9 @@ constexpr int kMog2K = 5;
 #define BGS_MOG2_TILE 256
 #endif
 constexpr int kMog2Tile = BGS_MOG2_TILE;                                          // pixels per tile
-constexpr size_t kMog2TileBytes = (size_t)kMog2Tile * (4 * kMog2K + 4 * kMog2K + 16 * kMog2K + 2);  // 122 B per pixel: 31 232 B
+constexpr size_t kMog2TileBytes = (size_t)kMog2Tile * (4 * kMog2K + 2 * kMog2K + 16 * kMog2K + 2);  // 112 B per pixel: 28 672 B
 constexpr size_t kMog2SumOff = (size_t)kMog2Tile * 4 * kMog2K;                    // byte offset of summary plane 0 inside a tile
-constexpr size_t kMog2RecOff = kMog2SumOff + (size_t)kMog2Tile * 4 * kMog2K;      // ... of record plane 0
+constexpr size_t kMog2RecOff = kMog2SumOff + (size_t)kMog2Tile * 2 * kMog2K;      // ... of record plane 0 (16-byte aligned)
 constexpr size_t kMog2MetaOff = kMog2RecOff + (size_t)kMog2Tile * 16 * kMog2K;   // ... of the meta row
 static_assert(kMog2Tile % 64 == 0, "a wave never straddles two tiles");
 
@@ -80,7 +81,7 @@ struct Mog2Args {
 
 struct Mog2Ptr {
   float* w;        // weight of rank r at w[r * kMog2Tile]
-  uint32_t* sum;   // summary of slot s at sum[s * kMog2Tile]: q0 | q1 << 8 | q2 << 16 | vb << 24
+  uint16_t* sum;   // summary of slot s at sum[s * kMog2Tile]: q0 | q1 << 5 | q2 << 10 | class << 15 (see below)
   float4* rec;     // record of slot s at rec[s * kMog2Tile]: {variance, mean0, mean1, mean2}
   uint16_t* meta;
 };
@@ -89,7 +90,7 @@ __device__ __forceinline__ Mog2Ptr mog2_ptr(uint8_t* state, size_t sp) {
   const size_t in = sp % kMog2Tile;
   Mog2Ptr p;
   p.w = reinterpret_cast<float*>(tb) + in;
-  p.sum = reinterpret_cast<uint32_t*>(tb + kMog2SumOff) + in;
+  p.sum = reinterpret_cast<uint16_t*>(tb + kMog2SumOff) + in;
   p.rec = reinterpret_cast<float4*>(tb + kMog2RecOff) + in;
   p.meta = reinterpret_cast<uint16_t*>(tb + kMog2MetaOff) + in;
   return p;
@@ -102,55 +103,46 @@ __device__ __host__ __forceinline__ int mog2_meta_count(unsigned meta) {
 }
 
 // ---- summaries (see the header comment) -------------------------------------------------------------------------------------
-// Invariants of a live slot's summary: |mean_c - q_c| <= kMog2SumTol for every channel, and var <= 2 vb unless vb == 255.
-constexpr float kMog2SumTol = 2.f;
-__device__ __host__ __forceinline__ uint32_t mog2_summary_byte(float m) {
-  float r = m + 0.5f;  // floor(m + 0.5): within 0.5 of m (any tie rule does; NaN and out-of-range means end up clamped - such a mode matches nothing)
-  r = r > 0.f ? r : 0.f;
-  r = r < 255.f ? r : 255.f;
-  return (uint32_t)(int)r;
-}
+// Round 4: 16 bits per slot (round 3: 32).  q_c = floor(mean_c) >> 3, five bits per channel - the 8-level bucket the mean lies in -
+// and a variance class in bit 15.  Invariants of a live slot's summary:
+//   8 q_c - 2 <= mean_c <= 8 q_c + 9 for every channel (the bucket, two levels of hysteresis either side), and
+//   class 0  =>  var <= kMog2SumVar (= 32); class 1 says nothing about the variance (such a mode is never ruled out).
+// Ten bytes less to read per pixel and frame than the byte-exact means of round 3; what it costs is resolving power: modes closer than
+// ~20 grey levels in every channel are not told apart any more (round 3: ~13) - more records read there, never a different result.
+constexpr float kMog2SumVar = 32.f, kMog2SumVarTight = 24.f;
 __device__ __host__ __forceinline__ uint32_t mog2_summary(float var, float m0, float m1, float m2) {
-  // variance bound with 16 of slack above the current value so that ordinary fluctuation does not outgrow it; unbounded past the byte range
-  uint32_t vb = 255;
-  if (var <= 470.f) vb = (uint32_t)(int)(var * 0.5f + 9.f);
-  return mog2_summary_byte(m0) | (mog2_summary_byte(m1) << 8) | (mog2_summary_byte(m2) << 16) | (vb << 24);
+  const bool inside = m0 >= 0.f && m0 < 256.f && m1 >= 0.f && m1 < 256.f && m2 >= 0.f && m2 < 256.f;  // (false for NaN: class 1)
+  const uint32_t cls = (inside && var <= kMog2SumVarTight) ? 0u : 1u;
+  const uint32_t q0 = inside ? (uint32_t)(int)m0 >> 3 : 0u, q1 = inside ? (uint32_t)(int)m1 >> 3 : 0u, q2 = inside ? (uint32_t)(int)m2 >> 3 : 0u;
+  return q0 | (q1 << 5) | (q2 << 10) | (cls << 15);
 }
-// may the stored summary be kept for this (changed) record?  the invariants, plus "the variance bound is not uselessly loose"
+// may the stored summary be kept for this (changed) record?  the invariants, plus "not uselessly loose": a class-1 summary is rewritten
+// as soon as the record would get class 0
 __device__ __host__ __forceinline__ bool mog2_summary_ok(uint32_t word, float var, float m0, float m1, float m2) {
-  const float q0 = (float)(word & 0xffu), q1 = (float)((word >> 8) & 0xffu), q2 = (float)((word >> 16) & 0xffu);
-  const uint32_t vb = word >> 24;
-  const float V = 2.f * (float)vb;
-  const float e0 = m0 - q0, e1 = m1 - q1, e2 = m2 - q2;
-  const bool means = (e0 <= kMog2SumTol && e0 >= -kMog2SumTol) && (e1 <= kMog2SumTol && e1 >= -kMog2SumTol) && (e2 <= kMog2SumTol && e2 >= -kMog2SumTol);
-  const bool varok = vb == 255 ? var > 440.f : (var <= V && var + 48.f >= V);
-  return means && varok;
+  const float b0 = (float)((word & 0x1fu) << 3), b1 = (float)(((word >> 5) & 0x1fu) << 3), b2 = (float)(((word >> 10) & 0x1fu) << 3);
+  const float e0 = m0 - b0, e1 = m1 - b1, e2 = m2 - b2;
+  const bool means = (e0 >= -2.f && e0 <= 9.f) && (e1 >= -2.f && e1 <= 9.f) && (e2 >= -2.f && e2 <= 9.f);
+  const bool tightable = var <= kMog2SumVarTight && m0 >= 0.f && m0 < 256.f && m1 >= 0.f && m1 < 256.f && m2 >= 0.f && m2 < 256.f;
+  return (word >> 15) ? !tightable : (means && var <= kMog2SumVar);
 }
 // does the summary PROVE dist2 >= Tmax * var, i.e. both of the reference's comparisons false for this pixel value?
-// Round 4: in integers, from ONE v_sad_u8.  `pix` = the pixel as b | g << 8 | r << 16 - the packing of the summary's low 24 bits - so
-// S = sad(pix, q) = sum_c |x_c - q_c|.  With |mean_c - q_c| <= 2 (the invariant): sum_c |x_c - mean_c| >= S - 6, and by Cauchy-Schwarz
-// dist2 = sum_c (x_c - mean_c)^2 >= (S - 6)^2 / 3.  So B = S - 7 > 0 (one more for every float rounding on either side: the values are
-// <= 2e5, relative error ~1e-7) and B^2 > 3 (2 Tmax vb + 1) with var <= 2 vb proves dist2 > Tmax var + 1.  c6T = ceil(6 Tmax), clamped to 23
-// bits (a threshold that large rejects nothing).  Twelve integer instructions per mode where the float form of round 3 (per channel
-// max(|x - q| - 2, 0)^2) took twenty-six - five modes per pixel and frame, a fifth of the kernel's vector instructions; the price is a
-// weaker bound when the modes differ in ONE channel only (factor 3), i.e. more records read there, never a different result.
-__device__ __host__ __forceinline__ uint32_t mog2_c6T(float Tmax) {
-  const float c = 6.f * Tmax;
-  return c < 8388607.f ? (uint32_t)(int)c + 1u : 8388607u;  // > 6 Tmax (NaN / negative thresholds end up at the clamp or at 1: both safe)
+// In integers, from ONE v_sad_u8 (round 4).  `pixq` = the pixel's channels >> 3 in bytes 0..2, `word` a class-0 summary, unpacked to
+// the same byte positions: S = sum_c |xq_c - q_c|.  x_c lies in bucket xq_c, mean_c within two levels of bucket q_c, so
+// |x_c - mean_c| >= 8 |xq_c - q_c| - 9, hence sum_c |x_c - mean_c| >= 8 S - 27, and by Cauchy-Schwarz
+// dist2 = sum_c (x_c - mean_c)^2 >= (8 S - 27)^2 / 3.  B = 8 S - 28 > 0 (one more for every float rounding on either side: the values
+// are <= 2e5, relative error ~1e-7) and B^2 > 3 (Tmax kMog2SumVar + 1) with var <= kMog2SumVar proves dist2 > Tmax var + 1.
+// tq = ceil(3 Tmax kMog2SumVar) + 3, clamped (a threshold that large rejects nothing).  The price of integers and buckets is a
+// weaker bound when the modes differ in ONE channel only (factor 3) or by less than ~20 levels: more records read there.
+__device__ __host__ __forceinline__ uint32_t mog2_tq(float Tmax) {
+  const float c = 3.f * kMog2SumVar * Tmax;
+  return c < 1.0e9f ? (uint32_t)(int)c + 4u : 0xffffffffu;  // > 3 (Tmax var + 1) for every var <= kMog2SumVar (NaN / negative thresholds: the clamp or 4, both safe)
 }
-__device__ __forceinline__ bool mog2_reject(uint32_t word, uint32_t pix, uint32_t c6T) {
-  const uint32_t S = __builtin_amdgcn_sad_u8(pix, word & 0xffffffu, 0u), vb = word >> 24;
-  const uint32_t B = S - 7u;  // (wraps for S < 7: caught by the first test)
-  return S > 7u && vb != 255u && B * B > c6T * vb + 3u;
-}
-inline bool mog2_reject_host(uint32_t word, uint32_t pix, uint32_t c6T) {  // the same test for host-side checks
-  uint32_t S = 0;
-  for (int c = 0; c < 3; ++c) {
-    const int d = (int)((pix >> (8 * c)) & 0xffu) - (int)((word >> (8 * c)) & 0xffu);
-    S += (uint32_t)(d < 0 ? -d : d);
-  }
-  const uint32_t vb = word >> 24, B = S - 7u;
-  return S > 7u && vb != 255u && B * B > c6T * vb + 3u;
+__device__ __forceinline__ uint32_t mog2_pixq(uint32_t pix) { return (pix >> 3) & 0x1f1f1fu; }
+__device__ __forceinline__ bool mog2_reject(uint32_t word, uint32_t pixq, uint32_t tq) {
+  const uint32_t qb = (word & 0x1fu) | ((word & 0x3e0u) << 3) | ((word & 0x7c00u) << 6);
+  const uint32_t S = __builtin_amdgcn_sad_u8(pixq, qb, 0u);
+  const uint32_t B = 8u * S - 28u;  // (wraps for S < 4: caught by the first test)
+  return S > 3u && !(word >> 15) && B * B > tq;
 }
 
 // One pixel's model in registers.  Weights and slot ids in rank order, as MOG2Invoker sees its array.  The records {var, mean0,
@@ -603,14 +595,14 @@ __device__ __forceinline__ void mog2_body(const Mog2Args& a, const size_t frame_
     // and not waiting for the meta word saves a whole round trip
 #pragma unroll
     for (int k = 0; k < kMog2K; ++k) wv[k] = mp.w[(size_t)k * kMog2Tile], sm[k] = mp.sum[(size_t)k * kMog2Tile];
-    const uint32_t c6T = mog2_c6T(a.Tb > a.Tg ? a.Tb : a.Tg);
+    const uint32_t tq = mog2_tq(a.Tb > a.Tg ? a.Tb : a.Tg), pixq = mog2_pixq(pix[0]);
     unsigned need = 0;  // bit k: the record of slot k must be read
 #pragma unroll
     for (int k = 0; k < kMog2K; ++k) {
       const bool live = k < nm_in;
       wv[k] = live ? wv[k] : 0.f;
       sm[k] = live ? sm[k] : 0u;
-      const bool r = live && valid_in && can_reject && mog2_reject(sm[k], pix[0], c6T);
+      const bool r = live && valid_in && can_reject && mog2_reject(sm[k], pixq, tq);
       rej |= (unsigned)r << (k + 1);
       need |= (unsigned)(live && !r) << k;
     }
@@ -644,7 +636,7 @@ __device__ __forceinline__ void mog2_body(const Mog2Args& a, const size_t frame_
 #pragma unroll
         for (int j = 0; j < kMog2K; ++j) {
           const float4 c = R.rc[j];
-          if (j < R.cnt && !mog2_reject(mog2_summary(c.x, c.y, c.z, c.w), pix[0], c6T)) ++would;
+          if (j < R.cnt && !mog2_reject(mog2_summary(c.x, c.y, c.z, c.w), pixq, tq)) ++would;
         }
       }
       unsigned s_live = 0, s_need = 0;
@@ -732,7 +724,7 @@ __device__ __forceinline__ void mog2_body(const Mog2Args& a, const size_t frame_
     unsigned d2, d8, d16;
     mog2_group_or(d, d2, d8, d16);
     unsigned c = (d8 & 0x1fu) | (d16 & 0x20u);
-    if constexpr (MODE == kMog2Filter) c |= d8 & 0xf800u;  // it holds every summary of the pixel (live ones loaded or rebuilt, the rest unused)
+    if constexpr (MODE == kMog2Filter) c |= d16 & 0xf800u;  // it holds every summary of the pixel (live ones loaded or rebuilt, the rest unused); 16 lanes x 2 bytes share a sector
     if constexpr (MODE == kMog2Eager) c |= d2 & 0x7c0u;    // it holds every record
     d |= c;
   }
@@ -745,7 +737,7 @@ __device__ __forceinline__ void mog2_body(const Mog2Args& a, const size_t frame_
     // (a slot the pixel does not own holds nothing anyone reads: zeros)
 #pragma unroll
     for (int q = 0; q < kMog2K; ++q) {
-      if ((d >> (11 + q)) & 1u) mp.sum[(size_t)q * kMog2Tile] = sm[q];  // dense only
+      if ((d >> (11 + q)) & 1u) mp.sum[(size_t)q * kMog2Tile] = (uint16_t)sm[q];  // dense only
       if ((d >> (6 + q)) & 1u) {
         float4 v;
         if constexpr (T == 1) {
@@ -768,7 +760,7 @@ __device__ __forceinline__ void mog2_body(const Mog2Args& a, const size_t frame_
     if constexpr (MODE == kMog2Filter) {
 #pragma unroll
       for (int q = 0; q < kMog2K; ++q)
-        if ((d >> (11 + q)) & 1u) mp.sum[(size_t)q * kMog2Tile] = sm[q];
+        if ((d >> (11 + q)) & 1u) mp.sum[(size_t)q * kMog2Tile] = (uint16_t)sm[q];
     }
   }
 }
@@ -792,7 +784,7 @@ __global__ __launch_bounds__(kBlock) void mog2_clear_kernel(const Mog2Args a) {
 #pragma unroll
   for (int k = 0; k < kMog2K; ++k) {
     mp.w[(size_t)k * kMog2Tile] = 0.f;
-    mp.sum[(size_t)k * kMog2Tile] = 0u;
+    mp.sum[(size_t)k * kMog2Tile] = 0;
     mp.rec[(size_t)k * kMog2Tile] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   *mp.meta = 0;
