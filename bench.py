@@ -124,7 +124,7 @@ def _hostpath_diag(e):
     return d
 
 
-def host_leg(local, clip, frames_n=120):
+def host_leg(local, clip, frames_n=120, cameras_only=False):
     """The drop-in call today's IBGS::process callers make - bgs_process, host buffers, one 1080p stream, synchronous - through the
     ctypes binding: staged (default: every image goes through the engine's pinned buffers) and with BGS_OPT_HOST_REGISTER (the caller's
     frame and mask buffers stay allocated, as OpenCV's capture loop keeps them: page-locked once, DMA'd in place).  PCIe-inclusive,
@@ -134,6 +134,8 @@ def host_leg(local, clip, frames_n=120):
     out = {"note": "bgs_process (host buffers, 1 x 1920x1080x3 stream, mask only, synchronous) through the ctypes binding; PCIe-inclusive; never `value`; "
                    "`diag` = the engine's own counters after the leg (buffers page-locked in place / refused per role, hipHostRegister calls and ms, CPU ms in staging copies)"}
     fb = ROWS * COLS * CH
+    if cameras_only:
+        out = {}
     pcie = {}
     for label, reg in (("pinned_hipHostMalloc", 0), ("registered_pageable", 1)):
         try:
@@ -142,7 +144,7 @@ def host_leg(local, clip, frames_n=120):
         except Exception as ex:  # noqa: BLE001
             pcie[label] = {"error": repr(ex)}
     out["pcie_calibration"] = dict(pcie, note="bgs_calibrate_pcie: 20 copies of one 1080p BGR frame (6.2 MB) each way; what the staged and the registered legs can at best reach on this box")
-    for label, reg in (("staged", 0), ("registered_buffers", 3)):
+    for label, reg in (() if cameras_only else (("staged", 0), ("registered_buffers", 3))):
         e = Engine(capi.MOG2, device=local)
         e.set_option(capi.OPT_HOST_REGISTER, reg)
         frame = np.empty_like(clip[0])  # ONE frame buffer, refilled per frame: what cvQueryFrame's image is
@@ -412,6 +414,16 @@ def main():
 
     S = args.streams
     first_global, _ = stream_block(S * world, world, rank)
+    # The host path FIRST, in a process that has not yet allocated and freed gigabytes of device memory: tools/r04_hostleg.py showed that
+    # such a history (the copy calibration, a torch pool that came and went, a 7 GB engine) slows the multi-camera legs down 2-3x - 8
+    # cameras with separately page-locked buffers 0.25 ms per frame in a fresh process, 0.57-0.84 ms after - while one synchronous camera
+    # is unaffected; a property of the runtime's DMA path, not of the engine.  The same camera legs run AGAIN at the end of this process
+    # (`host_path.after_large_allocations`) so that the line shows both.
+    host = None
+    if rank == 0 and world == 1 and not args.main_only and not selftest:
+        hclip = make_source("sat", 1, dev, 1234).pool(25)[:, 0].cpu().numpy()
+        host = host_leg(local, hclip)
+        del hclip
     calibration = calibrate(local, S) if (rank == 0 and not pmc_child) else None  # before the model exists
 
     nd = None
@@ -564,7 +576,6 @@ def main():
                                 "which enqueues and never waits); the rank's own wall time per step; `ms_per_step` is the MAX over ranks"}
     live_modes = None
     single = None
-    host = None
     configs = None
     cpu = None
     surv = None
@@ -643,8 +654,11 @@ def main():
         with open(args.pmc_child, "w") as f:
             json.dump(marks, f)
     if rank == 0 and not args.main_only:
-        if world == 1 and not selftest:
-            host = host_leg(local, clip0)
+        if world == 1 and not selftest and host is not None:
+            late = host_leg(local, clip0, cameras_only=True)
+            late.pop("pcie_calibration", None)
+            host["after_large_allocations"] = dict(late, note="the three 8-camera legs again at the END of this process, after the calibration ranges, the 7 GB model, 40 GB of frame pools "
+                                                                "and the scene legs' engines have been allocated and freed: the runtime's multi-stream DMA path is slower then (tools/r04_hostleg.py)")
         if world == 1 and not args.no_configs and not selftest:
             # BASELINE configs[2] (WMV + ABL at 3840x2160) and configs[3] (SuBSENSE / LBSP at 1080p) in the driver-timed line, never `value`
             from tools import bench_configs

@@ -180,9 +180,9 @@ int bgs_set_params(bgs_engine* e, const bgs_params* params);
  *   BGS_OPT_PLACEMENT_PROBE  rounds 1-2 looked for a fast physical placement of a multi-GB model by trial; accepted and ignored since
  *                          round 3, which places models deterministically (BGS_OPT_MODEL_CHUNK_MB).
  *   BGS_OPT_MODEL_CHUNK_MB multi-GB models (MOG2, MOG1, dp/) are ONE virtual range backed by separately created physical chunks of this
- *                          many MiB (default 256; any size from 2 MiB to 1 GiB lands in the fast placement class on MI355X, 15 of 15
- *                          processes, where one big hipMalloc is fast or 8-10 % slower by luck); 0 = one plain allocation; before the
- *                          geometry is set. */
+ *                          many MiB (default 256; any size from 2 MiB to 1 GiB avoids the slow placement - a physically contiguous run
+ *                          above ~1 GiB - that one big hipMalloc of a long-lived process sometimes gets: 8-10 % on the MOG2 kernel; it is
+ *                          not faster than a fresh plain allocation); 0 = one plain allocation; before the geometry is set. */
 #define BGS_OPT_BORROW_FRAMES 1
 #define BGS_OPT_MOG2_PIXELS_PER_LANE 2
 #define BGS_OPT_MOG2_TILED 3

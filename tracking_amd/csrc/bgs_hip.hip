@@ -402,15 +402,17 @@ size_t mog2_state_bytes(const bgs_engine* e) {
   return (P + bgs::kMog2Tile - 1) / bgs::kMog2Tile * bgs::kMog2TileBytes;
 }
 
-// Model allocation for the big, long-lived models (MOG2, MOG1, dp): DETERMINISTIC PLACEMENT.
+// Model allocation for the big, long-lived models (MOG2, MOG1, dp): ONE virtual range backed by separately created physical chunks.
 // Measured on MI355X in rounds 1-3 (profiles/r02_placement_probe.txt, profiles/r03_placement.txt): the same kernel on
-// the same layout streams a multi-GB model at one of 2-3 speeds, 8-10 % apart, depending only on which physical VRAM one big
-// hipMalloc handed out.  Rounds 1-2 looked for a fast placement by trial (up to 20 candidates of the whole model allocated and
-// timed).  Round 3 found the construction that needs no luck: ONE virtual range backed by separately created physical chunks of at
-// most 1 GiB (hipMemCreate / hipMemMap) - 15 of 15 fresh processes landed in the fast class for chunk sizes 2 MiB .. 1 GiB
-// (1.103-1.110 ms per 32 x 1080p MOG2 launch), 3 of 3 in the slow class with 4 GiB chunks (1.21 ms), while plain hipMalloc gave
-// 1.11 1.11 1.12 1.19 1.21 1.21.  So: chunks of 256 MiB (BGS_MODEL_CHUNK_MB; 0 = one plain hipMalloc), no probe, no transient memory.
-// one virtual range backed by separately created physical chunks of `chunk` bytes each
+// the same layout streamed a multi-GB model at one of 2-3 speeds, 8-10 % apart, depending on which physical VRAM one big hipMalloc
+// handed out - a physically contiguous run above ~1 GiB, which a LATER large hipMalloc of a long-lived process tends to get, was the
+// slow one.  Rounds 1-2 looked for a fast placement by trial (up to 20 candidates of the whole model allocated and timed); round 3
+// found that chunks of at most 1 GiB (hipMemCreate / hipMemMap) never land there: 15 of 15 fresh processes at 1.103-1.110 ms per
+// launch for chunk sizes 2 MiB .. 1 GiB, 3 of 3 slow with 4 GiB chunks, plain hipMalloc 1.11 1.11 1.12 1.19 1.21 1.21.
+// Round 4 checked the claim from the other side (bench.py `calibration`, the round-3 verdict's question): a float4 copy through a chunked
+// range is NOT faster than through a fresh plain allocation (6.14-6.21 against 6.19-6.27 TB/s on every box) - the construction does
+// not buy bandwidth, it avoids the bad placement - and it does not explain the 6-9 % between BOXES of the pool, which show the same
+// copy rate.  So: chunks of 256 MiB (BGS_MODEL_CHUNK_MB; 0 = one plain hipMalloc), no probe, no transient memory.
 int vmm_allocate(VmmRange& v, int device, void** out, size_t bytes, size_t chunk) {
   hipMemAllocationProp prop = {};
   prop.type = hipMemAllocationTypePinned;
