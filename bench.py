@@ -701,11 +701,20 @@ def main():
                         leg_s["hbm_frac_of_peak_measured"] = round(tb["hbm_bytes_per_launch"] / (leg_s["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
             else:
                 traffic_source = "live PMC passes unavailable (%s); " % why
-        if traffic is None and os.path.exists(pmc):
+        if traffic is None and os.path.exists(pmc) and S == 32 and args.input == "sat" and not args.with_bg:  # (the constants are for the default workload)
             try:
-                rec = json.load(open(pmc)).get("mog2_update_kernel", {})
+                consts = json.load(open(pmc))
+                rec = consts.get("mog2_update_kernel", {})
                 traffic = rec.get("hbm_bytes_per_launch")
+                traffic_detail = {k: rec[k] for k in ("hbm_bytes_per_launch", "read_bytes", "write_bytes") if k in rec}
                 traffic_source = (traffic_source if traffic_source != "none" else "") + "NOT measured in this run: constant read from profiles/pmc_traffic.json (%s)" % rec.get("source", "rocprofv3 --pmc passes of the same workload")
+                for key, leg_s in (("s_surv", surv and surv.get("default")), ("s_dense", dense)):  # the scene legs fall back the same way, and say so
+                    if leg_s and "traffic" not in leg_s and key in consts:
+                        tb = {k: consts[key][k] for k in ("hbm_bytes_per_launch", "read_bytes", "write_bytes")}
+                        leg_s["traffic"] = tb
+                        leg_s["traffic_source"] = "NOT measured in this run: constant read from profiles/pmc_traffic.json (%s)" % consts[key].get("source", "")
+                        leg_s["traffic_B_per_pixel"] = round(tb["hbm_bytes_per_launch"] / px_per_step_rank, 2)
+                        leg_s["hbm_GBps_measured"] = round(tb["hbm_bytes_per_launch"] / (leg_s["kernel_ms"] * 1e-3) / 1e9, 1)
             except Exception:
                 traffic = None
 

@@ -192,3 +192,41 @@ def test_device_calls_refuse_a_stream_with_a_submission_in_flight():
     torch.cuda.synchronize()
     assert [eng.frames_seen(s) for s in range(S)] == [2, 3, 2]
     eng.close()
+
+
+def test_host_arena_cameras_dma_in_place_equal_the_oracle():
+    """bgs_host_arena: all cameras' frames in ONE array and all their masks / backgrounds in others, each page-locked once; every image
+    inside an arena is read / written by the DMA engine in place (no staging copy: the engine's own counter says so) through
+    bgs_submit / bgs_wait and through bgs_process; results equal every camera's own oracle; dropping the arena falls back to staging."""
+    _torch()
+    S, T, H, W = 3, 6, 96, 160
+    clips = np.stack([synth.random_frames(T, H, W, 3, seed=210 + s) for s in range(S)])
+    eng = Engine(capi.MOG2, n_streams=S)
+    frames, fgs, bgs_ = np.empty((S, H, W, 3), np.uint8), np.empty((S, H, W), np.uint8), np.empty((S, H, W, 3), np.uint8)
+    eng.set_geometry(H, W, 3)
+    for a in (frames, fgs, bgs_):
+        eng.host_arena(a)
+    orcs = [pyoracle.Oracle(capi.MOG2) for _ in range(S)]
+    for t in range(T):
+        frames[...] = clips[:, t]
+        if t % 2 == 0:
+            for s in range(S):
+                eng.submit(frames[s], fgs[s], bgs_[s], stream=s)
+            for s in range(S):
+                eng.wait(stream=s)
+        else:
+            for s in range(S):
+                eng.process_into(frames[s], fgs[s], bgs_[s], stream=s)
+        for s in range(S):
+            ofg, obg = orcs[s].process(clips[s, t])
+            assert np.array_equal(fgs[s], ofg) and np.array_equal(bgs_[s], obg), (t, s)
+    d = eng.get_state("hostpath", (15,), np.float64)
+    assert d[14] == 3 and d[6] == 3 and d[12] == 0 and d[13] == 0, d  # three arenas, three registrations, no CPU staging copies either way
+    eng.host_arena(frames, on=False)
+    frames[...] = clips[:, 0]
+    eng.process_into(frames[0], fgs[0], bgs_[0], stream=0)
+    d2 = eng.get_state("hostpath", (15,), np.float64)
+    assert d2[14] == 2 and d2[12] > 0, d2  # the input goes through the pinned staging buffer again
+    ofg, _ = orcs[0].process(clips[0, 0])
+    assert np.array_equal(fgs[0], ofg)
+    eng.close()
