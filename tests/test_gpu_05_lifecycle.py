@@ -202,7 +202,12 @@ def test_host_arena_cameras_dma_in_place_equal_the_oracle():
     S, T, H, W = 3, 6, 96, 160
     clips = np.stack([synth.random_frames(T, H, W, 3, seed=210 + s) for s in range(S)])
     eng = Engine(capi.MOG2, n_streams=S)
-    frames, fgs, bgs_ = np.empty((S, H, W, 3), np.uint8), np.empty((S, H, W), np.uint8), np.empty((S, H, W, 3), np.uint8)
+    def own_pages(shape):  # an arena on pages of its own (small numpy arrays share heap pages; a page cannot be page-locked twice)
+        n = int(np.prod(shape))
+        raw = np.empty(n + 2 * 4096, np.uint8)
+        off = (-raw.ctypes.data) % 4096
+        return raw[off:off + (n + 4095) // 4096 * 4096][:n].reshape(shape), raw
+    (frames, k0), (fgs, k1), (bgs_, k2) = own_pages((S, H, W, 3)), own_pages((S, H, W)), own_pages((S, H, W, 3))
     eng.set_geometry(H, W, 3)
     for a in (frames, fgs, bgs_):
         eng.host_arena(a)
