@@ -385,10 +385,13 @@ def configs_block(device=0, S=8, steps=40, cpu=True):
     del pool, fg1, fg2
     out["configs2_wmv_abl_4k"] = c2
     # ---- configs[3]: SuBSENSE (LBSP descriptor path) at 1920x1080: whole frame step, young and aged model; lbsp_kernel alone
-    rows, cols, T = 1080, 1920, 8
-    pool = torch.empty((T, S, rows, cols, 3), dtype=torch.uint8, device=dev)
-    for s in range(S):
-        pool[:, s] = synth.s_surv(T, rows, cols, seed=4321 + s, device=dev)
+    # frames: fresh sensor noise in every frame the model sees (tools/synth.py SurvStreams; round 3 cycled a pool of 8 frames, whose values
+    # the 50-sample model then holds exactly): the timed steps run over pools of DISTINCT frames resident in HBM, the untimed ageing
+    # generates its frames one by one
+    rows, cols, T = 1080, 1920, 36
+    src = synth.SurvStreams(S, rows, cols, seed0=4321, device=dev)
+    pool = src.pool(T)
+    cur = torch.empty((S, rows, cols, 3), dtype=torch.uint8, device=dev)
     e = Engine(capi.SUBSENSE, device=device, n_streams=S)
     t0 = time.perf_counter()
     e.set_geometry(rows, cols, 3)
@@ -397,7 +400,7 @@ def configs_block(device=0, S=8, steps=40, cpu=True):
     torch.cuda.synchronize()
     init_ms = (time.perf_counter() - t0) * 1e3
     px = S * rows * cols
-    c3 = {"workload": "SuBSENSEBGS (LBSP + colour sample consensus, 50 samples per pixel, feedback, post-processing), %d x 1920x1080x3 uint8 S_surv in HBM, all streams per launch" % S,
+    c3 = {"workload": "SuBSENSEBGS (LBSP + colour sample consensus, 50 samples per pixel, feedback, post-processing), %d x 1920x1080x3 uint8 S_surv in HBM (fresh sensor noise in every frame), all streams per launch" % S,
           "bytes_per_pixel_note": "data-dependent; SURVEY.md 8(a) a11 gives >= 110 B/pixel (two matching samples, the float maps, frame and mask): `frac` prices the whole step at that floor",
           "first_frame_ms_incl_allocation": round(init_ms, 2)}
     t_seen = 1
@@ -424,8 +427,10 @@ def configs_block(device=0, S=8, steps=40, cpu=True):
         t_seen += 1
     c3["young_model"] = dict(timed(30), model_age_frames=6)
     while t_seen < 300:
-        e.process_batch_device(pool[t_seen % T], fg, None, None)
+        e.process_batch_device(src.into(cur), fg, None, None)
         t_seen += 1
+    pool[:30] = src.pool(30)
+    t_seen = T * 9  # (pool index 0 again: the 30 timed aged steps read 30 frames the model has never seen)
     c3["aged_model"] = dict(timed(30), model_age_frames=300)
     e.close()
     from oracle import pyoracle

@@ -1616,12 +1616,13 @@ static int lane_wait(bgs_engine* e, int stream, uint32_t* out_flags) {
   HIP_TRY(hipEventSynchronize(ln.done));
   ln.pending = false;
   const int bg_ch = e->algo == BGS_ASBL ? 1 : e->ch;
+  const bool copy_fg = ln.fg && !ln.fg_direct && (ln.flags & BGS_FG_VALID), copy_bg = ln.bg && !ln.bg_direct && (ln.flags & BGS_BG_VALID);
   const auto st0 = std::chrono::steady_clock::now();
-  if (ln.fg && !ln.fg_direct && (ln.flags & BGS_FG_VALID))
+  if (copy_fg)
     for (int y = 0; y < e->rows; ++y) std::memcpy(ln.fg + (size_t)y * ln.fg_step, ln.h_fg + (size_t)y * e->cols, (size_t)e->cols);
-  if (ln.bg && !ln.bg_direct && (ln.flags & BGS_BG_VALID))
+  if (copy_bg)
     for (int y = 0; y < e->rows; ++y) std::memcpy(ln.bg + (size_t)y * ln.bg_step, ln.h_bg + (size_t)y * e->cols * bg_ch, (size_t)e->cols * bg_ch);
-  e->diag_stage_out_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - st0).count();
+  if (copy_fg || copy_bg) e->diag_stage_out_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - st0).count();
   if (out_flags) *out_flags = ln.flags;
   return BGS_OK;
 }
