@@ -567,6 +567,10 @@ def main():
     if args.only == "subsense8":
         run_subsense(8)
         return
+    if args.only == "subsense8both":  # young and aged model in one process (A/B scripts)
+        run_subsense(8)
+        run_subsense(8, warm=300)
+        return
     if args.only == "subsense8x2":  # the 8 streams as two / four ranges on their own HIP streams
         run_subsense(8)
         run_subsense(8, groups=2)

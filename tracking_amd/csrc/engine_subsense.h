@@ -126,6 +126,8 @@ void ss_fill_args(const bgs_engine* e, bgs::SsArgs& a, int first, int cur_pp, un
   a.selfInA = (e->algo == BGS_SUBSENSE && self_in_a) ? 1 : 0;  // (LOBSTER's phase A leaves every write to phase B)
   static const int refill = getenv("BGS_SS_REFILL") ? std::max(1, std::min(64, atoi(getenv("BGS_SS_REFILL")))) : bgs::kSsRefill;  // tuning knob
   a.refill = refill;
+  static const int ipass_min = getenv("BGS_SS_IPASS_MIN") ? std::max(1, std::min(64, atoi(getenv("BGS_SS_IPASS_MIN")))) : bgs::kSsIpassMin;  // 1 = the round-3 form
+  a.ipassMin = ipass_min;
   a.frameIndex = frameIndex, a.first = first;
   const int64_t fi = frameIndex ? frameIndex : 1;
   a.fLT = 1.0f / (float)std::min<int64_t>(fi, p.subsense_samples_for_moving_avgs);
@@ -152,8 +154,11 @@ void ss_initial_lut(const bgs_params& p, int channels, uint8_t lut[256]) {
 // a wave per 64x64 tile otherwise (BGS_SS_FLOOD_TILES=1 forces the latter: A/B and test knob).
 void ss_launch_flood(dim3 tile_grid, int count, int tilesY, hipStream_t s, const uint64_t* mbits, uint64_t* rbits, int rows, int W64, int* fl, int k) {
   static const bool tiles_only = getenv("BGS_SS_FLOOD_TILES") && atoi(getenv("BGS_SS_FLOOD_TILES")) == 1;
-  if (tilesY <= 16 * bgs::kSsFloodKT && !tiles_only)
-    hipLaunchKernelGGL(bgs::ss_flood_strip_kernel, dim3(W64, count), dim3(1024), 0, s, mbits, rbits, rows, W64, fl, k);
+  static const bool wide_groups = getenv("BGS_SS_FLOOD_WG1024") && atoi(getenv("BGS_SS_FLOOD_WG1024")) == 1;  // A/B and test knob: round 3's 1024-lane workgroups for every height
+  if (tilesY <= bgs::kSsFloodNWSmall * bgs::kSsFloodKTSmall && !tiles_only && !wide_groups)
+    hipLaunchKernelGGL((bgs::ss_flood_strip_kernel<bgs::kSsFloodNWSmall, bgs::kSsFloodKTSmall>), dim3(W64, count), dim3(bgs::kSsFloodNWSmall * 64), 0, s, mbits, rbits, rows, W64, fl, k);
+  else if (tilesY <= 16 * bgs::kSsFloodKT && !tiles_only)
+    hipLaunchKernelGGL((bgs::ss_flood_strip_kernel<16, bgs::kSsFloodKT>), dim3(W64, count), dim3(1024), 0, s, mbits, rbits, rows, W64, fl, k);
   else
     hipLaunchKernelGGL(bgs::ss_flood_kernel, tile_grid, dim3(bgs::kBlock), 0, s, mbits, rbits, rows, W64, fl, k);
 }
@@ -256,29 +261,47 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
   // on both: phase B goes to a side stream and rejoins at the end, so its memory-bound scatter overlaps the LDS-bound morphology.
   static const bool overlap = !(getenv("BGS_SS_OVERLAP") && atoi(getenv("BGS_SS_OVERLAP")) == 0);
   if (overlap && !d->side) {
-    HIP_TRY(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));  // (round 4: the lowest stream priority for it changed nothing in the step's timeline)
     HIP_TRY(hipEventCreateWithFlags(&d->evA, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&d->evB, hipEventDisableTiming));
   }
   // Round 4: the per-pixel rules behind the loop (:498-576) are ss_feedback_kernel; it produces the update requests phase B applies, so
   // it goes in front of phase B on the side stream - both beside the post-processing chain, which only needs phase A's `raw`.
   const dim3 gridF((e->cols + bgs::kBlock - 1) / bgs::kBlock, e->rows, count);
-  if (overlap) {
-    HIP_TRY(hipEventRecord(d->evA, s));
-    HIP_TRY(hipStreamWaitEvent(d->side, d->evA, 0));
-    if (split) SS_LAUNCH(ss_feedback_kernel, gridF, block, d->side, a);
-    SS_LAUNCH(ss_phase_b_kernel, tilesB, block, d->side, a);
-    HIP_TRY(hipEventRecord(d->evB, d->side));
-  } else {
-    if (split) SS_LAUNCH(ss_feedback_kernel, gridF, block, s, a);
-    SS_LAUNCH(ss_phase_b_kernel, tilesB, block, s, a);
+  // WHERE phase B starts (round 4).  Rounds 2-3 started it right behind phase A.  The timeline of an 8 x 1080p step on the aged model
+  // (profiles/r04_subsense_step_timeline.txt): phase B alone 368 us, the chain alone 288 us, both together 600 - 640 us, hardly better
+  // than one after the other.  The chain's first half is a string of small, latency-bound launches up to the flood fill (its strip
+  // kernel walks the image in rounds of memory round trips): beside phase B's ~8 M scattered 16-byte writes each of them took four to
+  // five times as long (the first strip launch 224 us instead of 43) and the chain ended when phase B did.  So phase B now starts
+  // BEHIND the flood fill: the first half runs alone (~110 us), the second half (box filters, median, the byte maps: streaming
+  // kernels) beside phase B.  BGS_SS_B_EARLY=1: the old order (A/B knob).
+  static const bool b_early = getenv("BGS_SS_B_EARLY") && atoi(getenv("BGS_SS_B_EARLY")) == 1;
+  auto launch_b = [&]() -> int {
+    if (overlap) {
+      HIP_TRY(hipEventRecord(d->evA, s));
+      HIP_TRY(hipStreamWaitEvent(d->side, d->evA, 0));
+      if (split) SS_LAUNCH(ss_feedback_kernel, gridF, block, d->side, a);
+      SS_LAUNCH(ss_phase_b_kernel, tilesB, block, d->side, a);
+      HIP_TRY(hipEventRecord(d->evB, d->side));
+    } else {
+      if (split) SS_LAUNCH(ss_feedback_kernel, gridF, block, s, a);
+      SS_LAUNCH(ss_phase_b_kernel, tilesB, block, s, a);
+    }
+    return BGS_OK;
+  };
+  if (b_early || !overlap) {
+    const int rc = launch_b();
+    if (rc != BGS_OK) return rc;
   }
   // byte maps of this launch as vectors when the pixel count and the caller's buffers allow it (the engine's own planes are 256-byte aligned)
   const bool v16 = npix % 16 == 0 && (off % 16) == 0, v4 = npix % 4 == 0 && (off % 4) == 0 && e->cols % 4 == 0 && (!d_fg || aligned(d_fg, 4));
-  if (v16)
-    hipLaunchKernelGGL(bgs::ss_blink_kernel<16>, dim3(blocks_for(npix / 16)), block, 0, s, a, npix);
-  else
-    hipLaunchKernelGGL(bgs::ss_blink_kernel<1>, dim3(blocks_for(npix)), block, 0, s, a, npix);
+  auto launch_blink = [&]() {  // :624-627; only reads phase A's `raw`
+    if (v16)
+      hipLaunchKernelGGL(bgs::ss_blink_kernel<16>, dim3(blocks_for(npix / 16)), block, 0, s, a, npix);
+    else
+      hipLaunchKernelGGL(bgs::ss_blink_kernel<1>, dim3(blocks_for(npix)), block, 0, s, a, npix);
+  };
+  if (b_early || !overlap) launch_blink();
   uint8_t* raw = d->u8[SS_RAW] + off;
   uint8_t* lastFG = d->u8[SS_LASTFG] + off;
   // :628-636 on bit planes (kernel_subsense.h): a lane owns 64 pixels of a row
@@ -306,8 +329,15 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
   int* fl = d->flood_flags + (size_t)first * bgs::kSsFloodFlags;
   HIP_TRY(hipMemsetAsync(fl, 0, (size_t)count * bgs::kSsFloodFlags * sizeof(int), s));
   static const int batch = getenv("BGS_SS_FLOOD_BATCH") ? std::max(0, std::min(bgs::kSsFloodBatch, atoi(getenv("BGS_SS_FLOOD_BATCH")))) : bgs::kSsFloodBatch;  // test knob: 0/1 force the finish kernel to do the work
+  // (the finish kernel almost always returns at once; 256 lanes so that it does not wait for a quarter of a CU beside phase B - see ss_flood_strip_kernel)
+  static const bool wide_finish = getenv("BGS_SS_FLOOD_WG1024") && atoi(getenv("BGS_SS_FLOOD_WG1024")) == 1;
   for (int k = 0; k < batch; ++k) ss_launch_flood(fgrid, count, tilesY, s, mbits, rbits, e->rows, W64, fl, k);
-  hipLaunchKernelGGL(bgs::ss_flood_finish_kernel, dim3(count), dim3(1024), 0, s, (const uint64_t*)mbits, rbits, e->rows, W64, fl, batch);
+  hipLaunchKernelGGL(bgs::ss_flood_finish_kernel, dim3(count), dim3(wide_finish ? 1024 : 256), 0, s, (const uint64_t*)mbits, rbits, e->rows, W64, fl, batch);
+  if (!(b_early || !overlap)) {
+    const int rc = launch_b();
+    if (rc != BGS_OK) return rc;
+    launch_blink();
+  }
   // erode x3 :632 = one 7x7 box -> b_tmp;  :631-634 -> b_cur
   hipLaunchKernelGGL((bgs::ss_bits_box_kernel<0, 3>), wgrid, block, 0, s, (const uint64_t*)b_pre, b_tmp, e->rows, e->cols, W64, nwords);
   hipLaunchKernelGGL(bgs::ss_bits_combine_kernel, wgrid, block, 0, s, (const uint64_t*)b_raw, (const uint64_t*)b_pre, (const uint64_t*)rbits, (const uint64_t*)b_tmp, b_cur, e->cols, W64, nwords);
@@ -511,6 +541,16 @@ int lob_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, ui
 }
 
 void ss_free(bgs_engine* e) {
+#ifdef BGS_SS_STATS
+  {
+    unsigned long long h[16] = {0};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(bgs::g_ss_stats), sizeof h) == hipSuccess)
+      fprintf(stderr, "ss_stats trips %llu active_lanes %llu refills %llu | R narrow %llu lanes %llu wide %llu lanes %llu | passes %llu lanes %llu | put off %llu lanes %llu\n", h[0], h[1], h[2], h[3], h[4], h[5],
+              h[6], h[7], h[8], h[9], h[10]);
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(bgs::g_ss_stats), z, sizeof z);
+  }
+#endif
   if (e->ss) {
     e->ss->release();
     delete e->ss;

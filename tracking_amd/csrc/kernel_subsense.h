@@ -58,7 +58,7 @@ struct SsArgs {
   float *dsLT, *dsST;    // [S][dsh][dsw][3]
   uint8_t* fg;           // [S][N] output mask (may be null)
   uint8_t* bgimg;        // [S][N][3] output background (may be null)
-  int rows, cols, nS, nReq, nMinColor, nDescOff, nMov, lbspOff, use3x3, lrScaling, medK, refill;
+  int rows, cols, nS, nReq, nMinColor, nDescOff, nMov, lbspOff, use3x3, lrScaling, medK, refill, ipassMin;
   float relT, fLT, fST;
   unsigned frameIndex;
   int first;             // first stream of this launch (blockIdx.z is relative to it)
@@ -178,7 +178,7 @@ __device__ __forceinline__ size_t ss_rec(const SsArgs& a, int stream, size_t N, 
 //      a quarter of them (kSsRefill) have finished, and every lane keeps its own sample index;
 //   3. per pixel (static map again): rolling means, update requests, T / v / R feedback, stores.
 // The result of a pixel does not depend on when or where it is processed: every model read is of start-of-frame state.
-constexpr int kSsATH = 32, kSsAPix = kSsTW * kSsATH, kSsRefill = 16;
+constexpr int kSsATH = 32, kSsAPix = kSsTW * kSsATH, kSsRefill = 16, kSsIpassMin = 16;
 constexpr uint32_t kSsNotInterior = 0xffffffffu;
 
 
@@ -186,6 +186,12 @@ constexpr uint32_t kSsNotInterior = 0xffffffffu;
 // QUEUE (BGR only): the inter-LBSP tests of a wave go through a per-wave work list in LDS and are computed by WHOEVER is free, 64 at a
 // time (stage 2, "rounds"); the tile is 64 x 16 then (kSsQATH) so that the extra LDS still allows four workgroups per CU.
 constexpr int kSsQATH = 16, kSsQList = 256;
+#ifdef BGS_SS_STATS  // experiment builds only (tools/r04_ss_stats.sh): what the waves of stage 2 did, summed over the process
+__device__ unsigned long long g_ss_stats[16];
+#define SS_STAT(i, v) (st[i] += (unsigned)(v))
+#else
+#define SS_STAT(i, v) ((void)0)
+#endif
 template <int C, bool SPLIT, bool QUEUE>
 __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
   static_assert(!QUEUE || C == 3, "the candidate queue is built for BGR records");
@@ -370,7 +376,8 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
   // the end of round 2 the kernel is VALU-bound (92 % of the SIMD cycles are vector issue).
   {
     const int lane = threadIdx.x & (kWave - 1);
-    bool active = false, qempty = false;
+    bool active = false, qempty = false, fresh = false, wide = false;
+    uint32_t cand = 0;  // candidate bits of the held samples that no I pass has taken yet
     int q = 0, idx = 0, good = 0;
     uint32_t minDesc = maxDesc, minSum = maxColor, colorThr = 0, descThr = 0;
     int cur[C];
@@ -389,11 +396,16 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
     for (int j = 0; j < B; ++j) bt[j] = SsSample<C>{}, nbt[j] = SsSample<C>{};
 #pragma unroll
     for (int c = 0; c < C; ++c) cur[c] = 0, intra[c] = 0, curm[c] = 0;
+#ifdef BGS_SS_STATS
+    unsigned st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (;;) {
       const unsigned long long idle = __ballot(!active);
       const int nidle = __popcll(idle);
       if (qempty && nidle == kWave) break;
+      SS_STAT(0, 1), SS_STAT(1, kWave - nidle);  // trips, active lanes
       if (!qempty && nidle >= a.refill) {  // wave-uniform
+        SS_STAT(2, 1);
         const int leader = __ffsll((long long)idle) - 1;
         unsigned base = 0;
         if (lane == leader) base = atomicAdd(&qhead, (unsigned)nidle);
@@ -431,7 +443,7 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
 #pragma unroll
             for (int j = 0; j < B; ++j) bt[j] = SsSample<C>::load(a.samples, rec + j * N);
             idx = 0, good = 0, minDesc = maxDesc, minSum = maxColor;
-            active = true;
+            active = true, fresh = true;
           }
         }
       }
@@ -440,9 +452,14 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
       // every lane busy -> candidate bits.  I: the inter-LBSP test (~150 instructions per channel set), one candidate per lane and
       // pass in sample order, stopping at the nReq-th match exactly like the reference's loop (:469).  Rejected samples and samples
       // behind the nReq-th match have no side effects, and min() does not care about order.
-      uint32_t cand = 0;
-      bool wide = false;
-      if (active) {  // :469-497 (BGR) / :334-357 (gray); an active lane always has good < nReq and idx < nS here
+      // (round 4) A lane whose candidates were left over by the I passes below keeps its batch and its candidate bits (`fresh` false):
+      // it neither loads nor re-tests anything until a pass has taken them.
+      {
+        const unsigned long long fm = __ballot(active && fresh), wm = __ballot(active && fresh && idx > 0);
+        SS_STAT(3, fm != 0), SS_STAT(4, __popcll(fm)), SS_STAT(5, wm != 0), SS_STAT(6, __popcll(wm));
+        (void)fm, (void)wm;
+      }
+      if (active && fresh) {  // :469-497 (BGR) / :334-357 (gray); an active lane always has good < nReq and idx < nS here
         wide = idx > 0;
         auto reject_bits = [&](const SsSample<C>(&bb)[B], int first) -> uint32_t {
           uint32_t bits = 0;
@@ -478,6 +495,7 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
           const uint32_t hi = reject_bits(nbt, idx + B);
           if (wide) cand |= hi << B;
         }
+        fresh = false;
       }
       if constexpr (QUEUE) {
         // ROUNDS (round 4, BGS_SS_QUEUE=1; NOT the default: measured slower).  One candidate per lane and pass leaves the wave at
@@ -588,6 +606,19 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
           const bool go = active && cand != 0 && good < a.nReq;
           const unsigned long long gm = __ballot(go);
           if (!gm) break;
+          // DENSE PASSES (round 4): a pass costs the same ~230 vector instructions for one candidate as for 64, and once the lanes
+          // with two or three candidates in their batch are the only ones left it ran at a few lanes.  So a pass that fewer than
+          // ipassMin lanes would join is put off while some other active lane has something else to do (its next batch, or finishing
+          // and handing its lane to a new pixel): the waiting lanes keep batch and candidate bits and join the passes of the next trip.
+          // Every trip still makes progress - either a pass runs, or a lane without candidates moves on - and each pixel still sees
+          // its samples in order up to its nReq-th match: the same integers for any ipassMin (1 = every pass at once, the round-3 form).
+          // Not once the tile's queue is empty: no new pixel can join then, a trip is a memory round trip, and waiting only strings
+          // more of them together (measured: the aged model, whose pixels mostly take one trip, lost 13 % without this condition).
+          if (!qempty && __popcll(gm) < a.ipassMin && __any(active && !go)) {
+            SS_STAT(9, 1), SS_STAT(10, __popcll(gm));
+            break;
+          }
+          SS_STAT(7, 1), SS_STAT(8, __popcll(gm));
           SsSample<C> smp = bt[0];
           if (go) {
             const int j = __ffs((int)cand) - 1;
@@ -641,17 +672,23 @@ __global__ __launch_bounds__(kBlock) void ss_phase_a_kernel(const SsArgs a) {
           }
         }
       }
-      if (active) {
+      if (active && !(cand != 0 && good < a.nReq)) {  // (a lane with candidates left waits for the next trip's passes)
         idx += wide ? 2 * B : B;
         if (good < a.nReq && idx < a.nS) {  // not done: the next eight samples (the first trip leaves the sample-major part here)
           rec = wide ? rec + 2 * B : rnext;
 #pragma unroll
           for (int j = 0; j < B; ++j) bt[j] = SsSample<C>::load(a.samples, rec + j), nbt[j] = SsSample<C>::load(a.samples, rec + B + j);
+          fresh = true;
         } else {
           ctx[q][2] = (uint32_t)good | (minDesc << 8) | (minSum << 16);
           active = false;
         }
-      }    }
+      }
+    }
+#ifdef BGS_SS_STATS
+    if (lane == 0)
+      for (int i = 0; i < 12; ++i) atomicAdd(&g_ss_stats[i], (unsigned long long)st[i]);
+#endif
   }
   __syncthreads();
 
@@ -1101,7 +1138,8 @@ __device__ __forceinline__ bool ss_req_is_last(const uint32_t (*rq)[HW], int tly
 }
 
 // append to a list in LDS, one atomic per wave; every lane of the wave must make the call
-__device__ __forceinline__ void ss_list_push(uint32_t* list, unsigned* n, bool push, uint32_t value, int lane) {
+template <typename T>
+__device__ __forceinline__ void ss_list_push(T* list, unsigned* n, bool push, T value, int lane) {
   const unsigned long long mask = __ballot(push);
   if (mask) {  // (wave-uniform)
     unsigned base = 0;
@@ -1116,8 +1154,8 @@ __global__ __launch_bounds__(kBlock) void ss_phase_b_kernel(const SsArgs a) {
   constexpr int HW = kSsTW + 4, HH = kSsBTH + 4;
   static_assert(kSsTW * kSsBTH / 4 == kBlock, "one dword of target counters per lane");
   __shared__ uint32_t rq[HH][HW];          // both requests of a source pixel in one dword
-  __shared__ uint32_t list[HH * HW * 2];   // ly << 16 | lx << 8 | q of every request whose target is in this tile
-  __shared__ uint32_t list2[HH * HW * 2];  // those whose target has other requests too
+  __shared__ uint16_t list[HH * HW * 2];   // ly << 8 | lx << 1 | q of every request whose target is in this tile
+  __shared__ uint16_t list2[HH * HW * 2];  // those whose target has other requests too
   __shared__ uint32_t cnt[kBlock];         // requests aimed at each target of the tile, one byte each (<= 26)
   __shared__ unsigned nlist, nlist2;
   const int stream = a.first + blockIdx.z;
@@ -1127,12 +1165,24 @@ __global__ __launch_bounds__(kBlock) void ss_phase_b_kernel(const SsArgs a) {
   if (threadIdx.x == 0) nlist = 0, nlist2 = 0;
   cnt[threadIdx.x] = 0;
   __syncthreads();
-  for (int i0 = 0; i0 < HH * HW; i0 += kBlock) {  // (every lane makes every trip: the ballots see whole waves)
-    const int i = i0 + (int)threadIdx.x;
+  // Round 4: a workgroup's requests are loaded in ONE go.  The loop below used to load its dword at the top of each of its six trips and
+  // then ballot on it: six memory round trips in a row per workgroup, and with ~5 workgroups resident per CU (LDS) the launch took
+  // 0.25 ms on 8 x 1080p even when hardly any pixel made a request (the step's timeline: phase B is the longest thing behind phase A).
+  constexpr int NT = (HH * HW + kBlock - 1) / kBlock;
+  uint32_t vv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int i = t * kBlock + (int)threadIdx.x;
     const int ly = i / HW, lx = i - ly * HW;
     const int y = y0 + ly - 2, x = x0 + lx - 2;
-    uint32_t v = 0;
-    if (i < HH * HW && y >= 2 && y < a.rows - 2 && x >= 2 && x < a.cols - 2) v = *reinterpret_cast<const uint32_t*>(a.req + (sN + (size_t)y * a.cols + x) * 2);
+    vv[t] = 0;
+    if (i < HH * HW && y >= 2 && y < a.rows - 2 && x >= 2 && x < a.cols - 2) vv[t] = *reinterpret_cast<const uint32_t*>(a.req + (sN + (size_t)y * a.cols + x) * 2);
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {  // (every lane makes every trip: the ballots see whole waves)
+    const int i = t * kBlock + (int)threadIdx.x;
+    const int ly = i / HW, lx = i - ly * HW;
+    const uint32_t v = vv[t];
     if (i < HH * HW) rq[ly][lx] = v;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {  // self request first, then the neighbour request
@@ -1144,7 +1194,7 @@ __global__ __launch_bounds__(kBlock) void ss_phase_b_kernel(const SsArgs a) {
         atomicAdd(&cnt[t >> 2], 1u << (8 * (t & 3)));
       }
       const bool push = aimed && !(q == 0 && a.selfInA);
-      ss_list_push(list, &nlist, push, ((uint32_t)ly << 16) | ((uint32_t)lx << 8) | (uint32_t)q, lane);
+      ss_list_push(list, &nlist, push, (uint16_t)((ly << 8) | (lx << 1) | q), lane);
     }
   }
   __syncthreads();
@@ -1171,10 +1221,10 @@ __global__ __launch_bounds__(kBlock) void ss_phase_b_kernel(const SsArgs a) {
   for (unsigned e0 = 0; e0 < n; e0 += kBlock) {  // the only request of its target: write; else: second list
     const unsigned e = e0 + threadIdx.x;
     bool contested = false;
-    uint32_t ent = 0;
+    uint16_t ent = 0;
     if (e < n) {
       ent = list[e];
-      const int ly = (int)(ent >> 16), lx = (int)((ent >> 8) & 0xffu), q = (int)(ent & 1u);
+      const int ly = (int)(ent >> 8), lx = (int)((ent >> 1) & 0x7fu), q = (int)(ent & 1u);
       const uint32_t r = (rq[ly][lx] >> (16 * q)) & 0xffffu;
       const int code = (int)(r & 0x1fu), tly = ly + code / 5 - 2, tlx = lx + code % 5 - 2;
       const int t = (tly - 2) * kSsTW + (tlx - 2);
@@ -1188,8 +1238,8 @@ __global__ __launch_bounds__(kBlock) void ss_phase_b_kernel(const SsArgs a) {
   // no source of this tile (+ halo) had a diffusion target clamped into the image: x +- 2, y +- 2 of every source lie in [2, cols - 3] x [2, rows - 3]
   const bool interior = x0 - 4 >= 2 && x0 + kSsTW + 3 <= a.cols - 3 && y0 - 4 >= 2 && y0 + kSsBTH + 3 <= a.rows - 3;
   for (unsigned e = threadIdx.x; e < n2; e += kBlock) {
-    const uint32_t ent = list2[e];
-    const int ly = (int)(ent >> 16), lx = (int)((ent >> 8) & 0xffu), q = (int)(ent & 1u);
+    const unsigned ent = list2[e];
+    const int ly = (int)(ent >> 8), lx = (int)((ent >> 1) & 0x7fu), q = (int)(ent & 1u);
     const uint32_t r = (rq[ly][lx] >> (16 * q)) & 0xffffu;
     const int code = (int)(r & 0x1fu), tly = ly + code / 5 - 2, tlx = lx + code % 5 - 2;
     const uint32_t slot = ss_req_slot(r);
@@ -1560,21 +1610,27 @@ __global__ __launch_bounds__(kBlock) void ss_flood_kernel(const uint64_t* mbits,
 // come from memory (the neighbouring strips' words, read past the L1).  A relaxation round of the tile kernel above cost a trip
 // to memory (its launches ran 40-70 us with ten rounds each, 170 us per frame for 8 x 1080p); here the ring-seeded fill of an
 // empty 1080p mask - the common case - is complete after the first pass over the strip.  Same flags, same finish kernel.
-constexpr int kSsFloodKT = 4;  // tiles per wave: images up to 16 * 4 * 64 = 4096 rows (taller ones take ss_flood_kernel)
-__global__ __launch_bounds__(1024) void ss_flood_strip_kernel(const uint64_t* mbits, uint64_t* rbits, int rows, int W64, int* flags, int k) {
+// Round 4: NW waves per strip, KT tiles per wave.  <4, 5> (images up to 1280 rows) is the usual form: the step's timeline showed the
+// 1024-lane workgroups of <16, 4> waiting out phase B, which runs beside the chain on its own stream and keeps every CU's wave
+// slots taken with 256-lane workgroups - a quarter of a CU never fell free at once, the first strip launch ended 30 us after phase
+// B did (245 us instead of ~40; a low stream priority for phase B changed nothing).  A 256-lane workgroup takes the slots phase B's
+// workgroups leave one by one.  <16, 4>: images up to 4096 rows (taller ones take ss_flood_kernel).
+constexpr int kSsFloodKT = 4, kSsFloodKTSmall = 5, kSsFloodNWSmall = 4;
+template <int NW, int KT>
+__global__ __launch_bounds__(NW * 64) void ss_flood_strip_kernel(const uint64_t* mbits, uint64_t* rbits, int rows, int W64, int* flags, int k) {
   int* fl = flags + (size_t)blockIdx.y * kSsFloodFlags;
   if (k > 0 && fl[k - 1] == 0) return;  // converged in an earlier launch
-  __shared__ uint64_t top[16 * kSsFloodKT], bot[16 * kSsFloodKT];
+  __shared__ uint64_t top[NW * KT], bot[NW * KT];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, w = blockIdx.x;
   const int tilesY = (rows + 63) / 64;
   const size_t base = (size_t)blockIdx.y * rows * W64;
   const uint64_t* mb = mbits + base;
   uint64_t* rb = rbits + base;
   auto rd = [&](size_t idx) -> uint64_t { return __hip_atomic_load(reinterpret_cast<unsigned long long*>(rb + idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-  uint64_t m[kSsFloodKT], r[kSsFloodKT], stored[kSsFloodKT], side_seen[kSsFloodKT];
+  uint64_t m[KT], r[KT], stored[KT], side_seen[KT];
 #pragma unroll
-  for (int j = 0; j < kSsFloodKT; ++j) {
-    const int t = wave + 16 * j, y = t * 64 + lane;
+  for (int j = 0; j < KT; ++j) {
+    const int t = wave + NW * j, y = t * 64 + lane;
     const bool in = t < tilesY && y < rows;
     m[j] = in ? mb[(size_t)y * W64 + w] : 0;
     stored[j] = in ? rd((size_t)y * W64 + w) : 0;
@@ -1586,8 +1642,8 @@ __global__ __launch_bounds__(1024) void ss_flood_strip_kernel(const uint64_t* mb
     // the columns beside the strip as they stand in memory now
     bool news = round == 0;
 #pragma unroll
-    for (int j = 0; j < kSsFloodKT; ++j) {
-      const int t = wave + 16 * j, y = t * 64 + lane;
+    for (int j = 0; j < KT; ++j) {
+      const int t = wave + NW * j, y = t * 64 + lane;
       uint64_t side = 0;
       if (t < tilesY && y < rows) {
         if (w > 0 && (rd((size_t)y * W64 + w - 1) >> 63)) side |= 1ull;
@@ -1598,12 +1654,12 @@ __global__ __launch_bounds__(1024) void ss_flood_strip_kernel(const uint64_t* mb
       r[j] |= side & m[j];
     }
     if (!__syncthreads_or(news)) break;  // nothing new came in from the sides: whatever the neighbours still do is the next launch's business
-    unsigned dirty = (1u << kSsFloodKT) - 1;  // tiles that received pixels since they were last relaxed (wave-uniform)
+    unsigned dirty = (1u << KT) - 1;  // tiles that received pixels since they were last relaxed (wave-uniform)
     for (;;) {  // the strip to its fixed point: tiles to theirs, first / last rows across tile borders through LDS
       bool ch = false;
 #pragma unroll
-      for (int j = 0; j < kSsFloodKT; ++j) {
-        const int t = wave + 16 * j;
+      for (int j = 0; j < KT; ++j) {
+        const int t = wave + NW * j;
         if (t < tilesY && ((dirty >> j) & 1u)) {  // (wave-uniform)
           if (__all(m[j] == ~0ull) && __any(r[j] != 0)) {
             r[j] = ~0ull;  // an empty 64 x 64 tile with a reached pixel anywhere: all of it (the common case, no scan needed)
@@ -1622,8 +1678,8 @@ __global__ __launch_bounds__(1024) void ss_flood_strip_kernel(const uint64_t* mb
       dirty = 0;
       __syncthreads();
 #pragma unroll
-      for (int j = 0; j < kSsFloodKT; ++j) {
-        const int t = wave + 16 * j;
+      for (int j = 0; j < KT; ++j) {
+        const int t = wave + NW * j;
         if (t < tilesY) {
           uint64_t v = 0;
           if (lane == 0 && t > 0) v = bot[t - 1];
@@ -1637,8 +1693,8 @@ __global__ __launch_bounds__(1024) void ss_flood_strip_kernel(const uint64_t* mb
     }
     bool grew = false;
 #pragma unroll
-    for (int j = 0; j < kSsFloodKT; ++j) {
-      const int t = wave + 16 * j, y = t * 64 + lane;
+    for (int j = 0; j < KT; ++j) {
+      const int t = wave + NW * j, y = t * 64 + lane;
       if (t < tilesY && y < rows && r[j] != stored[j]) {
         __hip_atomic_store(reinterpret_cast<unsigned long long*>(rb + (size_t)y * W64 + w), r[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         stored[j] = r[j], grew = true;
