@@ -448,11 +448,13 @@ def test_round2_forms_of_the_round3_kernels_still_match(golden_frames):
     assert r.returncode == 0 and "round-2 forms OK" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("knob", ["BGS_SS_FEEDBACK_SPLIT", "BGS_SS_QUEUE"])
+@pytest.mark.parametrize("knob", ["BGS_SS_FEEDBACK_SPLIT=1", "BGS_SS_QUEUE=1", "BGS_SS_IPASS_MIN=1 BGS_SS_FLOOD_WG1024=1 BGS_SS_B_LATE=1", "BGS_SS_IPASS_MIN=48 BGS_SS_REFILL=4"])
 def test_subsense_round4_forms_behind_knobs_match_the_oracle(knob):
     """Round 4 built the two restructurings of phase A the verdict asked for - the rules behind the loop as a kernel of their own
     (BGS_SS_FEEDBACK_SPLIT=1) and the inter-LBSP tests worked off a per-wave list by whichever lane is free (BGS_SS_QUEUE=1) - measured
-    both slower than the form that runs by default and kept them as A/B knobs.  Knobs are read once per process: one
+    both slower than the form that runs by default and kept them as A/B knobs.  Also behind knobs: the inter-LBSP passes
+    taken at once (BGS_SS_IPASS_MIN=1, round 3's form; the default puts off a pass that fewer than 16 lanes would join) or put off
+    until 48 lanes join, the flood strips in 1024-lane workgroups, phase B started behind the flood fill.  Knobs are read once per process: one
     child process each, same masks, backgrounds and whole model as the oracle incl. a scene cut (model reset) and a large frame."""
     import subprocess
     import sys
@@ -471,7 +473,7 @@ def test_subsense_round4_forms_behind_knobs_match_the_oracle(knob):
             "eng, orc, _ = run_pair(capi.SUBSENSE, g)\n"
             "check_subsense_state(eng, orc, 360, 640)\n"
             "print('knob form OK')\n") % (os.path.dirname(here), here, os.path.join(here, "golden", "frames_96x80.npz"))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{knob: "1"}), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **dict(kv.split("=") for kv in knob.split())), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "knob form OK" in r.stdout, r.stdout + r.stderr
 
 

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <atomic>
@@ -52,6 +53,32 @@ int fail(int code, const char* fmt, ...) {
   } while (0)
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// Device -> pageable host memory (bgs_get_state, the blob lists): through a page-locked bounce buffer of the library's own, never
+// hipMemcpy straight into the caller's memory.  For copies past a size threshold the HIP runtime page-locks the caller's buffer on the
+// fly and KEEPS the last eight such mappings, looked up by host ADDRESS (ROCclr: hsaCopyStagedOrPinned -> pinHostMemory / addPinnedMem
+// / findPinnedMem).  A caller that frees such a buffer and gets the same address back from the next allocation - numpy does, for every
+// array past malloc's mmap threshold - is served the stale mapping, and the copy engine then writes through pages that are gone:
+// round 4's GPU suite died twice that way (rocr::core::Runtime::VMFaultHandler -> abort while a test read a model plane back,
+// profiles/r04_vmfault_backtrace.txt), in different tests, with no kernel of this library running.  A page-locked destination takes
+// the direct path.  One buffer per process, serialised: these are diagnostics and small result lists, not the frame path (bgs_process
+// stages through the engine's own page-locked images).
+int d2h_staged(void* dst, const void* src, size_t bytes) {
+  static std::mutex mu;
+  static uint8_t* bounce = nullptr;
+  constexpr size_t kBounce = (size_t)4 << 20;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!bounce && hipHostMalloc((void**)&bounce, kBounce, hipHostMallocPortable) != hipSuccess) {
+    bounce = nullptr;
+    return fail(BGS_ERR_HIP, "hipHostMalloc of the read-back buffer failed");
+  }
+  for (size_t o = 0; o < bytes; o += kBounce) {
+    const size_t n = std::min(kBounce, bytes - o);
+    if (hipMemcpy(bounce, (const uint8_t*)src + o, n, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy (device to host) failed");
+    std::memcpy((uint8_t*)dst + o, bounce, n);
+  }
+  return BGS_OK;
+}
 inline unsigned blocks_for(size_t groups) { return (unsigned)((groups + bgs::kBlock - 1) / bgs::kBlock); }
 
 }  // namespace
@@ -1732,7 +1759,7 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
   const int C = e->ch;
   auto copy_bytes = [&](const uint8_t* src, size_t nb) -> int64_t {
     if (cap < nb) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
-    if (hipMemcpy(dst, src, nb, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+    if (d2h_staged(dst, src, nb) != BGS_OK) return fail(BGS_ERR_HIP, "hipMemcpy failed");
     return (int64_t)nb;
   };
   if (!strcmp(plane, "hostpath")) {  // diagnostics of bgs_process / bgs_submit since creation: 15 doubles (see bench.py host_path)
@@ -1767,7 +1794,7 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
       const size_t T = bgs::kMog2Tile, TB = bgs::kMog2TileBytes;
       const size_t t0 = off / T, t1 = (off + n + T - 1) / T;
       std::vector<uint8_t> tiles((t1 - t0) * TB);
-      if (hipMemcpy(tiles.data(), e->mog2_state + t0 * TB, tiles.size(), hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+      if (d2h_staged(tiles.data(), e->mog2_state + t0 * TB, tiles.size()) != BGS_OK) return fail(BGS_ERR_HIP, "hipMemcpy failed");
       for (size_t i = 0; i < n; ++i) {
         const size_t sp = off + i, in = sp % T;
         const uint8_t* tb = tiles.data() + (sp / T - t0) * TB;
@@ -1804,7 +1831,7 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
   if (e->algo == BGS_GMG && e->gmg_rec) {  // canonical: colors int32 [F][n], weights f32 [F][n] (entries past the count exported as 0), nfeatures int32 [n]
     const size_t F = (size_t)e->p.gmg_max_features;
     std::vector<uint8_t> nf(n);
-    if (hipMemcpy(nf.data(), e->gmg_nfeat + off, n, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+    if (d2h_staged(nf.data(), e->gmg_nfeat + off, n) != BGS_OK) return fail(BGS_ERR_HIP, "hipMemcpy failed");
     if (!strcmp(plane, "nfeatures")) {
       if (cap < n * 4) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
       for (size_t i = 0; i < n; ++i) ((int32_t*)dst)[i] = nf[i];
@@ -1815,7 +1842,7 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
       const int which = !strcmp(plane, "colors") ? 0 : 1;  // the device holds {colour, weight} records (kernel_gmg.h)
       std::vector<uint32_t> recs(n * 2);
       for (size_t f = 0; f < F; ++f) {
-        if (hipMemcpy(recs.data(), e->gmg_rec + f * P + off, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+        if (d2h_staged(recs.data(), e->gmg_rec + f * P + off, n * 8) != BGS_OK) return fail(BGS_ERR_HIP, "hipMemcpy failed");
         for (size_t i = 0; i < n; ++i) ((uint32_t*)dst)[f * n + i] = f >= nf[i] ? 0u : recs[2 * i + which];
       }
       return (int64_t)(n * F * 4);
@@ -1833,7 +1860,7 @@ int64_t bgs_get_state(bgs_engine* e, int stream, const char* plane, void* dst, s
       if (cap < need) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
       const size_t T = bgs::kMog1Tile, TF = C == 3 ? bgs::mog1_tile_floats<3>() : bgs::mog1_tile_floats<1>(), t0 = off / T, t1 = (off + n + T - 1) / T;
       std::vector<float> tiles((t1 - t0) * TF);
-      if (hipMemcpy(tiles.data(), e->mog1_state + t0 * TF, tiles.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+      if (d2h_staged(tiles.data(), e->mog1_state + t0 * TF, tiles.size() * 4) != BGS_OK) return fail(BGS_ERR_HIP, "hipMemcpy failed");
       for (size_t i = 0; i < n; ++i) {
         const size_t sp = off + i, l = sp % T;
         const float* tb = tiles.data() + (sp / T - t0) * TF;
@@ -2231,8 +2258,8 @@ int bgs_last_mask_blobs(bgs_engine* e, int stream, int connectivity, int min_w, 
   std::vector<bgs_box> hb((size_t)n);
   std::vector<bgs_moments> hm((size_t)n);
   if (n) {
-    HIP_TRY(hipMemcpy(hb.data(), d_boxes, (size_t)n * sizeof(bgs_box), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(hm.data(), d_mom, (size_t)n * sizeof(bgs_moments), hipMemcpyDeviceToHost));
+    { const int rc__ = d2h_staged(hb.data(), d_boxes, (size_t)n * sizeof(bgs_box)); if (rc__ != BGS_OK) return rc__; }
+    { const int rc__ = d2h_staged(hm.data(), d_mom, (size_t)n * sizeof(bgs_moments)); if (rc__ != BGS_OK) return rc__; }
   }
   int kept = 0;
   for (int i = 0; i < n; ++i) {

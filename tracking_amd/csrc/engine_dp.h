@@ -102,7 +102,7 @@ int64_t dp_export_planes(bgs_engine* e, int stream, int planes, void* dst, size_
   if (cap < (size_t)planes * n * 4) return fail(BGS_ERR_STATE, "buffer too small for %d planes", planes);
   const size_t t0 = g0 / T, t1 = (g0 + n - 1) / T + 1, TF = (size_t)planes * T;
   std::vector<float> tiles((t1 - t0) * TF);
-  if (hipMemcpy(tiles.data(), e->dp_state + t0 * TF, tiles.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+  if (d2h_staged(tiles.data(), e->dp_state + t0 * TF, tiles.size() * 4) != BGS_OK) return fail(BGS_ERR_HIP, "hipMemcpy failed");
   for (int q = 0; q < planes; ++q)
     for (size_t i = 0; i < n; ++i) {
       const size_t g = g0 + i;

@@ -432,7 +432,7 @@ int64_t bgs_group_get_state(bgs_group* g, int index, int stream, const char* pla
   }
   if (!src) return fail(BGS_ERR_STATE, "unknown state plane '%s' for class %d of the group", plane, index);
   if (cap < nb) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
-  if (hipMemcpy(dst, src + off, nb, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+  if (d2h_staged(dst, src + off, nb) != BGS_OK) return fail(BGS_ERR_HIP, "hipMemcpy failed");
   return (int64_t)nb;
 }
 

@@ -268,14 +268,15 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
   // Round 4: the per-pixel rules behind the loop (:498-576) are ss_feedback_kernel; it produces the update requests phase B applies, so
   // it goes in front of phase B on the side stream - both beside the post-processing chain, which only needs phase A's `raw`.
   const dim3 gridF((e->cols + bgs::kBlock - 1) / bgs::kBlock, e->rows, count);
-  // WHERE phase B starts (round 4).  Rounds 2-3 started it right behind phase A.  The timeline of an 8 x 1080p step on the aged model
-  // (profiles/r04_subsense_step_timeline.txt): phase B alone 368 us, the chain alone 288 us, both together 600 - 640 us, hardly better
-  // than one after the other.  The chain's first half is a string of small, latency-bound launches up to the flood fill (its strip
-  // kernel walks the image in rounds of memory round trips): beside phase B's ~8 M scattered 16-byte writes each of them took four to
-  // five times as long (the first strip launch 224 us instead of 43) and the chain ended when phase B did.  So phase B now starts
-  // BEHIND the flood fill: the first half runs alone (~110 us), the second half (box filters, median, the byte maps: streaming
-  // kernels) beside phase B.  BGS_SS_B_EARLY=1: the old order (A/B knob).
-  static const bool b_early = getenv("BGS_SS_B_EARLY") && atoi(getenv("BGS_SS_B_EARLY")) == 1;
+  // WHERE phase B starts.  The timeline of an 8 x 1080p step on the aged model (round 4, profiles/r04_subsense_step_timeline.txt):
+  // phase B alone 368 us, the chain alone 288 us, both together 600 - 640 us - hardly better than one after the other.  Beside phase
+  // B's ~8 M scattered 16-byte writes (DRAM row activations) every launch of the chain takes four to five times as long
+  // and phase B itself 10 - 20 % longer.  Tried: the lowest stream priority for the side stream (no change); 256-lane instead of
+  // 1024-lane workgroups for the flood strips (kept; 250 -> 224 us beside phase B, 43 us alone either way); and phase B started
+  // BEHIND the flood fill, so that the chain's latency-bound first half runs alone (BGS_SS_B_LATE=1): the second half (median, box
+  // filters, byte maps) then takes the slowdown instead - median 21 -> 170 - 250 us - and the step is the same or 2 % longer.  The
+  // two share DRAM, not compute; the default stays phase B right behind phase A.
+  static const bool b_early = !(getenv("BGS_SS_B_LATE") && atoi(getenv("BGS_SS_B_LATE")) == 1);
   auto launch_b = [&]() -> int {
     if (overlap) {
       HIP_TRY(hipEventRecord(d->evA, s));
@@ -408,7 +409,7 @@ int64_t ss_get_state(bgs_engine* e, int stream, const char* plane, void* dst, si
   for (const Ent& t : tab)
     if (!strcmp(plane, t.name)) {
       if (cap < t.bytes) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
-      if (hipMemcpy(dst, t.p, t.bytes, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+      if (d2h_staged(dst, t.p, t.bytes) != BGS_OK) return fail(BGS_ERR_HIP, "hipMemcpy failed");
       return (int64_t)t.bytes;
     }
   if (!strcmp(plane, "color") || !strcmp(plane, "desc")) {  // canonical export: color u8 [nS][N][C], desc u16 [nS][N][C], whatever the record layout
@@ -417,7 +418,7 @@ int64_t ss_get_state(bgs_engine* e, int stream, const char* plane, void* dst, si
     if (cap < need) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
     const size_t per = d->pixelMajor ? (size_t)d->nSpad : nS;  // records per pixel held on the device
     std::vector<uint8_t> recs(N * per * recB);
-    if (hipMemcpy(recs.data(), (const uint8_t*)d->samples + off * per * recB, recs.size(), hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+    if (d2h_staged(recs.data(), (const uint8_t*)d->samples + off * per * recB, recs.size()) != BGS_OK) return fail(BGS_ERR_HIP, "hipMemcpy failed");
     for (size_t k = 0; k < nS; ++k)
       for (size_t px = 0; px < N; ++px) {  // export: [nS][N][C], whatever the device order
         const size_t B = bgs::kSsBatch;  // same mapping as ss_rec (kernel_subsense.h)
@@ -436,18 +437,18 @@ int64_t ss_get_state(bgs_engine* e, int stream, const char* plane, void* dst, si
     if (e->algo != BGS_SUBSENSE) return fail(BGS_ERR_STATE, "floodflags: SuBSENSE only");
     const size_t nb = (size_t)bgs::kSsFloodFlags * sizeof(int);
     if (cap < nb) return fail(BGS_ERR_STATE, "buffer too small for plane floodflags");
-    if (hipMemcpy(dst, d->flood_flags + (size_t)stream * bgs::kSsFloodFlags, nb, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+    if (d2h_staged(dst, d->flood_flags + (size_t)stream * bgs::kSsFloodFlags, nb) != BGS_OK) return fail(BGS_ERR_HIP, "hipMemcpy failed");
     return (int64_t)nb;
   }
   if (!strcmp(plane, "magic") && d->magic) {  // ss_mod's table (kernel_subsense.h), for the test that checks it against plain integer division
     if (cap < bgs::kSsMagicN * 4) return fail(BGS_ERR_STATE, "buffer too small for plane %s", plane);
-    if (hipMemcpy(dst, d->magic, bgs::kSsMagicN * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+    if (d2h_staged(dst, d->magic, bgs::kSsMagicN * 4) != BGS_OK) return fail(BGS_ERR_HIP, "hipMemcpy failed");
     return bgs::kSsMagicN * 4;
   }
   if (!strcmp(plane, "scalars")) {
     if (cap < 7 * sizeof(double)) return fail(BGS_ERR_STATE, "buffer too small for plane scalars");
     bgs::SsScalars sc;
-    if (hipMemcpy(&sc, d->sc + stream, sizeof(sc), hipMemcpyDeviceToHost) != hipSuccess) return fail(BGS_ERR_HIP, "hipMemcpy failed");
+    if (d2h_staged(&sc, d->sc + stream, sizeof(sc)) != BGS_OK) return fail(BGS_ERR_HIP, "hipMemcpy failed");
     double* o = (double*)dst;
     o[0] = (double)e->seen[stream], o[1] = sc.framesSinceReset, o[2] = sc.cooldown, o[3] = sc.capLo, o[4] = sc.capHi, o[5] = sc.autoReset, o[6] = sc.lastNZ;
     return 7 * sizeof(double);

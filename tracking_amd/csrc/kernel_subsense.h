@@ -1165,9 +1165,10 @@ __global__ __launch_bounds__(kBlock) void ss_phase_b_kernel(const SsArgs a) {
   if (threadIdx.x == 0) nlist = 0, nlist2 = 0;
   cnt[threadIdx.x] = 0;
   __syncthreads();
-  // Round 4: a workgroup's requests are loaded in ONE go.  The loop below used to load its dword at the top of each of its six trips and
-  // then ballot on it: six memory round trips in a row per workgroup, and with ~5 workgroups resident per CU (LDS) the launch took
-  // 0.25 ms on 8 x 1080p even when hardly any pixel made a request (the step's timeline: phase B is the longest thing behind phase A).
+  // Round 4: a workgroup's requests are loaded in ONE go (the loop below used to load its dword at the top of each of its six trips and
+  // then ballot on it: six memory round trips in a row) and the lists hold 16-bit entries (28 -> 17 KB of LDS: 8 instead of 5
+  // workgroups per CU).  Neither moved the launch time on the aged model (0.37 - 0.41 ms on 8 x 1080p): it is the ~8 M scattered
+  // 16-byte writes, i.e. DRAM row activations, that take the time, not the waves' latency chains.
   constexpr int NT = (HH * HW + kBlock - 1) / kBlock;
   uint32_t vv[NT];
 #pragma unroll
@@ -1610,11 +1611,11 @@ __global__ __launch_bounds__(kBlock) void ss_flood_kernel(const uint64_t* mbits,
 // come from memory (the neighbouring strips' words, read past the L1).  A relaxation round of the tile kernel above cost a trip
 // to memory (its launches ran 40-70 us with ten rounds each, 170 us per frame for 8 x 1080p); here the ring-seeded fill of an
 // empty 1080p mask - the common case - is complete after the first pass over the strip.  Same flags, same finish kernel.
-// Round 4: NW waves per strip, KT tiles per wave.  <4, 5> (images up to 1280 rows) is the usual form: the step's timeline showed the
-// 1024-lane workgroups of <16, 4> waiting out phase B, which runs beside the chain on its own stream and keeps every CU's wave
-// slots taken with 256-lane workgroups - a quarter of a CU never fell free at once, the first strip launch ended 30 us after phase
-// B did (245 us instead of ~40; a low stream priority for phase B changed nothing).  A 256-lane workgroup takes the slots phase B's
-// workgroups leave one by one.  <16, 4>: images up to 4096 rows (taller ones take ss_flood_kernel).
+// Round 4: NW waves per strip, KT tiles per wave.  <4, 5> (images up to 1280 rows) is the usual form: 240 workgroups of 256 lanes for
+// 8 x 1080p find wave slots beside phase B (which runs on its own stream at the same time) more easily than 1024-lane ones - the
+// first strip launch 224 instead of 250 us there, 43 us alone either way; what slows it beside phase B is its rounds of memory
+// round trips queueing behind phase B's scattered writes (engine_subsense.h).  <16, 4>: images up to 4096 rows (taller ones take
+// ss_flood_kernel); BGS_SS_FLOOD_WG1024=1 forces it for every height (tests).
 constexpr int kSsFloodKT = 4, kSsFloodKTSmall = 5, kSsFloodNWSmall = 4;
 template <int NW, int KT>
 __global__ __launch_bounds__(NW * 64) void ss_flood_strip_kernel(const uint64_t* mbits, uint64_t* rbits, int rows, int W64, int* flags, int k) {
