@@ -567,6 +567,12 @@ def main():
     if args.only == "subsense8":
         run_subsense(8)
         return
+    if args.only == "driverconfigs":  # the configs[2] / configs[3] block exactly as bench.py puts it into the driver's line (no CPU legs): A/B scripts
+        out = configs_block(S=S, cpu=False)
+        c3 = out["configs3_subsense_1080p"]
+        for k in ("young_model", "aged_model"):
+            print("driver configs3 SuBSENSE %-11s %.4f ms/step wall, phase A %.4f ms, fg ratio %.4f" % (k, c3[k]["ms_per_step_wall"], c3[k]["dominant_kernel_avg_ms"], c3[k]["foreground_ratio"]))
+        return
     if args.only == "subsense8both":  # young and aged model in one process (A/B scripts)
         run_subsense(8)
         run_subsense(8, warm=300)
