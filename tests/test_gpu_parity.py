@@ -427,7 +427,8 @@ def test_subsense_flood_fill_finish_kernel_path(golden_frames, tmp_path):
 def test_round2_forms_of_the_round3_kernels_still_match(golden_frames):
     """Round 3 replaced several kernels and kept the earlier forms behind knobs that are read once per process (A/B builds, and the
     fallbacks for geometries the new forms do not take): SuBSENSE with the self updates in phase B, the tile flood fill and the
-    LDS-count median; AdaptiveSelectiveBackgroundLearning through the LDS-tile kernel.  One child process with all of them set:
+    LDS-count median; AdaptiveSelectiveBackgroundLearning through the LDS-tile kernel; LOBSTER's phase A with one pixel per lane in lock
+    step (round 4 feeds the lanes from a queue).  One child process with all of them set:
     same masks, backgrounds and models as the oracle."""
     import subprocess
     import sys
@@ -442,8 +443,11 @@ def test_round2_forms_of_the_round3_kernels_still_match(golden_frames):
             "eng, orc, _ = run_pair(capi.SUBSENSE, g)\n"
             "check_subsense_state(eng, orc, 240, 320)\n"
             "run_pair(capi.ASBL, synth.random_frames(8, 40, 300, 3, seed=2))\n"
+            "from gpu_helpers import check_lobster_state\n"
+            "eng, orc, _ = run_pair(capi.LOBSTER, g)\n"
+            "check_lobster_state(eng, orc, 240, 320)\n"
             "print('round-2 forms OK')\n") % (os.path.dirname(here), here, os.path.join(here, "golden", "frames_96x80.npz"))
-    env = dict(os.environ, BGS_SS_SELF_IN_A="0", BGS_SS_FLOOD_TILES="1", BGS_SS_MEDIAN_BITS="0", BGS_ASBL_TABLE="0")
+    env = dict(os.environ, BGS_SS_SELF_IN_A="0", BGS_SS_FLOOD_TILES="1", BGS_SS_MEDIAN_BITS="0", BGS_ASBL_TABLE="0", BGS_LOB_QUEUE="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "round-2 forms OK" in r.stdout, r.stdout + r.stderr
 

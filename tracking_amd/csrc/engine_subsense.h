@@ -489,6 +489,8 @@ void lob_fill_args(const bgs_engine* e, bgs::SsArgs& a, int first, unsigned fram
   a.rows = e->rows, a.cols = e->cols, a.nS = p.subsense_n_samples, a.nReq = p.subsense_n_required;
   a.nMinColor = p.subsense_min_color_dist_threshold, a.nDescOff = p.subsense_desc_dist_threshold_offset;
   a.frameIndex = frameIndex, a.first = first;
+  static const int refill = getenv("BGS_LOB_REFILL") ? std::max(1, std::min(64, atoi(getenv("BGS_LOB_REFILL")))) : bgs::kSsRefill;  // tuning knob (lob_phase_a_queue_kernel)
+  a.refill = refill;
 }
 
 int lob_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uint8_t* d_fg, uint8_t* d_bg, hipStream_t s, int64_t t) {
@@ -529,8 +531,15 @@ int lob_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, ui
   const dim3 tiles((e->cols + bgs::kSsTW - 1) / bgs::kSsTW, (e->rows + bgs::kSsTH - 1) / bgs::kSsTH, count);
   const dim3 tilesB((e->cols + bgs::kSsTW - 1) / bgs::kSsTW, (e->rows + bgs::kSsBTH - 1) / bgs::kSsBTH, count);
   {
+    // round 4: lanes fed from a queue (kernel_subsense.h); BGS_LOB_QUEUE=0: one pixel per lane in lock step (rounds 1-3; A/B and test knob)
+    static const bool queue = !(getenv("BGS_LOB_QUEUE") && atoi(getenv("BGS_LOB_QUEUE")) == 0);
     Timed tm(e, s, "lob_phase_a_kernel");
-    SS_LAUNCH(lob_phase_a_kernel, tiles, block, s, a);
+    if (queue) {
+      const dim3 tilesQ((e->cols + bgs::kSsTW - 1) / bgs::kSsTW, (e->rows + bgs::kLobATH - 1) / bgs::kLobATH, count);
+      SS_LAUNCH(lob_phase_a_queue_kernel, tilesQ, block, s, a);
+    } else {
+      SS_LAUNCH(lob_phase_a_kernel, tiles, block, s, a);
+    }
   }
   SS_LAUNCH(ss_phase_b_kernel, tilesB, block, s, a);
   uint8_t* lastFG = d->u8[SS_LASTFG] + off;

@@ -1098,6 +1098,188 @@ __global__ __launch_bounds__(kBlock) void lob_phase_a_kernel(const SsArgs a) {
   a.req[i * 2] = reqSelf, a.req[i * 2 + 1] = reqNbr;
 }
 
+// Round 4: LOBSTER's phase A with the LANES FED FROM A QUEUE (the form SuBSENSE's phase A took in round 2).  lob_phase_a_kernel above
+// gives every lane one pixel and walks the samples in lock step: a wave runs as many trips as its slowest pixel needs, and on a scene
+// with a few percent of foreground nearly every wave holds a pixel that matches nothing and walks all 35 samples (8 x 1080p, S_surv:
+// 2.36 - 2.53 ms although the average pixel tests six).  Here a workgroup owns a 64 x 16 tile (four pixels per lane), a lane that has
+// finished its pixel takes the next one from the tile's queue, and a trip tests one sample per active lane: the cheap part (colour
+// distances, exact: a sample matches only if EVERY test of :192-205 / :241-258 passes, so their order is free) for everybody, the
+// inter-LBSP part only when some lane's sample got that far.  What a pixel leaves behind is its match count in LDS; the update
+// requests and the colour / descriptor a requesting pixel hands to phase B are made afterwards, densely, for the whole tile.
+// Same results as lob_phase_a_kernel (BGS_LOB_QUEUE=0), whole-model parity tests.
+constexpr int kLobATH = 16;
+template <int C>
+__global__ __launch_bounds__(kBlock) void lob_phase_a_queue_kernel(const SsArgs a) {
+  constexpr int ATH = kLobATH, APIX = kSsTW * ATH, PPL = APIX / kBlock;
+  constexpr int HW = kSsTW + 4, HH = ATH + 4;
+  constexpr int ROWB = (HW * C + 3 + 3) / 4 * 4;
+  constexpr uint32_t kLearningRate = 16;
+  __shared__ uint32_t tile[HH][ROWB / 4];
+  __shared__ uint8_t lut[256];
+  __shared__ uint8_t res[APIX];  // matches found for the pixel (stage 2 -> stage 3)
+  __shared__ unsigned qhead;
+  const int stream = a.first + blockIdx.z;
+  const size_t N = (size_t)a.rows * a.cols, sN = (size_t)stream * N;
+  const uint8_t* img = a.frame + (size_t)blockIdx.z * N * C;
+  const int x0 = blockIdx.x * kSsTW, y0 = blockIdx.y * ATH;
+  const long imgsz = (long)N * C, rb = (long)(x0 - 2) * C;
+  for (int i = threadIdx.x; i < HH * (ROWB / 4); i += kBlock) {
+    const int ry = i / (ROWB / 4), rd = i - ry * (ROWB / 4);
+    const int y = min(max(y0 + ry - 2, 0), a.rows - 1);
+    const long off = (((long)y * a.cols * C + rb) & ~3L) + 4L * rd;
+    uint32_t v = 0;
+    if (off >= 0 && off + 4 <= imgsz)
+      v = *reinterpret_cast<const uint32_t*>(img + off);
+    else if (off < imgsz && off + 4 > 0)
+      for (int b = 0; b < 4; ++b)
+        if (off + b >= 0 && off + b < imgsz) v |= (uint32_t)img[off + b] << (8 * b);
+    tile[ry][rd] = v;
+  }
+  lut[threadIdx.x] = a.lut[(size_t)stream * 256 + threadIdx.x];
+  if (threadIdx.x == 0) qhead = 0;
+  __syncthreads();
+  const int rowShift0 = (int)(((long)(y0 - 2) * a.cols * C + rb) & 3L), rowShiftStep = (a.cols * C) & 3;
+  auto gather = [&](int ly, int lx, int (&cur)[C], uint32_t (&nb)[C][8]) {
+    LbspWin<C> win;
+    win.load(&tile[0][0], ROWB / 4, ly, lx, rowShift0, rowShiftStep);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      cur[c] = win.centre(c);
+      win.pack(c, nb[c]);
+    }
+  };
+  auto interior_of = [&](int x, int y) { return x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2; };  // LBSP::validateROI
+  const uint32_t colorThr = (uint32_t)a.nMinColor, descThr = (uint32_t)a.nDescOff;
+  const uint32_t descThr3 = descThr * 3, colorThr3 = colorThr * 3, scDesc = descThr3 / 2, scColor = colorThr3 / 2;  // :225-228
+  const size_t rstep = a.pixelMajor ? 1 : N;
+
+  // ---- stage 2: the sample loop (:192-205 gray / :241-258 BGR), lanes fed from the queue
+  {
+    const int lane = threadIdx.x & (kWave - 1);
+    bool active = false, qempty = false;
+    int q = 0, idx = 0, good = 0;
+    int cur[C];
+    uint32_t nb[C][8];
+    uint32_t curm[C];
+    size_t rec = ss_rec(a, stream, N, 0, 0);  // (a valid record for lanes that never get a pixel: their loads are unconditional)
+    SsSample<C> smp = SsSample<C>{}, nsmp = SsSample<C>{};
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      cur[c] = 0, curm[c] = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) nb[c][k] = 0;
+    }
+    for (;;) {
+      const unsigned long long idle = __ballot(!active);
+      const int nidle = __popcll(idle);
+      if (qempty && nidle == kWave) break;
+      if (!qempty && nidle >= a.refill) {  // wave-uniform
+        const int leader = __ffsll((long long)idle) - 1;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(&qhead, (unsigned)nidle);
+        base = (unsigned)__shfl((int)base, leader);
+        if (base + (unsigned)nidle >= (unsigned)APIX) qempty = true;
+        if (!active) {
+          const unsigned my = base + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+          const int lx = (int)(my % kSsTW), ly = (int)(my / kSsTW);
+          if (my < (unsigned)APIX && interior_of(x0 + lx, y0 + ly)) {
+            q = (int)my;
+            gather(ly, lx, cur, nb);
+#pragma unroll
+            for (int c = 0; c < C; ++c) curm[c] = (uint32_t)cur[c] << (8 * c);
+            rec = ss_rec(a, stream, N, (size_t)(y0 + ly) * a.cols + (x0 + lx), 0);
+            smp = SsSample<C>::load(a.samples, rec);
+            idx = 0, good = 0;
+            active = true;
+          }
+        }
+      }
+      // sample idx + 1 is in flight while idx is tested (the loaded registers must BE nsmp for the load to stay in flight)
+      rec += (active && idx + 1 < a.nS) ? rstep : 0;
+      nsmp = SsSample<C>::load(a.samples, rec);
+      bool cand = false;
+      if (active) {
+        if constexpr (C == 1) {
+          cand = (uint32_t)abs(cur[0] - smp.color(0)) <= colorThr / 2;
+        } else {
+          const uint32_t sx = smp.v.x;
+          const uint32_t c0 = __builtin_amdgcn_sad_u8(curm[0], sx & 0x0000ffu, 0u), c1 = __builtin_amdgcn_sad_u8(curm[1], sx & 0x00ff00u, 0u),
+                         c2 = __builtin_amdgcn_sad_u8(curm[2], sx & 0xff0000u, 0u);
+          cand = max(max(c0, c1), c2) <= scColor && c0 + c1 + c2 <= colorThr3;
+        }
+      }
+      if (__any(cand)) {  // wave-uniform: the expensive part only when some lane's sample got this far
+        if (cand) {
+          if constexpr (C == 1) {
+            const int bcc = smp.color(0);
+            const unsigned inter = ss_lbsp(nb[0], bcc, lut[bcc]);
+            if ((uint32_t)__popc(inter ^ smp.desc(0)) <= descThr) good++;
+          } else {
+            uint32_t totD = 0;
+            bool ok = true;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const int bcc = smp.color(c);
+              const unsigned inter = ss_lbsp(nb[c], bcc, lut[bcc]);
+              const uint32_t dd = (uint32_t)__popc(inter ^ smp.desc(c));
+              ok = ok && dd <= scDesc;
+              totD += dd;
+            }
+            if (ok && totD <= descThr3) good++;
+          }
+        }
+      }
+      if (active) {
+        idx++;
+        if (good >= a.nReq || idx >= a.nS) {
+          res[q] = (uint8_t)good;
+          active = false;
+        }
+      }
+      ss_wait_here(nsmp);
+      smp = nsmp;
+    }
+  }
+  __syncthreads();
+
+  // ---- stage 3: the segmentation and the update requests (:207-222 / :260-279), every pixel of the tile
+#pragma unroll 1
+  for (int r = 0; r < PPL; ++r) {
+    const int qq = r * kBlock + threadIdx.x, lx = qq % kSsTW, ly = qq / kSsTW;
+    const int x = x0 + lx, y = y0 + ly;
+    const bool inimg = x < a.cols && y < a.rows, in = inimg && interior_of(x, y);
+    const size_t p = (size_t)(inimg ? y : 0) * a.cols + (inimg ? x : 0), i = sN + p;
+    uint16_t reqSelf = 0, reqNbr = 0;
+    const int good = in ? (int)res[qq] : 0;
+    if (in && good >= a.nReq) {
+      const uint32_t fr = a.frameIndex, pi = (uint32_t)p;
+      if ((ss_rand(fr, pi, 0) % kLearningRate) == 0) reqSelf = ss_req(ss_rand(fr, pi, 1) % (uint32_t)a.nS, 12);  // :209-214 / :262-269
+      if ((ss_rand(fr, pi, 2) % kLearningRate) == 0) {                                                             // :215-222 / :270-279
+        const int rr = (int)(ss_rand(fr, pi, 3) % 8u);
+        const int xn = min(max(x + kSsN3[rr][0], 2), a.cols - 3), yn = min(max(y + kSsN3[rr][1], 2), a.rows - 3);
+        reqNbr = ss_req(ss_rand(fr, pi, 4) % (uint32_t)a.nS, (yn - y + 2) * 5 + (xn - x + 2));
+      }
+    }
+    const bool need = (reqSelf | reqNbr) != 0;
+    if (__any(need)) {  // what a requesting pixel will write: its current colour and intra descriptor
+      int cur[C];
+      uint32_t nb[C][8];
+      gather(min(ly, ATH - 1), lx, cur, nb);
+      if (need) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          a.lastColor[i * C + c] = (uint8_t)cur[c];
+          a.lastDesc[i * C + c] = (uint16_t)ss_lbsp(nb[c], cur[c], lut[cur[c]]);
+        }
+      }
+    }
+    if (inimg) {
+      a.raw[i] = (in && good < a.nReq) ? 255 : 0;  // :207 / :260; outside LBSP::validateROI: never foreground, never updated
+      a.req[i * 2] = reqSelf, a.req[i * 2 + 1] = reqNbr;
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------------------------- phase B
 // Applies the sample writes phase A decided, in the reference's order: sources in raster order, a source's self update before its
 // neighbour diffusion, a later write to the same (pixel, sample slot) replacing an earlier one.
