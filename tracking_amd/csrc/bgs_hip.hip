@@ -2374,29 +2374,42 @@ int bgs_ingest_host(int hip_device, const bgs_ingest* c, const uint8_t* src, int
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(BGS_ERR_HIP, "no HIP device visible: libbgs_hip has no CPU path");
   HIP_TRY(hipSetDevice(hip_device));
   const size_t in_bytes = (size_t)src_rows * src_cols * channels, out_bytes = (size_t)pl.rows * out_row, ws = bgs_ingest_workspace(c, 1, src_rows, src_cols, channels);
-  uint8_t *d_in = nullptr, *d_out = nullptr, *d_ws = nullptr;
+  uint8_t *d_in = nullptr, *d_out = nullptr, *d_ws = nullptr, *h_in = nullptr, *h_out = nullptr;
   hipStream_t s = nullptr;
   auto cleanup = [&]() {
     if (d_in) (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);
     if (d_ws) (void)hipFree(d_ws);
+    if (h_in) (void)hipHostFree(h_in);
+    if (h_out) (void)hipHostFree(h_out);
     if (s) (void)hipStreamDestroy(s);
   };
   hipError_t er = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
   if (er == hipSuccess) er = hipMalloc((void**)&d_in, in_bytes);
   if (er == hipSuccess) er = hipMalloc((void**)&d_out, out_bytes);
   if (er == hipSuccess && ws) er = hipMalloc((void**)&d_ws, ws);
-  // rows are packed on the way up (the caller's step may exceed the row), one 2-D copy each way
-  if (er == hipSuccess) er = hipMemcpy2DAsync(d_in, (size_t)src_cols * channels, src, src_step, (size_t)src_cols * channels, src_rows, hipMemcpyHostToDevice, s);
+  // the caller's images never go to hipMemcpy themselves (d2h_staged above: the runtime's by-address cache of pinned caller
+  // buffers): rows are packed into / unpacked from page-locked images of this call's own (the caller's step may exceed the row)
+  if (er == hipSuccess) er = hipHostMalloc((void**)&h_in, in_bytes, hipHostMallocDefault);
+  if (er == hipSuccess) er = hipHostMalloc((void**)&h_out, out_bytes, hipHostMallocDefault);
+  if (er == hipSuccess) {
+    const size_t in_row = (size_t)src_cols * channels;
+    for (int y = 0; y < src_rows; ++y) std::memcpy(h_in + (size_t)y * in_row, src + (size_t)y * src_step, in_row);
+    er = hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, s);
+  }
   if (er != hipSuccess) {
+    (void)hipGetLastError();
     cleanup();
     return fail(BGS_ERR_HIP, "bgs_ingest_host: %s", hipGetErrorString(er));
   }
   rc = bgs_ingest_device(hip_device, c, d_in, 1, src_rows, src_cols, channels, (size_t)src_cols * channels, d_out, d_ws, s);
   if (!rc) {
-    er = hipMemcpy2DAsync(dst, dst_step, d_out, out_row, out_row, pl.rows, hipMemcpyDeviceToHost, s);
+    er = hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, s);
     if (er == hipSuccess) er = hipStreamSynchronize(s);
-    if (er != hipSuccess) rc = fail(BGS_ERR_HIP, "bgs_ingest_host: %s", hipGetErrorString(er));
+    if (er != hipSuccess)
+      rc = fail(BGS_ERR_HIP, "bgs_ingest_host: %s", hipGetErrorString(er));
+    else
+      for (int y = 0; y < pl.rows; ++y) std::memcpy(dst + (size_t)y * dst_step, h_out + (size_t)y * out_row, out_row);
   } else {
     (void)hipStreamSynchronize(s);
   }

@@ -222,15 +222,16 @@ __device__ __forceinline__ void mog1_rec_store(float* p, const float (&mu)[C], c
   }
 }
 
-// Load a pixel's model in rank order.  ALL: every rank's record; else only ranks 0 and 1 (the caller knows that no lane of the
-// wave holds more than two modes).  Every load is unconditional - a rank without a mode reads slot 0, whose values are never
-// used (its weight is 0: the reference's scan stops there) - so that none of them is waited for before the last is issued.
-template <int C, bool ALL>
+// Load a pixel's model in rank order: the records of ranks 0 .. M-1 (the caller knows that no lane of the wave holds more than M
+// modes; the ranks that ever held a mode are a prefix).  Every load is unconditional - a rank without a mode reads slot 0, whose
+// values are never used (its weight is 0: the reference's scan stops there) - so that none of them is waited for before the last
+// is issued.
+template <int C, int M>
 __device__ __forceinline__ void mog1_load(const Mog1Ptr<C>& q, unsigned meta, Mog1Px<C>& s) {
 #pragma unroll
   for (int k = 0; k < kMog1K; ++k) {
     s.sl[k] = (int)((meta >> (3 * k)) & 7u);
-    if (ALL || k < 2) {
+    if (k < M) {
       mog1_rec_load<C>(q.rec + (size_t)(s.sl[k] ? s.sl[k] - 1 : 0) * (kMog1Tile * 2 * C), s.mu[k], s.var[k]);
     } else {
 #pragma unroll
@@ -267,11 +268,17 @@ __global__ __launch_bounds__(kBlock) void mog1_update_kernel(const Mog1Args a) {
 #pragma unroll
   for (int c = 0; c < C; ++c) px[c] = a.frame[pc * C + c];
   Mog1Px<C> s;
-  // one wave-uniform choice: does any lane hold more than two modes?  (S_surv: hardly any wave does)
-  if (__any((meta >> 6) != 0))
-    mog1_load<C, true>(q, meta, s);
+  // one wave-uniform choice: the most modes any lane of the wave holds (at least two are loaded).  Round 3 chose between two and
+  // all five; with fresh sensor noise in every frame (round 4's benchmark frames) a quiet scene keeps spawning short-lived third
+  // modes, and most waves have a lane with three - which then cost every lane of the wave five records.
+  if (!__any((meta >> 6) != 0))
+    mog1_load<C, 2>(q, meta, s);
+  else if (!__any((meta >> 9) != 0))
+    mog1_load<C, 3>(q, meta, s);
+  else if (!__any((meta >> 12) != 0))
+    mog1_load<C, 4>(q, meta, s);
   else
-    mog1_load<C, false>(q, meta, s);
+    mog1_load<C, 5>(q, meta, s);
 #pragma unroll
   for (int k = 0; k < K; ++k) s.sk[k] = sk0[k], s.w[k] = w0[k];
   float pix[C];
@@ -342,7 +349,7 @@ __global__ __launch_bounds__(kBlock) void mog1_clip_kernel(const Mog1ClipArgs c)
 #pragma unroll
   for (int k = 0; k < K; ++k) sk0[k] = q.skw[k * kMog1Tile], w0[k] = q.skw[(K + k) * kMog1Tile];
   Mog1Px<C> s;
-  mog1_load<C, true>(q, meta, s);
+  mog1_load<C, kMog1K>(q, meta, s);
 #pragma unroll
   for (int k = 0; k < K; ++k) s.sk[k] = sk0[k], s.w[k] = w0[k];
   unsigned wrote = 0;  // bit (slot + 1): some frame of the clip wrote that slot's record
