@@ -417,10 +417,21 @@ def configs_block(device=0, S=8, steps=40, cpu=True):
         wall_ms = (time.perf_counter() - w0) / n * 1e3
         ms, _, kname = e.kernel_timing()
         e.enable_kernel_timing(False)
+        # the same steps once more, untimed, with the clock reader running (phase A is bound by vector issue: its time follows the
+        # engine clock, and boxes of the pool differ by ~10 % on it)
+        from tools.clocks import ClockSampler
+        cs = ClockSampler(device)
+        cs.start()
+        for _ in range(n):
+            e.process_batch_device(pool[t_seen % T], fg, None, None)
+            t_seen += 1
+        torch.cuda.synchronize()
+        clk = cs.stop()
         r = _leg(wall_ms, px, 110)
         r["ms_per_step_wall"] = r.pop("kernel_avg_ms")
         r.update({"frames_1080p_per_s": round(S / (wall_ms * 1e-3), 1), "dominant_kernel": kname, "dominant_kernel_avg_ms": round(ms, 4),
-                  "foreground_ratio": round(float((fg != 0).float().mean()), 4)})
+                  "foreground_ratio": round(float((fg != 0).float().mean()), 4),
+                  "clocks_during_the_same_steps_repeated": {k: clk.get(k) for k in ("engine_clock_MHz", "board_power_W", "samples", "error") if k in clk}})
         return r
     for _ in range(5):
         e.process_batch_device(pool[t_seen % T], fg, None, None)
@@ -571,7 +582,9 @@ def main():
         out = configs_block(S=S, cpu=False)
         c3 = out["configs3_subsense_1080p"]
         for k in ("young_model", "aged_model"):
-            print("driver configs3 SuBSENSE %-11s %.4f ms/step wall, phase A %.4f ms, fg ratio %.4f" % (k, c3[k]["ms_per_step_wall"], c3[k]["dominant_kernel_avg_ms"], c3[k]["foreground_ratio"]))
+            clk = c3[k].get("clocks_during_the_same_steps_repeated") or {}
+            print("driver configs3 SuBSENSE %-11s %.4f ms/step wall, phase A %.4f ms, fg ratio %.4f; engine clock %s MHz, board power %s W" % (
+                k, c3[k]["ms_per_step_wall"], c3[k]["dominant_kernel_avg_ms"], c3[k]["foreground_ratio"], (clk.get("engine_clock_MHz") or {}).get("median"), (clk.get("board_power_W") or {}).get("median")))
         return
     if args.only == "subsense8both":  # young and aged model in one process (A/B scripts)
         run_subsense(8)
