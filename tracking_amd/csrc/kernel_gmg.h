@@ -6,8 +6,9 @@
 //
 // Layout: planes of 8-byte RECORDS  rec {colour int32, weight f32} [F][P], nfeatures u8 [P]  (F = maxFeatures <= 64); entry f of every
 // pixel lives in plane f, so each step of the per-pixel list walk is one coalesced 512-byte access per wave (round 4; rounds 1-3 kept
-// colours and weights in separate planes: 19 load and 12 store instructions per pixel on a settled scene, now 11 and 12 - a weight that
-// changes while its colour stays is a 4-byte store into the record).  One lane owns one pixel; all list walks run to the largest
+// colours and weights in separate planes: 19 load and 12 store instructions per pixel on a settled scene, now 11 and 12; a weight that
+// changes while its colour stays goes back as the whole record - a 4-byte store into it leaves every other dword of the line untouched,
+// i.e. partial sectors, and measured 4 % slower).  One lane owns one pixel; all list walks run to the largest
 // count in the wave (wave-uniform trip counts via __any).
 // Traffic is data-dependent: ~ (8 B read + 8 B written) x features of the pixel, up to 1 KiB/pixel; HBM-bound.
 #pragma once
@@ -21,7 +22,7 @@ struct GmgArgs {
   int2* rec;             // [F][plane] {colour, weight (float bits)}
   uint8_t* nfeat;        // [plane]
   size_t plane, state_off, npix;
-  int F, C, levels, typical, update, normalize_now;  // typical = frameNum >= init; normalize_now = frameNum == init - 1
+  int F, C, levels, typical, update, normalize_now, fullStore;  // typical = frameNum >= init; normalize_now = frameNum == init - 1
   double lr, prior, thr;
 };
 
@@ -108,7 +109,7 @@ __device__ __forceinline__ void gmg_fast(const GmgArgs& a, bool active, size_t s
     for (int i = 0; i < kGmgFast; ++i)
       if (i < nf) {
         int2* r = a.rec + (size_t)i * a.plane + sp;
-        if (i >= nf_in || c[i] != c_in[i])
+        if (a.fullStore || i >= nf_in || c[i] != c_in[i])
           *r = make_int2(c[i], __float_as_int(w[i]));
         else
           reinterpret_cast<float*>(r)[1] = w[i];
@@ -174,6 +175,8 @@ __global__ __launch_bounds__(kBlock) void gmg_kernel(const GmgArgs a) {
         if (i <= shift_end) {
           *rp = make_int2(i == 0 ? color : prev_c, __float_as_int(i == 0 ? front_w : prev_w));
           prev_c = c, prev_w = w;
+        } else if (a.fullStore) {
+          *rp = make_int2(c, __float_as_int(w));
         } else {
           reinterpret_cast<float*>(rp)[1] = w;
         }
