@@ -481,6 +481,50 @@ def test_subsense_round4_forms_behind_knobs_match_the_oracle(knob):
     assert r.returncode == 0 and "knob form OK" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("knob", ["BGS_SS_PARTS=4 BGS_SS_PART_MIN_PIXELS=1", "BGS_SS_PARTS=2 BGS_SS_PART_MIN_PIXELS=1 GPU_MAX_HW_QUEUES=8", "BGS_SS_PARTS=1 BGS_SS_PART_MIN_PIXELS=1",
+                                  "BGS_SS_A_TOKEN=1 BGS_SS_PART_MIN_PIXELS=1"])
+def test_subsense_batch_in_parts_and_ranges_on_their_own_streams_match_the_oracle(knob):
+    """Round 4, engine_subsense.h: callers may drive stream ranges on HIP streams of their own (every call has its own pair of events on
+    the side stream); behind knobs - measured, no gain, off by default - a large batch is cut into parts on HIP streams of the engine
+    (BGS_SS_PARTS) and the phase A launches of all calls take turns (the "phase A token", BGS_SS_A_TOKEN=1) so that one part's phase B
+    and post-processing run beside another part's phase A.  Five cameras with different scenes (one with a scene cut: refreshModel(0.1)),
+    (a) as one batch call cut into 4 / 2 / 1 parts (5 streams: uneven parts), (b) as the ranges [0, 2) and [2, 5) on two HIP streams -
+    every mask, background and whole model equals its own oracle's.  The size threshold is lowered so that 240 x 320 frames take the paths
+    1080p batches take; knobs are read once per process: child processes."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from gpu_helpers import check_subsense_state, capi, Engine, pyoracle\n"
+            "from tools import synth\n"
+            "S, T, H, W = 5, 16, 240, 320\n"
+            "clips = [synth.numpy_frames('surv', T, H, W, seed=30 + s) // (1 + s %% 3) for s in range(S)]\n"
+            "clips[3][10:] = 255 - clips[3][10:]\n"
+            "clips = np.stack(clips)\n"
+            "for ranges in ([(0, 5)], [(0, 2), (2, 3)]):\n"
+            "    eng = Engine(capi.SUBSENSE, n_streams=S); eng.set_geometry(H, W, 3)\n"
+            "    orcs = [pyoracle.Oracle(capi.SUBSENSE) for _ in range(S)]\n"
+            "    hs = [torch.cuda.Stream() for _ in ranges]\n"
+            "    for t in range(T):\n"
+            "        d_frames = torch.from_numpy(np.ascontiguousarray(clips[:, t])).cuda()\n"
+            "        d_fg = torch.zeros((S, H, W), dtype=torch.uint8, device='cuda'); d_bg = torch.zeros((S, H, W, 3), dtype=torch.uint8, device='cuda')\n"
+            "        torch.cuda.synchronize()\n"
+            "        for (f, n), h in zip(ranges, hs):\n"
+            "            if len(ranges) == 1: eng.process_batch_device(d_frames, d_fg, d_bg, None)\n"
+            "            else: eng.process_batch_device(d_frames[f:f + n], d_fg[f:f + n], d_bg[f:f + n], None, hip_stream=h.cuda_stream, first=f, count=n)\n"
+            "        torch.cuda.synchronize()\n"
+            "        fg, bg = d_fg.cpu().numpy(), d_bg.cpu().numpy()\n"
+            "        for s in range(S):\n"
+            "            ofg, obg = orcs[s].process(clips[s, t])\n"
+            "            assert np.array_equal(fg[s], ofg), (ranges, t, s, int((fg[s] != ofg).sum()))\n"
+            "            assert np.array_equal(bg[s], obg), (ranges, t, s)\n"
+            "    for s in range(S): check_subsense_state(eng, orcs[s], H, W, stream=s)\n"
+            "    eng.close()\n"
+            "print('parts and ranges OK')\n") % (os.path.dirname(here), here)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **dict(kv.split("=") for kv in knob.split())), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "parts and ranges OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_subsense_qvga_with_frame_level_block():
     """320x240 = QVGA: learning-rate scaling + auto model reset enabled; a scene cut at frame 12 triggers refreshModel(0.1)."""
     a = synth.numpy_frames("surv", 30, 240, 320, seed=21) // 6          # dark scene, long enough for ST (1/25) and LT (1/30) to part

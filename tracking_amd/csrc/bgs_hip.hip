@@ -367,12 +367,16 @@ int launch_mog2(bgs_engine* e, bgs::Mog2Args& a, hipStream_t s, bool timed = tru
   unsigned every = 1;  // sample about 256 workgroups per launch whatever the grid: enough to decide, few enough atomics not to show
   while (grid.x / every > 256) every <<= 1;
   a.stat_mask = every - 1;
+  // BGS_MOG2_LDS_PAD=bytes: unused dynamic LDS per workgroup - fewer workgroups fit a CU (160 KB): the occupancy study of DESIGN.md 6.1
+  // (round 4: 2 / 3 / 4 / 5 waves per SIMD 2.15 / 1.50 / 1.22 / 1.09 ms; a build of the filter kernel without the shadow and background
+  // code - 66 instead of 91 VGPRs, 7 waves - ran no faster than this one's 5: profiles/r04_mog2_occupancy_ab.txt)
+  static const unsigned lds_pad = getenv("BGS_MOG2_LDS_PAD") ? (unsigned)std::max(0, std::min(65536, atoi(getenv("BGS_MOG2_LDS_PAD")))) : 0u;
   if (mode >= 4)
-    hipLaunchKernelGGL((bgs::mog2_update_kernel<bgs::kMog2Filter>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((bgs::mog2_update_kernel<bgs::kMog2Filter>), grid, block, lds_pad, s, a);
   else if (mode >= 2)
-    hipLaunchKernelGGL((bgs::mog2_update_kernel<bgs::kMog2Count>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((bgs::mog2_update_kernel<bgs::kMog2Count>), grid, block, lds_pad, s, a);
   else
-    hipLaunchKernelGGL((bgs::mog2_update_kernel<bgs::kMog2Eager>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((bgs::mog2_update_kernel<bgs::kMog2Eager>), grid, block, lds_pad, s, a);
   if (a.stat) mog2_stat_post(e, s);
   return BGS_OK;
 }

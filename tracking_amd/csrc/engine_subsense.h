@@ -36,7 +36,15 @@ struct SsDevice {
   uint32_t* magic = nullptr;         // ss_mod's multipliers
   int* flood_flags = nullptr;  // [S][kSsFloodFlags], see ss_flood_kernel
   hipStream_t side = nullptr;  // phase B runs here, beside the post-processing chain (both only need phase A)
-  hipEvent_t evA = nullptr, evB = nullptr;
+  // One {evA, evB} pair per call in flight (a ring: calls for disjoint stream ranges may be in flight on several HIP streams), and the
+  // "phase A token": evTok[k] is recorded behind a call's phase A, and the next call's phase A - whatever HIP stream it is on - waits
+  // for it (ss_process).  part[]: the engine's own streams for the parts of one large batch (ss_process).
+  static constexpr int kRing = 8, kParts = 4;
+  hipEvent_t evA[kRing] = {nullptr}, evB[kRing] = {nullptr}, evTok[kRing] = {nullptr};
+  int ring = 0, tok = -1;        // next pair to use; the token of the last call (-1: none yet)
+  hipStream_t tokStream = nullptr;
+  hipStream_t part[kParts] = {nullptr};  // part 0 runs on the caller's stream
+  hipEvent_t evFork = nullptr, evPart[kParts] = {nullptr};
   uint64_t *mbits = nullptr, *rbits = nullptr;  // flood fill: bit-packed mask / reached set, [S][rows][W64]
   uint64_t* bitws = nullptr;                     // SS_NBITS more bit planes of the same shape: the post-processing chain's intermediates
   std::vector<uint8_t> pp;   // per stream: which copy of Dlast / RawST is current
@@ -50,9 +58,16 @@ struct SsDevice {
       if (q) (void)hipFree(q), q = nullptr;
     for (auto& q : u8)
       if (q) (void)hipFree(q), q = nullptr;
-    if (side) (void)hipStreamDestroy(side), side = nullptr;
-    if (evA) (void)hipEventDestroy(evA), evA = nullptr;
-    if (evB) (void)hipEventDestroy(evB), evB = nullptr;
+    if (side) (void)hipStreamSynchronize(side), (void)hipStreamDestroy(side), side = nullptr;
+    for (auto& q : part)
+      if (q) (void)hipStreamSynchronize(q), (void)hipStreamDestroy(q), q = nullptr;
+    for (int i = 0; i < kRing; ++i)
+      for (hipEvent_t* q : {&evA[i], &evB[i], &evTok[i]})
+        if (*q) (void)hipEventDestroy(*q), *q = nullptr;
+    for (auto& q : evPart)
+      if (q) (void)hipEventDestroy(q), q = nullptr;
+    if (evFork) (void)hipEventDestroy(evFork), evFork = nullptr;
+    ring = 0, tok = -1, tokStream = nullptr;
     samples = nullptr, lut = lastColor = curColor = nullptr, lastDesc = req = curDesc = nullptr, dsLT = dsST = nullptr, sc = nullptr, scSnap = nullptr, ho = nullptr, lastRec = nullptr, magic = nullptr, flood_flags = nullptr, mbits = rbits = nullptr, bitws = nullptr;
   }
 };
@@ -222,7 +237,15 @@ int ss_init_streams(bgs_engine* e, int first, int count, const uint8_t* d_frames
   return BGS_OK;
 }
 
-int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uint8_t* d_fg, uint8_t* d_bg, hipStream_t s, int64_t t) {
+// the smallest launch of phase A that takes part in the token / is a part of its own: 2^20 pixels (4 096 workgroups; BGS_SS_PART_MIN_PIXELS:
+// the tests set 1 so that small frames take the same paths)
+size_t ss_part_min_pixels() {
+  static const size_t v = getenv("BGS_SS_PART_MIN_PIXELS") ? (size_t)std::max(1ll, atoll(getenv("BGS_SS_PART_MIN_PIXELS"))) : (size_t)1 << 20;
+  return v;
+}
+
+// streams [first, first + count) on HIP stream s; ss_process (below) decides how a batch is cut into such calls
+int ss_process_range(bgs_engine* e, int first, int count, const uint8_t* d_frames, uint8_t* d_fg, uint8_t* d_bg, hipStream_t s, int64_t t) {
   SsDevice* d = e->ss;
   const size_t N = e->n, off = N * first, npix = N * count;
   // (frames need no particular alignment: the tile loaders read dwords relative to each image's own base, which is unaligned anyway for
@@ -241,6 +264,30 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
   // BGS_SS_FEEDBACK_SPLIT=1: the rules behind the loop as ss_feedback_kernel in front of phase B instead of stage 3 of phase A
   // (identical results; measured slower, kernel_subsense.h - kept as an A/B knob)
   static const bool split = getenv("BGS_SS_FEEDBACK_SPLIT") && atoi(getenv("BGS_SS_FEEDBACK_SPLIT")) == 1;
+  static const bool overlap = !(getenv("BGS_SS_OVERLAP") && atoi(getenv("BGS_SS_OVERLAP")) == 0);
+  if (overlap && !d->side) {
+    HIP_TRY(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));  // (round 4: the lowest stream priority for it changed nothing in the step's timeline)
+    for (int i = 0; i < SsDevice::kRing; ++i) {
+      HIP_TRY(hipEventCreateWithFlags(&d->evA[i], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&d->evB[i], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&d->evTok[i], hipEventDisableTiming));
+    }
+  }
+  const int slot = d->ring;  // this call's {evA, evB, evTok}
+  d->ring = (d->ring + 1) % SsDevice::kRing;
+  // The phase A token (round 4; OFF by default - measured, no gain).  Phase A is bound by vector issue, everything behind it (phase
+  // B's scattered writes, the post-processing chain's many small launches) by DRAM and by latency: a step is A followed by a tail that
+  // leaves the vector units idle.  When the cameras are driven as several stream ranges on HIP streams of their own
+  // (bgs_process_range_device), one range's tail can run beside another range's phase A - but left to themselves the ranges stay
+  // aligned (round 2).  With the token, large launches of phase A take turns: each waits for the phase A of the call
+  // before it, on whatever HIP stream that was, so that A0 A1 A0' A1' ... run back to back and every tail beside the other range's
+  // phase A.  Measured on 8 x 1080p, fresh-noise frames (profiles/r04_subsense_token_parts.txt): two ranges on two streams WITHOUT the
+  // token 2.56 ms young / 1.50-1.57 aged (one batch call: 2.82 / 1.60-1.67), with it 2.67 / 1.55-1.62; four ranges are slower either
+  // way (3.1-3.3 / 2.0-2.2).  Phase A beside another range's tail runs 25 % longer (1.2 -> 1.5 ms per 8 frames: it is not as purely
+  // issue-bound as its counters suggest), and a tail of ~25 launches does not shrink with its range.  BGS_SS_A_TOKEN=1: on (A/B knob).
+  static const bool token_on = (getenv("BGS_SS_A_TOKEN") && atoi(getenv("BGS_SS_A_TOKEN")) == 1) || (getenv("BGS_SS_PARTS") && atoi(getenv("BGS_SS_PARTS")) > 1);  // (the parts of a batch rely on it)
+  const bool token = token_on && overlap && npix >= ss_part_min_pixels();
+  if (token && d->tok >= 0 && d->tokStream != s) HIP_TRY(hipStreamWaitEvent(s, d->evTok[d->tok], 0));
   {
     Timed tm(e, s, "ss_phase_a_kernel");
     // BGS_SS_QUEUE=1: BGR frames through the per-wave candidate list (kernel_subsense.h "rounds"; identical results; measured slower: the
@@ -257,14 +304,14 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
       else hipLaunchKernelGGL((bgs::ss_phase_a_kernel<1, false, false>), tilesA, block, 0, s, a);
     }
   }
+  if (token) {
+    HIP_TRY(hipEventRecord(d->evTok[slot], s));
+    d->tok = slot, d->tokStream = s;
+  }
   // Phase B (the scattered sample writes) and the post-processing chain both depend on phase A only, and the next frame depends
   // on both: phase B goes to a side stream and rejoins at the end, so its memory-bound scatter overlaps the LDS-bound morphology.
-  static const bool overlap = !(getenv("BGS_SS_OVERLAP") && atoi(getenv("BGS_SS_OVERLAP")) == 0);
-  if (overlap && !d->side) {
-    HIP_TRY(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));  // (round 4: the lowest stream priority for it changed nothing in the step's timeline)
-    HIP_TRY(hipEventCreateWithFlags(&d->evA, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&d->evB, hipEventDisableTiming));
-  }
+  // (One side stream for every call: phase B launches then run in the order of their calls, which is the order the token gives
+  // their phase A launches anyway.)
   // Round 4: the per-pixel rules behind the loop (:498-576) are ss_feedback_kernel; it produces the update requests phase B applies, so
   // it goes in front of phase B on the side stream - both beside the post-processing chain, which only needs phase A's `raw`.
   const dim3 gridF((e->cols + bgs::kBlock - 1) / bgs::kBlock, e->rows, count);
@@ -279,11 +326,11 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
   static const bool b_early = !(getenv("BGS_SS_B_LATE") && atoi(getenv("BGS_SS_B_LATE")) == 1);
   auto launch_b = [&]() -> int {
     if (overlap) {
-      HIP_TRY(hipEventRecord(d->evA, s));
-      HIP_TRY(hipStreamWaitEvent(d->side, d->evA, 0));
+      HIP_TRY(hipEventRecord(d->evA[slot], s));
+      HIP_TRY(hipStreamWaitEvent(d->side, d->evA[slot], 0));
       if (split) SS_LAUNCH(ss_feedback_kernel, gridF, block, d->side, a);
       SS_LAUNCH(ss_phase_b_kernel, tilesB, block, d->side, a);
-      HIP_TRY(hipEventRecord(d->evB, d->side));
+      HIP_TRY(hipEventRecord(d->evB[slot], d->side));
     } else {
       if (split) SS_LAUNCH(ss_feedback_kernel, gridF, block, s, a);
       SS_LAUNCH(ss_phase_b_kernel, tilesB, block, s, a);
@@ -367,11 +414,46 @@ int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uin
     SS_LAUNCH(ss_downsample_kernel, dim3(blocks_for(dsn), 1, count), block, s, a);
   }
   hipLaunchKernelGGL(bgs::ss_frame_level_kernel, dim3(count), dim3(256), 0, s, a);
-  if (overlap) HIP_TRY(hipStreamWaitEvent(s, d->evB, 0));  // the refresh below and the next frame need phase B's writes
+  if (overlap) HIP_TRY(hipStreamWaitEvent(s, d->evB[slot], 0));  // the refresh below and the next frame need phase B's writes
   ss_launch_refresh(e, a, N, count, 1, s);  // refreshModel(0.1f) if asked (:680)
   if (d_bg) SS_LAUNCH(ss_background_kernel, dim3(blocks_for(N * e->ch), 1, count), block, s, a);
   HIP_TRY(hipGetLastError());
   for (int i = first; i < first + count; ++i) d->pp[i] = (uint8_t)(cur ^ 1);
+  return BGS_OK;
+}
+
+// One batch = SuBSENSEBGS::process for streams [first, first + count).  BGS_SS_PARTS=n (default 1: off - measured slower) cuts a large
+// batch into up to SsDevice::kParts parts, part 0 on the caller's stream, the others on streams of the engine, each an
+// ss_process_range call of its own with the phase A token, so that each part's tail (phase B, post-processing) runs beside the next
+// part's phase A and only the last part's tail is left standing alone; the caller's stream continues behind all of it.  8 x 1080p:
+// 2 parts 3.01 ms young / 2.24 aged, 4 parts 3.99 / 2.30 against 2.82 / 1.60-1.67 as one launch (profiles/r04_subsense_token_parts.txt;
+// same reasons as the token's).  Same kernels on the same per-stream state: results do not depend on the cut (tests: 1, 2, 4 parts in
+// child processes).
+int ss_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, uint8_t* d_fg, uint8_t* d_bg, hipStream_t s, int64_t t) {
+  SsDevice* d = e->ss;
+  static const int parts_env = getenv("BGS_SS_PARTS") ? std::max(1, std::min((int)SsDevice::kParts, atoi(getenv("BGS_SS_PARTS")))) : bgs::kSsParts;
+  static const bool overlap = !(getenv("BGS_SS_OVERLAP") && atoi(getenv("BGS_SS_OVERLAP")) == 0);
+  const size_t N = e->n, C = (size_t)e->ch;
+  const int P = std::min<int>({parts_env, count, (int)std::min<size_t>(N * (size_t)count / ss_part_min_pixels(), (size_t)SsDevice::kParts)});  // a part is a launch that fills the device
+  if (t == 0 || !overlap || P < 2) return ss_process_range(e, first, count, d_frames, d_fg, d_bg, s, t);  // (the first frame's full refresh is one launch)
+  if (!d->evFork) {
+    HIP_TRY(hipEventCreateWithFlags(&d->evFork, hipEventDisableTiming));
+    for (int p = 1; p < SsDevice::kParts; ++p) {
+      HIP_TRY(hipStreamCreateWithFlags(&d->part[p], hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&d->evPart[p], hipEventDisableTiming));
+    }
+  }
+  HIP_TRY(hipEventRecord(d->evFork, s));  // the frames are ready, and every earlier call has been joined into s
+  for (int p = 0; p < P; ++p) {
+    const int f = first + (int)((int64_t)count * p / P), n = first + (int)((int64_t)count * (p + 1) / P) - f;
+    const size_t o = (size_t)(f - first) * N;
+    hipStream_t ps = p == 0 ? s : d->part[p];
+    if (p) HIP_TRY(hipStreamWaitEvent(ps, d->evFork, 0));
+    const int rc = ss_process_range(e, f, n, d_frames + o * C, d_fg ? d_fg + o : nullptr, d_bg ? d_bg + o * C : nullptr, ps, t);
+    if (rc != BGS_OK) return rc;
+    if (p) HIP_TRY(hipEventRecord(d->evPart[p], ps));
+  }
+  for (int p = 1; p < P; ++p) HIP_TRY(hipStreamWaitEvent(s, d->evPart[p], 0));
   return BGS_OK;
 }
 
