@@ -66,6 +66,23 @@ def calibrate(local, streams):
         except Exception as ex:  # noqa: BLE001 - diagnostics only
             out[label] = None
             out[label + "_error"] = repr(ex)
+    try:  # what WRITES alone reach (the yardstick of kernels that only store: SuBSENSE's model initialisation): hipMemsetAsync over the same size
+        import torch
+        buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda:%d" % local)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(2):
+            buf.zero_()
+        a.record()
+        for _ in range(5):
+            buf.zero_()
+        b.record()
+        torch.cuda.synchronize()
+        out["fill_GBps_plain"] = round(nbytes * 5 / (a.elapsed_time(b) * 1e-3) / 1e9, 1)
+        del buf
+        torch.cuda.empty_cache()
+    except Exception as ex:  # noqa: BLE001 - diagnostics only
+        out["fill_GBps_plain"] = None
+        out["fill_GBps_plain_error"] = repr(ex)
     return out
 
 

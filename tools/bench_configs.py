@@ -405,6 +405,33 @@ def configs_block(device=0, S=8, steps=40, cpu=True):
           "first_frame_ms_incl_allocation": round(init_ms, 2)}
     t_seen = 1
 
+    two = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)] if S >= 2 else None
+
+    def step_two_ranges(frames):  # the same batch as two stream ranges, each on a HIP stream of its own (bgs_process_range_device)
+        h = S // 2
+        e.process_batch_device(frames[:h], fg[:h], None, None, hip_stream=two[0].cuda_stream, first=0, count=h)
+        e.process_batch_device(frames[h:], fg[h:], None, None, hip_stream=two[1].cuda_stream, first=h, count=S - h)
+
+    def timed_two_ranges(n):
+        """Not a different workload: the S cameras driven as two ranges on two HIP streams, as a host with several capture threads would -
+        one range's phase B and post-processing then run beside the other's phase A once the two have drifted apart."""
+        nonlocal t_seen
+        if two is None:
+            return None
+        torch.cuda.synchronize()
+        for _ in range(3):
+            step_two_ranges(pool[t_seen % T])
+            t_seen += 1
+        torch.cuda.synchronize()
+        w0 = time.perf_counter()
+        for _ in range(n):
+            step_two_ranges(pool[t_seen % T])
+            t_seen += 1
+        torch.cuda.synchronize()
+        wall_ms = (time.perf_counter() - w0) / n * 1e3
+        return {"ms_per_step_wall": round(wall_ms, 4), "frames_1080p_per_s": round(S / (wall_ms * 1e-3), 1),
+                "note": "the same %d cameras and frames as ranges [0, %d) and [%d, %d) on two HIP streams, %d steps" % (S, S // 2, S // 2, S, n)}
+
     def timed(n):
         nonlocal t_seen
         e.enable_kernel_timing(True)
@@ -443,6 +470,25 @@ def configs_block(device=0, S=8, steps=40, cpu=True):
     pool[:30] = src.pool(30)
     t_seen = T * 9  # (pool index 0 again: the 30 timed aged steps read 30 frames the model has never seen)
     c3["aged_model"] = dict(timed(30), model_age_frames=300)
+    c3["aged_model"]["as_two_ranges_on_two_hip_streams"] = timed_two_ranges(30)
+    # model initialisation again (every stream reset: the next frame runs SuBSENSE::initialize - LBSP of the frame, refreshModel(1.0):
+    # 50 samples x 16 bytes per pixel written - and then the ordinary step), buffers already allocated
+    for s_ in range(S):
+        e.reset_stream(s_)
+    torch.cuda.synchronize()
+    w0 = time.perf_counter()
+    e.process_batch_device(pool[0], fg, None, None)
+    torch.cuda.synchronize()
+    reinit_ms = (time.perf_counter() - w0) * 1e3
+    model_bytes = S * rows * cols * 50 * 16
+    c3["model_initialisation"] = {"first_frame_ms_buffers_allocated": round(reinit_ms, 3), "model_bytes_written": model_bytes,
+                                  "note": "one call: initialise + the first ordinary step (~1.7 ms of it); the full refresh writes every record of the model once (ss_refresh_kernel; "
+                                          "no separate clear since round 4) - compare calibration.fill_GBps_plain"}
+    t_seen = 1
+    for _ in range(5):
+        e.process_batch_device(pool[t_seen % T], fg, None, None)
+        t_seen += 1
+    c3["young_model"]["as_two_ranges_on_two_hip_streams"] = timed_two_ranges(30)  # (the re-initialised model at the same age as the leg above)
     e.close()
     from oracle import pyoracle
     lut = pyoracle.lbsp_lut(0.333, 0, 3)

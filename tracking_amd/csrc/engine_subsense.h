@@ -218,7 +218,10 @@ int ss_init_streams(bgs_engine* e, int first, int count, const uint8_t* d_frames
     HIP_TRY(hipMemsetAsync(d->dsLT + dsn * first, 0, dsn * count * sizeof(float), s));
     HIP_TRY(hipMemsetAsync(d->dsST + dsn * first, 0, dsn * count * sizeof(float), s));
   }
-  HIP_TRY(hipMemsetAsync((uint8_t*)d->samples + off * (size_t)d->nSpad * (C == 3 ? 16 : 4), 0, npix * (size_t)d->nSpad * (C == 3 ? 16 : 4), s));
+  // BGR: the full refresh below writes every record of these streams, zeros included (kernel_subsense.h: ss_refresh_kernel, mode 0) -
+  // clearing the 13 GB of an 8 x 1080p model first took 3 ms beside the refresh's 5
+  const bool refresh_fills = C == 3 && d->pixelMajor && e->p.subsense_n_samples > bgs::kSsBatch;
+  if (!refresh_fills) HIP_TRY(hipMemsetAsync((uint8_t*)d->samples + off * (size_t)d->nSpad * (C == 3 ? 16 : 4), 0, npix * (size_t)d->nSpad * (C == 3 ? 16 : 4), s));
   // first-frame descriptors (:229-243) with the initial LUT, border = 0; LastColor interior = frame
   bgs::LbspArgs la{};
   la.img = d_frames, la.desc = d->lastDesc + off * C, la.rows = e->rows, la.cols = e->cols;

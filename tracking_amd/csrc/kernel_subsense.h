@@ -1541,8 +1541,12 @@ __global__ __launch_bounds__(kBlock) void ss_refresh_kernel(const SsArgs a, int 
   if (p >= N) continue;
   if (mode == 1) a.T[sN + p] = 1.0f;  // m_oUpdateRateFrame = cv::Scalar(1.0f), every pixel (:682)
   const int x = (int)(p % (uint32_t)a.cols), y = (int)(p / (uint32_t)a.cols);
-  if (!(x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2)) continue;
-  if (a.lastFG[sN + p]) continue;  // bForceFGUpdate = false
+  // BGR, mode 0 (initialisation): this kernel writes EVERY record of the stream - zeros where no sample goes (the two border rows and
+  // columns, the padding slots behind sample nS - 1, a sample whose neighbour is foreground) - so that the engine need not clear the
+  // 13 GB of an 8 x 1080p model first (round 4: that hipMemsetAsync alone took as long as two thirds of this kernel)
+  const bool fill = C == 3 && mode == 0;
+  const bool live = x >= 2 && x < a.cols - 2 && y >= 2 && y < a.rows - 2 && !a.lastFG[sN + p];  // LBSP::validateROI; bForceFGUpdate = false
+  if (!live && !fill) continue;
   if constexpr (FAST) {
     // A lane's samples are s (first batch, s < 4), 4 + s, 20 + s, 36 + s, ...: the first four go through three STAGES - position
     // table, the neighbours' foreground bytes, the neighbours' colour / descriptor - each stage's loads issued together (one sample
@@ -1576,14 +1580,21 @@ __global__ __launch_bounds__(kBlock) void ss_refresh_kernel(const SsArgs a, int 
       uint4* recs = reinterpret_cast<uint4*>(a.samples) + (size_t)stream * N * (size_t)a.nSpad;
       uint4* mine = recs + (size_t)kSsBatch * N + (size_t)p * (size_t)(a.nSpad - kSsBatch) - kSsBatch;  // + m for m >= kSsBatch
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (ok[k] && !(rv[k].x >> 24)) {
-          const uint4 v = make_uint4(rv[k].x & 0x00ffffffu, rv[k].y, rv[k].z, 0u);
+      for (int k = 0; k < 4; ++k) {
+        const bool put = live && ok[k] && !(rv[k].x >> 24);
+        if (put || (fill && (k == 0 ? s < kSsBatch : mm[k] < a.nSpad))) {
+          const uint4 v = put ? make_uint4(rv[k].x & 0x00ffffffu, rv[k].y, rv[k].z, 0u) : make_uint4(0u, 0u, 0u, 0u);
           if (k == 0)
             recs[(size_t)s * N + p] = v;
           else
             mine[mm[k]] = v;
         }
+      }
+      if (fill) {  // (more than 52 samples: the loop below writes the samples, this one the zeros it leaves out)
+        for (int m = kSsBatch + s + 48; m < a.nSpad; m += 16)
+          if (!live || m >= a.nS) mine[m] = make_uint4(0u, 0u, 0u, 0u);
+      }
+      if (!live) continue;
     } else {
       const uint8_t* fgS = a.lastFG + sN;
       (void)fgS;
