@@ -20,6 +20,14 @@ enum { SS_UNSTABLE, SS_BLINKS, SS_LASTFG, SS_LASTRAW, SS_LASTRAWBLINK, SS_LASTDI
       hipLaunchKernelGGL((bgs::KERNEL<1>), grid, block, 0, stream, __VA_ARGS__);                \
   } while (0)
 
+#define SS_LAUNCH_LDS(KERNEL, grid, block, lds, stream, ...)                                     \
+  do {                                                                                          \
+    if (e->ch == 3)                                                                             \
+      hipLaunchKernelGGL((bgs::KERNEL<3>), grid, block, lds, stream, __VA_ARGS__);              \
+    else                                                                                        \
+      hipLaunchKernelGGL((bgs::KERNEL<1>), grid, block, lds, stream, __VA_ARGS__);              \
+  } while (0)
+
 constexpr int SS_NBITS = 6;  // raw, closed-tmp / eroded, pre (closed), combined, final mask, dilated
 struct SsDevice {
   void* samples = nullptr;  // records of colour + descriptor (kernel_subsense.h: SsSample, ss_rec)
@@ -327,12 +335,19 @@ int ss_process_range(bgs_engine* e, int first, int count, const uint8_t* d_frame
   // filters, byte maps) then takes the slowdown instead - median 21 -> 170 - 250 us - and the step is the same or 2 % longer.  The
   // two share DRAM, not compute; the default stays phase B right behind phase A.
   static const bool b_early = !(getenv("BGS_SS_B_LATE") && atoi(getenv("BGS_SS_B_LATE")) == 1);
+  // Phase B beside the chain is held to 4 workgroups per CU by unused dynamic LDS (round 4).  Its workgroups (17 KB of LDS, 4 waves) fit
+  // eight to a CU = every wave slot of the CU, and each lives long (scattered 16-byte writes): the chain's small launches on the
+  // caller's stream then wait for wave slots - 50-130 us each instead of 5 (profiles/r04_subsense_step_timeline.txt) - and the chain
+  // makes no progress until phase B is done.  Phase B is bound by DRAM row activations, not by its resident waves: with four workgroups
+  // per CU it takes as long, and the chain gets through beside it: 8 x 1080p step 2.75 -> 2.67 ms young, 1.63 -> 1.56 aged (same box,
+  // alternating processes; 3 / 2 per CU the same, 1 per CU slower: profiles/r04_subsense_phase_b_occupancy.txt).  BGS_SS_B_LDS_PAD=bytes
+  static const unsigned b_lds_pad = getenv("BGS_SS_B_LDS_PAD") ? (unsigned)std::max(0, std::min(140000, atoi(getenv("BGS_SS_B_LDS_PAD")))) : bgs::kSsBLdsPad;
   auto launch_b = [&]() -> int {
     if (overlap) {
       HIP_TRY(hipEventRecord(d->evA[slot], s));
       HIP_TRY(hipStreamWaitEvent(d->side, d->evA[slot], 0));
       if (split) SS_LAUNCH(ss_feedback_kernel, gridF, block, d->side, a);
-      SS_LAUNCH(ss_phase_b_kernel, tilesB, block, d->side, a);
+      SS_LAUNCH_LDS(ss_phase_b_kernel, tilesB, block, b_lds_pad, d->side, a);
       HIP_TRY(hipEventRecord(d->evB[slot], d->side));
     } else {
       if (split) SS_LAUNCH(ss_feedback_kernel, gridF, block, s, a);

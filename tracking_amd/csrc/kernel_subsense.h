@@ -179,6 +179,7 @@ __device__ __forceinline__ size_t ss_rec(const SsArgs& a, int stream, size_t N, 
 //   3. per pixel (static map again): rolling means, update requests, T / v / R feedback, stores.
 // The result of a pixel does not depend on when or where it is processed: every model read is of start-of-frame state.
 constexpr int kSsATH = 32, kSsAPix = kSsTW * kSsATH, kSsRefill = 16, kSsIpassMin = 16;
+constexpr unsigned kSsBLdsPad = 22000;  // unused dynamic LDS of phase B beside the chain: 4 instead of 8 of its workgroups per CU (engine_subsense.h; BGS_SS_B_LDS_PAD)
 constexpr int kSsParts = 1;  // parts a large batch is cut into (engine_subsense.h: ss_process); BGS_SS_PARTS
 constexpr uint32_t kSsNotInterior = 0xffffffffu;
 
