@@ -248,6 +248,18 @@ int ss_init_streams(bgs_engine* e, int first, int count, const uint8_t* d_frames
   return BGS_OK;
 }
 
+// the side stream phase B runs on, and the ring of events that tie it to the callers' streams
+int ss_side_stream(SsDevice* d) {
+  if (d->side) return BGS_OK;
+  HIP_TRY(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));  // (round 4: the lowest stream priority for it changed nothing in the step's timeline)
+  for (int i = 0; i < SsDevice::kRing; ++i) {
+    HIP_TRY(hipEventCreateWithFlags(&d->evA[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&d->evB[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&d->evTok[i], hipEventDisableTiming));
+  }
+  return BGS_OK;
+}
+
 // the smallest launch of phase A that takes part in the token / is a part of its own: 2^20 pixels (4 096 workgroups; BGS_SS_PART_MIN_PIXELS:
 // the tests set 1 so that small frames take the same paths)
 size_t ss_part_min_pixels() {
@@ -276,13 +288,9 @@ int ss_process_range(bgs_engine* e, int first, int count, const uint8_t* d_frame
   // (identical results; measured slower, kernel_subsense.h - kept as an A/B knob)
   static const bool split = getenv("BGS_SS_FEEDBACK_SPLIT") && atoi(getenv("BGS_SS_FEEDBACK_SPLIT")) == 1;
   static const bool overlap = !(getenv("BGS_SS_OVERLAP") && atoi(getenv("BGS_SS_OVERLAP")) == 0);
-  if (overlap && !d->side) {
-    HIP_TRY(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));  // (round 4: the lowest stream priority for it changed nothing in the step's timeline)
-    for (int i = 0; i < SsDevice::kRing; ++i) {
-      HIP_TRY(hipEventCreateWithFlags(&d->evA[i], hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&d->evB[i], hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&d->evTok[i], hipEventDisableTiming));
-    }
+  if (overlap) {
+    const int rc = ss_side_stream(d);
+    if (rc != BGS_OK) return rc;
   }
   const int slot = d->ring;  // this call's {evA, evB, evTok}
   d->ring = (d->ring + 1) % SsDevice::kRing;
@@ -641,6 +649,8 @@ int lob_process(bgs_engine* e, int first, int count, const uint8_t* d_frames, ui
       SS_LAUNCH(lob_phase_a_kernel, tiles, block, s, a);
     }
   }
+  // (Phase B beside the median on the side stream, as in SuBSENSE's step, was tried at the end of round 4: LOBSTER's tail is only 0.15-0.2
+  // ms and the two event hops cost more than the overlap gives - 8 x 1080p 2.39 against 2.34 ms on S_surv, 0.64 against 0.59 on smooth input.)
   SS_LAUNCH(ss_phase_b_kernel, tilesB, block, s, a);
   uint8_t* lastFG = d->u8[SS_LASTFG] + off;
   ss_morph(d->u8[SS_RAW] + off, lastFG, e->rows, e->cols, count, 3, d->medK, s);  // cv::medianBlur(oCurrFGMask, m_oLastFGMask, 9) :281
