@@ -6,7 +6,8 @@
 // (BackgroundSubtractorSuBSENSE.cpp:643-699) runs on the device, the flood fill (:630) is a fixed batch of launches that stop
 // working on a device-side flag (kernel_subsense.h: ss_flood_kernel / ss_flood_finish_kernel), per-stream constants travel in
 // kernel arguments.  Calls on one engine must come from one host thread at a time; ranges of streams in flight on different
-// HIP streams must be disjoint (flood flags are per stream; the side stream and its two events are shared, which only serialises).
+// HIP streams must be disjoint (flood flags are per stream; every call takes its own {evA, evB} pair from a ring of eight, the one side
+// stream is shared: phase B launches run in the order of their calls).
 
 enum { SS_R, SS_V, SS_T, SS_DLAST0, SS_DLAST1, SS_DMINLT, SS_DMINST, SS_RAWLT, SS_RAWST0, SS_RAWST1, SS_FINLT, SS_FINST, SS_NF32 };
 enum { SS_UNSTABLE, SS_BLINKS, SS_LASTFG, SS_LASTRAW, SS_LASTRAWBLINK, SS_LASTDILINV, SS_RAW, SS_NU8 };
