@@ -349,7 +349,9 @@ int ss_process_range(bgs_engine* e, int first, int count, const uint8_t* d_frame
   // caller's stream then wait for wave slots - 50-130 us each instead of 5 (profiles/r04_subsense_step_timeline.txt) - and the chain
   // makes no progress until phase B is done.  Phase B is bound by DRAM row activations, not by its resident waves: with four workgroups
   // per CU it takes as long, and the chain gets through beside it: 8 x 1080p step 2.75 -> 2.67 ms young, 1.63 -> 1.56 aged (same box,
-  // alternating processes; 3 / 2 per CU the same, 1 per CU slower: profiles/r04_subsense_phase_b_occupancy.txt).  BGS_SS_B_LDS_PAD=bytes
+  // alternating processes; 3 / 2 per CU the same, 1 per CU slower: profiles/r04_subsense_phase_b_occupancy.txt).  The same limit through
+  // the register allocation (__attribute__((amdgpu_waves_per_eu(1, 4))): the kernel descriptor then claims 97 VGPRs, no LDS taken) measured
+  // 1-2 % slower than the pad, not faster.  BGS_SS_B_LDS_PAD=bytes
   static const unsigned b_lds_pad = getenv("BGS_SS_B_LDS_PAD") ? (unsigned)std::max(0, std::min(140000, atoi(getenv("BGS_SS_B_LDS_PAD")))) : bgs::kSsBLdsPad;
   auto launch_b = [&]() -> int {
     if (overlap) {
