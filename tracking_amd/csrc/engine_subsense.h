@@ -252,7 +252,9 @@ int ss_init_streams(bgs_engine* e, int first, int count, const uint8_t* d_frames
 // the side stream phase B runs on, and the ring of events that tie it to the callers' streams
 int ss_side_stream(SsDevice* d) {
   if (d->side) return BGS_OK;
-  HIP_TRY(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));  // (round 4: the lowest stream priority for it changed nothing in the step's timeline)
+  // (round 4: the lowest stream priority for it changed nothing - neither while phase B held every wave slot of the CUs nor with four
+  // workgroups per CU: 2.69 / 1.58-1.59 ms per 8 x 1080p step either way)
+  HIP_TRY(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
   for (int i = 0; i < SsDevice::kRing; ++i) {
     HIP_TRY(hipEventCreateWithFlags(&d->evA[i], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&d->evB[i], hipEventDisableTiming));
